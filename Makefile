@@ -1,0 +1,34 @@
+# Build of the MI355X-native gmove path. `make` builds everything the tests/bench need:
+#   poregen_amd/libpgmove.so      HIP kernels + C ABI (include/pgmove.h), gfx950 only
+#   poregen_amd/_pg_hosttest.so   host-only build of the shared host/device arithmetic (CPU tests)
+#   bin/poregen                   the drop-in `poregen gmove` CLI (host C++ over the C ABI)
+#   oracle/                       the CPU oracle (test infrastructure)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result
+CSRC = poregen_amd/csrc
+
+all: poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so oracle_build
+
+# libpgmove.so deliberately does NOT carry a DT_NEEDED on libamdhip64: a process must hold exactly one HIP
+# runtime, and under Python that has to be the copy PyTorch bundles (poregen_amd/_abi.py preloads it
+# RTLD_GLOBAL); the CLI links /opt/rocm's libamdhip64 itself.
+build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_select.h include/pgmove.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_api.o
+	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined
+
+poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -o $@ $(CSRC)/pg_hosttest.cpp
+
+oracle_build:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all clean oracle_build

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- the gmove hot path on N MI355X GPUs (BASELINE.json metric: signal samples/s into k-mer buckets).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+walk/filter events -> deterministic per-k-mer ranking -> (N>1: RCCL all-gather of per-k-mer counts) ->
+sample_limit cut -> med-MAD statistics of every read -> gather of the kept windows. Workload at N=1 is
+BASELINE.json configs[1]: synthetic RNA004, 50 000 reads x 4 000 samples, k=5, --rna --scaling 1,
+min/max_dur 20/40, sample_limit 100, all 1024 k-mers. At N>1 every rank holds its own 50 000-read shard of
+one PAF-ordered job (weak scaling); value = samples of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0). Extra objects: "roofline" (k_read_stats, the kernel that streams the signal,
+timed with HIP events on the library's stream) and, at N=1, "cpu_baseline" (the CPU oracle, a port of the
+reference algorithm, timed on a bounded sample of the same workload on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=4000)
+    ap.add_argument("--kind", default="rna004")
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--sample-limit", type=int, default=100)
+    ap.add_argument("--lazy", action="store_true", help="statistics only for reads that own a kept event")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from poregen_amd import dist as pgdist
+    from poregen_amd import synth
+    from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    rna = args.kind == "rna004"
+    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy)
+    if rna:
+        p.update(min_dur=20, max_dur=40)
+    kmers = generate_kmers(args.k, rna=rna)
+
+    t0 = time.time()
+    host = synth.make_batch_fast(args.reads, read_len=args.read_len, kind=args.kind, seed=20251003 + 1 + 1000 * rank)
+    gen_s = time.time() - t0
+    shard = host.to_device(dev)
+    n_samples = host.n_samples
+    n_ops = int(host.op_off[-1])
+
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    counts_buf = torch.empty(len(kmers), dtype=torch.int64, device=dev)
+
+    def step():
+        eng.reset()
+        if world > 1:
+            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf)
+            pgdist.merged_freq(total, args.sample_limit)
+        else:
+            eng.submit(shard)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n_samples / (dt / args.steps)
+
+    # ---- per-kernel times with HIP events on the library's own stream (separate, untimed passes) ----------
+    prof = GmoveEngine(GmoveParams(kmers=kmers, profile=True, **p))
+    for _ in range(2):
+        prof.reset(); prof.submit(shard)
+    prof.sync(); prof.kernel_stats_reset()
+    n_prof = 10
+    for _ in range(n_prof):
+        prof.reset(); prof.submit(shard)
+    prof.sync()
+    ks = prof.kernel_stats()
+    res = prof.finish()
+    kept_events = int(res.counts.sum()); kept_samples = int(res.samples.size)
+    prof.close()
+    stats_ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]  # k_read_plan + k_read_stats launches
+    # algorithmic bytes of the statistics kernels per launch: every int16 sample once, the three
+    # doubles + two offsets of each read in, median + MAD out
+    stats_bytes = 2 * n_samples + (24 + 16 + 16) * host.n_reads
+    roofline = {
+        "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+        "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
+    }
+    kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
+
+    out = {
+        "metric": "signal samples/sec aggregated into k-mer buckets", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16 in / f64 arithmetic",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: synthetic {args.kind} SLOW5+PAF, {args.reads} reads x {args.read_len} samples per GPU, "
+                        f"k={args.k}, scaling med-MAD, sample_limit={args.sample_limit}" + (", min/max_dur 20/40, --rna" if rna else ""),
+            "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
+            "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
+            "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples,
+        },
+        "roofline": roofline,
+        "kernels_ms_per_step": kernels_ms,
+        "gen_seconds": gen_s,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(host, kmers, p, args.cpu_seconds)
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(host, kmers, p, budget_s):
+    """The CPU oracle (oracle/, a single-threaded port of the reference algorithm; the reference itself cannot be
+    built in this image) on successive 4000-read slices of the same workload until ~budget_s of CPU work."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from poregen_amd import synth
+    spent = 0.0; samples = 0; reads = 0; runs = 0
+    lo = 0
+    while spent < budget_s and lo < host.n_reads:
+        hi = min(host.n_reads, lo + 4000)
+        o = orc.Oracle(kmers, kmer_size=p["kmer_size"], scaling=1, sample_limit=p["sample_limit"], flag_rna=int(p["rna"]),
+                       min_dur=p.get("min_dur", 5), max_dur=p.get("max_dur", 70))
+        prepared = []
+        for r in range(lo, hi):
+            ts, te = int(host.target_start[r]), int(host.target_end[r])
+            prepared.append((host.sig[int(host.sig_off[r]):int(host.sig_off[r + 1])], float(host.digitisation[r]), float(host.offset[r]),
+                             float(host.range[r]), int(host.query_start[r]), ts, te, synth.seq_string(host, r), synth.ss_string(host, r)))
+        t0 = time.perf_counter()
+        for a in prepared:
+            rc = o.paf_read(*a)
+            if rc == orc.ORC_STOPPED:
+                break
+        spent += time.perf_counter() - t0
+        samples += o.total_samples(); reads += int(o.L.orc_reads_seen(o.h))
+        runs += 1; lo = hi
+    return {"value": samples / spent if spent > 0 else 0.0, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{runs} oracle runs over successive 4000-read slices of the workload (each run stops, like the reference, once all "
+                      f"k-mers are complete); {reads} reads / {samples} samples actually processed in {spent:.2f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+/* pgmove.h -- C ABI of libpgmove: the MI355X (gfx950) implementation of poregen's `gmove` collector.
+ *
+ * The reference (hiruna72/poregen) has no plugin/FFI interface; its only seam for this path is the
+ * internal C++ function
+ *     void process_move_table_paf(char *move_table, std::map<std::string,FILE*>&, slow5_file_t **sp,
+ *                                 opt_t*, std::map<std::string,uint64_t>&, std::vector<std::string>& kmers,
+ *                                 char *fastq)                                   (src/gmove.cpp:76, 707-975)
+ * called once from gmove() (src/gmove.cpp:515). This header is the boundary a maintainer would bind
+ * at that seam: the host keeps all I/O (slow5lib / PAF / FASTQ parsing, the k-mer
+ * list, output files) and hands batches of parsed reads to the device; the device does the per-read
+ * ss walk, event filtering, deterministic first-`sample_limit` selection per k-mer, pA conversion,
+ * med-MAD normalisation and the gather of kept windows.
+ *
+ * Conventions: plain C types only; no exceptions cross the ABI; every call returns a pg_status
+ * (0 = ok, <0 = error, text via pg_last_error); the library never calls exit(). One pg_ctx per host
+ * thread (like the reference, a context is not thread-safe). There is NO CPU fallback: pg_create
+ * fails with PG_ERR_NO_DEVICE when no HIP device is usable.
+ *
+ * Entry point                      replaces (reference file:line)
+ * -------------------------------  ---------------------------------------------------------------
+ * pg_default_params                init_opt defaults                      src/poregen.cpp:209-237
+ * pg_build_slot_tables             kmer_file_pointer_array/kmer_frequency_map keyed by k-mer string
+ *                                                                         src/gmove.cpp:460-477
+ * pg_create / pg_destroy           per-run state set up in gmove()        src/gmove.cpp:460-503
+ * pg_submit                        one batch of while(getline) iterations src/gmove.cpp:732-969
+ * pg_count + pg_collect            the same, split at the "count == sample_limit" test
+ *                                  (src/gmove.cpp:925-927) so that several GPUs can exchange
+ *                                  per-k-mer counts between the two halves
+ * pg_finish                        the bytes the fprintf calls would have produced, as binary
+ *                                                                         src/gmove.cpp:938-950
+ * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
+ */
+#ifndef PGMOVE_H
+#define PGMOVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t pg_status;
+enum {
+    PG_OK = 0,
+    PG_ERR_NO_DEVICE = -1,    /* no usable HIP device / HIP runtime error at create */
+    PG_ERR_INVALID_ARG = -2,  /* bad parameter or malformed batch layout */
+    PG_ERR_INPUT = -3,        /* a read is outside the reference's defined behaviour (see pg_last_error) */
+    PG_ERR_RNA_FLAG = -4,     /* RNA-oriented record without allow_rna (src/gmove.cpp:795-797) */
+    PG_ERR_HIP = -5,          /* HIP runtime failure */
+    PG_ERR_STATE = -6,        /* calls made in the wrong order */
+    PG_ERR_UNSUPPORTED = -7   /* valid input this build cannot process (reported, never silently wrong) */
+};
+
+enum { PG_LOC_HOST = 0, PG_LOC_DEVICE = 1 };
+
+/* pg_params.flags */
+enum {
+    PG_FLAG_LAZY_STATS = 1u << 0, /* compute median/MAD only for reads that contribute a kept event
+                                     (legal: event acceptance is signal-independent in the PAF path);
+                                     default is to touch every read's signal like the reference does */
+    PG_FLAG_PROFILE = 1u << 1     /* record HIP events around every kernel (pg_kernel_stats) */
+};
+
+typedef struct pg_ctx pg_ctx;
+
+/* Mirrors the gmove-relevant members of opt_t (src/poregen.h:48-79). */
+typedef struct {
+    uint32_t struct_size;         /* sizeof(pg_params), for ABI evolution */
+    uint32_t kmer_size;           /* -k                       default 9 */
+    uint32_t sig_move_offset;     /* -m                       default 0; must be <= kmer_size */
+    uint32_t signal_print_margin; /* --margin                 default 0 */
+    uint32_t sample_limit;        /* --sample_limit           default 100 */
+    uint32_t max_dur;             /* --max_dur                default 70 */
+    uint32_t min_dur;             /* --min_dur                default 5 */
+    int32_t  kmer_pick_margin;    /* --kmer_pick_margin       default 2; must be >= 0 */
+    int32_t  scaling;             /* --scaling: 0 none, 1 med-MAD (effective default 0) */
+    int32_t  allow_rna;           /* --rna */
+    double   pa_min;              /* --pa_min                 default 40.0 */
+    double   pa_max;              /* --pa_max                 default 180.0 */
+    uint32_t n_slots;             /* number of k-mers in the slice [index_start, index_end] */
+    uint32_t flags;               /* PG_FLAG_* */
+    int32_t  device;              /* HIP device ordinal */
+    int32_t  reserved;
+    /* code -> slot tables, int32[4^k], host memory, copied at pg_create; -1 = k-mer not in the slice.
+     * The code of a k-mer is its base-4 value, first base most significant, A=0 C=1 G=2 T/U=3.
+     * table_t is used for DNA-oriented records (sequence spelled with T), table_u for RNA-oriented
+     * records (T->U applied, src/gmove.cpp:815-817). pg_build_slot_tables fills both. */
+    const int32_t *table_t;
+    const int32_t *table_u;
+} pg_params;
+
+/* One batch of reads in PAF line order, structure-of-arrays. All arrays are caller-owned and only
+ * read during the call. `location` says whether every pointer is a host or a device pointer
+ * (device pointers must belong to pg_params.device). sig must be 16-byte aligned.
+ *
+ * Read r:  signal   sig[sig_off[r] .. sig_off[r+1])               slow5_rec_t.raw_signal
+ *          digitisation/offset/range[r]                            slow5_rec_t fields
+ *          query_start[r], target_start[r], target_end[r]          PAF columns 3, 8, 9
+ *          seq[seq_off[r] .. seq_off[r+1])  = faidx_fetch_seq(tid, min(ts,te), max(ts,te)-1) as
+ *                                             fetched (ASCII, no T->U); empty if the name is absent
+ *          ss ops  op_n/op_t[op_off[r] .. op_off[r+1]): op_t 0=',' (match) 1='I' 2='D'
+ */
+typedef struct {
+    uint32_t struct_size;
+    int32_t  location;
+    uint32_t n_reads;
+    uint32_t reserved;
+    const int16_t  *sig;
+    const uint64_t *sig_off;      /* [n_reads+1] */
+    const double   *digitisation; /* [n_reads] */
+    const double   *offset;
+    const double   *range;
+    const int32_t  *query_start;
+    const int32_t  *target_start;
+    const int32_t  *target_end;
+    const uint8_t  *seq;
+    const uint64_t *seq_off;      /* [n_reads+1] */
+    const uint32_t *op_n;
+    const uint8_t  *op_t;
+    const uint64_t *op_off;       /* [n_reads+1] */
+} pg_batch;
+
+/* Host-side view of everything collected so far, in reference order: for slot s, its kept events are
+ * e in [ev_off[s], ev_off[s+1]); event e has ev_len[e] samples at samples[samp_off[e] ..], and came
+ * from read ev_read[e] (0-based index over all reads submitted to this context, in order).
+ * Memory is owned by the context and valid until the next pg_submit/pg_collect/pg_reset/pg_destroy. */
+typedef struct {
+    uint32_t n_slots;
+    uint32_t reserved;
+    uint64_t n_events;
+    uint64_t n_samples;
+    uint64_t n_reads;             /* reads submitted so far */
+    const uint64_t *counts;       /* [n_slots]   freq.txt values (<= sample_limit) */
+    const uint64_t *ev_off;       /* [n_slots+1] */
+    const uint32_t *ev_len;       /* [n_events]  */
+    const uint32_t *ev_read;      /* [n_events]  */
+    const uint64_t *samp_off;     /* [n_events+1] */
+    const double   *samples;      /* [n_samples] */
+    const uint8_t  *read_skipped; /* [n_reads] 1 = silently skipped (fetched length < k, gmove.cpp:806-808) */
+} pg_result;
+
+typedef struct {
+    const char *name;     /* kernel name */
+    uint64_t launches;
+    double   total_ms;    /* HIP-event time on the launching stream */
+} pg_kernel_stat;
+
+void        pg_default_params(pg_params *p);
+const char *pg_last_error(const pg_ctx *ctx); /* ctx may be NULL: error of the last failed pg_create */
+const char *pg_version(void);
+
+/* Fill int32[4^k] tables from the slice's k-mer strings (slot i = kmers[i]). K-mers containing
+ * characters outside ACGTU, or both T and U, can never equal a fetched window and get no entry.
+ * Returns PG_ERR_INVALID_ARG on duplicate k-mers or k > 13. */
+pg_status pg_build_slot_tables(uint32_t kmer_size, const char *const *kmers, uint32_t n_slots,
+                               int32_t *table_t, int32_t *table_u);
+
+pg_status pg_create(const pg_params *params, pg_ctx **out);
+void      pg_destroy(pg_ctx *ctx);
+pg_status pg_reset(pg_ctx *ctx); /* forget all reads/events, keep parameters and buffers */
+
+/* count + collect with base = events accepted by earlier batches of this context */
+pg_status pg_submit(pg_ctx *ctx, const pg_batch *batch);
+
+/* Phase 1: walk/filter/rank one batch; writes the batch's accepted-event count per slot (uncapped)
+ * to counts_out (uint64[n_slots]) in host or device memory. */
+pg_status pg_count(pg_ctx *ctx, const pg_batch *batch, uint64_t *counts_out, int32_t counts_location);
+/* Phase 2: keep the events whose rank (base[slot] + rank inside the batch) is < sample_limit and
+ * gather their windows. base = uint64[n_slots], number of accepted events that precede this batch in
+ * reference order (earlier batches, lower ranks of a multi-GPU job); NULL = the context's own running
+ * count. The batch pointers given to pg_count must still be valid. */
+pg_status pg_collect(pg_ctx *ctx, const uint64_t *base, int32_t base_location);
+
+pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work of the context */
+pg_status pg_finish(pg_ctx *ctx, pg_result *out);    /* sync, copy results to host, merge batches */
+int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events */
+
+/* device-resident view of the LAST collected batch (for callers that keep results on the GPU) */
+typedef struct {
+    uint64_t n_events, n_samples;
+    const uint64_t *d_keep;     /* [n_slots] kept events of this batch per slot */
+    const uint64_t *d_ev_off;   /* [n_slots+1] */
+    const uint32_t *d_ev_len;
+    const uint32_t *d_ev_read;  /* read index inside the batch */
+    const uint64_t *d_samp_off;
+    const double   *d_samples;
+    const double   *d_med;      /* [n_reads] (scaling==1; NaN where not computed) */
+    const double   *d_mad;
+} pg_device_view;
+pg_status pg_last_batch_device(pg_ctx *ctx, pg_device_view *out);
+
+/* profiling (PG_FLAG_PROFILE): per-kernel launch counts and HIP-event times since the last reset */
+pg_status pg_kernel_stats(pg_ctx *ctx, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out);
+pg_status pg_kernel_stats_reset(pg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

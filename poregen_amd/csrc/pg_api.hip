@@ -1,0 +1,569 @@
+// pg_api.hip -- C ABI of libpgmove (include/pgmove.h): context, buffers, launch sequence, result merge.
+// Host code only; every device computation lives in pg_kernels.hip. There is no CPU fallback here:
+// without a usable HIP device pg_create fails.
+#include "../../include/pgmove.h"
+#include "pg_internal.h"
+#include "pg_select.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define PG_VERSION_STR "pgmove 0.1.0 (gfx950)"
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostBatchResult { // one collected batch, downloaded
+    uint64_t n_reads = 0, n_events = 0, n_samples = 0;
+    std::vector<uint64_t> keep, ev_off, samp_off;
+    std::vector<uint32_t> ev_len, ev_read;
+    std::vector<double> samples;
+    std::vector<uint8_t> skipped;
+};
+
+struct ProfEntry { const char *name; hipEvent_t a, b; };
+
+} // namespace
+
+struct pg_ctx {
+    pg_params prm{};
+    int device = 0;
+    hipStream_t st = nullptr, st2 = nullptr;
+    hipEvent_t ev_join = nullptr, ev_fork = nullptr;
+    std::string err;
+    uint32_t n_codes = 0, key_bits = 1;
+
+    DevBuf table_t, table_u;
+    // staged copy of a host batch
+    DevBuf s_sig, s_sig_off, s_dig, s_off, s_range, s_qs, s_ts, s_te, s_seq, s_seq_off, s_op_n, s_op_t, s_op_off;
+    // per-batch work buffers
+    DevBuf m_start, m_len, m_base, p_int, ev_slot, n_match, status, errflag;
+    DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
+    DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
+    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan;
+
+    PgDevBatch B{};       // current batch (device view)
+    bool have_count = false, have_batch_result = false, downloaded = true;
+    int sorted_idx = 0;
+    uint64_t cur_n_kept = 0, cur_n_samples = 0;
+    uint64_t reads_before = 0; // reads submitted in earlier batches
+    uint64_t full_slots = 0;
+
+    std::vector<HostBatchResult> batches;
+    // merged view
+    std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
+    std::vector<uint32_t> r_ev_len, r_ev_read;
+    std::vector<double> r_samples;
+    std::vector<uint8_t> r_skipped;
+
+    std::vector<ProfEntry> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    std::map<std::string, std::pair<uint64_t, double>> prof_acc;
+    std::vector<std::string> prof_names;
+};
+
+static pg_status fail(pg_ctx *c, pg_status code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                              \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail((c), PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+static const char *read_status_text(int code) {
+    switch (code) {
+        case PGR_ERR_RNA: return "record is RNA-oriented (target_start > target_end) but allow_rna is 0 (gmove.cpp:795-797)";
+        case PGR_ERR_NEG: return "negative PAF column or query_start >= len_raw_signal (assert at gmove.cpp:752)";
+        case PGR_ERR_OP: return "ss op type outside {',','I','D'}";
+        case PGR_ERR_SEQ_OVERRUN: return "ss consumes more bases than the fetched sequence holds (undefined in the reference, gmove.cpp:850-852)";
+        case PGR_ERR_SHORT: return "fewer than k matched bases (unsigned wrap at gmove.cpp:891 in the reference)";
+        case PGR_ERR_WINDOW: return "an accepted event has an empty/out-of-signal window or margin > start (undefined in the reference, gmove.cpp:928-941)";
+        case PGR_ERR_RANGE: return "sample index exceeds INT32_MAX";
+        case PGR_ERR_SCALE: return "range/digitisation is not a positive finite number";
+        case PGR_ERR_WIDE: return "[pa_min, pa_max] spans more than 2048 raw codes for this read (wide statistics path not implemented)";
+        default: return "unknown";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// profiling helpers
+static void prof_begin(pg_ctx *c, const char *name, hipStream_t st) {
+    if (!(c->prm.flags & PG_FLAG_PROFILE)) return;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!c->prof_pool.empty()) { ev = c->prof_pool.back(); c->prof_pool.pop_back(); }
+    else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
+    (void)hipEventRecord(ev.first, st);
+    c->prof.push_back({name, ev.first, ev.second});
+}
+static void prof_end(pg_ctx *c, hipStream_t st) {
+    if (!(c->prm.flags & PG_FLAG_PROFILE)) return;
+    (void)hipEventRecord(c->prof.back().b, st);
+}
+static void prof_drain(pg_ctx *c) { // requires the streams to be idle
+    for (auto &p : c->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto it = c->prof_acc.find(p.name);
+            if (it == c->prof_acc.end()) { c->prof_acc[p.name] = {1, (double)ms}; c->prof_names.push_back(p.name); }
+            else { it->second.first++; it->second.second += ms; }
+        }
+        c->prof_pool.push_back({p.a, p.b});
+    }
+    c->prof.clear();
+}
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *pg_version(void) { return PG_VERSION_STR; }
+
+const char *pg_last_error(const pg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void pg_default_params(pg_params *p) {
+    // init_opt, src/poregen.cpp:209-237 + src/poregen.h:30-43; scaling 0 is the effective default (gmove.cpp:229)
+    memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(pg_params);
+    p->kmer_size = 9; p->sig_move_offset = 0; p->signal_print_margin = 0; p->sample_limit = 100;
+    p->max_dur = 70; p->min_dur = 5; p->kmer_pick_margin = 2; p->scaling = 0; p->allow_rna = 0;
+    p->pa_min = 40.0; p->pa_max = 180.0; p->n_slots = 0; p->flags = 0; p->device = 0;
+}
+
+pg_status pg_build_slot_tables(uint32_t k, const char *const *kmers, uint32_t n_slots, int32_t *table_t, int32_t *table_u) {
+    if (k < 1 || k > 13 || !kmers || !table_t || !table_u) return fail(nullptr, PG_ERR_INVALID_ARG, "pg_build_slot_tables: bad arguments (1 <= k <= 13)");
+    const size_t n_codes = (size_t)1 << (2 * k);
+    for (size_t i = 0; i < n_codes; i++) table_t[i] = table_u[i] = -1;
+    std::map<std::string, uint32_t> seen;
+    for (uint32_t s = 0; s < n_slots; s++) {
+        const char *km = kmers[s];
+        if (!km || strlen(km) != k) return fail(nullptr, PG_ERR_INVALID_ARG, "k-mer %u does not have length %u", s, k);
+        if (!seen.emplace(km, s).second) return fail(nullptr, PG_ERR_INVALID_ARG, "duplicate k-mer %s in the slice", km);
+        uint32_t code = 0; bool has_t = false, has_u = false, other = false;
+        for (uint32_t i = 0; i < k; i++) {
+            uint32_t b;
+            switch (km[i]) {
+                case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break;
+                case 'T': b = 3; has_t = true; break; case 'U': b = 3; has_u = true; break;
+                default: b = 0; other = true;
+            }
+            code = (code << 2) | b;
+        }
+        if (other || (has_t && has_u)) continue; // can never equal a window of the fetched sequence
+        if (!has_u) table_t[code] = (int32_t)s;  // matches DNA-oriented windows (spelled with T)
+        if (!has_t) table_u[code] = (int32_t)s;  // matches RNA-oriented windows (T->U applied)
+    }
+    return PG_OK;
+}
+
+void pg_destroy(pg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
+    DevBuf *bufs[] = {&c->table_t, &c->table_u, &c->s_sig, &c->s_sig_off, &c->s_dig, &c->s_off, &c->s_range, &c->s_qs, &c->s_ts,
+                      &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
+                      &c->p_int, &c->ev_slot, &c->n_match, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
+                      &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
+                      &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
+    delete c;
+}
+
+pg_status pg_create(const pg_params *p, pg_ctx **out) {
+    if (!p || !out) return fail(nullptr, PG_ERR_INVALID_ARG, "pg_create: null argument");
+    *out = nullptr;
+    if (p->struct_size != sizeof(pg_params)) return fail(nullptr, PG_ERR_INVALID_ARG, "pg_params.struct_size mismatch");
+    if (p->kmer_size < 1 || p->kmer_size > 13) return fail(nullptr, PG_ERR_INVALID_ARG, "kmer_size must be in [1,13]");
+    if (p->sig_move_offset > p->kmer_size) return fail(nullptr, PG_ERR_INVALID_ARG, "sig_move_offset > kmer_size indexes past the reference's arrays (gmove.cpp:892)");
+    if (p->kmer_pick_margin < 0) return fail(nullptr, PG_ERR_INVALID_ARG, "negative kmer_pick_margin is undefined in the reference (gmove.cpp:204-211)");
+    if (p->scaling != 0 && p->scaling != 1) return fail(nullptr, PG_ERR_INVALID_ARG, "scaling must be 0 or 1");
+    if (p->n_slots < 1 || !p->table_t || !p->table_u) return fail(nullptr, PG_ERR_INVALID_ARG, "n_slots/table_t/table_u missing");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, PG_ERR_NO_DEVICE, "no HIP device available (%s); libpgmove has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, PG_ERR_NO_DEVICE, "device %d out of range (have %d)", p->device, ndev);
+    e = hipSetDevice(p->device);
+    if (e != hipSuccess) return fail(nullptr, PG_ERR_NO_DEVICE, "hipSetDevice(%d): %s", p->device, hipGetErrorString(e));
+
+    pg_ctx *c = new pg_ctx();
+    c->prm = *p;
+    c->device = p->device;
+    c->n_codes = 1u << (2 * p->kmer_size);
+    c->key_bits = 1; while ((1ull << c->key_bits) < (uint64_t)p->n_slots) c->key_bits++;
+    auto bail = [&](pg_status s) { g_create_error = c->err; pg_destroy(c); return s; };
+#define CTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(PG_ERR_HIP); } } while (0)
+    CTRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    CTRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    CTRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
+    CTRY(c->table_t.ensure(tb)); CTRY(c->table_u.ensure(tb));
+    CTRY(hipMemcpy(c->table_t.p, p->table_t, tb, hipMemcpyHostToDevice));
+    CTRY(hipMemcpy(c->table_u.p, p->table_u, tb, hipMemcpyHostToDevice));
+    c->prm.table_t = nullptr; c->prm.table_u = nullptr;
+    const uint32_t ns = p->n_slots;
+    CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
+    CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull));
+    CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
+    CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
+    CTRY(hipMemset(c->running.p, 0, ns * 8ull));
+#undef CTRY
+    *out = c;
+    return PG_OK;
+}
+
+pg_status pg_reset(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    prof_drain(c);
+    HIP_TRY(c, hipMemsetAsync(c->running.p, 0, c->prm.n_slots * 8ull, c->st));
+    c->batches.clear();
+    c->have_count = c->have_batch_result = false; c->downloaded = true;
+    c->reads_before = 0; c->full_slots = 0; c->cur_n_kept = c->cur_n_samples = 0;
+    return PG_OK;
+}
+
+// copy the finished batch's device results to the host (needed before its buffers are reused)
+static pg_status download_last(pg_ctx *c) {
+    if (!c->have_batch_result || c->downloaded) return PG_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    c->batches.emplace_back();
+    HostBatchResult &h = c->batches.back();
+    const uint32_t ns = c->prm.n_slots;
+    h.n_reads = c->B.n_reads; h.n_events = c->cur_n_kept; h.n_samples = c->cur_n_samples;
+    h.keep.resize(ns); h.ev_off.resize(ns + 1); h.samp_off.resize(h.n_events + 1);
+    h.ev_len.resize(h.n_events); h.ev_read.resize(h.n_events); h.samples.resize(h.n_samples);
+    HIP_TRY(c, hipMemcpy(h.keep.data(), c->keep.p, ns * 8ull, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(h.ev_off.data(), c->ev_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost));
+    if (h.n_events) {
+        HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off.p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
+    } else h.samp_off[0] = 0;
+    if (h.n_samples) HIP_TRY(c, hipMemcpy(h.samples.data(), c->samples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
+    std::vector<int32_t> st(h.n_reads);
+    if (h.n_reads) HIP_TRY(c, hipMemcpy(st.data(), c->status.p, h.n_reads * 4ull, hipMemcpyDeviceToHost));
+    h.skipped.resize(h.n_reads);
+    for (uint64_t i = 0; i < h.n_reads; i++) h.skipped[i] = st[i] == PGR_SKIPPED;
+    c->downloaded = true;
+    return PG_OK;
+}
+
+static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
+    const uint32_t n = b->n_reads;
+    if (!b->sig_off || !b->seq_off || !b->op_off) return fail(c, PG_ERR_INVALID_ARG, "batch offsets missing");
+    const uint64_t ns = b->sig_off[n], nq = b->seq_off[n], no = b->op_off[n];
+    if (b->sig_off[0] != 0 || b->seq_off[0] != 0 || b->op_off[0] != 0) return fail(c, PG_ERR_INVALID_ARG, "host batch offsets must start at 0");
+    for (uint32_t r = 0; r < n; r++)
+        if (b->sig_off[r + 1] < b->sig_off[r] || b->seq_off[r + 1] < b->seq_off[r] || b->op_off[r + 1] < b->op_off[r])
+            return fail(c, PG_ERR_INVALID_ARG, "batch offsets of read %u are not monotone", r);
+    struct Item { DevBuf *d; const void *src; size_t bytes; };
+    Item items[] = {{&c->s_sig, b->sig, ns * 2}, {&c->s_sig_off, b->sig_off, (n + 1) * 8ull}, {&c->s_dig, b->digitisation, n * 8ull},
+                    {&c->s_off, b->offset, n * 8ull}, {&c->s_range, b->range, n * 8ull}, {&c->s_qs, b->query_start, n * 4ull},
+                    {&c->s_ts, b->target_start, n * 4ull}, {&c->s_te, b->target_end, n * 4ull}, {&c->s_seq, b->seq, nq},
+                    {&c->s_seq_off, b->seq_off, (n + 1) * 8ull}, {&c->s_op_n, b->op_n, no * 4}, {&c->s_op_t, b->op_t, no},
+                    {&c->s_op_off, b->op_off, (n + 1) * 8ull}};
+    for (auto &it : items) {
+        if (it.bytes && !it.src) return fail(c, PG_ERR_INVALID_ARG, "batch array missing");
+        HIP_TRY(c, it.d->ensure(it.bytes + 16));
+        if (it.bytes) HIP_TRY(c, hipMemcpyAsync(it.d->p, it.src, it.bytes, hipMemcpyHostToDevice, c->st));
+    }
+    PgDevBatch &B = c->B;
+    B.n_reads = n; B.n_ops = no;
+    B.sig = c->s_sig.as<int16_t>(); B.sig_off = c->s_sig_off.as<uint64_t>();
+    B.dig = c->s_dig.as<double>(); B.off = c->s_off.as<double>(); B.range = c->s_range.as<double>();
+    B.qstart = c->s_qs.as<int32_t>(); B.tstart = c->s_ts.as<int32_t>(); B.tend = c->s_te.as<int32_t>();
+    B.seq = c->s_seq.as<uint8_t>(); B.seq_off = c->s_seq_off.as<uint64_t>();
+    B.op_n = c->s_op_n.as<uint32_t>(); B.op_t = c->s_op_t.as<uint8_t>(); B.op_off = c->s_op_off.as<uint64_t>();
+    return PG_OK;
+}
+
+static pg_status check_read_errors(pg_ctx *c) {
+    int32_t errv[2] = {INT_MAX, 0};
+    HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
+    if (errv[0] == INT_MAX) return PG_OK;
+    int32_t code = 0;
+    HIP_TRY(c, hipMemcpy(&code, c->status.as<int32_t>() + errv[0], 4, hipMemcpyDeviceToHost));
+    pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : PG_ERR_INPUT);
+    return fail(c, s, "read %llu of the batch (global read %llu): %s", (unsigned long long)errv[0],
+                (unsigned long long)(c->reads_before + errv[0]), read_status_text(code));
+}
+
+pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t counts_location) {
+    if (!c || !b) return PG_ERR_INVALID_ARG;
+    if (b->struct_size != sizeof(pg_batch)) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    pg_status s = download_last(c);
+    if (s != PG_OK) return s;
+    if (c->have_batch_result) { c->reads_before += c->B.n_reads; c->have_batch_result = false; }
+    c->have_count = false;
+    const uint32_t n = b->n_reads;
+
+    if (b->location == PG_LOC_HOST) {
+        s = stage_host_batch(c, b);
+        if (s != PG_OK) return s;
+    } else if (b->location == PG_LOC_DEVICE) {
+        PgDevBatch &B = c->B;
+        B.n_reads = n;
+        B.sig = b->sig; B.sig_off = b->sig_off; B.dig = b->digitisation; B.off = b->offset; B.range = b->range;
+        B.qstart = b->query_start; B.tstart = b->target_start; B.tend = b->target_end; B.seq = b->seq; B.seq_off = b->seq_off;
+        B.op_n = b->op_n; B.op_t = b->op_t; B.op_off = b->op_off;
+        if (!B.sig_off || !B.seq_off || !B.op_off) return fail(c, PG_ERR_INVALID_ARG, "batch offsets missing");
+        uint64_t no = 0;
+        HIP_TRY(c, hipMemcpy(&no, b->op_off + n, 8, hipMemcpyDeviceToHost));
+        B.n_ops = no;
+    } else return fail(c, PG_ERR_INVALID_ARG, "pg_batch.location must be PG_LOC_HOST or PG_LOC_DEVICE");
+    if (((uintptr_t)c->B.sig & 15) != 0) return fail(c, PG_ERR_INVALID_ARG, "sig must be 16-byte aligned");
+    const uint64_t N = c->B.n_ops;
+    if (N >= 0x7fffffffull) return fail(c, PG_ERR_INVALID_ARG, "more than 2^31 ss ops in one batch; split the batch");
+
+    // work buffers
+    const uint64_t Nn = N ? N : 1;
+    HIP_TRY(c, c->m_start.ensure(Nn * 4)); HIP_TRY(c, c->m_len.ensure(Nn * 4)); HIP_TRY(c, c->m_base.ensure(Nn));
+    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4));
+    HIP_TRY(c, c->n_match.ensure((n + 1) * 4ull)); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
+    const uint32_t n_tiles = (uint32_t)((Nn + PG_SORT_TILE - 1) / PG_SORT_TILE);
+    for (int i = 0; i < 2; i++) { HIP_TRY(c, c->sk[i].ensure(Nn * 4)); HIP_TRY(c, c->sv[i].ensure(Nn * 4)); }
+    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * 256 * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * 1024 * 4));
+
+    const int32_t errinit[2] = {INT_MAX, 0};
+    HIP_TRY(c, hipMemcpyAsync(c->errflag.p, errinit, 8, hipMemcpyHostToDevice, c->st));
+
+    PgWalkParams W{};
+    W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
+    W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
+    W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
+    PgWalkOut O{};
+    O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
+    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>(); O.n_match = c->n_match.as<uint32_t>();
+    O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
+
+    // the statistics kernel only needs the signal and the read status: fork it onto the second stream
+    // right after the walk so that it overlaps the (latency-bound) sort/plan chain
+    prof_begin(c, "k_walk_events", c->st);
+    pg_launch_walk_events(c->st, c->B, W, O);
+    prof_end(c, c->st);
+
+    PgSortBufs S{};
+    S.keys[0] = c->sk[0].as<uint32_t>(); S.keys[1] = c->sk[1].as<uint32_t>();
+    S.vals[0] = c->sv[0].as<uint32_t>(); S.vals[1] = c->sv[1].as<uint32_t>();
+    S.hist = c->hist.as<uint32_t>(); S.wcnt = c->wcnt.as<uint32_t>(); S.totals = c->totals.as<uint32_t>();
+    S.dbase = c->dbase.as<uint32_t>(); S.count = c->scount.as<uint32_t>(); S.n_tiles = n_tiles;
+    prof_begin(c, "sort_events", c->st);
+    if (N) c->sorted_idx = pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S);
+    else { c->sorted_idx = 0; HIP_TRY(c, hipMemsetAsync(c->scount.p, 0, 8, c->st)); }
+    prof_end(c, c->st);
+    prof_begin(c, "slot_bounds", c->st);
+    pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
+                          c->prm.n_slots, c->acc_cnt.as<uint64_t>());
+    prof_end(c, c->st);
+
+    if (counts_out) {
+        if (counts_location == PG_LOC_DEVICE)
+            HIP_TRY(c, hipMemcpyAsync(counts_out, c->acc_cnt.p, c->prm.n_slots * 8ull, hipMemcpyDeviceToDevice, c->st));
+        else {
+            HIP_TRY(c, hipMemcpyAsync(counts_out, c->acc_cnt.p, c->prm.n_slots * 8ull, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+        }
+    }
+    c->have_count = true;
+    return PG_OK;
+}
+
+pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t ns = c->prm.n_slots, n = c->B.n_reads;
+    const uint64_t N = c->B.n_ops;
+    const uint64_t *d_base = c->running.as<uint64_t>();
+    if (base) {
+        HIP_TRY(c, hipMemcpyAsync(c->base_stage.p, base, ns * 8ull,
+                                  base_location == PG_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
+        d_base = c->base_stage.as<uint64_t>();
+    }
+    uint64_t *totals = c->plan_totals.as<uint64_t>();
+    prof_begin(c, "k_slot_plan", c->st);
+    pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
+                        c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals);
+    prof_end(c, c->st);
+
+    // upper bound on kept events of this batch
+    uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
+    if (ke_cap == 0) ke_cap = 1;
+    HIP_TRY(c, c->ev_len.ensure(ke_cap * 4)); HIP_TRY(c, c->ev_read.ensure(ke_cap * 4)); HIP_TRY(c, c->ev_start.ensure(ke_cap * 4));
+    HIP_TRY(c, c->samp_off.ensure((ke_cap + 1) * 8)); HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 2) * 8));
+    HIP_TRY(c, c->read_needed.ensure(n + 1ull));
+    HIP_TRY(c, hipMemsetAsync(c->read_needed.p, 0, n + 1ull, c->st));
+
+    PgWalkParams W{};
+    W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
+    PgWalkOut O{};
+    O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>();
+    PgKeptOut K{};
+    K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_start = c->ev_start.as<uint32_t>();
+    K.read_needed = c->read_needed.as<uint8_t>(); K.totals = totals;
+    prof_begin(c, "k_kept_meta", c->st);
+    pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
+                        c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
+    prof_end(c, c->st);
+
+    // statistics: med/MAD per read (scaling == 1 only). Eager mode touches every read like the reference;
+    // lazy mode only the reads that own a kept event.
+    const bool lazy = (c->prm.flags & PG_FLAG_LAZY_STATS) != 0;
+    if (c->prm.scaling == 1) {
+        HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull)); HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull));
+        prof_begin(c, "k_read_stats", c->st);
+        pg_launch_read_stats(c->st, c->B, c->prm.pa_min, c->prm.pa_max, lazy ? c->read_needed.as<uint8_t>() : nullptr, c->read_plan.p,
+                             c->med.as<double>(), c->mad.as<double>(), c->status.as<int32_t>(), c->errflag.as<int32_t>());
+        prof_end(c, c->st);
+    }
+
+    // one host sync per batch: how many events were kept (sizes the remaining launches and buffers)
+    uint64_t tot[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(tot, totals, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    pg_status s = check_read_errors(c);
+    if (s != PG_OK) { c->have_count = false; return s; }
+    const uint64_t n_kept = tot[0];
+    c->full_slots = tot[1];
+    prof_begin(c, "scan_ev_len", c->st);
+    pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), n_kept, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>());
+    prof_end(c, c->st);
+    uint64_t n_samples = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_samples, c->samp_off.as<uint64_t>() + n_kept, 8, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, c->samples.ensure((n_samples + 1) * 8));
+    prof_begin(c, "k_gather", c->st);
+    pg_launch_gather(c->st, c->B, n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
+                     c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med.as<double>(), c->mad.as<double>(),
+                     c->samples.as<double>());
+    prof_end(c, c->st);
+    c->cur_n_kept = n_kept; c->cur_n_samples = n_samples;
+    c->have_count = false; c->have_batch_result = true; c->downloaded = false;
+    return PG_OK;
+}
+
+pg_status pg_submit(pg_ctx *c, const pg_batch *b) {
+    pg_status s = pg_count(c, b, nullptr, PG_LOC_HOST);
+    if (s != PG_OK) return s;
+    return pg_collect(c, nullptr, PG_LOC_HOST);
+}
+
+pg_status pg_sync(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    return PG_OK;
+}
+
+int32_t pg_all_slots_full(pg_ctx *c) { return c && c->full_slots == c->prm.n_slots; }
+
+pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
+    if (!c || !v) return PG_ERR_INVALID_ARG;
+    if (!c->have_batch_result) return fail(c, PG_ERR_STATE, "no collected batch");
+    v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
+    v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
+    v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off.as<uint64_t>(); v->d_samples = c->samples.as<double>();
+    v->d_med = c->prm.scaling == 1 ? c->med.as<double>() : nullptr; v->d_mad = c->prm.scaling == 1 ? c->mad.as<double>() : nullptr;
+    return PG_OK;
+}
+
+pg_status pg_finish(pg_ctx *c, pg_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    pg_status s = download_last(c);
+    if (s != PG_OK) return s;
+    const uint32_t ns = c->prm.n_slots;
+    // merge the batches slot-major, batch-minor: reference order is PAF-line order inside every k-mer file
+    uint64_t n_events = 0, n_samples = 0, n_reads = 0;
+    for (auto &h : c->batches) { n_events += h.n_events; n_samples += h.n_samples; n_reads += h.n_reads; }
+    c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.assign(n_events + 1, 0);
+    c->r_ev_len.resize(n_events); c->r_ev_read.resize(n_events); c->r_samples.resize(n_samples);
+    c->r_skipped.resize(n_reads);
+    uint64_t e = 0, sp = 0;
+    for (uint32_t sl = 0; sl < ns; sl++) {
+        c->r_ev_off[sl] = e;
+        uint64_t rbase = 0;
+        for (auto &h : c->batches) {
+            const uint64_t a = h.ev_off[sl], b = h.ev_off[sl + 1];
+            for (uint64_t i = a; i < b; i++) {
+                c->r_ev_len[e] = h.ev_len[i]; c->r_ev_read[e] = (uint32_t)(rbase + h.ev_read[i]); c->r_samp_off[e] = sp;
+                const uint64_t so = h.samp_off[i], len = h.ev_len[i];
+                if (len) memcpy(&c->r_samples[sp], &h.samples[so], len * sizeof(double));
+                sp += len; e++;
+            }
+            c->r_counts[sl] += b - a;
+            rbase += h.n_reads;
+        }
+    }
+    c->r_ev_off[ns] = e; c->r_samp_off[n_events] = sp;
+    uint64_t rb = 0;
+    for (auto &h : c->batches) { if (h.n_reads) memcpy(&c->r_skipped[rb], h.skipped.data(), h.n_reads); rb += h.n_reads; }
+    out->n_slots = ns; out->reserved = 0; out->n_events = n_events; out->n_samples = n_samples; out->n_reads = n_reads;
+    out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
+    out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+    out->read_skipped = c->r_skipped.data();
+    return PG_OK;
+}
+
+pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out) {
+    if (!c || !n_out) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    prof_drain(c);
+    uint32_t n = 0;
+    for (auto &name : c->prof_names) {
+        if (out && n < cap) { auto &a = c->prof_acc[name]; out[n].name = name.c_str(); out[n].launches = a.first; out[n].total_ms = a.second; }
+        n++;
+    }
+    *n_out = n;
+    return PG_OK;
+}
+
+pg_status pg_kernel_stats_reset(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    prof_drain(c);
+    c->prof_acc.clear(); c->prof_names.clear();
+    return PG_OK;
+}
+
+} // extern "C"

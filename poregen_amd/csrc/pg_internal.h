@@ -1,0 +1,102 @@
+// pg_internal.h -- device-side data layout and kernel launch interface of libpgmove (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- batch as the kernels see it (all device pointers) ------------------------------------------
+struct PgDevBatch {
+    uint32_t n_reads;
+    uint64_t n_ops;      // op_off[n_reads]
+    const int16_t *sig;
+    const uint64_t *sig_off;
+    const double *dig, *off, *range;
+    const int32_t *qstart, *tstart, *tend;
+    const uint8_t *seq;
+    const uint64_t *seq_off;
+    const uint32_t *op_n;
+    const uint8_t *op_t;
+    const uint64_t *op_off;
+};
+
+struct PgWalkParams {
+    uint32_t k, sig_move_offset, print_margin, max_dur, min_dur;
+    int32_t pick_margin, allow_rna;
+    uint32_t n_codes; // 4^k
+    const int32_t *table_t, *table_u;
+};
+
+// per-read status codes written by k_walk_events (negative = error, reported through the C ABI)
+enum {
+    PGR_OK = 0,
+    PGR_SKIPPED = 1,          // fetched sequence shorter than k (gmove.cpp:806-808)
+    PGR_ERR_RNA = -1,         // RNA-oriented record without --rna (gmove.cpp:795-797)
+    PGR_ERR_NEG = -2,         // negative query_start/target_start/target_end or query_start >= len (gmove.cpp:752)
+    PGR_ERR_OP = -3,          // op type not in {0,1,2}
+    PGR_ERR_SEQ_OVERRUN = -4, // ss consumes more bases than were fetched (reads past the string in the reference)
+    PGR_ERR_SHORT = -5,       // fewer than k matched bases: unsigned wrap at gmove.cpp:891
+    PGR_ERR_WINDOW = -6,      // an accepted event's window is empty / starts beyond the signal / margin > start
+    PGR_ERR_RANGE = -7,       // sample index does not fit the reference's int arrays
+    PGR_ERR_SCALE = -8,       // range/digitisation not positive finite (pg_select.h)
+    PGR_ERR_WIDE = -9         // pa window spans more than PG_STATS_BINS codes (not implemented yet)
+};
+
+struct PgWalkOut {
+    uint32_t *m_start; // [n_ops] window start of match j of read r at op_off[r]+j  (end_raw_idx in the reference)
+    uint32_t *m_len;   // [n_ops] window length
+    uint8_t *m_base;   // [n_ops] 2-bit base code of the matched base, 4 = not ACGT/U
+    int32_t *p_int;    // [n_ops] matched-base count at each I/D op (interior of indel_pos, gmove.cpp:843,845)
+    uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
+    uint32_t *n_match; // [n_reads]
+    int32_t *status;   // [n_reads]
+    int32_t *err;      // [2] err[0] = lowest read index with an error (init INT32_MAX), err[1] = its code
+};
+
+#define PG_INVALID_SLOT 0xFFFFFFFFu
+
+// ---- radix sort geometry ---------------------------------------------------------------------------
+#define PG_SORT_ROWS 16                       // rows of 64 keys per wave
+#define PG_SORT_TILE (4 * PG_SORT_ROWS * 64)  // keys per 256-thread workgroup
+
+struct PgSortBufs {
+    uint32_t *keys[2];
+    uint32_t *vals[2];
+    uint32_t *hist;   // [256][n_tiles]  (digit-major)
+    uint32_t *wcnt;   // [n_tiles][4][256]
+    uint32_t *totals; // [256]
+    uint32_t *dbase;  // [256]
+    uint32_t *count;  // [2] count[0] = number of keys entering the current pass, count[1] = scratch
+    uint32_t n_tiles; // for the capacity N the buffers were sized for
+};
+
+// ---- stats ---------------------------------------------------------------------------------------
+#define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global path
+
+// ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
+void pg_launch_walk_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+// stable LSD radix sort of (ev_slot, index) pairs by slot, dropping PG_INVALID_SLOT; result in
+// S.keys[out]/S.vals[out], number of sorted pairs in S.count[0]. Returns `out`.
+int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S);
+void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
+                           uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt);
+// keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
+// totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] += cnt[s] if running != nullptr
+void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
+                         uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals);
+struct PgKeptOut {
+    uint32_t *ev_len;   // [n_kept] window length incl. margin, clamped to the signal
+    uint32_t *ev_read;  // [n_kept] read index inside the batch
+    uint32_t *ev_start; // [n_kept] window start inside the read
+    uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
+    uint64_t *totals;   // totals[2] += sum of ev_len
+};
+void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
+                         const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off,
+                         const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
+// out[i] = sum_{j<i} in[j] for i in [0, n]; scratch >= ceil(n/4096)+1 uint64
+void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch);
+// plan_buf: 16 bytes per read of scratch
+void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max,
+                          const uint8_t *read_needed, void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err);
+void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept, const uint32_t *ev_len, const uint32_t *ev_read,
+                      const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min, double pa_max,
+                      const double *med, const double *mad, double *samples);

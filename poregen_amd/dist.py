@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of the gmove path: one process per GPU, contiguous PAF-order shards, one exchange step.
+
+Because the reference keeps the FIRST sample_limit accepted events of every k-mer in PAF-line order
+(src/gmove.cpp:732, 925-927), rank g only needs to know how many accepted events ranks < g hold per k-mer:
+    1. every rank:   counts_g = pg_count(shard_g)                       (uint64[n_slots], on the GPU)
+    2. all ranks:    all_gather(counts)  -> base_g = sum_{h<g} counts_h  (RCCL over xGMI; 8 KB at k=5, 2 MB at k=9)
+    3. every rank:   pg_collect(base_g)  keeps the events whose global rank is < sample_limit
+The per-k-mer stream of the whole job is the concatenation of the ranks' streams in rank order; freq.txt is
+min(sum_g counts_g, sample_limit). Works with backend "nccl" (= RCCL, CUDA tensors) and "gloo" (CPU tensors).
+"""
+from typing import List, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_reads: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, PAF-ordered read range of `rank` (sizes differ by at most one read)."""
+    q, r = divmod(n_reads, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def exchange_bases(counts, group=None):
+    """counts: int64 tensor [n_slots] of this rank's accepted events (the bytes of pg_count's uint64 output).
+    Returns (base, total): events held by lower ranks, and the job-wide total, per slot."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    allc = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(allc, counts.contiguous(), group=group)
+    base = allc[:rank].sum(dim=0) if rank > 0 else torch.zeros_like(counts)
+    return base, allc.sum(dim=0)
+
+
+def merged_freq(total_counts, sample_limit: int):
+    """freq.txt of the whole job from the job-wide accepted counts."""
+    import torch
+    return torch.clamp(total_counts, max=sample_limit)
+
+
+def sharded_step(engine, shard, group=None, counts_buf=None):
+    """count -> exchange -> collect for one shard. Device-resident shards exchange on the GPU (RCCL); host
+    shards exchange CPU tensors (gloo). Returns the job-wide accepted counts."""
+    import torch
+    if shard.on_device:
+        if counts_buf is None:
+            counts_buf = torch.empty(engine.n_slots, dtype=torch.int64, device=shard.sig.device)
+        engine.count(shard, out=counts_buf)
+        engine.sync()  # the library works on its own stream; RCCL runs on torch's
+        base, total = exchange_bases(counts_buf, group)
+        torch.cuda.current_stream().synchronize()
+        engine.collect(base.contiguous())
+    else:
+        c = engine.count(shard)
+        t = torch.from_numpy(c.view(np.int64).copy())
+        base, total = exchange_bases(t, group)
+        engine.collect(base.numpy().view(np.uint64).copy())
+    return total
+
+
+def concat_rank_results(results: List["Result"]):
+    """Per-slot concatenation of the ranks' kept events in rank order (what a single writer would dump)."""
+    n_slots = results[0].counts.size
+    counts = np.zeros(n_slots, np.uint64)
+    vals = []
+    for s in range(n_slots):
+        vs = [r.slot_values(s) for r in results]
+        vals.append(np.concatenate(vs) if vs else np.zeros(0))
+        counts[s] = sum(int(r.counts[s]) for r in results)
+    return counts, vals

@@ -1,0 +1,286 @@
+"""Host-side mirror of the gmove seam over libpgmove's C ABI (include/pgmove.h).
+
+Names follow the reference's vocabulary (reads, ss ops, k-mer slice, slots, dump events); see
+src/gmove.cpp:707-975 of hiruna72/poregen for the loop this replaces. All computation happens in
+libpgmove.so on the GPU; this module only marshals pointers (numpy arrays for host batches, torch
+tensors for device-resident batches).
+"""
+import ctypes as C
+import itertools
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+
+class PgError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"libpgmove status {status}: {text}")
+        self.status = status
+        self.text = text
+
+
+def generate_kmers(k: int, rna: bool = False) -> List[str]:
+    """Lexicographic 4^k k-mers over ACGT / ACGU (generate_kmers, src/poregen.cpp:248-267)."""
+    return ["".join(t) for t in itertools.product("ACGU" if rna else "ACGT", repeat=k)]
+
+
+def reconcile_slice(n_kmers: int, index_start: int = 1, index_end: int = 500, file_limit: int = 500):
+    """The slice reconciliation of gmove() (src/gmove.cpp:428-440) -> final (index_start, index_end)."""
+    if file_limit < n_kmers:
+        pass
+    elif file_limit > n_kmers - index_start + 1:
+        if index_end > n_kmers:
+            file_limit = n_kmers - index_start + 1
+            index_end = index_start + file_limit - 1
+    return index_start, index_end
+
+
+@dataclass
+class GmoveParams:
+    kmers: Sequence[str]                 # the k-mer slice, in list order: slot i = kmers[i]
+    kmer_size: int = 9
+    sig_move_offset: int = 0
+    margin: int = 0
+    sample_limit: int = 100
+    max_dur: int = 70
+    min_dur: int = 5
+    kmer_pick_margin: int = 2
+    scaling: int = 0
+    rna: bool = False
+    pa_min: float = 40.0
+    pa_max: float = 180.0
+    device: int = 0
+    lazy_stats: bool = False
+    profile: bool = False
+
+
+_BATCH_FIELDS = [
+    ("sig", np.int16), ("sig_off", np.uint64), ("digitisation", np.float64), ("offset", np.float64),
+    ("range", np.float64), ("query_start", np.int32), ("target_start", np.int32), ("target_end", np.int32),
+    ("seq", np.uint8), ("seq_off", np.uint64), ("op_n", np.uint32), ("op_t", np.uint8), ("op_off", np.uint64),
+]
+
+
+@dataclass
+class Batch:
+    """One batch of reads in PAF-line order (layout: pg_batch in include/pgmove.h)."""
+    n_reads: int
+    sig: object
+    sig_off: object
+    digitisation: object
+    offset: object
+    range: object
+    query_start: object
+    target_start: object
+    target_end: object
+    seq: object
+    seq_off: object
+    op_n: object
+    op_t: object
+    op_off: object
+    on_device: bool = False
+
+    def validate_host(self):
+        for name, dt in _BATCH_FIELDS:
+            a = getattr(self, name)
+            assert isinstance(a, np.ndarray) and a.dtype == dt and a.flags["C_CONTIGUOUS"], (name, getattr(a, "dtype", None))
+        return self
+
+    def to_device(self, device):
+        import torch
+        kw = {}
+        for name, dt in _BATCH_FIELDS:
+            a = getattr(self, name)
+            # torch has no uint64/uint32: ship the bytes as int64/int32 of the same width
+            view = {np.uint64: np.int64, np.uint32: np.int32}.get(dt, dt)
+            t = torch.from_numpy(np.ascontiguousarray(a).view(view))
+            if name == "sig":  # 16-byte slack so the tail vector of the last read stays inside the allocation
+                t = torch.cat([t, torch.zeros(8, dtype=t.dtype)])
+            kw[name] = t.to(device)
+        return Batch(n_reads=self.n_reads, on_device=True, **kw)
+
+    def slice_reads(self, lo: int, hi: int) -> "Batch":
+        """Host batch holding reads [lo, hi) (used to shard a PAF-ordered batch across ranks)."""
+        assert not self.on_device
+        so, qo, oo = self.sig_off, self.seq_off, self.op_off
+        return Batch(
+            n_reads=hi - lo,
+            sig=np.ascontiguousarray(self.sig[int(so[lo]):int(so[hi])]), sig_off=(so[lo:hi + 1] - so[lo]).astype(np.uint64),
+            digitisation=np.ascontiguousarray(self.digitisation[lo:hi]), offset=np.ascontiguousarray(self.offset[lo:hi]),
+            range=np.ascontiguousarray(self.range[lo:hi]), query_start=np.ascontiguousarray(self.query_start[lo:hi]),
+            target_start=np.ascontiguousarray(self.target_start[lo:hi]), target_end=np.ascontiguousarray(self.target_end[lo:hi]),
+            seq=np.ascontiguousarray(self.seq[int(qo[lo]):int(qo[hi])]), seq_off=(qo[lo:hi + 1] - qo[lo]).astype(np.uint64),
+            op_n=np.ascontiguousarray(self.op_n[int(oo[lo]):int(oo[hi])]), op_t=np.ascontiguousarray(self.op_t[int(oo[lo]):int(oo[hi])]),
+            op_off=(oo[lo:hi + 1] - oo[lo]).astype(np.uint64))
+
+    @property
+    def n_samples(self) -> int:
+        return int(self.sig_off[-1]) if not self.on_device else int(self.sig_off[-1].item())
+
+
+@dataclass
+class Result:
+    counts: np.ndarray
+    ev_off: np.ndarray
+    ev_len: np.ndarray
+    ev_read: np.ndarray
+    samp_off: np.ndarray
+    samples: np.ndarray
+    read_skipped: np.ndarray
+    n_reads: int
+
+    def slot_values(self, s: int) -> np.ndarray:
+        a, b = int(self.ev_off[s]), int(self.ev_off[s + 1])
+        return self.samples[int(self.samp_off[a]):int(self.samp_off[b])]
+
+    def slot_text(self, s: int, delimit: bool = False, sample_limit: Optional[int] = None) -> str:
+        """dump/<KMER> content (src/gmove.cpp:941-944, 196-203) -- test helper; the CLI formats in C++."""
+        out = []
+        a, b = int(self.ev_off[s]), int(self.ev_off[s + 1])
+        closed_at = None
+        if sample_limit is not None and b - a == sample_limit and sample_limit > 0:
+            closed_at = int(self.ev_read[b - 1])
+        e = a
+        for r in range(self.n_reads if delimit else 0):
+            while e < b and self.ev_read[e] == r:
+                out.append(self._ev_text(e)); e += 1
+            if not self.read_skipped[r] and (closed_at is None or r < closed_at):
+                out.append(":")
+        if not delimit:
+            out = [self._ev_text(i) for i in range(a, b)]
+        return "".join(out)
+
+    def _ev_text(self, e: int) -> str:
+        v = self.samples[int(self.samp_off[e]):int(self.samp_off[e + 1])]
+        return ",".join("%.8f" % x for x in v) + ";"
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch tensor
+
+
+class GmoveEngine:
+    """One gmove run on one GPU: the state the reference keeps in gmove() + process_move_table_paf()."""
+
+    def __init__(self, params: GmoveParams):
+        self._lib = _abi.load()
+        self.params = params
+        self.n_slots = len(params.kmers)
+        k = params.kmer_size
+        n_codes = 4 ** k
+        self._table_t = np.empty(n_codes, dtype=np.int32)
+        self._table_u = np.empty(n_codes, dtype=np.int32)
+        arr = (C.c_char_p * self.n_slots)(*[s.encode() for s in params.kmers])
+        st = self._lib.pg_build_slot_tables(k, arr, self.n_slots, self._table_t.ctypes.data, self._table_u.ctypes.data)
+        if st != 0:
+            raise PgError(st, self._lib.pg_last_error(None).decode())
+        p = _abi.PgParams()
+        self._lib.pg_default_params(C.byref(p))
+        p.kmer_size = k; p.sig_move_offset = params.sig_move_offset; p.signal_print_margin = params.margin
+        p.sample_limit = params.sample_limit; p.max_dur = params.max_dur; p.min_dur = params.min_dur
+        p.kmer_pick_margin = params.kmer_pick_margin; p.scaling = params.scaling; p.allow_rna = int(params.rna)
+        p.pa_min = params.pa_min; p.pa_max = params.pa_max; p.n_slots = self.n_slots
+        p.flags = (_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
+        p.device = params.device
+        p.table_t = self._table_t.ctypes.data; p.table_u = self._table_u.ctypes.data
+        h = C.c_void_p()
+        st = self._lib.pg_create(C.byref(p), C.byref(h))
+        if st != 0:
+            raise PgError(st, self._lib.pg_last_error(None).decode())
+        self._h = h
+        self._keep = None  # keeps the arrays of the batch between count and collect alive
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise PgError(st, self._lib.pg_last_error(self._h).decode())
+
+    def _c_batch(self, b: Batch):
+        cb = _abi.PgBatch()
+        cb.struct_size = C.sizeof(_abi.PgBatch)
+        cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
+        cb.n_reads = b.n_reads
+        for name, _ in _BATCH_FIELDS:
+            setattr(cb, name, _ptr(getattr(b, name)))
+        return cb
+
+    def submit(self, b: Batch):
+        self._keep = b
+        self._check(self._lib.pg_submit(self._h, C.byref(self._c_batch(b))))
+
+    def count(self, b: Batch, out=None):
+        """Phase 1. Returns the per-slot accepted-event counts of this batch (uncapped): a numpy uint64
+        array, or fills `out` (a torch int64 CUDA tensor) in place when given."""
+        self._keep = b
+        if out is None:
+            res = np.empty(self.n_slots, dtype=np.uint64)
+            self._check(self._lib.pg_count(self._h, C.byref(self._c_batch(b)), res.ctypes.data, _abi.PG_LOC_HOST))
+            return res
+        self._check(self._lib.pg_count(self._h, C.byref(self._c_batch(b)), out.data_ptr(), _abi.PG_LOC_DEVICE))
+        return out
+
+    def collect(self, base=None):
+        """Phase 2. base: per-slot count of accepted events that precede this batch (numpy uint64 or a
+        torch int64 CUDA tensor); None = this engine's own running count."""
+        if base is None:
+            self._check(self._lib.pg_collect(self._h, None, _abi.PG_LOC_HOST))
+        elif isinstance(base, np.ndarray):
+            base = np.ascontiguousarray(base, dtype=np.uint64)
+            self._check(self._lib.pg_collect(self._h, base.ctypes.data, _abi.PG_LOC_HOST))
+        else:
+            self._check(self._lib.pg_collect(self._h, base.data_ptr(), _abi.PG_LOC_DEVICE))
+
+    def sync(self):
+        self._check(self._lib.pg_sync(self._h))
+
+    def reset(self):
+        self._check(self._lib.pg_reset(self._h))
+
+    def all_slots_full(self) -> bool:
+        return bool(self._lib.pg_all_slots_full(self._h))
+
+    def finish(self) -> Result:
+        r = _abi.PgResult()
+        self._check(self._lib.pg_finish(self._h, C.byref(r)))
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+        ns, ne, nsmp, nr = r.n_slots, r.n_events, r.n_samples, r.n_reads
+        return Result(counts=arr(r.counts, ns, np.uint64), ev_off=arr(r.ev_off, ns + 1, np.uint64),
+                      ev_len=arr(r.ev_len, ne, np.uint32), ev_read=arr(r.ev_read, ne, np.uint32),
+                      samp_off=arr(r.samp_off, ne + 1, np.uint64), samples=arr(r.samples, nsmp, np.float64),
+                      read_skipped=arr(r.read_skipped, nr, np.uint8), n_reads=int(nr))
+
+    def device_view(self):
+        v = _abi.PgDeviceView()
+        self._check(self._lib.pg_last_batch_device(self._h, C.byref(v)))
+        return v
+
+    def kernel_stats(self):
+        n = C.c_uint32(0)
+        buf = (_abi.PgKernelStat * 64)()
+        self._check(self._lib.pg_kernel_stats(self._h, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n.value, 64))}
+
+    def kernel_stats_reset(self):
+        self._check(self._lib.pg_kernel_stats_reset(self._h))

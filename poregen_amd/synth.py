@@ -1,0 +1,198 @@
+"""Deterministic synthetic SLOW5+PAF+FASTQ workloads of the shapes BASELINE.json names.
+
+The generator produces the parsed, structure-of-arrays form directly (what the host parsers would hand to
+libpgmove) and can also write the three files for CLI runs. Shapes:
+  rna004  : reads x 4000 samples, ~31 samples/base, RNA-oriented PAF (target_start > target_end)
+  dna_r10 : reads x 4000 samples, stride-5 dwells with mean ~12.5, DNA-oriented PAF
+Optional indels put `nD` / `nI` ops into the ss strings (config 4 of BASELINE.json).
+"""
+import numpy as np
+
+from .engine import Batch
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _splitmix(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def make_batch(n_reads=1000, read_len=4000, kind="rna004", seed=20251003, indel_rate=0.0, spike_rate=0.005,
+               chunk_reads=4000, homopolymer_frac=0.0):
+    """Returns (Batch, meta) where meta holds per-read base strings (for FASTQ / the oracle)."""
+    rng = np.random.default_rng(seed)
+    rna = kind == "rna004"
+    mean_extra = 5.2 if rna else 1.5          # dwell = 5*(1+Geom) -> mean ~31 (RNA004) / ~12.5 (DNA stride 5)
+    p_geom = 1.0 / (1.0 + mean_extra)
+    cand = int(read_len / (5 * (1 + mean_extra)) * 3) + 64
+
+    sig_parts, op_n_parts, op_t_parts, seq_parts = [], [], [], []
+    sig_off = [0]; seq_off = [0]; op_off = [0]
+    dig = np.full(n_reads, 2048.0)
+    offset = rng.integers(-260, -229, n_reads).astype(np.float64)
+    rng_range = rng.uniform(280.0, 285.0, n_reads)
+    qstart = np.zeros(n_reads, np.int32); tstart = np.zeros(n_reads, np.int32); tend = np.zeros(n_reads, np.int32)
+
+    for c0 in range(0, n_reads, chunk_reads):
+        c1 = min(n_reads, c0 + chunk_reads)
+        nr = c1 - c0
+        dw = 5 * (1 + (rng.geometric(p_geom, size=(nr, cand)) - 1))
+        dw = np.clip(dw, 5, 200).astype(np.int64)
+        cs = np.cumsum(dw, axis=1)
+        nb = (cs < read_len).sum(axis=1) + 1                      # bases per read; the last dwell absorbs the remainder
+        nb = np.minimum(nb, cand)
+        for i in range(nr):
+            r = c0 + i
+            n = int(nb[i])
+            d = dw[i, :n].copy()
+            d[n - 1] = read_len - (cs[i, n - 2] if n > 1 else 0)
+            if d[n - 1] <= 0:                                      # cannot happen with cand large enough; keep dwells >= 1
+                d[n - 1] = 1
+            bases = rng.integers(0, 4, n)
+            if homopolymer_frac > 0 and rng.random() < homopolymer_frac:
+                run = rng.integers(0, 4); a = rng.integers(0, max(1, n - 40)); bases[a:a + 40] = run
+            # 5-mer context level: 70 + 60 * hash / 2^64 pA
+            code = np.zeros(n, np.uint64)
+            for t in range(5):
+                sh = np.roll(bases, t).astype(np.uint64); sh[:t] = 0
+                code |= sh << np.uint64(2 * t)
+            level = 70.0 + 60.0 * (_splitmix(code).astype(np.float64) / 2.0 ** 64)
+            # ops: matches, optionally with insertions (skip samples) / deletions (skip bases)
+            if indel_rate > 0:
+                ops_n, ops_t, seq_b, lv, dd = [], [], [], [], []
+                for j in range(n):
+                    u = rng.random()
+                    if u < indel_rate and j > 8 and j < n - 8:     # deletion: bases present in the sequence, no samples
+                        nd = int(rng.integers(1, 4)); ops_n.append(nd); ops_t.append(2)
+                        seq_b.extend(rng.integers(0, 4, nd).tolist())
+                    elif u < 2 * indel_rate and j > 8 and j < n - 8:  # insertion: samples that belong to no base
+                        ni = int(rng.integers(5, 41)); ops_n.append(ni); ops_t.append(1)
+                        lv.append(100.0); dd.append(ni)
+                    ops_n.append(int(d[j])); ops_t.append(0); seq_b.append(int(bases[j])); lv.append(level[j]); dd.append(int(d[j]))
+                lv = np.asarray(lv); dd = np.asarray(dd, np.int64)
+                seq_codes = np.asarray(seq_b, np.int64)
+                ops_n = np.asarray(ops_n, np.uint32); ops_t = np.asarray(ops_t, np.uint8)
+            else:
+                lv, dd, seq_codes = level, d, bases
+                ops_n = d.astype(np.uint32); ops_t = np.zeros(n, np.uint8)
+            L = int(dd.sum())
+            pa = np.repeat(lv, dd) + rng.normal(0.0, 3.0, L)
+            sp = rng.random(L) < spike_rate
+            nsp = int(sp.sum())
+            if nsp:
+                pa[sp] = np.where(rng.random(nsp) < 0.5, rng.uniform(5.0, 38.0, nsp), rng.uniform(182.0, 250.0, nsp))
+            scale = rng_range[r] / dig[r]
+            raw = np.clip(np.rint(pa / scale - offset[r]), -32768, 32767).astype(np.int16)
+            sig_parts.append(raw); sig_off.append(sig_off[-1] + L)
+            ns = len(seq_codes)
+            # PAF orientation. The sequence in the FASTQ is in basecall (5'->3') order; for RNA the signal is
+            # 3'->5', i.e. the first matched base of the walk is the LAST base of the fetched sequence.
+            if rna:
+                seq_parts.append(BASES[seq_codes[::-1]]); tstart[r] = ns; tend[r] = 0
+            else:
+                seq_parts.append(BASES[seq_codes]); tstart[r] = 0; tend[r] = ns
+            seq_off.append(seq_off[-1] + ns)
+            op_n_parts.append(ops_n); op_t_parts.append(ops_t); op_off.append(op_off[-1] + len(ops_n))
+
+    b = Batch(
+        n_reads=n_reads,
+        sig=np.concatenate(sig_parts) if sig_parts else np.zeros(0, np.int16), sig_off=np.asarray(sig_off, np.uint64),
+        digitisation=dig, offset=offset, range=rng_range, query_start=qstart, target_start=tstart, target_end=tend,
+        seq=np.concatenate(seq_parts) if seq_parts else np.zeros(0, np.uint8), seq_off=np.asarray(seq_off, np.uint64),
+        op_n=np.concatenate(op_n_parts) if op_n_parts else np.zeros(0, np.uint32),
+        op_t=np.concatenate(op_t_parts) if op_t_parts else np.zeros(0, np.uint8), op_off=np.asarray(op_off, np.uint64))
+    return b.validate_host()
+
+
+def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, spike_rate=0.005, chunk_reads=5000):
+    """Vectorised generator for throughput-sized batches (matches only, no indels): same distributions as
+    make_batch but without the per-read Python loop."""
+    rng = np.random.default_rng(seed)
+    rna = kind == "rna004"
+    mean_extra = 5.2 if rna else 1.5
+    p_geom = 1.0 / (1.0 + mean_extra)
+    cand = int(read_len / (5 * (1 + mean_extra)) * 3) + 64
+    dig = np.full(n_reads, 2048.0)
+    offset = rng.integers(-260, -229, n_reads).astype(np.float64)
+    rng_range = rng.uniform(280.0, 285.0, n_reads)
+    sig = np.empty(n_reads * read_len, np.int16)
+    seq_parts, opn_parts, nbs = [], [], []
+    for c0 in range(0, n_reads, chunk_reads):
+        c1 = min(n_reads, c0 + chunk_reads); nr = c1 - c0
+        dw = np.clip(5 * rng.geometric(p_geom, size=(nr, cand)), 5, 200).astype(np.int64)
+        cs = np.cumsum(dw, axis=1)
+        nb = np.minimum((cs < read_len).sum(axis=1) + 1, cand)
+        col = np.arange(cand)[None, :]
+        valid = col < nb[:, None]
+        last = col == (nb[:, None] - 1)
+        prev = np.where(nb > 1, cs[np.arange(nr), np.maximum(nb - 2, 0)], 0)
+        dw = np.where(last, (read_len - prev)[:, None], dw)
+        dw = np.where(valid, dw, 0)
+        bases = rng.integers(0, 4, size=(nr, cand))
+        code = np.zeros((nr, cand), np.uint64)
+        for t in range(5):
+            sh = np.roll(bases, t, axis=1).astype(np.uint64); sh[:, :t] = 0
+            code |= sh << np.uint64(2 * t)
+        level = 70.0 + 60.0 * (_splitmix(code).astype(np.float64) / 2.0 ** 64)
+        flat_d = dw[valid]; flat_l = level[valid]
+        pa = np.repeat(flat_l, flat_d)
+        assert pa.size == nr * read_len
+        pa += rng.standard_normal(pa.size, dtype=np.float32) * np.float32(3.0)
+        sp = np.flatnonzero(rng.random(pa.size, dtype=np.float32) < spike_rate)
+        nsp = sp.size
+        pa[sp] = np.where(rng.random(nsp) < 0.5, rng.uniform(5.0, 38.0, nsp), rng.uniform(182.0, 250.0, nsp))
+        pa = pa.reshape(nr, read_len)
+        pa /= (rng_range[c0:c1] / dig[c0:c1])[:, None]
+        pa -= offset[c0:c1][:, None]
+        np.rint(pa, out=pa); np.clip(pa, -32768, 32767, out=pa)
+        sig[c0 * read_len:c1 * read_len] = pa.reshape(-1).astype(np.int16)
+        opn_parts.append(flat_d.astype(np.uint32)); nbs.append(nb)
+        if rna:  # fetched sequence is in basecall order: reverse of the walk order
+            rev = np.where(valid, bases, -1)[:, ::-1]
+            seq_parts.append(BASES[rev[rev >= 0]])
+        else:
+            seq_parts.append(BASES[bases[valid]])
+    nb = np.concatenate(nbs).astype(np.int64)
+    off_b = np.concatenate([[0], np.cumsum(nb)]).astype(np.uint64)
+    op_n = np.concatenate(opn_parts)
+    b = Batch(
+        n_reads=n_reads, sig=sig, sig_off=(np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)),
+        digitisation=dig, offset=offset, range=rng_range, query_start=np.zeros(n_reads, np.int32),
+        target_start=(nb if rna else np.zeros(n_reads)).astype(np.int32), target_end=(np.zeros(n_reads) if rna else nb).astype(np.int32),
+        seq=np.concatenate(seq_parts), seq_off=off_b, op_n=op_n, op_t=np.zeros(op_n.size, np.uint8), op_off=off_b.copy())
+    return b.validate_host()
+
+
+OP_CHARS = ",ID"
+
+
+def ss_string(b: Batch, r: int) -> str:
+    a, e = int(b.op_off[r]), int(b.op_off[r + 1])
+    return "".join(f"{int(n)}{OP_CHARS[int(t)]}" for n, t in zip(b.op_n[a:e], b.op_t[a:e]))
+
+
+def seq_string(b: Batch, r: int) -> str:
+    return b.seq[int(b.seq_off[r]):int(b.seq_off[r + 1])].tobytes().decode()
+
+
+def write_files(b: Batch, prefix: str):
+    """ASCII SLOW5 + PAF(ss) + FASTQ for the batch (formats: SURVEY.md Appendix B). Read ids are r<index>."""
+    with open(prefix + ".slow5", "w") as f:
+        f.write("#slow5_version\t0.2.0\n#num_read_groups\t1\n@asic_id\tsynthetic\n")
+        f.write("#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n")
+        f.write("#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
+        for r in range(b.n_reads):
+            s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+            f.write(f"r{r}\t0\t{b.digitisation[r]:.17g}\t{b.offset[r]:.17g}\t{b.range[r]:.17g}\t4000\t{len(s)}\t" + ",".join(map(str, s.tolist())) + "\n")
+    with open(prefix + ".fastq", "w") as f:
+        for r in range(b.n_reads):
+            s = seq_string(b, r)
+            f.write(f"@r{r} synthetic\n{s}\n+\n{'I' * len(s)}\n")
+    with open(prefix + ".paf", "w") as f:
+        for r in range(b.n_reads):
+            L = int(b.sig_off[r + 1] - b.sig_off[r]); ns = int(b.seq_off[r + 1] - b.seq_off[r])
+            f.write(f"r{r}\t{L}\t{int(b.query_start[r])}\t{L}\t+\tr{r}\t{ns}\t{int(b.target_start[r])}\t{int(b.target_end[r])}\t{ns}\t{ns}\t255\tss:Z:{ss_string(b, r)}\n")

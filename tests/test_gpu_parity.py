@@ -1,0 +1,134 @@
+"""GPU parity: libpgmove (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from helpers import assert_result_equals_oracle, oracle_for
+from poregen_amd import synth
+from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def run_engine(batches, **p):
+    eng = GmoveEngine(GmoveParams(**p))
+    for b in batches:
+        eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    return res
+
+
+CASES = [
+    # BASELINE.json config 1 shape at oracle-friendly size: RNA004, k=5, med-MAD, dur 20/40
+    dict(name="rna_k5_medmad", kind="rna004", n=600, gen={}, p=dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=100)),
+    dict(name="rna_k5_noscale_limit7", kind="rna004", n=300, gen={}, p=dict(kmer_size=5, rna=True, scaling=0, min_dur=20, max_dur=40, sample_limit=7)),
+    # DNA, defaults of the reference except k
+    dict(name="dna_k5_medmad", kind="dna_r10", n=300, gen={}, p=dict(kmer_size=5, scaling=1, sample_limit=1000)),
+    dict(name="dna_k9", kind="dna_r10", n=200, gen=dict(homopolymer_frac=0.1), p=dict(kmer_size=9, scaling=1, sample_limit=3)),
+    # indels + pick margin (config 4 shape)
+    dict(name="rna_indel_margin2", kind="rna004", n=300, gen=dict(indel_rate=0.02), p=dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, kmer_pick_margin=2)),
+    dict(name="dna_indel_margin0", kind="dna_r10", n=200, gen=dict(indel_rate=0.03), p=dict(kmer_size=6, scaling=1, kmer_pick_margin=0, sample_limit=50)),
+    dict(name="dna_indel_margin5_off1", kind="dna_r10", n=200, gen=dict(indel_rate=0.03), p=dict(kmer_size=6, scaling=0, kmer_pick_margin=5, sig_move_offset=1, sample_limit=50)),
+    # zero-fill quirk in the middle of the value range, print margin
+    dict(name="rna_pamin100", kind="rna004", n=200, gen={}, p=dict(kmer_size=5, rna=True, scaling=1, pa_min=100.0, min_dur=20, max_dur=40)),
+    dict(name="dna_margin3", kind="dna_r10", n=150, gen={}, p=dict(kmer_size=5, scaling=1, margin=3, sample_limit=20)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_batch_matches_oracle(case):
+    b = synth.make_batch(case["n"], kind=case["kind"], seed=20251003 + len(case["name"]), **case["gen"])
+    p = case["p"]
+    kmers = generate_kmers(p["kmer_size"], rna=p.get("rna", False))
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(b)
+    assert all(rc in (0, 1, 2) for rc in rcs), rcs  # 2 = every k-mer complete, the reference stops reading
+    res = run_engine([b], kmers=kmers, **p)
+    assert_result_equals_oracle(res, o, sample_limit=p.get("sample_limit", 100))
+
+
+def test_multi_batch_equals_single_batch_and_oracle():
+    b = synth.make_batch(500, kind="rna004", seed=11)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    parts = [b.slice_reads(0, 100), b.slice_reads(100, 101), b.slice_reads(101, 380), b.slice_reads(380, 500)]
+    res = run_engine(parts, kmers=kmers, **p)
+    assert_result_equals_oracle(res, o, sample_limit=40)
+
+
+def test_kmer_whitelist_slice_and_delimiters():
+    # config 4: shuffled whitelist over ACGU, slice [51, 250] of it
+    rng = np.random.default_rng(5)
+    full = generate_kmers(5, rna=True)
+    wl = [full[i] for i in rng.permutation(len(full))[:300]]
+    b = synth.make_batch(250, kind="rna004", seed=12, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, kmer_pick_margin=2, sample_limit=5)
+    o = oracle_for(wl, index_start=51, index_end=250, delimit=True, **p)
+    o.run_batch(b)
+    res = run_engine([b], kmers=wl[50:250], **p)
+    assert_result_equals_oracle(res, o, delimit=True, sample_limit=5)
+
+
+def test_two_phase_shards_equal_single_run():
+    """pg_count / pg_collect with explicit bases: two contiguous shards on one GPU reproduce the whole."""
+    b = synth.make_batch(400, kind="rna004", seed=13)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=30)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    shards = [b.slice_reads(0, 170), b.slice_reads(170, 400)]
+    engs = [GmoveEngine(GmoveParams(kmers=kmers, **p)) for _ in shards]
+    cnts = [e.count(s) for e, s in zip(engs, shards)]
+    base = np.zeros_like(cnts[0])
+    results = []
+    for e, c in zip(engs, cnts):
+        e.collect(base.copy())
+        results.append(e.finish())
+        base += c
+    total = sum(int(r.counts.sum()) for r in results)
+    assert total == int(o.counts().sum())
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in results])
+        assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
+    for e in engs:
+        e.close()
+
+
+def test_device_resident_batch_and_reset():
+    import torch
+    b = synth.make_batch(300, kind="rna004", seed=14)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=25)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    db = b.to_device(torch.device("cuda:0"))
+    for _ in range(3):  # the same batch after reset must give identical results (determinism)
+        eng.reset()
+        eng.submit(db)
+        res = eng.finish()
+        assert_result_equals_oracle(res, o, sample_limit=25)
+    eng.close()
+
+
+def test_lazy_stats_same_output():
+    b = synth.make_batch(300, kind="rna004", seed=15)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=10)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    res = run_engine([b], kmers=kmers, lazy_stats=True, **p)
+    assert_result_equals_oracle(res, o, sample_limit=10)
+
+
+def test_error_paths():
+    from poregen_amd.engine import PgError
+    b = synth.make_batch(20, kind="rna004", seed=16)
+    kmers = generate_kmers(5, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, rna=False))  # RNA-oriented records without --rna
+    with pytest.raises(PgError) as ei:
+        eng.submit(b)
+    assert ei.value.status == -4
+    eng.close()
