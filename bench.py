@@ -114,7 +114,7 @@ def main():
     res = prof.finish()
     kept_events = int(res.counts.sum()); kept_samples = int(res.samples.size)
     prof.close()
-    stats_ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]  # k_read_plan + k_read_stats launches
+    stats_ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]
     # algorithmic bytes of the statistics kernels per launch: every int16 sample once, the three
     # doubles + two offsets of each read in, median + MAD out
     stats_bytes = 2 * n_samples + (24 + 16 + 16) * host.n_reads

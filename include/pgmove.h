@@ -59,7 +59,8 @@ enum {
     PG_FLAG_LAZY_STATS = 1u << 0, /* compute median/MAD only for reads that contribute a kept event
                                      (legal: event acceptance is signal-independent in the PAF path);
                                      default is to touch every read's signal like the reference does */
-    PG_FLAG_PROFILE = 1u << 1     /* record HIP events around every kernel (pg_kernel_stats) */
+    PG_FLAG_PROFILE = 1u << 1,    /* record HIP events around every kernel (pg_kernel_stats) */
+    PG_FLAG_NO_OVERLAP = 1u << 2  /* run the statistics kernel on the main stream instead of next to the sort chain */
 };
 
 typedef struct pg_ctx pg_ctx;

@@ -63,7 +63,11 @@ struct pg_ctx {
     DevBuf m_start, m_len, m_base, p_int, ev_slot, n_match, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
-    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan;
+    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan, stat_status, stat_err;
+    DevBuf n_indel, tile_read;
+    int32_t *h_max_span = nullptr; // pinned
+    bool stats_in_flight = false, totals_known = false;
+    const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
 
     PgDevBatch B{};       // current batch (device view)
     bool have_count = false, have_batch_result = false, downloaded = true;
@@ -189,10 +193,11 @@ void pg_destroy(pg_ctx *c) {
                       &c->p_int, &c->ev_slot, &c->n_match, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan};
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->n_indel, &c->tile_read};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    if (c->h_max_span) (void)hipHostFree(c->h_max_span);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->st) (void)hipStreamDestroy(c->st);
@@ -237,6 +242,8 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull));
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
+    CTRY(c->stat_err.ensure(16));
+    CTRY(hipHostMalloc((void **)&c->h_max_span, 64));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
 #undef CTRY
     *out = c;
@@ -246,21 +253,27 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
 pg_status pg_reset(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
-    prof_drain(c);
+    if (c->prm.flags & PG_FLAG_PROFILE) {
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st2));
+        prof_drain(c);
+    }
+    // stream order is enough: the next batch's work is queued behind everything already submitted, and its
+    // statistics stream waits on an event recorded after this memset
     HIP_TRY(c, hipMemsetAsync(c->running.p, 0, c->prm.n_slots * 8ull, c->st));
     c->batches.clear();
-    c->have_count = c->have_batch_result = false; c->downloaded = true;
+    c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
 }
 
+static pg_status settle_batch(pg_ctx *c);
+static pg_status check_read_errors(pg_ctx *c);
+
 // copy the finished batch's device results to the host (needed before its buffers are reused)
 static pg_status download_last(pg_ctx *c) {
     if (!c->have_batch_result || c->downloaded) return PG_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    { pg_status s0 = settle_batch(c); if (s0 != PG_OK) return s0; }
     c->batches.emplace_back();
     HostBatchResult &h = c->batches.back();
     const uint32_t ns = c->prm.n_slots;
@@ -313,14 +326,55 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 }
 
 static pg_status check_read_errors(pg_ctx *c) {
-    int32_t errv[2] = {INT_MAX, 0};
+    int32_t errv[2] = {INT_MAX, 0}, errs[2] = {INT_MAX, 0};
     HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
-    if (errv[0] == INT_MAX) return PG_OK;
+    HIP_TRY(c, hipMemcpy(errs, c->stat_err.p, 4, hipMemcpyDeviceToHost));
+    if (errv[0] == INT_MAX && errs[0] == INT_MAX) return PG_OK;
+    const bool walk = errv[0] <= errs[0];
+    const int32_t idx = walk ? errv[0] : errs[0];
     int32_t code = 0;
-    HIP_TRY(c, hipMemcpy(&code, c->status.as<int32_t>() + errv[0], 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&code, (walk ? c->status.as<int32_t>() : c->stat_status.as<int32_t>()) + idx, 4, hipMemcpyDeviceToHost));
     pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : PG_ERR_INPUT);
-    return fail(c, s, "read %llu of the batch (global read %llu): %s", (unsigned long long)errv[0],
-                (unsigned long long)(c->reads_before + errv[0]), read_status_text(code));
+    return fail(c, s, "read %llu of the batch (global read %llu): %s", (unsigned long long)idx,
+                (unsigned long long)(c->reads_before + idx), read_status_text(code));
+}
+
+// statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
+// handles the reads whose in-range code interval fits it (no host decision, no sync)
+static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
+    const uint32_t n = c->B.n_reads;
+    HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull));
+    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull)); HIP_TRY(c, c->stat_status.ensure((n + 1) * 4ull));
+    HIP_TRY(c, hipMemsetAsync(c->stat_status.p, 0, (n + 1) * 4ull, st));
+    prof_begin(c, "k_read_plan", st);
+    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p, c->stat_err.as<int32_t>() + 1);
+    prof_end(c, st);
+    prof_begin(c, "k_read_stats", st);
+    pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>());
+    prof_end(c, st);
+    prof_begin(c, "k_read_stats_wide", st);
+    pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>());
+    prof_end(c, st);
+    return PG_OK;
+}
+
+static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
+    W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
+    W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
+    W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
+    O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
+    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>(); O.n_match = c->n_match.as<uint32_t>();
+    O.n_indel = c->n_indel.as<uint32_t>(); O.tile_read = c->tile_read.as<uint32_t>();
+    O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
+}
+
+static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
+    S.keys[0] = c->sk[0].as<uint32_t>(); S.keys[1] = c->sk[1].as<uint32_t>();
+    S.vals[0] = c->sv[0].as<uint32_t>(); S.vals[1] = c->sv[1].as<uint32_t>();
+    S.hist = c->hist.as<uint32_t>(); S.wcnt = c->wcnt.as<uint32_t>(); S.totals = c->totals.as<uint32_t>();
+    S.dbase = c->dbase.as<uint32_t>(); S.count = c->scount.as<uint32_t>(); S.n_tiles = n_tiles;
 }
 
 pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t counts_location) {
@@ -338,14 +392,17 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         if (s != PG_OK) return s;
     } else if (b->location == PG_LOC_DEVICE) {
         PgDevBatch &B = c->B;
-        B.n_reads = n;
         B.sig = b->sig; B.sig_off = b->sig_off; B.dig = b->digitisation; B.off = b->offset; B.range = b->range;
         B.qstart = b->query_start; B.tstart = b->target_start; B.tend = b->target_end; B.seq = b->seq; B.seq_off = b->seq_off;
         B.op_n = b->op_n; B.op_t = b->op_t; B.op_off = b->op_off;
         if (!B.sig_off || !B.seq_off || !B.op_off) return fail(c, PG_ERR_INVALID_ARG, "batch offsets missing");
-        uint64_t no = 0;
-        HIP_TRY(c, hipMemcpy(&no, b->op_off + n, 8, hipMemcpyDeviceToHost));
-        B.n_ops = no;
+        if (c->dev_batch_key != (const void *)b->op_off || c->dev_batch_reads != n) { // op_off[n] of a new device batch
+            uint64_t no = 0;
+            HIP_TRY(c, hipMemcpy(&no, b->op_off + n, 8, hipMemcpyDeviceToHost));
+            c->dev_batch_key = b->op_off; c->dev_batch_reads = n; c->dev_batch_ops = no;
+        }
+        B.n_reads = n;
+        B.n_ops = c->dev_batch_ops;
     } else return fail(c, PG_ERR_INVALID_ARG, "pg_batch.location must be PG_LOC_HOST or PG_LOC_DEVICE");
     if (((uintptr_t)c->B.sig & 15) != 0) return fail(c, PG_ERR_INVALID_ARG, "sig must be 16-byte aligned");
     const uint64_t N = c->B.n_ops;
@@ -353,44 +410,67 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
 
     // work buffers
     const uint64_t Nn = N ? N : 1;
+    const bool direct = c->prm.n_slots <= PG_DIRECT_MAX_SLOTS;
     HIP_TRY(c, c->m_start.ensure(Nn * 4)); HIP_TRY(c, c->m_len.ensure(Nn * 4)); HIP_TRY(c, c->m_base.ensure(Nn));
-    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4));
-    HIP_TRY(c, c->n_match.ensure((n + 1) * 4ull)); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4)); HIP_TRY(c, c->tile_read.ensure((Nn / 256 + 2) * 4));
+    HIP_TRY(c, c->n_match.ensure((n + 1) * 4ull)); HIP_TRY(c, c->n_indel.ensure((n + 1) * 4ull)); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
     const uint32_t n_tiles = (uint32_t)((Nn + PG_SORT_TILE - 1) / PG_SORT_TILE);
-    for (int i = 0; i < 2; i++) { HIP_TRY(c, c->sk[i].ensure(Nn * 4)); HIP_TRY(c, c->sv[i].ensure(Nn * 4)); }
-    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * 256 * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * 1024 * 4));
+    uint32_t ndig;
+    if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
+    else {
+        const uint32_t passes = (c->key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
+        ndig = 1u << ((c->key_bits + passes - 1) / passes);
+        for (int i = 0; i < 2; i++) { HIP_TRY(c, c->sk[i].ensure(Nn * 4)); HIP_TRY(c, c->sv[i].ensure(Nn * 4)); }
+    }
+    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16));
+    HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
     const int32_t errinit[2] = {INT_MAX, 0};
     HIP_TRY(c, hipMemcpyAsync(c->errflag.p, errinit, 8, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(c, hipMemcpyAsync(c->stat_err.p, errinit, 8, hipMemcpyHostToDevice, c->st));
+    const bool eager_stats = c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS);
+    const bool overlap = !(c->prm.flags & PG_FLAG_NO_OVERLAP);
+    if (eager_stats && overlap) { // the second stream may start once the batch is resident
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+        HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    }
 
-    PgWalkParams W{};
-    W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
-    W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
-    W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
-    PgWalkOut O{};
-    O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
-    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>(); O.n_match = c->n_match.as<uint32_t>();
-    O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
-
-    // the statistics kernel only needs the signal and the read status: fork it onto the second stream
-    // right after the walk so that it overlaps the (latency-bound) sort/plan chain
-    prof_begin(c, "k_walk_events", c->st);
-    pg_launch_walk_events(c->st, c->B, W, O);
+    PgWalkParams W{}; PgWalkOut O{};
+    fill_walk(c, W, O);
+    prof_begin(c, "k_walk", c->st);
+    pg_launch_walk(c->st, c->B, W, O);
+    prof_end(c, c->st);
+    prof_begin(c, "k_events", c->st);
+    pg_launch_events(c->st, c->B, W, O);
     prof_end(c, c->st);
 
     PgSortBufs S{};
-    S.keys[0] = c->sk[0].as<uint32_t>(); S.keys[1] = c->sk[1].as<uint32_t>();
-    S.vals[0] = c->sv[0].as<uint32_t>(); S.vals[1] = c->sv[1].as<uint32_t>();
-    S.hist = c->hist.as<uint32_t>(); S.wcnt = c->wcnt.as<uint32_t>(); S.totals = c->totals.as<uint32_t>();
-    S.dbase = c->dbase.as<uint32_t>(); S.count = c->scount.as<uint32_t>(); S.n_tiles = n_tiles;
-    prof_begin(c, "sort_events", c->st);
-    if (N) c->sorted_idx = pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S);
-    else { c->sorted_idx = 0; HIP_TRY(c, hipMemsetAsync(c->scount.p, 0, 8, c->st)); }
-    prof_end(c, c->st);
-    prof_begin(c, "slot_bounds", c->st);
-    pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
-                          c->prm.n_slots, c->acc_cnt.as<uint64_t>());
-    prof_end(c, c->st);
+    fill_sort(c, S, n_tiles);
+    if (direct) {
+        prof_begin(c, "rank_count", c->st);
+        pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>());
+        prof_end(c, c->st);
+    } else {
+        prof_begin(c, "sort_events", c->st);
+        if (N) c->sorted_idx = pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S);
+        else { c->sorted_idx = 0; HIP_TRY(c, hipMemsetAsync(c->scount.p, 0, 8, c->st)); }
+        prof_end(c, c->st);
+        prof_begin(c, "slot_bounds", c->st);
+        pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
+                              c->prm.n_slots, c->acc_cnt.as<uint64_t>());
+        prof_end(c, c->st);
+    }
+
+    // Statistics only need the signal: in eager mode they run on the second stream, overlapping the
+    // latency-bound walk/rank chain above; pg_collect joins the two streams before the gather.
+    c->stats_in_flight = false;
+    if (eager_stats) {
+        hipStream_t ss = overlap ? c->st2 : c->st;
+        pg_status s2 = launch_stats(c, ss, nullptr);
+        if (s2 != PG_OK) return s2;
+        if (overlap) HIP_TRY(c, hipEventRecord(c->ev_join, c->st2));
+        c->stats_in_flight = overlap;
+    }
 
     if (counts_out) {
         if (counts_location == PG_LOC_DEVICE)
@@ -410,6 +490,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t ns = c->prm.n_slots, n = c->B.n_reads;
     const uint64_t N = c->B.n_ops;
+    const bool direct = ns <= PG_DIRECT_MAX_SLOTS;
     const uint64_t *d_base = c->running.as<uint64_t>();
     if (base) {
         HIP_TRY(c, hipMemcpyAsync(c->base_stage.p, base, ns * 8ull,
@@ -422,59 +503,80 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals);
     prof_end(c, c->st);
 
-    // upper bound on kept events of this batch
+    // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
+    // actual counts from device memory, so the batch needs no host round trip
     uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
-    if (ke_cap == 0) ke_cap = 1;
-    HIP_TRY(c, c->ev_len.ensure(ke_cap * 4)); HIP_TRY(c, c->ev_read.ensure(ke_cap * 4)); HIP_TRY(c, c->ev_start.ensure(ke_cap * 4));
-    HIP_TRY(c, c->samp_off.ensure((ke_cap + 1) * 8)); HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 2) * 8));
+    const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
+    const uint64_t samp_cap = ke_cap * win_cap;
+    HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
+    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 2) * 8));
     HIP_TRY(c, c->read_needed.ensure(n + 1ull));
     HIP_TRY(c, hipMemsetAsync(c->read_needed.p, 0, n + 1ull, c->st));
 
-    PgWalkParams W{};
-    W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
-    PgWalkOut O{};
-    O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>();
+    PgWalkParams W{}; PgWalkOut O{};
+    fill_walk(c, W, O);
     PgKeptOut K{};
     K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_start = c->ev_start.as<uint32_t>();
-    K.read_needed = c->read_needed.as<uint8_t>(); K.totals = totals;
-    prof_begin(c, "k_kept_meta", c->st);
-    pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
-                        c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
-    prof_end(c, c->st);
-
-    // statistics: med/MAD per read (scaling == 1 only). Eager mode touches every read like the reference;
-    // lazy mode only the reads that own a kept event.
-    const bool lazy = (c->prm.flags & PG_FLAG_LAZY_STATS) != 0;
-    if (c->prm.scaling == 1) {
-        HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull)); HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull));
-        prof_begin(c, "k_read_stats", c->st);
-        pg_launch_read_stats(c->st, c->B, c->prm.pa_min, c->prm.pa_max, lazy ? c->read_needed.as<uint8_t>() : nullptr, c->read_plan.p,
-                             c->med.as<double>(), c->mad.as<double>(), c->status.as<int32_t>(), c->errflag.as<int32_t>());
+    K.read_needed = c->read_needed.as<uint8_t>();
+    if (direct) {
+        PgSortBufs S{};
+        fill_sort(c, S, 0);
+        prof_begin(c, "k_rank_emit", c->st);
+        pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
+        prof_end(c, c->st);
+    } else {
+        prof_begin(c, "k_kept_meta", c->st);
+        pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
+                            c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
         prof_end(c, c->st);
     }
 
-    // one host sync per batch: how many events were kept (sizes the remaining launches and buffers)
-    uint64_t tot[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(tot, totals, 16, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    pg_status s = check_read_errors(c);
-    if (s != PG_OK) { c->have_count = false; return s; }
-    const uint64_t n_kept = tot[0];
-    c->full_slots = tot[1];
+    // lazy statistics: only the reads that own a kept event (flags written above)
+    const bool lazy = c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS);
+    if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>()); if (s2 != PG_OK) return s2; }
+
     prof_begin(c, "scan_ev_len", c->st);
-    pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), n_kept, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>());
+    pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>());
     prof_end(c, c->st);
-    uint64_t n_samples = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_samples, c->samp_off.as<uint64_t>() + n_kept, 8, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, c->samples.ensure((n_samples + 1) * 8));
+
+    uint64_t gather_cap = ke_cap;
+    if (samp_cap * 8 > c->samples.cap) {
+        // grow once to the worst case if that is moderate; otherwise size exactly from the device total (one sync)
+        if (samp_cap * 8 <= (4ull << 30)) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));
+        else {
+            uint64_t tot[1] = {0};
+            HIP_TRY(c, hipMemcpyAsync(tot, totals, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
+            uint64_t n_samples = 0;
+            HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off.as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
+            HIP_TRY(c, c->samples.ensure((n_samples + 1) * 8));
+            gather_cap = tot[0];
+        }
+    }
+    if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", c->st);
-    pg_launch_gather(c->st, c->B, n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
+    pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
                      c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med.as<double>(), c->mad.as<double>(),
                      c->samples.as<double>());
     prof_end(c, c->st);
-    c->cur_n_kept = n_kept; c->cur_n_samples = n_samples;
-    c->have_count = false; c->have_batch_result = true; c->downloaded = false;
+    c->have_count = false; c->have_batch_result = true; c->downloaded = false; c->totals_known = false;
+    return PG_OK;
+}
+
+// after a collect: wait for the batch, surface per-read errors, learn how many events/samples were kept
+static pg_status settle_batch(pg_ctx *c) {
+    if (!c->have_batch_result || c->totals_known) return PG_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    pg_status s = check_read_errors(c);
+    if (s != PG_OK) { c->have_batch_result = false; c->downloaded = true; return s; }
+    uint64_t tot[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(tot, c->plan_totals.p, 16, hipMemcpyDeviceToHost));
+    c->cur_n_kept = tot[0]; c->full_slots = tot[1];
+    uint64_t n_samples = 0;
+    HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off.as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
+    c->cur_n_samples = n_samples;
+    c->totals_known = true;
     return PG_OK;
 }
 
@@ -489,14 +591,19 @@ pg_status pg_sync(pg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st2));
-    return PG_OK;
+    return settle_batch(c);
 }
 
-int32_t pg_all_slots_full(pg_ctx *c) { return c && c->full_slots == c->prm.n_slots; }
+int32_t pg_all_slots_full(pg_ctx *c) {
+    if (!c) return 0;
+    if (settle_batch(c) != PG_OK) return 0;
+    return c->full_slots == c->prm.n_slots;
+}
 
 pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     if (!c || !v) return PG_ERR_INVALID_ARG;
     if (!c->have_batch_result) return fail(c, PG_ERR_STATE, "no collected batch");
+    { pg_status s0 = settle_batch(c); if (s0 != PG_OK) return s0; }
     v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
     v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
     v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off.as<uint64_t>(); v->d_samples = c->samples.as<double>();

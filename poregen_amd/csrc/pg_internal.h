@@ -46,7 +46,9 @@ struct PgWalkOut {
     uint8_t *m_base;   // [n_ops] 2-bit base code of the matched base, 4 = not ACGT/U
     int32_t *p_int;    // [n_ops] matched-base count at each I/D op (interior of indel_pos, gmove.cpp:843,845)
     uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
-    uint32_t *n_match; // [n_reads]
+    uint32_t *n_match; // [n_reads] matched bases (fastq_len after refinement, gmove.cpp:872); 0 for skipped/failed reads
+    uint32_t *n_indel; // [n_reads] number of I/D ops
+    uint32_t *tile_read; // [ceil(n_ops/256)] read that owns op index 256*t
     int32_t *status;   // [n_reads]
     int32_t *err;      // [2] err[0] = lowest read index with an error (init INT32_MAX), err[1] = its code
 };
@@ -56,14 +58,17 @@ struct PgWalkOut {
 // ---- radix sort geometry ---------------------------------------------------------------------------
 #define PG_SORT_ROWS 16                       // rows of 64 keys per wave
 #define PG_SORT_TILE (4 * PG_SORT_ROWS * 64)  // keys per 256-thread workgroup
+#define PG_RANK_MAX_BITS 10                   // digit width: 1024 LDS counters per wave
+#define PG_RANK_MAX_DIGITS (1 << PG_RANK_MAX_BITS)
+#define PG_DIRECT_MAX_SLOTS PG_RANK_MAX_DIGITS // up to this many slots the slot itself is the (only) digit
 
 struct PgSortBufs {
     uint32_t *keys[2];
     uint32_t *vals[2];
-    uint32_t *hist;   // [256][n_tiles]  (digit-major)
-    uint32_t *wcnt;   // [n_tiles][4][256]
-    uint32_t *totals; // [256]
-    uint32_t *dbase;  // [256]
+    uint32_t *hist;   // [ndig][n_tiles]  (digit-major), ndig <= PG_RANK_MAX_DIGITS
+    uint32_t *wcnt;   // [n_tiles][4][ndig]
+    uint32_t *totals; // [ndig]
+    uint32_t *dbase;  // [ndig]
     uint32_t *count;  // [2] count[0] = number of keys entering the current pass, count[1] = scratch
     uint32_t n_tiles; // for the capacity N the buffers were sized for
 };
@@ -72,31 +77,39 @@ struct PgSortBufs {
 #define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global path
 
 // ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
-void pg_launch_walk_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
-// stable LSD radix sort of (ev_slot, index) pairs by slot, dropping PG_INVALID_SLOT; result in
+struct PgKeptOut {
+    uint32_t *ev_len;     // [n_kept] window length incl. margin, clamped to the signal
+    uint32_t *ev_read;    // [n_kept] read index inside the batch
+    uint32_t *ev_start;   // [n_kept] window start inside the read
+    uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
+};
+void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+// direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
+void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+                                 uint64_t *acc_cnt);
+void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+                                const uint64_t *keep, const uint64_t *ev_off, const PgDevBatch &B, const PgWalkParams &W,
+                                const PgWalkOut &O, const PgKeptOut &K);
+// generic ranking: stable LSD radix sort of (ev_slot, index) pairs by slot, dropping PG_INVALID_SLOT; result in
 // S.keys[out]/S.vals[out], number of sorted pairs in S.count[0]. Returns `out`.
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S);
 void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
                            uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt);
-// keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
-// totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] += cnt[s] if running != nullptr
-void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
-                         uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals);
-struct PgKeptOut {
-    uint32_t *ev_len;   // [n_kept] window length incl. margin, clamped to the signal
-    uint32_t *ev_read;  // [n_kept] read index inside the batch
-    uint32_t *ev_start; // [n_kept] window start inside the read
-    uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
-    uint64_t *totals;   // totals[2] += sum of ev_len
-};
 void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
                          const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off,
                          const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
-// out[i] = sum_{j<i} in[j] for i in [0, n]; scratch >= ceil(n/4096)+1 uint64
-void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch);
-// plan_buf: 16 bytes per read of scratch
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max,
-                          const uint8_t *read_needed, void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err);
-void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept, const uint32_t *ev_len, const uint32_t *ev_read,
-                      const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min, double pa_max,
-                      const double *med, const double *mad, double *samples);
+// keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
+// totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] = base[s] + cnt[s]
+void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
+                         uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals);
+// out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+1 uint64
+void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
+// plan_buf: 16 bytes per read. max_span (device int32) receives the widest in-range code interval of the batch.
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *max_span);
+// bins: LDS histogram size of this launch (1024 or PG_STATS_BINS); reads with a wider interval are flagged PGR_ERR_WIDE
+void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
+                          double *med, double *mad, int32_t *status, int32_t *err);
+void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
+                      const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
+                      double pa_max, const double *med, const double *mad, double *samples);

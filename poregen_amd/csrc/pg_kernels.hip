@@ -1,10 +1,12 @@
 // pg_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the gmove hot path.
 //
 // Pipeline per batch (reference lines are src/gmove.cpp of hiruna72/poregen):
-//   k_walk_events   ss walk + event filters (lines 822-927), one wave per read, prefix sums by wave scans
-//   k_sort_*        stable LSD radix sort of accepted events by k-mer slot: the deterministic stand-in for
-//                   "first sample_limit events in PAF-line order, then event order" (lines 732, 891, 925-927)
-//   k_slot_* / k_kept_meta / k_scan_*   per-slot counts, the sample_limit cut, output offsets
+//   k_walk          ss walk (lines 822-871), one wave per read, prefix sums by DPP wave scans
+//   k_events        event filters (lines 891-927), one thread per (read, event)
+//   k_rank_*        stable ranking of accepted events inside their k-mer slot: the deterministic stand-in for
+//                   "first sample_limit events in PAF-line order, then event order" (lines 732, 891, 925-927);
+//                   direct for <= 1024 slots, LSD radix sort (k_sort_*) beyond
+//   k_slot_plan / k_scan_*   the sample_limit cut and the output offsets
 //   k_read_plan + k_read_stats          pA conversion, zero-fill, exact median and MAD (lines 754-771)
 //   k_gather        window copy + normalisation of the kept events (lines 773-775, 928-944)
 // All of this is HBM/LDS-bound integer and FP64 work: there is no contraction here, so no MFMA.
@@ -17,6 +19,21 @@
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// Inclusive wave64 scan with DPP row shifts + row broadcasts (no LDS traffic, 6 VALU ops): rows of 16 lanes
+// are scanned with row_shr:1/2/4/8, then lane 15 of each row is broadcast into the next row (rows 1,3) and
+// lane 31 into rows 2,3.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_zero(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += dpp_zero<0x111, 0xF>(v); // row_shr:1
+    v += dpp_zero<0x112, 0xF>(v); // row_shr:2
+    v += dpp_zero<0x114, 0xF>(v); // row_shr:4
+    v += dpp_zero<0x118, 0xF>(v); // row_shr:8
+    v += dpp_zero<0x142, 0xA>(v); // row_bcast:15 -> rows 1 and 3
+    v += dpp_zero<0x143, 0xC>(v); // row_bcast:31 -> rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
     const int lane = lane_id();
 #pragma unroll
@@ -26,18 +43,28 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
     }
     return v;
 }
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+
+// smallest t in [0, n) for which the monotone predicate holds, n if none. All 64 lanes call it together;
+// every round tests 64 candidates at once (two rounds cover n <= 4096).
+template <class Pred> __device__ __forceinline__ int wave_first_true(int n, Pred pred) {
     const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
+    int lo = 0, len = n;
+    while (len > 0) {
+        const int step = (len + WAVE - 1) / WAVE;
+        int t = lo + (lane + 1) * step - 1;
+        if (t > lo + len - 1) t = lo + len - 1;
+        const uint64_t m = __ballot(pred(t));
+        if (m == 0) return n; // only possible in the first round
+        const int l = __ffsll((long long)m) - 1;
+        if (step == 1) return lo + l;
+        lo += l * step;
+        len = (lo + step > n) ? n - lo : step;
     }
-    return v;
+    return n;
 }
 
 // =====================================================================================================
-// k_walk_events: one wave per read, four reads per workgroup.
+// k_walk: the ss walk (gmove.cpp:831-871), one wave per read, four reads per workgroup.
 // =====================================================================================================
 
 __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
@@ -55,11 +82,10 @@ __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
 
 __device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int code) {
     O.status[r] = code;
-    int prev = atomicMin(&O.err[0], (int)r);
-    (void)prev;
+    atomicMin(&O.err[0], (int)r);
 }
 
-__global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+__global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
     const int lane = lane_id();
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (r >= B.n_reads) return; // wave-uniform
@@ -71,15 +97,14 @@ __global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams 
     const int32_t ts = B.tstart[r], te = B.tend[r], qs = B.qstart[r];
     const uint32_t k = W.k;
 
-    // everything this read owns in ev_slot starts out "not accepted"
-    for (uint32_t i = lane; i < nops; i += WAVE) O.ev_slot[o0 + i] = PG_INVALID_SLOT;
-    if (lane == 0) { O.n_match[r] = 0; O.status[r] = PGR_OK; }
+    // k_events finds the read of an op index through the read that owns the first op of its 256-op tile
+    if (nops) for (uint64_t t = (o0 + 255) >> 8; (t << 8) < o0 + nops; t += 1) { if (lane == 0) O.tile_read[t] = r; }
+    if (lane == 0) { O.n_match[r] = 0; O.n_indel[r] = 0; O.status[r] = PGR_OK; }
 
     int status = PGR_OK;
     // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
     if (qs < 0 || ts < 0 || te < 0 || (uint64_t)qs >= L || L > 0x7fffffffull) status = PGR_ERR_NEG;
-    const bool rna = ts > te;                       // gmove.cpp:793
-    const int32_t st_k = rna ? te : ts, end_k = rna ? ts : te;
+    const bool rna = ts > te;                                          // gmove.cpp:793
     if (status == PGR_OK && rna && !W.allow_rna) status = PGR_ERR_RNA; // gmove.cpp:795-798
     if (status == PGR_OK && slen < k) status = PGR_SKIPPED;            // gmove.cpp:806-808
     if (status != PGR_OK) {
@@ -87,25 +112,33 @@ __global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams 
         return;
     }
 
-    // ---- phase 1: the ss walk (gmove.cpp:831-871) as wave-wide prefix sums over the op list -------
     uint64_t raw_carry = (uint64_t)qs;   // i_raw
     uint32_t match_carry = 0;            // i_k_raw  (matched bases so far)
     uint64_t del_carry = 0;              // num_deletion
     uint32_t indel_carry = 0;            // entries pushed to indel_pos so far (interior only)
     int err = 0;
+    // software pipeline: the ops of chunk c+1 are in flight while chunk c is scanned
+    uint32_t n_nx = lane < nops ? B.op_n[o0 + lane] : 0u;
+    uint32_t t_nx = lane < nops ? (uint32_t)B.op_t[o0 + lane] : 3u;
     for (uint32_t c = 0; c < nops; c += WAVE) {
         const uint32_t i = c + lane;
         const bool act = i < nops;
-        const uint32_t n = act ? B.op_n[o0 + i] : 0u;
-        const uint32_t t = act ? (uint32_t)B.op_t[o0 + i] : 3u;
+        const uint32_t n = n_nx, t = t_nx;
+        {
+            const uint32_t i2 = i + WAVE;
+            n_nx = i2 < nops ? B.op_n[o0 + i2] : 0u;
+            t_nx = i2 < nops ? (uint32_t)B.op_t[o0 + i2] : 3u;
+        }
         const bool is_m = act && t == 0, is_i = act && t == 1, is_d = act && t == 2;
         if (act && t > 2) err = PGR_ERR_OP;
+        if (n >= (1u << 25)) err = PGR_ERR_RANGE; // keeps the 32-bit chunk scans below exact (64 ops x 2^25 < 2^31)
         const uint64_t mm = __ballot(is_m), mi = __ballot(is_i || is_d);
         const uint32_t j = match_carry + (uint32_t)__popcll(mm & lanemask_lt());
         const uint32_t tix = indel_carry + (uint32_t)__popcll(mi & lanemask_lt());
-        const uint64_t radv = (is_m || is_i) ? (uint64_t)n : 0ull;
-        const uint64_t dadv = is_d ? (uint64_t)n : 0ull;
-        const uint64_t rinc = wave_incl_scan_u64(radv), dinc = wave_incl_scan_u64(dadv);
+        const uint32_t radv = (is_m || is_i) ? (n & 0x1ffffffu) : 0u;
+        const uint32_t dadv = is_d ? (n & 0x1ffffffu) : 0u;
+        const uint32_t rinc = wave_incl_scan_u32(radv);
+        const uint32_t dinc = __ballot(is_d) ? wave_incl_scan_u32(dadv) : 0u; // most chunks hold no deletion
         const uint64_t start = raw_carry + rinc - radv;
         if (is_m) {
             const uint64_t ik = (uint64_t)j + del_carry + dinc - dadv; // i_k at this op
@@ -119,33 +152,46 @@ __global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams 
             }
         }
         if (is_i || is_d) O.p_int[o0 + tix] = (int32_t)j;                // i_k - num_deletion == matched bases so far
-        raw_carry += __shfl(rinc, WAVE - 1, WAVE);
-        del_carry += __shfl(dinc, WAVE - 1, WAVE);
+        raw_carry += (uint32_t)__builtin_amdgcn_readlane((int)rinc, WAVE - 1);
+        del_carry += (uint32_t)__builtin_amdgcn_readlane((int)dinc, WAVE - 1);
         match_carry += (uint32_t)__popcll(mm);
         indel_carry += (uint32_t)__popcll(mi);
     }
-    const uint32_t n = match_carry;  // fastq_len after refinement (gmove.cpp:872)
-    const uint32_t m = indel_carry;
-    if (__ballot(err != 0)) {
-        // lowest failing lane decides the code
-        const uint64_t bm = __ballot(err != 0);
+    const uint64_t bm = __ballot(err != 0);
+    if (bm) { // lowest failing lane decides the code
         const int code = __shfl(err, __ffsll((long long)bm) - 1, WAVE);
         if (lane == 0) report_error(O, r, code);
         return;
     }
-    if (n < k) { if (lane == 0) report_error(O, r, PGR_ERR_SHORT); return; } // unsigned wrap at gmove.cpp:891
-    if (lane == 0) O.n_match[r] = n;
-    __threadfence_block(); // phase 2 reads m_* / p_int written by other lanes of this wave
+    if (match_carry < k) { if (lane == 0) report_error(O, r, PGR_ERR_SHORT); return; } // unsigned wrap at gmove.cpp:891
+    if (lane == 0) { O.n_match[r] = match_carry; O.n_indel[r] = indel_carry; }
+}
 
-    // ---- phase 2: the event loop (gmove.cpp:891-927), 64 events per iteration --------------------
-    const int32_t *table = rna ? W.table_u : W.table_t;
-    const int32_t M = W.pick_margin;
-    const uint32_t n_ev = n - k + 1;
-    for (uint32_t c = 0; c < n_ev; c += WAVE) {
-        const uint32_t i = c + lane;
-        if (i >= n_ev) continue;
-        const uint32_t e = i + W.sig_move_offset;
-        if (e >= n) continue; // end_raw_idx[e] == -1 (gmove.cpp:892-894)
+// the read that owns op index g
+__device__ __forceinline__ uint32_t find_read(const PgDevBatch &B, const uint32_t *__restrict__ tile_read, uint64_t g) {
+    uint32_t r = tile_read[g >> 8];
+    while (B.op_off[r + 1] <= g) ++r;
+    return r;
+}
+
+// =====================================================================================================
+// k_events: the event loop (gmove.cpp:891-927), one thread per (read, event index) = per op index
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= B.n_ops) return;
+    const uint32_t r = find_read(B, O.tile_read, g);
+    uint32_t out = PG_INVALID_SLOT;
+    const uint32_t k = W.k;
+    const uint32_t n = O.n_match[r]; // 0 for skipped / failed reads
+    const uint64_t o0 = B.op_off[r];
+    const uint32_t i = (uint32_t)(g - o0);
+    const uint32_t e = i + W.sig_move_offset;
+    if (n >= k && i <= n - k && e < n) { // e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
+        const int32_t ts = B.tstart[r], te = B.tend[r];
+        const bool rna = ts > te;
+        const int32_t st_k = rna ? te : ts, end_k = rna ? ts : te;
+        const uint32_t m = O.n_indel[r];
         // k-mer of matched bases [i, i+k); RNA reads it reversed (gmove.cpp:883, 899)
         uint32_t code = 0; bool bad = false;
         for (uint32_t t = 0; t < k; ++t) {
@@ -153,9 +199,11 @@ __global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams 
             bad |= b > 3;
             code = (code << 2) | (b & 3u);
         }
-        if (bad) continue;
-        const int32_t slot = table[code];
+        const uint32_t len = O.m_len[o0 + e];
+        const uint32_t start = O.m_start[o0 + e];
+        const int32_t slot = bad ? -1 : (rna ? W.table_u : W.table_t)[code];
         // pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M]
+        const int32_t M = W.pick_margin;
         const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
         const int32_t X = left + (int32_t)k + M, Y = left - M;
         auto interior = [&](uint32_t u) -> int32_t { // sorted ascending in both orientations (gmove.cpp:877-882)
@@ -165,20 +213,23 @@ __global__ __launch_bounds__(256) void k_walk_events(PgDevBatch B, PgWalkParams 
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (interior(mid) >= X) hi = mid; else lo = mid + 1; }
         const int32_t prev = lo == 0 ? -st_k : interior(lo - 1);
         const bool pick = (lo < m) ? (prev <= Y) : (X <= end_k + M && prev <= Y);
-        if (!pick) continue;
-        const uint32_t len = O.m_len[o0 + e];
-        if (len > W.max_dur || len < W.min_dur) continue; // gmove.cpp:916-921
-        if (slot < 0) continue;                            // gmove.cpp:922-924
-        // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
-        const uint32_t start = O.m_start[o0 + e];
-        const uint64_t wend = (uint64_t)start + len + W.print_margin > L ? L : (uint64_t)start + len + W.print_margin;
-        if (W.print_margin > start || wend <= (uint64_t)(start - W.print_margin)) { report_error(O, r, PGR_ERR_WINDOW); continue; }
-        O.ev_slot[o0 + i] = (uint32_t)slot;
+        if (pick && slot >= 0 && len <= W.max_dur && len >= W.min_dur) { // gmove.cpp:916-924
+            // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
+            const uint64_t L = B.sig_off[r + 1] - B.sig_off[r];
+            const uint64_t wend = (uint64_t)start + len + W.print_margin > L ? L : (uint64_t)start + len + W.print_margin;
+            if (W.print_margin > start || wend <= (uint64_t)(start - W.print_margin)) report_error(O, r, PGR_ERR_WINDOW);
+            else out = (uint32_t)slot;
+        }
     }
+    O.ev_slot[g] = out;
 }
 
 // =====================================================================================================
-// stable LSD radix sort, 8-bit digits, 256-thread workgroups, one tile = 4 waves x ROWS rows x 64 keys
+// Stable ranking of accepted events by slot. One tile = 4 waves x ROWS rows x 64 keys; digits of up to
+// 10 bits (1024 LDS counters per wave). Two uses:
+//   direct  (n_slots <= 1024): digit == slot, so tile-prefix + in-tile rank IS the event's rank inside its
+//           k-mer; k_rank_emit applies the sample_limit cut and writes only the kept events;
+//   generic (more slots): LSD radix sort by slot in ceil(bits/10) passes, ranks from the sorted order.
 // =====================================================================================================
 
 // lanes holding the same digit (among valid lanes)
@@ -192,37 +243,46 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbit
     return peers;
 }
 
-__global__ __launch_bounds__(256) void k_sort_count(const uint32_t *__restrict__ keys, uint32_t n_scalar,
+__global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__ keys, uint32_t n_scalar,
                                                     const uint32_t *__restrict__ n_ptr, uint32_t shift, int nbits,
                                                     uint32_t n_tiles, uint32_t *__restrict__ hist, uint32_t *__restrict__ wcnt) {
-    __shared__ uint32_t cnt[4][256];
+    __shared__ uint32_t cnt[4][PG_RANK_MAX_DIGITS];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
     const int lane = lane_id();
-    for (uint32_t i = tid; i < 1024; i += 256) (&cnt[0][0])[i] = 0;
+    const uint32_t ndig = 1u << nbits;
+    for (uint32_t ww = 0; ww < 4; ++ww) for (uint32_t d = tid; d < ndig; d += 256) cnt[ww][d] = 0;
     __syncthreads();
     const uint32_t n = n_ptr ? *n_ptr : n_scalar;
-    const uint32_t mask = (1u << nbits) - 1u;
+    const uint32_t mask = ndig - 1u;
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
+    uint32_t kv[PG_SORT_ROWS]; // all rows in flight before the (serial) ranking
+#pragma unroll
     for (int row = 0; row < PG_SORT_ROWS; ++row) {
         const uint64_t idx = base + (uint64_t)row * WAVE + lane;
-        bool valid = idx < n;
-        const uint32_t key = valid ? keys[idx] : PG_INVALID_SLOT;
-        valid = valid && key != PG_INVALID_SLOT;
+        kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
+    }
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+        const uint32_t key = kv[row];
+        const bool valid = key != PG_INVALID_SLOT;
         const uint32_t d = (key >> shift) & mask;
         const uint64_t peers = match_digit(d, valid, nbits);
         if (valid && lane == __ffsll((long long)peers) - 1) cnt[w][d] += (uint32_t)__popcll(peers);
     }
     __syncthreads();
-    uint32_t sum = 0;
-    for (uint32_t ww = 0; ww < 4; ++ww) {
-        const uint32_t c = cnt[ww][tid];
-        wcnt[((uint64_t)tile * 4 + ww) * 256 + tid] = c;
-        sum += c;
+    for (uint32_t d = tid; d < ndig; d += 256) {
+        uint32_t sum = 0;
+        for (uint32_t ww = 0; ww < 4; ++ww) {
+            const uint32_t c = cnt[ww][d];
+            wcnt[((uint64_t)tile * 4 + ww) * ndig + d] = c;
+            sum += c;
+        }
+        hist[(uint64_t)d * n_tiles + tile] = sum;
     }
-    hist[(uint64_t)tid * n_tiles + tile] = sum;
 }
 
-__global__ __launch_bounds__(64) void k_sort_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals) {
+// exclusive prefix over tiles, one wave per digit; totals[d] = number of keys with that digit
+__global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals) {
     const uint32_t d = blockIdx.x;
     const int lane = lane_id();
     uint32_t run = 0;
@@ -231,23 +291,33 @@ __global__ __launch_bounds__(64) void k_sort_scan(uint32_t *__restrict__ hist, u
         const uint32_t v = i < n_tiles ? hist[(uint64_t)d * n_tiles + i] : 0u;
         const uint32_t inc = wave_incl_scan_u32(v);
         if (i < n_tiles) hist[(uint64_t)d * n_tiles + i] = run + inc - v;
-        run += __shfl(inc, WAVE - 1, WAVE);
+        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
     }
     if (lane == 0) totals[d] = run;
 }
 
-__global__ __launch_bounds__(256) void k_sort_dbase(const uint32_t *__restrict__ totals, uint32_t *__restrict__ dbase,
+// direct mode: totals[slot] are the accepted-event counts of the batch
+__global__ __launch_bounds__(256) void k_totals_to_counts(const uint32_t *__restrict__ totals, uint32_t n_slots,
+                                                          uint64_t *__restrict__ acc_cnt) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_slots) acc_cnt[s] = totals[s];
+}
+
+// generic mode: exclusive prefix over the digits (<= 1024) -> first output index of each digit
+__global__ __launch_bounds__(256) void k_sort_dbase(const uint32_t *__restrict__ totals, uint32_t ndig, uint32_t *__restrict__ dbase,
                                                     uint32_t *__restrict__ count_out) {
     __shared__ uint32_t wsum[4];
     const uint32_t tid = threadIdx.x;
-    const uint32_t v = totals[tid];
-    const uint32_t inc = wave_incl_scan_u32(v);
+    const uint32_t per = ndig >= 256 ? ndig / 256 : 1;
+    uint32_t v[4] = {0, 0, 0, 0}, s = 0;
+    for (uint32_t i = 0; i < per; ++i) { const uint32_t d = tid * per + i; v[i] = d < ndig ? totals[d] : 0u; s += v[i]; }
+    const uint32_t inc = wave_incl_scan_u32(s);
     if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
     __syncthreads();
-    uint32_t off = 0;
+    uint32_t off = inc - s;
     for (uint32_t w = 0; w < (tid >> 6); ++w) off += wsum[w];
-    dbase[tid] = off + inc - v;
-    if (tid == 255) *count_out = off + inc;
+    for (uint32_t i = 0; i < per; ++i) { const uint32_t d = tid * per + i; if (d < ndig) dbase[d] = off; off += v[i]; }
+    if (tid == 255) *count_out = off;
 }
 
 __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
@@ -255,16 +325,17 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t *__restrict
                                                       int nbits, uint32_t n_tiles, const uint32_t *__restrict__ hist,
                                                       const uint32_t *__restrict__ dbase, const uint32_t *__restrict__ wcnt,
                                                       uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
-    __shared__ uint32_t wbase[4][256];
+    __shared__ uint32_t wbase[4][PG_RANK_MAX_DIGITS];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
     const int lane = lane_id();
-    {
-        uint32_t b = dbase[tid] + hist[(uint64_t)tid * n_tiles + tile];
-        for (uint32_t ww = 0; ww < 4; ++ww) { wbase[ww][tid] = b; b += wcnt[((uint64_t)tile * 4 + ww) * 256 + tid]; }
+    const uint32_t ndig = 1u << nbits;
+    for (uint32_t d = tid; d < ndig; d += 256) {
+        uint32_t b = dbase[d] + hist[(uint64_t)d * n_tiles + tile];
+        for (uint32_t ww = 0; ww < 4; ++ww) { wbase[ww][d] = b; b += wcnt[((uint64_t)tile * 4 + ww) * ndig + d]; }
     }
     __syncthreads();
     const uint32_t n = n_ptr ? *n_ptr : n_scalar;
-    const uint32_t mask = (1u << nbits) - 1u;
+    const uint32_t mask = ndig - 1u;
     volatile uint32_t *mybase = wbase[w];
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
     for (int row = 0; row < PG_SORT_ROWS; ++row) {
@@ -287,8 +358,66 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t *__restrict
     }
 }
 
+// window of a kept event (gmove.cpp:928-937) and its bookkeeping
+__device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K,
+                                           uint64_t e, uint64_t g) {
+    const uint32_t rd = find_read(B, O.tile_read, g);
+    const uint64_t gm = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
+    const uint32_t start = O.m_start[gm], len = O.m_len[gm];
+    const uint64_t L = B.sig_off[rd + 1] - B.sig_off[rd];
+    const uint32_t ws = start - W.print_margin; // validated in k_events
+    const uint64_t we64 = (uint64_t)start + len + W.print_margin;
+    const uint32_t we = (uint32_t)(we64 > L ? L : we64);
+    K.ev_len[e] = we - ws;
+    K.ev_start[e] = ws;
+    K.ev_read[e] = rd;
+    if (K.read_needed) K.read_needed[rd] = 1;
+}
+
+// direct mode: rank = (events of the same slot in earlier tiles / waves / rows) + in-row rank; events with
+// rank < keep[slot] are the first sample_limit ones in (read, event) order (gmove.cpp:925-927)
+__global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
+                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ wcnt,
+                                                   const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off,
+                                                   PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K) {
+    __shared__ uint32_t wbase[4][PG_RANK_MAX_DIGITS];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
+    const int lane = lane_id();
+    const uint32_t ndig = 1u << nbits;
+    for (uint32_t d = tid; d < ndig; d += 256) {
+        uint32_t b = hist[(uint64_t)d * n_tiles + tile];
+        for (uint32_t ww = 0; ww < 4; ++ww) { wbase[ww][d] = b; b += wcnt[((uint64_t)tile * 4 + ww) * ndig + d]; }
+    }
+    __syncthreads();
+    volatile uint32_t *mybase = wbase[w];
+    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
+    uint32_t kv[PG_SORT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+        const uint64_t idx = base + (uint64_t)row * WAVE + lane;
+        kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
+    }
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+        const uint64_t idx = base + (uint64_t)row * WAVE + lane;
+        const uint32_t key = kv[row];
+        const bool valid = key != PG_INVALID_SLOT;
+        const uint32_t d = key & (ndig - 1u);
+        const uint64_t peers = match_digit(d, valid, nbits);
+        uint32_t b = 0;
+        if (valid) b = mybase[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && lane == __ffsll((long long)peers) - 1) mybase[d] = b + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint64_t rank = (uint64_t)b + (uint32_t)__popcll(peers & lanemask_lt());
+            if (rank < keep[key]) write_kept(B, W, O, K, ev_off[key] + rank, idx);
+        }
+    }
+}
+
 // =====================================================================================================
-// per-slot bookkeeping
+// generic mode bookkeeping on the sorted (slot, op index) pairs
 // =====================================================================================================
 
 __global__ __launch_bounds__(256) void k_slot_bounds(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ m_ptr,
@@ -349,23 +478,7 @@ __global__ __launch_bounds__(256) void k_kept_meta(const uint32_t *__restrict__ 
     const uint32_t s = skey[pos];
     const uint64_t rank = pos - slot_start[s];
     if (rank >= keep[s]) return;
-    const uint64_t e = ev_off[s] + rank;
-    const uint64_t g = sval[pos];
-    uint32_t lo = 0, hi = B.n_reads; // the read that owns op index g: largest rd with op_off[rd] <= g
-    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (B.op_off[mid] <= g) lo = mid; else hi = mid - 1; }
-    const uint32_t rd = lo;
-    const uint64_t o0 = B.op_off[rd];
-    const uint64_t gm = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
-    const uint32_t start = O.m_start[gm], len = O.m_len[gm];
-    const uint64_t L = B.sig_off[rd + 1] - B.sig_off[rd];
-    const uint32_t ws = start - W.print_margin; // validated in k_walk_events
-    const uint64_t we64 = (uint64_t)start + len + W.print_margin;
-    const uint32_t we = (uint32_t)(we64 > L ? L : we64);
-    (void)o0;
-    K.ev_len[e] = we - ws;
-    K.ev_start[e] = ws;
-    K.ev_read[e] = rd;
-    if (K.read_needed) K.read_needed[rd] = 1;
+    write_kept(B, W, O, K, ev_off[s] + rank, sval[pos]);
 }
 
 // =====================================================================================================
@@ -433,93 +546,127 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
-__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, const int32_t *__restrict__ status,
-                                                   PgReadPlan *__restrict__ plan) {
+__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
+                                                   int32_t *__restrict__ max_span) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= B.n_reads) return;
-    PgReadPlan p;
-    if (status[r] != PGR_OK) { p.c_lo = 0; p.span = 0; p.z0 = 0; p.status = 1; } // skipped / failed reads are not scanned
-    else p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
+    const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
     plan[r] = p;
+    if (p.status == 0) atomicMax(max_span, p.span);
 }
 
-// One workgroup per read. The signal is streamed once with 16-byte loads (8 int16 per lane) and
-// binned by code into an LDS histogram of the in-range code interval; an inclusive prefix sum of
-// the histogram then gives both order statistics (pg_select.h) without touching the signal again.
-__global__ __launch_bounds__(256) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan,
-                                                    const uint8_t *__restrict__ needed, double *__restrict__ med,
-                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err) {
-    // TODO(wide): reads whose in-range code interval exceeds PG_STATS_BINS need the global-memory histogram path
-    __shared__ uint32_t hist[PG_STATS_BINS + 32];
-    __shared__ uint32_t wsum[4];
-    const uint32_t r = blockIdx.x, tid = threadIdx.x;
+// prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
+// dword per lane so that the column-wise reads/writes of the scan are bank-conflict free
+template <int LOG_BPL> struct PaddedPre {
+    const uint32_t *h;
+    __device__ __forceinline__ uint32_t operator[](int b) const { return h[b + (b >> LOG_BPL)]; }
+};
+
+// One WAVE per read (64-thread workgroups): no barriers, no idle waves. The signal is streamed once with
+// 16-byte loads (8 int16 per lane, 4 loads in flight per lane) and binned by raw code into an LDS
+// histogram of the in-range code interval [c_lo, c_lo+span); an inclusive prefix sum of the histogram
+// then yields both order statistics (pg_select.h) without touching the signal again.
+template <int BINS, int LOW> // handles reads with LOW < span <= BINS; the BINS == PG_STATS_BINS launch flags wider ones
+__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan,
+                                                   const uint8_t *__restrict__ needed, double *__restrict__ med,
+                                                   double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err) {
+    constexpr int BPL = BINS / WAVE;                  // bins per lane in the scan
+    constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
+    constexpr int TRASH = BINS + WAVE;                // padded size of the real bins
+    __shared__ uint32_t hist[TRASH + 32];
+    const uint32_t r = blockIdx.x;
+    const int lane = lane_id();
     const PgReadPlan pl = plan[r];
-    const bool skip = pl.status == 1 || (needed && !needed[r]);
-    if (skip || pl.status != 0 || pl.span > PG_STATS_BINS) {
-        if (tid == 0) {
+    const uint64_t beg = B.sig_off[r], end = B.sig_off[r + 1];
+    const bool skip = (needed && !needed[r]) || end == beg;
+    if (!skip && pl.status == 0 && pl.span <= LOW) return; // belongs to the narrower launch
+    if (skip || pl.status != 0 || pl.span > BINS) {
+        if (BINS == PG_STATS_BINS && lane == 0) { // the widest launch owns the bookkeeping of unprocessed reads
             med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
             if (!skip) { status[r] = pl.status != 0 ? PGR_ERR_SCALE : PGR_ERR_WIDE; atomicMin(&err[0], (int)r); }
         }
         return;
     }
-    for (uint32_t i = tid; i < PG_STATS_BINS + 32; i += 256) hist[i] = 0;
-    __syncthreads();
+    for (int i = lane; i < TRASH + 32; i += WAVE) hist[i] = 0;
 
-    const uint64_t beg = B.sig_off[r], end = B.sig_off[r + 1];
     const int c_lo = pl.c_lo;
     const uint32_t span = (uint32_t)pl.span;
-    const uint32_t trash = PG_STATS_BINS + (tid & 31u); // out-of-range samples: spread over 32 dummy bins
+    const uint32_t trash = TRASH + (lane & 31u); // out-of-range samples: spread over 32 dummy bins
     auto bin = [&](int code) {
         const uint32_t idx = (uint32_t)(code - c_lo);
-        atomicAdd(&hist[idx < span ? idx : trash], 1u);
+        atomicAdd(&hist[idx < span ? idx + (idx >> LOG_BPL) : trash], 1u);
+    };
+    auto bin8 = [&](const int4 &q) {
+        bin((int)(short)(q.x & 0xffff)); bin(q.x >> 16);
+        bin((int)(short)(q.y & 0xffff)); bin(q.y >> 16);
+        bin((int)(short)(q.z & 0xffff)); bin(q.z >> 16);
+        bin((int)(short)(q.w & 0xffff)); bin(q.w >> 16);
     };
     const int16_t *__restrict__ sig = B.sig;
-    const uint64_t v0 = beg >> 3, v1 = (end + 7) >> 3; // 16-byte vectors that overlap [beg, end)
-    for (uint64_t v = v0 + tid; v < v1; v += 256) {
-        const uint64_t s0 = v << 3;
-        if (s0 >= beg && s0 + 8 <= end) {
-            const int4 q = *reinterpret_cast<const int4 *>(sig + s0);
-            bin((int)(short)(q.x & 0xffff)); bin(q.x >> 16);
-            bin((int)(short)(q.y & 0xffff)); bin(q.y >> 16);
-            bin((int)(short)(q.z & 0xffff)); bin(q.z >> 16);
-            bin((int)(short)(q.w & 0xffff)); bin(q.w >> 16);
-        } else {
-            for (int e = 0; e < 8; ++e) { const uint64_t a = s0 + e; if (a >= beg && a < end) bin((int)sig[a]); }
+    // 16-byte vectors fully inside [beg, end): [va, vb); ragged head and tail handled element-wise
+    const uint64_t va = (beg + 7) >> 3, vb = end >> 3;
+    if (va < vb) {
+        for (uint64_t s = beg + lane; s < (va << 3); s += WAVE) bin((int)sig[s]);
+        for (uint64_t s = (vb << 3) + lane; s < end; s += WAVE) bin((int)sig[s]);
+        const int4 *__restrict__ vec = reinterpret_cast<const int4 *>(sig);
+        uint64_t v = va + lane;
+        for (; v + 3 * WAVE < vb; v += 4 * WAVE) { // 4 independent 16-byte loads in flight per lane
+            int4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = vec[v + u * WAVE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bin8(q[u]);
         }
+        for (; v < vb; v += WAVE) bin8(vec[v]);
+    } else {
+        for (uint64_t s = beg + lane; s < end; s += WAVE) bin((int)sig[s]);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    // inclusive prefix over the PG_STATS_BINS bins: 8 consecutive bins per thread
-    uint32_t h[8];
-    uint32_t s = 0;
+    // inclusive prefix over the bins: lane l owns bins [l*BPL, (l+1)*BPL) at padded address l*(BPL+1)+i
+    uint32_t ssum = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s += hist[tid * 8 + i]; h[i] = s; }
-    const uint32_t inc = wave_incl_scan_u32(s);
-    if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
-    __syncthreads();
-    uint32_t off = inc - s;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) off += wsum[w];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) hist[tid * 8 + i] = off + h[i];
-    __syncthreads();
+    for (int i = 0; i < BPL; ++i) ssum += hist[lane * (BPL + 1) + i];
+    uint32_t run = wave_incl_scan_u32(ssum) - ssum;
+#pragma unroll 8
+    for (int i = 0; i < BPL; ++i) { run += hist[lane * (BPL + 1) + i]; hist[lane * (BPL + 1) + i] = run; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
-    if (tid == 0) {
-        const double scale = B.range[r] / B.dig[r];
-        const PgMedMad mm = pg_medmad_from_prefix((const uint32_t *)hist, pl, end - beg, B.off[r], scale);
-        med[r] = mm.med;
-        mad[r] = mm.mad;
+    // order statistics: every search step tests 64 candidates (pg_select.h holds the arithmetic)
+    PgSel<PaddedPre<LOG_BPL>> sel;
+    sel.pre = PaddedPre<LOG_BPL>{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = end - beg;
+    sel.offset = B.off[r]; sel.scale = B.range[r] / B.dig[r];
+    sel.begin();
+    int bm = 0;
+    if (!sel.zmed) bm = wave_first_true(sel.span, [&](int b) { return sel.med_pred(b); });
+    sel.set_median(bm);
+    double best = INFINITY;
+    if (sel.L > 1) {
+        sel.begin_mad();
+        for (int side = 0; side < 2; ++side) {
+            const bool up = side == 0;
+            const int n = up ? sel.nU : sel.nD;
+            const int t = wave_first_true(n, [&](int tt) { return sel.mad_pred(up, tt); });
+            if (t < n) { const double v = sel.dev(up, t); if (v < best) best = v; }
+        }
+        if (sel.z_ok() && sel.dZ < best) best = sel.dZ;
     }
+    const PgMedMad mm = sel.finish(best);
+    if (lane == 0) { med[r] = mm.med; mad[r] = mm.mad; }
 }
 
 // =====================================================================================================
 // k_gather: one wave per kept event (gmove.cpp:773-775, 938-944)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, uint64_t n_kept, const uint32_t *__restrict__ ev_len,
+__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const uint32_t *__restrict__ ev_len,
                                                 const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
                                                 double *__restrict__ samples) {
     const int lane = lane_id();
+    const uint64_t n_kept = *n_kept_ptr;
     const uint64_t stride = (uint64_t)gridDim.x * 4;
     for (uint64_t e = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < n_kept; e += stride) {
         const uint32_t rd = ev_read[e], len = ev_len[e];
@@ -539,25 +686,55 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, uint64_t n_kept, c
 // launchers
 // =====================================================================================================
 
-void pg_launch_walk_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
+void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_reads == 0) return;
-    hipLaunchKernelGGL(k_walk_events, dim3((B.n_reads + 3) / 4), dim3(256), 0, st, B, W, O);
+    hipLaunchKernelGGL(k_walk, dim3((B.n_reads + 3) / 4), dim3(256), 0, st, B, W, O);
+}
+
+void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
+    if (B.n_ops == 0) return;
+    hipLaunchKernelGGL(k_events, dim3((uint32_t)((B.n_ops + 255) / 256)), dim3(256), 0, st, B, W, O);
+}
+
+static uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + PG_SORT_TILE - 1) / PG_SORT_TILE); }
+
+void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+                                 uint64_t *acc_cnt) {
+    int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
+    const uint32_t n_tiles = tiles_for(n);
+    if (n_tiles) {
+        hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, (const uint32_t *)nullptr, 0u, nbits,
+                           n_tiles, S.hist, S.wcnt);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals);
+    } else (void)hipMemsetAsync(S.totals, 0, sizeof(uint32_t) << nbits, st);
+    hipLaunchKernelGGL(k_totals_to_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, (const uint32_t *)S.totals, n_slots, acc_cnt);
+}
+
+void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+                                const uint64_t *keep, const uint64_t *ev_off, const PgDevBatch &B, const PgWalkParams &W,
+                                const PgWalkOut &O, const PgKeptOut &K) {
+    int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
+    const uint32_t n_tiles = tiles_for(n);
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, (const uint32_t *)S.hist,
+                       (const uint32_t *)S.wcnt, keep, ev_off, B, W, O, K);
 }
 
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S) {
-    const uint32_t n_tiles = (uint32_t)((n + PG_SORT_TILE - 1) / PG_SORT_TILE);
+    const uint32_t n_tiles = tiles_for(n);
     if (key_bits == 0) key_bits = 1;
-    const uint32_t passes = (key_bits + 7) / 8;
+    const uint32_t passes = (key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
+    const uint32_t per = (key_bits + passes - 1) / passes; // bits per pass, balanced
     const uint32_t *kin = ev_slot;
     const uint32_t *vin = nullptr;
     int out = 0;
     for (uint32_t p = 0; p < passes; ++p) {
-        const uint32_t shift = p * 8;
-        const int nbits = (int)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
+        const uint32_t shift = p * per;
+        const int nbits = (int)((key_bits - shift) < per ? (key_bits - shift) : per);
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
-        hipLaunchKernelGGL(k_sort_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
-        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(64), 0, st, S.hist, n_tiles, S.totals);
-        hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, S.dbase, S.count + 1);
+        hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals);
+        hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
         // count[0] = number of keys for the next pass (pass 0 drops the invalid ones; later passes keep all)
@@ -590,28 +767,37 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
                        ev_off, B, W, O, K);
 }
 
-void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n, uint64_t *out, uint64_t *scratch) {
-    const uint32_t nb = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
+    const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
     const uint32_t nbl = nb ? nb : 1;
-    hipLaunchKernelGGL(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n, (const uint64_t *)nullptr, scratch);
+    hipLaunchKernelGGL(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, scratch);
     hipLaunchKernelGGL(k_scan_partials_scan, dim3(1), dim3(256), 0, st, scratch, nbl);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n, (const uint64_t *)nullptr, (const uint64_t *)scratch, out);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)scratch, out);
 }
 
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, const uint8_t *read_needed,
-                          void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err) {
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *max_span) {
+    (void)hipMemsetAsync(max_span, 0, sizeof(int32_t), st);
     if (B.n_reads == 0) return;
-    PgReadPlan *plan = reinterpret_cast<PgReadPlan *>(plan_buf); // 16 bytes per read
-    hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max, (const int32_t *)status, plan);
-    hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(256), 0, st, B, (const PgReadPlan *)plan, read_needed, med, mad, status, err);
+    hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max,
+                       reinterpret_cast<PgReadPlan *>(plan_buf), max_span);
 }
 
-void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept, const uint32_t *ev_len, const uint32_t *ev_read,
-                      const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min, double pa_max,
-                      const double *med, const double *mad, double *samples) {
-    if (n_kept == 0) return;
-    uint64_t blocks = (n_kept + 3) / 4;
+void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
+                          double *med, double *mad, int32_t *status, int32_t *err) {
+    if (B.n_reads == 0) return;
+    const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
+    if (bins <= 1024)
+        hipLaunchKernelGGL((k_read_stats<1024, -1>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err);
+    else
+        hipLaunchKernelGGL((k_read_stats<PG_STATS_BINS, 1024>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err);
+}
+
+void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
+                      const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
+                      double pa_max, const double *med, const double *mad, double *samples) {
+    if (n_kept_cap == 0) return;
+    uint64_t blocks = (n_kept_cap + 3) / 4;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
-    hipLaunchKernelGGL(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept, ev_len, ev_read, ev_start, samp_off, scaling,
+    hipLaunchKernelGGL(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_start, samp_off, scaling,
                        pa_min, pa_max, med, mad, samples);
 }

@@ -62,86 +62,122 @@ PG_HD PgReadPlan pg_make_plan(double digitisation, double offset, double range, 
 // L = len_raw_signal. Returns med and mad (already scaled by 1.4826 and clamped to >= 1.0).
 struct PgMedMad { double med, mad, mad_raw; }; // mad_raw: sorted(|x-med|)[n/2] before *1.4826 and the clamp
 
+// The selection as a small state machine so that the same arithmetic can be driven by a scalar binary
+// search (host tests, pg_medmad_from_prefix below) or by a 64-lane search (k_read_stats):
+//   begin() -> rank of the median;  med_pred(b) is monotone in b;  set_median(bm);
+//   begin_mad();  mad_pred(up, t) is monotone in t for each side;  candidate(up, t), z_candidate().
 template <class PrePtr>
-PG_HD PgMedMad pg_medmad_from_prefix(PrePtr pre, const PgReadPlan &pl, uint64_t L, double offset, double scale) {
-    const int span = pl.span, c_lo = pl.c_lo, z0 = pl.z0;
-    auto P = [&](int b) -> uint64_t { return (b < 0 || span == 0) ? 0 : (uint64_t)pre[b >= span ? span - 1 : b]; };
-    auto first_above = [&](uint64_t j) { // smallest b with pre[b] > j
-        int lo = 0, hi = span;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if ((uint64_t)pre[mid] > j) hi = mid; else lo = mid + 1; }
-        return lo;
-    };
-    const uint64_t nV = span > 0 ? (uint64_t)pre[span - 1] : 0;
-    const uint64_t nZ = L - nV;
-    const uint64_t cb = P(z0 - 1);
-    const uint64_t k = L / 2; // upper median: ks_ksmall(n, copy, n/2), gmove.cpp:146
-    PgMedMad out;
-    bool zmed = false;
-    int bm = 0;
-    if (k < cb) bm = first_above(k);
-    else if (k < cb + nZ) zmed = true;
-    else bm = first_above(k - nZ);
-    const double med = zmed ? 0.0 : pg_pa(c_lo + bm, offset, scale);
-    out.med = med;
+struct PgSel {
+    PrePtr pre;
+    int span, c_lo, z0;
+    uint64_t L;
+    double offset, scale;
+    // begin()
+    uint64_t nV, nZ, cb, k, jmed;
+    bool zmed;
+    // set_median()
+    double med;
+    // begin_mad()
+    int sp, nU, nD;
+    uint64_t base, need;
+    double dZ, inv;
 
-    double mad_raw;
-    if (L == 1) mad_raw = 0.0; // calc_madf, gmove.cpp:166-168
-    else {
+    PG_HD uint64_t P(int b) const { return (b < 0 || span == 0) ? 0 : (uint64_t)pre[b >= span ? span - 1 : b]; }
+
+    PG_HD void begin() {
+        nV = span > 0 ? (uint64_t)pre[span - 1] : 0;
+        nZ = L - nV;
+        cb = P(z0 - 1);
+        k = L / 2; // upper median: ks_ksmall(n, copy, n/2), gmove.cpp:146
+        zmed = false; jmed = 0;
+        if (k < cb) jmed = k;
+        else if (k < cb + nZ) zmed = true;
+        else jmed = k - nZ;
+    }
+    // smallest b with med_pred(b) is the bin of the median (only when !zmed)
+    PG_HD bool med_pred(int b) const { return (uint64_t)pre[b] > jmed; }
+    PG_HD void set_median(int bm) { med = zmed ? 0.0 : pg_pa(c_lo + bm, offset, scale); sp = zmed ? z0 : bm; }
+
+    PG_HD void begin_mad() {
         // split point: first in-range index whose value is >= med
-        int sp;
-        if (zmed) sp = z0;
-        else { sp = bm; while (sp > 0 && pg_pa(c_lo + sp - 1, offset, scale) >= med) --sp; }
-        const int nU = span - sp, nD = sp;
-        const uint64_t base = P(sp - 1);
-        const double dZ = fabs(0.0 - med);
-        const double inv = 1.0 / scale;
-        auto U = [&](int t) { return fabs(pg_pa(c_lo + sp + t, offset, scale) - med); };     // t in [0,nU)
-        auto D = [&](int t) { return fabs(pg_pa(c_lo + sp - 1 - t, offset, scale) - med); }; // t in [0,nD)
-        // number of codes on one side whose deviation is <= v (deviations are monotone in t)
-        auto count_leq = [&](bool up, double v) -> int {
-            const int n = up ? nU : nD;
-            if (n == 0) return 0;
-            auto dev = [&](int t) { return up ? U(t) : D(t); };
-            const double d0 = dev(0);
-            int c;
+        if (!zmed) while (sp > 0 && pg_pa(c_lo + sp - 1, offset, scale) >= med) --sp;
+        nU = span - sp; nD = sp;
+        base = P(sp - 1);
+        dZ = fabs(0.0 - med);
+        inv = 1.0 / scale;
+        need = k + 1; // the k-th (0-based) smallest deviation is the least v with N(v) >= k+1
+    }
+    PG_HD double U(int t) const { return fabs(pg_pa(c_lo + sp + t, offset, scale) - med); }     // t in [0,nU)
+    PG_HD double D(int t) const { return fabs(pg_pa(c_lo + sp - 1 - t, offset, scale) - med); } // t in [0,nD)
+    PG_HD double dev(bool up, int t) const { return up ? U(t) : D(t); }
+    // number of codes on one side whose deviation is <= v (deviations are monotone in t). `hint` >= 0 says
+    // "code hint-1 is known to be <= v" (the candidate's own side), which skips the estimate.
+    PG_HD int count_leq(bool up, double v, int hint = -1) const {
+        const int n = up ? nU : nD;
+        if (n == 0) return 0;
+        int c;
+        if (hint >= 0) c = hint;
+        else {
+            const double d0 = dev(up, 0);
             if (!(v >= d0)) c = 0;
             else {
                 const double est = (v - d0) * inv + 1.0; // deviations are spaced ~scale apart
                 c = est >= (double)n ? n : (int)est;
                 if (c < 1) c = 1;
             }
-            int guard = 0;
-            while (c < n && dev(c) <= v) { ++c; if (++guard > 8) break; }
-            while (guard <= 8 && c > 0 && dev(c - 1) > v) { --c; if (++guard > 8) break; }
-            if (guard > 8) { // spacing assumption failed: plain binary search (first t with dev(t) > v)
-                int lo = 0, hi = n;
-                while (lo < hi) { int mid = (lo + hi) >> 1; if (dev(mid) > v) hi = mid; else lo = mid + 1; }
-                c = lo;
-            }
-            return c;
-        };
-        auto CU = [&](int t) -> uint64_t { return t <= 0 ? 0 : P(sp + t - 1) - base; };
-        auto CD = [&](int t) -> uint64_t { return t <= 0 ? 0 : base - P(sp - t - 1); };
-        auto N = [&](double v) -> uint64_t { // number of samples with |x - med| <= v
-            return CU(count_leq(true, v)) + CD(count_leq(false, v)) + (dZ <= v ? nZ : 0);
-        };
-        const uint64_t need = k + 1; // the k-th (0-based) smallest is the least v with N(v) >= k+1
-        double best = INFINITY;
+        }
+        int guard = 0;
+        while (c < n && dev(up, c) <= v) { ++c; if (++guard > 8) break; }
+        while (guard <= 8 && c > 0 && dev(up, c - 1) > v) { --c; if (++guard > 8) break; }
+        if (guard > 8) { // spacing assumption failed: plain binary search (first t with dev(t) > v)
+            int lo = 0, hi = n;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (dev(up, mid) > v) hi = mid; else lo = mid + 1; }
+            c = lo;
+        }
+        return c;
+    }
+    PG_HD uint64_t CU(int t) const { return t <= 0 ? 0 : P(sp + t - 1) - base; }
+    PG_HD uint64_t CD(int t) const { return t <= 0 ? 0 : base - P(sp - t - 1); }
+    // number of samples with |x - med| <= v
+    PG_HD uint64_t N(double v, int hintU = -1, int hintD = -1) const {
+        return CU(count_leq(true, v, hintU)) + CD(count_leq(false, v, hintD)) + (dZ <= v ? nZ : 0);
+    }
+    // monotone in t: does the t-th code of this side already cover the k-th smallest deviation?
+    PG_HD bool mad_pred(bool up, int t) const {
+        const double v = dev(up, t);
+        return N(v, up ? t + 1 : -1, up ? -1 : t + 1) >= need;
+    }
+    PG_HD bool z_ok() const { return nZ > 0 && N(dZ) >= need; }
+    PG_HD PgMedMad finish(double best) const {
+        PgMedMad out;
+        out.med = med;
+        out.mad_raw = (L == 1) ? 0.0 : best; // calc_madf, gmove.cpp:166-168
+        const double mad = out.mad_raw * 1.4826; // gmove.cpp:162,183
+        out.mad = (mad > 1.0) ? mad : 1.0;       // gmove.cpp:771
+        return out;
+    }
+};
+
+// scalar driver (binary searches): host tests and the reference point for the 64-lane driver
+template <class PrePtr>
+PG_HD PgMedMad pg_medmad_from_prefix(PrePtr pre, const PgReadPlan &pl, uint64_t L, double offset, double scale) {
+    PgSel<PrePtr> s;
+    s.pre = pre; s.span = pl.span; s.c_lo = pl.c_lo; s.z0 = pl.z0; s.L = L; s.offset = offset; s.scale = scale;
+    s.begin();
+    int bm = 0;
+    if (!s.zmed) { int lo = 0, hi = s.span; while (lo < hi) { int mid = (lo + hi) >> 1; if (s.med_pred(mid)) hi = mid; else lo = mid + 1; } bm = lo; }
+    s.set_median(bm);
+    double best = INFINITY;
+    if (L > 1) {
+        s.begin_mad();
         for (int side = 0; side < 2; ++side) {
             const bool up = side == 0;
-            const int n = up ? nU : nD;
+            const int n = up ? s.nU : s.nD;
             int lo = 0, hi = n; // smallest t with N(dev(t)) >= need
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (N(up ? U(mid) : D(mid)) >= need) hi = mid; else lo = mid + 1;
-            }
-            if (lo < n) { const double v = up ? U(lo) : D(lo); if (v < best) best = v; }
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (s.mad_pred(up, mid)) hi = mid; else lo = mid + 1; }
+            if (lo < n) { const double v = s.dev(up, lo); if (v < best) best = v; }
         }
-        if (nZ > 0 && N(dZ) >= need && dZ < best) best = dZ;
-        mad_raw = best;
+        if (s.z_ok() && s.dZ < best) best = s.dZ;
     }
-    out.mad_raw = mad_raw;
-    double mad = mad_raw * 1.4826;       // gmove.cpp:162,183
-    out.mad = (mad > 1.0) ? mad : 1.0;   // gmove.cpp:771
-    return out;
+    return s.finish(best);
 }

@@ -130,5 +130,6 @@ def test_error_paths():
     eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, rna=False))  # RNA-oriented records without --rna
     with pytest.raises(PgError) as ei:
         eng.submit(b)
+        eng.sync()  # per-read errors surface at the next synchronisation point
     assert ei.value.status == -4
     eng.close()
