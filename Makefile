@@ -9,7 +9,7 @@ ARCH ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result
 CSRC = poregen_amd/csrc
 
-all: poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so oracle_build
+all: poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so bin/poregen oracle_build
 
 # libpgmove.so deliberately does NOT carry a DT_NEEDED on libamdhip64: a process must hold exactly one HIP
 # runtime, and under Python that has to be the copy PyTorch bundles (poregen_amd/_abi.py preloads it
@@ -21,8 +21,14 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_select.h include/pgmov
 poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_api.o
 	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined
 
-poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h
-	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -o $@ $(CSRC)/pg_hosttest.cpp
+poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread
+
+HOST = $(CSRC)/host
+bin/poregen: $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp $(HOST)/pg_host.h include/pgmove.h poregen_amd/libpgmove.so
+	@mkdir -p bin
+	$(CXX) -O2 -g -std=c++17 -Wall -o $@ $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp \
+	    -Lporegen_amd -lpgmove -L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,'$$ORIGIN/../poregen_amd' -Wl,-rpath,/opt/rocm/lib
 
 oracle_build:
 	$(MAKE) -C oracle

@@ -1,0 +1,129 @@
+// dump.cpp -- k-mer list and the dump directory writer (exact "%.8f" text, -d delimiters, freq.txt).
+#include "pg_host.h"
+
+#include <atomic>
+#include <charconv>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <sys/stat.h>
+#include <thread>
+
+namespace pgh {
+
+static void gen_rec(const char *set, std::string &prefix, int k, std::vector<std::string> &out) {
+    if ((int)prefix.size() == k) { out.push_back(prefix); return; }
+    for (int i = 0; i < 4; i++) { prefix.push_back(set[i]); gen_rec(set, prefix, k, out); prefix.pop_back(); }
+}
+void generate_kmers(int k, bool rna, std::vector<std::string> &out) {
+    // generate_kmers (src/poregen.cpp:248-267): depth-first in alphabet order => lexicographic
+    std::string prefix;
+    out.reserve((size_t)1 << (2 * k));
+    gen_rec(rna ? "ACGU" : "ACGT", prefix, k, out);
+}
+
+int read_kmer_file(const std::string &path, int k, std::vector<std::string> &out, std::string &err) {
+    // src/gmove.cpp:396-418: getline; the last character is dropped; the line must have k+1 characters
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) { err = "Error in opening file " + path; return 1; }
+    char *line = nullptr; size_t cap = 0; ssize_t got;
+    int rc = 0;
+    while ((got = getline(&line, &cap, f)) != -1) {
+        if (got != (ssize_t)k + 1) {
+            err = "The length of kmers in " + path + " have a different value (" + std::to_string(got - 1) + ") than the kmer size " + std::to_string(k) + ".";
+            rc = 2; break;
+        }
+        out.emplace_back(line, (size_t)got - 1);
+    }
+    free(line); fclose(f);
+    return rc;
+}
+
+int create_dir(const char *dir_name) { // src/gmove.cpp:126-140
+    struct stat st;
+    if (stat(dir_name, &st) == -1) { if (mkdir(dir_name, 0700) == -1) return -2; }
+    else {
+        DIR *d = opendir(dir_name); size_t n = 0;
+        if (d) { while (readdir(d)) n++; closedir(d); }
+        if (n > 2) return -1;
+    }
+    return 0;
+}
+
+size_t format_f8(double v, char *buf) {
+    // printf("%.8f") prints the exactly-rounded (round-half-even on the binary value) decimal expansion with
+    // 8 fractional digits; std::to_chars(fixed, 8) is specified to produce the same digits as printf.
+    auto r = std::to_chars(buf, buf + 380, v, std::chars_format::fixed, 8);
+    return (size_t)(r.ptr - buf);
+}
+
+bool touch_dump_files(const std::string &out_dir, const std::vector<std::string> &slot_kmers, std::string &err) {
+    for (size_t i = 0; i < slot_kmers.size(); i++) { // src/gmove.cpp:460-473: one fopen(...,"w") per k-mer of the slice
+        const std::string path = out_dir + "/dump/" + slot_kmers[i];
+        FILE *f = fopen(path.c_str(), "w");
+        if (!f) { err = "Error in opening " + std::to_string(i + 1) + "th kmer-file " + path; return false; }
+        fclose(f);
+    }
+    return true;
+}
+
+static void slot_text(const DumpInput &in, uint32_t s, bool delimit, uint32_t sample_limit, std::string &out) {
+    char buf[400];
+    const uint64_t a = in.ev_off[s], b = in.ev_off[s + 1];
+    auto put_event = [&](uint64_t e) {
+        const uint64_t so = in.samp_off[e], n = in.ev_len[e];
+        for (uint64_t i = 0; i < n; i++) { // "%.8f," ... "%.8f;" (src/gmove.cpp:941-944)
+            size_t w = format_f8(in.samples[so + i], buf);
+            buf[w] = i + 1 == n ? ';' : ',';
+            out.append(buf, w + 1);
+        }
+    };
+    if (!delimit) { for (uint64_t e = a; e < b; e++) put_event(e); return; }
+    // -d (src/gmove.cpp:960-962, 196-203): after every read that was not skipped, ':' goes to every file that
+    // is still open; a file closes the moment its count reaches sample_limit (src/gmove.cpp:946-949)
+    uint64_t closed_at = UINT64_MAX;
+    if (sample_limit > 0 && b - a == sample_limit) closed_at = in.ev_read[b - 1];
+    uint64_t e = a;
+    for (uint64_t r = 0; r < in.n_reads; r++) {
+        while (e < b && in.ev_read[e] == r) put_event(e++);
+        if (!in.read_skipped[r] && r < closed_at) out.push_back(':');
+        if (r >= closed_at) break;
+    }
+}
+
+bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const DumpInput &in, bool delimit,
+                    uint32_t sample_limit, unsigned n_threads, std::string &err) {
+    std::atomic<uint32_t> next(0);
+    std::atomic<bool> ok(true);
+    std::string first_err;
+    auto work = [&]() {
+        std::string text;
+        for (;;) {
+            const uint32_t s = next.fetch_add(1);
+            if (s >= in.n_slots || !ok.load()) break;
+            text.clear();
+            slot_text(in, s, delimit, sample_limit, text);
+            if (text.empty()) continue; // the file already exists, empty (touch_dump_files)
+            const std::string path = out_dir + "/dump/" + slot_kmers[s];
+            FILE *f = fopen(path.c_str(), "w");
+            if (!f || fwrite(text.data(), 1, text.size(), f) != text.size()) { ok = false; if (f) fclose(f); break; }
+            fclose(f);
+        }
+    };
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (!ok) { err = "error writing dump files under " + out_dir; return false; }
+    // freq.txt (src/gmove.cpp:525-534)
+    const std::string fp = out_dir + "/freq.txt";
+    FILE *f = fopen(fp.c_str(), "w");
+    if (!f) { err = "Error in opening " + fp; return false; }
+    for (uint32_t s = 0; s < in.n_slots; s++) fprintf(f, "%s\t%llu\n", slot_kmers[s].c_str(), (unsigned long long)in.counts[s]);
+    fclose(f);
+    return true;
+}
+
+} // namespace pgh

@@ -1,0 +1,277 @@
+// gmove_cli.cpp -- `poregen gmove`: the reference's command line and output layout (src/gmove.cpp:213-537)
+// over libpgmove (include/pgmove.h). Host work here: option handling, k-mer list and slice, SLOW5/PAF/FASTQ
+// parsing into batches, writing the dump directory. The per-read computation runs on the GPU.
+#include "../../../include/pgmove.h"
+#include "pg_host.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <getopt.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define POREGEN_VERSION "0.1.0"
+
+namespace {
+
+struct Opt { // opt_t subset, defaults of init_opt (src/poregen.cpp:209-237, src/poregen.h:30-43)
+    uint32_t kmer_size = 9, sig_move_offset = 0, kmer_start_offset = 0, signal_print_margin = 0, sample_limit = 100;
+    uint32_t file_limit = 500, index_start = 1, index_end = 500, max_dur = 70, min_dur = 5, kmer_pick_margin = 2;
+    int delimit_files = 0, flag_rna = 0;
+    double pa_max = 180.0, pa_min = 40.0;
+};
+
+// same order as the reference's table: handlers below test longindex like the reference does (gmove.cpp:49-72)
+struct option long_options[] = {
+    {"kmer_size", required_argument, 0, 'k'}, {"sig_move_offset", required_argument, 0, 'm'},
+    {"kmer_start_offset", required_argument, 0, 's'}, {"scaling", required_argument, 0, 0},
+    {"margin", required_argument, 0, 0}, {"sample_limit", required_argument, 0, 0},
+    {"file_limit", required_argument, 0, 0}, {"kmer_file", required_argument, 0, 0},
+    {"index_start", required_argument, 0, 0}, {"index_end", required_argument, 0, 0},
+    {"fastq", required_argument, 0, 0}, {"", no_argument, 0, 'd'},
+    {"max_dur", required_argument, 0, 0}, {"min_dur", required_argument, 0, 0},
+    {"pa_min", required_argument, 0, 0}, {"pa_max", required_argument, 0, 0},
+    {"kmer_pick_margin", required_argument, 0, 0}, {"rna", no_argument, 0, 0},
+    {"verbose", required_argument, 0, 'v'}, {"help", no_argument, 0, 'h'},
+    {"version", no_argument, 0, 'V'}, {"debug-break", required_argument, 0, 0},
+    // extensions of this implementation (not in the reference)
+    {"batch_reads", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"lazy_stats", no_argument, 0, 0},
+    {0, 0, 0, 0}};
+
+void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
+    fprintf(fp, "Usage: poregen gmove reads.blow5 event_alignment_file output_dir\n");
+    fprintf(fp, "\nbasic options:\n");
+    fprintf(fp, "   -k INT                     kmer_size [%d]\n", o.kmer_size);
+    fprintf(fp, "   -m INT                     move start offset [%d]\n", o.sig_move_offset);
+    fprintf(fp, "   -s INT                     kmer start offset [%d]\n", o.kmer_start_offset);
+    fprintf(fp, "   --scaling INT              scaling [%d] (0-no scaling, 1-medmad)\n", 1);
+    fprintf(fp, "   --margin INT               signal print margin on both sides of the sub signal[%u] \n", o.signal_print_margin);
+    fprintf(fp, "   --sample_limit INT         maximum number of instances to output for a kmer [%u] \n", o.sample_limit);
+    fprintf(fp, "   --file_limit INT           maximum number of kmer files to output [%u] \n", o.file_limit);
+    fprintf(fp, "   --kmer_file FILE           kmer file (optional) \n");
+    fprintf(fp, "   --index_start INT          1-based closed interval index of start kmer [%u] \n", o.file_limit);
+    fprintf(fp, "   --index_end INT            1-based closed interval index of end kmer [%u] \n", o.file_limit);
+    fprintf(fp, "   --fastq FILE               fastq file (optional - should be provided with .paf) \n");
+    fprintf(fp, "   -d                         delimit output files per read\n");
+    fprintf(fp, "   --max_dur                  maximum move duration allowed for samples [%d]\n", o.max_dur);
+    fprintf(fp, "   --min_dur                  maximum move duration allowed for samples [%d]\n", o.min_dur);
+    fprintf(fp, "   --pa_min                   minimum pA level a sampling signal should have [%.3f]\n", o.pa_min);
+    fprintf(fp, "   --pa_max                  maximum pA level a sampling signal should have [%.3f]\n", o.pa_max);
+    fprintf(fp, "   --kmer_pick_margin         distance in bases from an indel when picking a kmer as sample [%d]\n", o.kmer_pick_margin);
+    fprintf(fp, "   --rna                      dataset is rna\n");
+    fprintf(fp, "   -h                         help\n");
+    fprintf(fp, "   --verbose INT              verbosity level [%d]\n", 3);
+    fprintf(fp, "   --version                  print version\n");
+    fprintf(fp, "\nMI355X implementation options:\n");
+    fprintf(fp, "   --batch_reads INT          reads per GPU batch [20000]\n");
+    fprintf(fp, "   --device INT               HIP device [0]\n");
+    fprintf(fp, "   --lazy_stats               median/MAD only for reads that contribute a kept event\n");
+}
+
+struct HostBatch {
+    std::vector<int16_t> sig; std::vector<uint64_t> sig_off{0}, seq_off{0}, op_off{0};
+    std::vector<double> dig, off, range;
+    std::vector<int32_t> qs, ts, te;
+    std::vector<uint8_t> seq, op_t;
+    std::vector<uint32_t> op_n;
+    uint32_t n() const { return (uint32_t)dig.size(); }
+    void clear() {
+        sig.clear(); sig_off.assign(1, 0); seq_off.assign(1, 0); op_off.assign(1, 0); dig.clear(); off.clear(); range.clear();
+        qs.clear(); ts.clear(); te.clear(); seq.clear(); op_t.clear(); op_n.clear();
+    }
+};
+
+int die(const char *fmt, const std::string &a = "") { fprintf(stderr, fmt, a.c_str()); fputc('\n', stderr); return EXIT_FAILURE; }
+
+} // namespace
+
+int gmove_main(int argc, char **argv) {
+    Opt opt;
+    int longindex = 0, c, signal_scale = 0;
+    const char *input_kmer_file = nullptr, *input_fastq_file = nullptr;
+    FILE *fp_help = stderr;
+    uint32_t batch_reads = 20000; int device = 0; bool lazy = false;
+    optind = 1;
+    while ((c = getopt_long(argc, argv, "k:m:s:d", long_options, &longindex)) >= 0) { // src/gmove.cpp:240-327
+        if (c == 'k') { if (atoi(optarg) < 1) { fprintf(stderr, "Kmer length should be larger than 0. You entered %d\n", atoi(optarg)); return EXIT_FAILURE; } opt.kmer_size = atoi(optarg); }
+        else if (c == 'm') { if (atoi(optarg) < 0) { fprintf(stderr, "signal move offset value must not be less than zero. You entered %d\n", atoi(optarg)); return EXIT_FAILURE; } opt.sig_move_offset = atoi(optarg); }
+        else if (c == 's') { if (atoi(optarg) < 1) { fprintf(stderr, "Kmer offset should be larger than 0. You entered %d\n", atoi(optarg)); return EXIT_FAILURE; } opt.kmer_start_offset = atoi(optarg); }
+        else if (c == 'd') opt.delimit_files = 1;
+        else if (c == 'v') {}
+        else if (c == 'V') { fprintf(stdout, "gmove %s\n", POREGEN_VERSION); return EXIT_SUCCESS; }
+        else if (c == 'h') fp_help = stdout;
+        else if (c == 0 && longindex == 3) signal_scale = atoi(optarg);
+        else if (c == 0 && longindex == 4) { if (atoi(optarg) < 0) return die("Signal print margin should be non negative."); opt.signal_print_margin = atoi(optarg); }
+        else if (c == 0 && longindex == 5) { if (atoi(optarg) < 0) return die("Maximum number of instances to output for a kmer should be non negative."); opt.sample_limit = atoi(optarg); }
+        else if (c == 0 && longindex == 6) { if (atoi(optarg) < 0) return die("Maximum number of kmer files to output should be non negative."); opt.file_limit = atoi(optarg); opt.index_end = opt.index_start + opt.file_limit - 1; }
+        else if (c == 0 && longindex == 7) input_kmer_file = optarg;
+        else if (c == 0 && longindex == 8) { if (atoi(optarg) < 1) return die("kmer index start should be a positive number."); opt.index_start = atoi(optarg); opt.file_limit = opt.index_end - opt.index_start + 1; }
+        else if (c == 0 && longindex == 9) { if (atoi(optarg) < 1) return die("kmer index end should be a positive number."); opt.index_end = atoi(optarg); opt.file_limit = opt.index_end - opt.index_start + 1; }
+        else if (c == 0 && longindex == 10) input_fastq_file = optarg;
+        else if (c == 0 && longindex == 12) opt.max_dur = atoi(optarg);
+        else if (c == 0 && longindex == 13) opt.min_dur = atoi(optarg);
+        else if (c == 0 && longindex == 14) opt.pa_min = atof(optarg);
+        else if (c == 0 && longindex == 15) opt.pa_max = atof(optarg);
+        else if (c == 0 && longindex == 16) opt.kmer_pick_margin = atoi(optarg);
+        else if (c == 0 && longindex == 17) opt.flag_rna = 1;
+        else if (c == 0 && longindex == 22) batch_reads = (uint32_t)std::max(1, atoi(optarg));
+        else if (c == 0 && longindex == 23) device = atoi(optarg);
+        else if (c == 0 && longindex == 24) lazy = true;
+    }
+    if (argc - optind != 3 || fp_help == stdout) { // src/gmove.cpp:330-336
+        print_help(fp_help, opt);
+        return fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE;
+    }
+    const char *slow5file = argv[optind], *move_table = argv[optind + 1], *output_dir = argv[optind + 2];
+    if (opt.kmer_size <= opt.sig_move_offset) fprintf(stderr, "[gmove::WARNING] signal move offset value should be less than the kmer length\n");
+
+    int rcd = pgh::create_dir(output_dir); // src/gmove.cpp:374-392
+    if (rcd == -1) { fprintf(stderr, "Output directory %s is not empty. Please remove it or specify another directory.\n", output_dir); return EXIT_FAILURE; }
+    if (rcd == -2) { fprintf(stderr, "Could not create the output dir %s.\n", output_dir); return EXIT_FAILURE; }
+    const std::string kmer_dump = std::string(output_dir) + "/dump";
+    rcd = pgh::create_dir(kmer_dump.c_str());
+    if (rcd == -1) { fprintf(stderr, "Output directory %s is not empty. Please remove it or specify another directory.", kmer_dump.c_str()); return EXIT_FAILURE; }
+    if (rcd == -2) { fprintf(stderr, "Could not create the output dir %s.", kmer_dump.c_str()); return EXIT_FAILURE; }
+
+    std::vector<std::string> kmers; // src/gmove.cpp:394-426
+    std::string err;
+    if (input_kmer_file) {
+        int r = pgh::read_kmer_file(input_kmer_file, (int)opt.kmer_size, kmers, err);
+        if (r != 0) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; }
+    } else {
+        if (opt.kmer_size > 13) return die("kmer sizes above 13 are not supported by this implementation");
+        pgh::generate_kmers((int)opt.kmer_size, opt.flag_rna != 0, kmers);
+    }
+
+    uint32_t num_kmers = (uint32_t)kmers.size(); // src/gmove.cpp:428-440
+    fprintf(stderr, "num_kmers: %d\n", num_kmers);
+    if (opt.file_limit < num_kmers) {
+        num_kmers = opt.file_limit;
+        fprintf(stderr, "only dumping %d kmers in kmer interval [%d-%d]\n", num_kmers, opt.index_start, opt.index_end);
+    } else if (opt.file_limit > num_kmers - opt.index_start + 1) {
+        if (opt.index_end > (uint32_t)kmers.size()) { opt.file_limit = (uint32_t)kmers.size() - opt.index_start + 1; opt.index_end = opt.index_start + opt.file_limit - 1; }
+        else opt.file_limit = opt.index_end - opt.index_start + 1;
+    }
+    // the reference indexes kmers[i] for i in [index_start-1, index_end) without a bounds check
+    if (opt.index_start < 1 || opt.index_end > kmers.size() || opt.index_end + 1 < opt.index_start) {
+        fprintf(stderr, "k-mer interval [%u-%u] is outside the k-mer list (%zu k-mers)\n", opt.index_start, opt.index_end, kmers.size());
+        return EXIT_FAILURE;
+    }
+    fprintf(stderr, "slow5_file_path: %s\n", slow5file);
+    fprintf(stderr, "guppy_sam_output_file: %s\n", move_table);
+    fprintf(stderr, "kmer_output_dir: %s\n", output_dir);
+    fprintf(stderr, "kmer_size: %d\n", opt.kmer_size);
+    fprintf(stderr, "sig_move_offset: %d\n", opt.sig_move_offset);
+    fprintf(stderr, "signal_print_margin: %d\n", opt.signal_print_margin);
+    fprintf(stderr, "kmer index closed interval : [%d-%d]\n", opt.index_start, opt.index_end);
+    fprintf(stderr, "no.of output files: %d\n", opt.file_limit);
+    fprintf(stderr, "sample limit : %d\n", opt.sample_limit);
+    fprintf(stderr, "sample max duration : %d\n", opt.max_dur);
+    fprintf(stderr, "sample min duration : %d\n", opt.min_dur);
+    fprintf(stderr, "sample kmer_pick_margin : %d\n", opt.kmer_pick_margin);
+    fprintf(stderr, "dataset: %s\n", opt.flag_rna ? "RNA" : "DNA");
+
+    std::vector<std::string> slot_kmers(kmers.begin() + (opt.index_start - 1), kmers.begin() + opt.index_end);
+    if (!pgh::touch_dump_files(output_dir, slot_kmers, err)) { fprintf(stderr, "%s\n", err.c_str()); return EXIT_FAILURE; } // gmove.cpp:460-473
+
+    int scaling; // src/gmove.cpp:479-491
+    if (signal_scale == 0) { scaling = 0; fprintf(stderr, "scaling: %s\n", "no scale"); }
+    else if (signal_scale == 1) { scaling = 1; fprintf(stderr, "scaling: %s\n", "medmad scale"); }
+    else { print_help(fp_help, opt); return EXIT_FAILURE; }
+
+    pgh::Slow5File s5;
+    if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return EXIT_FAILURE; } // gmove.cpp:493-503
+
+    const std::string mt(move_table); // src/gmove.cpp:505-521
+    const std::string ext = mt.size() >= 4 ? mt.substr(mt.size() - 4) : "";
+    if (ext != ".paf") {
+        fprintf(stderr, "this build implements the .paf (ss:Z:) front-end of gmove; move-table and SAM/BAM inputs are not implemented\n");
+        return EXIT_FAILURE;
+    }
+    if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return EXIT_FAILURE; } // gmove.cpp:510-513
+    pgh::FastxIndex fai;
+    if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return EXIT_FAILURE; }
+    FILE *paf_fp = fopen(move_table, "r");
+    if (!paf_fp) { fprintf(stderr, "Error in opening file %s\n", move_table); return EXIT_FAILURE; }
+
+    // ---- device context -----------------------------------------------------------------------------
+    if (opt.kmer_size > 13) return die("kmer sizes above 13 are not supported by this implementation");
+    std::vector<int32_t> table_t((size_t)1 << (2 * opt.kmer_size)), table_u(table_t.size());
+    {
+        std::vector<const char *> ptrs; for (auto &s : slot_kmers) ptrs.push_back(s.c_str());
+        if (pg_build_slot_tables(opt.kmer_size, ptrs.data(), (uint32_t)ptrs.size(), table_t.data(), table_u.data()) != PG_OK) {
+            fprintf(stderr, "%s\n", pg_last_error(nullptr)); return EXIT_FAILURE;
+        }
+    }
+    pg_params prm; pg_default_params(&prm);
+    prm.kmer_size = opt.kmer_size; prm.sig_move_offset = opt.sig_move_offset; prm.signal_print_margin = opt.signal_print_margin;
+    prm.sample_limit = opt.sample_limit; prm.max_dur = opt.max_dur; prm.min_dur = opt.min_dur; prm.kmer_pick_margin = (int32_t)opt.kmer_pick_margin;
+    prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
+    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = lazy ? PG_FLAG_LAZY_STATS : 0; prm.device = device;
+    prm.table_t = table_t.data(); prm.table_u = table_u.data();
+    pg_ctx *ctx = nullptr;
+    if (pg_create(&prm, &ctx) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(nullptr)); return EXIT_FAILURE; }
+
+    // ---- the read loop (src/gmove.cpp:732-969), batched ---------------------------------------------------
+    HostBatch hb;
+    pgh::Slow5Rec rec;
+    std::string seq;
+    char *line = nullptr; size_t cap = 0; ssize_t got;
+    int status = EXIT_SUCCESS;
+    uint64_t count_reads = 0, total_samples = 0;
+    bool stop = false;
+    auto flush = [&]() -> bool {
+        if (hb.n() == 0) return true;
+        pg_batch b; memset(&b, 0, sizeof b);
+        b.struct_size = sizeof b; b.location = PG_LOC_HOST; b.n_reads = hb.n();
+        b.sig = hb.sig.data(); b.sig_off = hb.sig_off.data(); b.digitisation = hb.dig.data(); b.offset = hb.off.data(); b.range = hb.range.data();
+        b.query_start = hb.qs.data(); b.target_start = hb.ts.data(); b.target_end = hb.te.data(); b.seq = hb.seq.data(); b.seq_off = hb.seq_off.data();
+        b.op_n = hb.op_n.data(); b.op_t = hb.op_t.data(); b.op_off = hb.op_off.data();
+        pg_status s = pg_submit(ctx, &b);
+        if (s == PG_OK) s = pg_sync(ctx);
+        if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); return false; }
+        hb.clear();
+        if (pg_all_slots_full(ctx)) stop = true; // every file is closed: nothing later can be written (gmove.cpp:733-735)
+        return true;
+    };
+    while (!stop && (got = getline(&line, &cap, paf_fp)) != -1) {
+        pgh::PafRec paf;
+        int pr = pgh::parse_paf_line(line, (size_t)got, paf);
+        if (pr == 1) { fprintf(stderr, "malformed PAF record (fewer than 12 columns)\n"); status = EXIT_FAILURE; break; }
+        if (pr == 2) { fprintf(stderr, "ss:Z: tag not found in paf record for %s\n", paf.rid.c_str()); status = EXIT_FAILURE; break; } // gmove.cpp:1046-1049
+        if (!s5.get(paf.rid, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }              // gmove.cpp:745-749
+        const size_t ops_before = hb.op_n.size();
+        if (!pgh::tokenize_ss(paf.ss, paf.ss_len, hb.op_n, hb.op_t, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; break; }
+        (void)ops_before;
+        // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
+        const int64_t a = paf.target_start, b2 = paf.target_end;
+        const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
+        fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), seq); // absent name: empty sequence -> the read is skipped on the device
+        hb.sig.insert(hb.sig.end(), rec.raw.begin(), rec.raw.end()); hb.sig_off.push_back(hb.sig.size());
+        hb.dig.push_back(rec.digitisation); hb.off.push_back(rec.offset); hb.range.push_back(rec.range);
+        hb.qs.push_back(paf.query_start); hb.ts.push_back(paf.target_start); hb.te.push_back(paf.target_end);
+        hb.seq.insert(hb.seq.end(), seq.begin(), seq.end()); hb.seq_off.push_back(hb.seq.size());
+        hb.op_off.push_back(hb.op_n.size());
+        total_samples += rec.raw.size();
+        if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
+        if (hb.n() >= batch_reads || hb.sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
+    }
+    if (status == EXIT_SUCCESS && !flush()) status = EXIT_FAILURE;
+    free(line); fclose(paf_fp);
+
+    if (status == EXIT_SUCCESS) {
+        pg_result res;
+        if (pg_finish(ctx, &res) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+        else {
+            pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads};
+            unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
+            if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
+            fprintf(stderr, "\n[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
+                    (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, device);
+        }
+    }
+    pg_destroy(ctx);
+    return status;
+}

@@ -1,0 +1,93 @@
+// pg_host.h -- host side of the `poregen gmove` drop-in: file parsers, k-mer list, dump writer.
+// Everything here is I/O and bookkeeping; the computation is behind include/pgmove.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace pgh {
+
+// ---- memory-mapped read-only file ---------------------------------------------------------------------
+struct MappedFile {
+    const char *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    bool open(const std::string &path);
+    void close();
+    ~MappedFile() { close(); }
+};
+
+// ---- SLOW5 / BLOW5 (replaces slow5_open / slow5_idx_load / slow5_get, src/gmove.cpp:493-503,745) --------
+struct Slow5Rec {
+    double digitisation = 0, offset = 0, range = 0;
+    std::vector<int16_t> raw;
+};
+class Slow5File {
+public:
+    bool open(const std::string &path, std::string &err); // opens and indexes (read id -> record location)
+    bool get(const std::string &read_id, Slow5Rec &out, std::string &err) const; // false if absent / malformed
+    size_t n_reads() const { return index_.size(); }
+    bool is_binary() const { return binary_; }
+    const std::vector<std::string> &ids_in_file_order() const { return order_; }
+private:
+    struct Loc { uint64_t off, len; };
+    MappedFile f_;
+    bool binary_ = false;
+    uint8_t rec_press_ = 0, sig_press_ = 0;
+    int col_dig_ = 2, col_off_ = 3, col_range_ = 4, col_len_ = 6, col_sig_ = 7;
+    std::unordered_map<std::string, Loc> index_;
+    std::vector<std::string> order_;
+    bool index_ascii(std::string &err);
+    bool index_blow5(std::string &err);
+    bool decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) const;
+};
+
+// ---- FASTA/FASTQ with faidx semantics (replaces fai_load / faidx_fetch_seq, src/gmove.cpp:724,805) -----
+class FastxIndex {
+public:
+    bool load(const std::string &path, std::string &err);
+    // htslib 1.17 faidx_fetch_seq(fai, name, beg, end, &len): [beg,end] 0-based inclusive, clamped into the
+    // sequence; returns false (len = -2 in htslib) when the name is absent
+    bool fetch(const std::string &name, int64_t beg, int64_t end, std::string &out) const;
+private:
+    struct Ent { uint64_t seq_off; int64_t len; uint32_t line_bases, line_width; };
+    MappedFile f_;
+    std::unordered_map<std::string, Ent> idx_;
+};
+
+// ---- PAF with ss:Z: (replaces parse_paf_rec, src/gmove.cpp:977-1052) -----------------------------------
+struct PafRec {
+    std::string rid, tid;
+    int32_t qlen = 0, query_start = 0, query_end = 0, tlen = 0, target_start = 0, target_end = 0;
+    const char *ss = nullptr; // points into the line buffer
+    size_t ss_len = 0;
+};
+// returns 0 ok, 1 = fewer than 12 columns (the reference asserts), 2 = no ss:Z: tag (the reference exits 1)
+int parse_paf_line(char *line, size_t len, PafRec &out);
+// tokenises "<n>," "<n>I" "<n>D" (src/gmove.cpp:831-871); returns false on the reference's "Bad ss" exits
+bool tokenize_ss(const char *ss, size_t len, std::vector<uint32_t> &op_n, std::vector<uint8_t> &op_t, std::string &err);
+
+// ---- k-mer list (src/poregen.cpp:248-267, src/gmove.cpp:394-426) ----------------------------------------
+void generate_kmers(int k, bool rna, std::vector<std::string> &out);
+// returns 0 ok, 1 cannot open, 2 a line does not have exactly k characters + '\n'
+int read_kmer_file(const std::string &path, int k, std::vector<std::string> &out, std::string &err);
+
+// ---- dump directory (src/gmove.cpp:107-140, 460-473, 525-534, 938-950, 196-203) -------------------------
+int create_dir(const char *dir_name); // 0 ok / created, -1 exists and not empty, -2 cannot create
+// "%.8f" exactly as glibc printf prints it; returns the number of characters written (buf >= 400 bytes)
+size_t format_f8(double v, char *buf);
+struct DumpInput {
+    uint32_t n_slots;
+    const uint64_t *counts, *ev_off, *samp_off;
+    const uint32_t *ev_len, *ev_read;
+    const double *samples;
+    const uint8_t *read_skipped;
+    uint64_t n_reads;
+};
+// writes dump/<kmer> for every slot and freq.txt; delimit = -d; returns false on I/O error
+bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const DumpInput &in, bool delimit,
+                    uint32_t sample_limit, unsigned n_threads, std::string &err);
+bool touch_dump_files(const std::string &out_dir, const std::vector<std::string> &slot_kmers, std::string &err);
+
+} // namespace pgh

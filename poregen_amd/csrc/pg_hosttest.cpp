@@ -26,3 +26,54 @@ extern "C" int pgt_medmad(const int16_t *raw, uint64_t n, double dig, double off
     *med = mm.med; *mad = mm.mad; *mad_raw = mm.mad_raw;
     return 0;
 }
+
+// ---- host parsers / writer of the CLI (poregen_amd/csrc/host) ------------------------------------------
+#include "host/pg_host.h"
+#include <cstring>
+#include <string>
+
+extern "C" size_t pgt_format_f8(double v, char *buf) { return pgh::format_f8(v, buf); }
+
+// returns number of ops, or -1 on a "Bad ss" condition; fills up to cap entries
+extern "C" long pgt_tokenize_ss(const char *ss, uint32_t *op_n, uint8_t *op_t, size_t cap) {
+    std::vector<uint32_t> n; std::vector<uint8_t> t; std::string err;
+    if (!pgh::tokenize_ss(ss, strlen(ss), n, t, err)) return -1;
+    for (size_t i = 0; i < n.size() && i < cap; i++) { op_n[i] = n[i]; op_t[i] = t[i]; }
+    return (long)n.size();
+}
+
+// fetch [beg,end] of `name`; returns length or -2 if the name is absent (htslib contract), -3 on I/O error
+extern "C" long pgt_fastx_fetch(const char *path, const char *name, long beg, long end, char *out, size_t cap) {
+    pgh::FastxIndex fx; std::string err, s;
+    if (!fx.load(path, err)) return -3;
+    if (!fx.fetch(name, beg, end, s)) return -2;
+    if (s.size() < cap) { memcpy(out, s.data(), s.size()); out[s.size()] = 0; }
+    return (long)s.size();
+}
+
+// decode one read of a SLOW5/BLOW5 file; returns len_raw_signal or -1; copies up to cap samples
+extern "C" long pgt_slow5_get(const char *path, const char *read_id, double *dig_off_range, int16_t *raw, size_t cap) {
+    pgh::Slow5File f; std::string err;
+    if (!f.open(path, err)) return -1;
+    pgh::Slow5Rec r;
+    if (!f.get(read_id, r, err)) return -1;
+    dig_off_range[0] = r.digitisation; dig_off_range[1] = r.offset; dig_off_range[2] = r.range;
+    for (size_t i = 0; i < r.raw.size() && i < cap; i++) raw[i] = r.raw[i];
+    return (long)r.raw.size();
+}
+
+extern "C" long pgt_slow5_count(const char *path) {
+    pgh::Slow5File f; std::string err;
+    if (!f.open(path, err)) return -1;
+    return (long)f.n_reads();
+}
+
+extern "C" int pgt_parse_paf(char *line, int32_t *cols6, char *rid, char *tid, char *ss, size_t cap) {
+    pgh::PafRec p;
+    int rc = pgh::parse_paf_line(line, strlen(line), p);
+    if (rc != 0) return rc;
+    cols6[0] = p.qlen; cols6[1] = p.query_start; cols6[2] = p.query_end; cols6[3] = p.tlen; cols6[4] = p.target_start; cols6[5] = p.target_end;
+    snprintf(rid, cap, "%s", p.rid.c_str()); snprintf(tid, cap, "%s", p.tid.c_str());
+    if (p.ss_len < cap) { memcpy(ss, p.ss, p.ss_len); ss[p.ss_len] = 0; }
+    return 0;
+}

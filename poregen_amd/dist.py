@@ -27,8 +27,9 @@ def exchange_bases(counts, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    allc = torch.empty((world,) + tuple(counts.shape), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(allc, counts.contiguous(), group=group)
+    flat = torch.empty(world * counts.numel(), dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(flat, counts.contiguous().view(-1), group=group)
+    allc = flat.view(world, -1)
     base = allc[:rank].sum(dim=0) if rank > 0 else torch.zeros_like(counts)
     return base, allc.sum(dim=0)
 

@@ -1,0 +1,143 @@
+"""`poregen gmove` (bin/poregen): argument handling on any box; on the GPU box whole output directories are
+diffed byte for byte against the CPU oracle's CLI on the reference fixtures and on synthetic SLOW5+PAF+FASTQ."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from poregen_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin", "poregen")
+G = os.path.join(ROOT, "tests", "golden", "single_read")
+
+
+def cli(args, **kw):
+    return subprocess.run([BIN, "gmove"] + [str(a) for a in args], capture_output=True, text=True, **kw)
+
+
+def oracle_cli(args):
+    return subprocess.run([orc.CLI] + [str(a) for a in args], capture_output=True, text=True)
+
+
+def assert_same_dirs(a, b):
+    assert open(os.path.join(a, "freq.txt")).read() == open(os.path.join(b, "freq.txt")).read()
+    cmp = filecmp.dircmp(os.path.join(a, "dump"), os.path.join(b, "dump"))
+    assert not cmp.left_only and not cmp.right_only
+    _, mismatch, errors = filecmp.cmpfiles(os.path.join(a, "dump"), os.path.join(b, "dump"), cmp.common_files, shallow=False)
+    assert not mismatch and not errors, mismatch[:5]
+
+
+# ---- any box ------------------------------------------------------------------------------------------
+
+def test_usage_and_exit_codes(tmp_path):
+    assert cli([]).returncode == 1                                                                   # test_gmove.sh 0.1
+    r = cli(["--help"]); assert r.returncode == 0 and "Usage: poregen gmove" in r.stdout
+    assert cli([f"{G}/reads.slow5", f"{G}/guppy_move", "--kmer_file", f"{G}/kmer_file.txt", tmp_path / "a"]).returncode == 1   # 0.3 (k=9 vs 6-mers)
+    r = cli([f"{G}/reads.slow5", f"{G}/guppy_move.paf", "--file_limit", "50", tmp_path / "b"])       # 0.5
+    assert r.returncode == 1 and ".paf input requires an additional .fastq file" in r.stderr
+    d = tmp_path / "d"; d.mkdir(); (d / "x").write_text("x")
+    r = cli([f"{G}/reads.slow5", f"{G}/guppy_move.paf", "--fastq", f"{G}/read_0.fastq", d])
+    assert r.returncode == 1 and "is not empty" in r.stderr
+    assert cli(["-k", "0", "a", "b", "c"]).returncode == 1
+    assert cli(["--scaling", "2", f"{G}/reads.slow5", f"{G}/guppy_move.paf", "--fastq", f"{G}/read_0.fastq", tmp_path / "e"]).returncode == 1
+    r = subprocess.run([BIN, "--version"], capture_output=True, text=True); assert r.returncode == 0
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    r = cli(["-k", "6", f"{G}/reads.slow5", f"{G}/guppy_move.paf", tmp_path / "o", "--fastq", f"{G}/read_0.fastq"])
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    # the output layout is created before the device is needed, exactly like the reference creates it up front
+    assert os.path.isdir(tmp_path / "o" / "dump")
+
+
+# ---- GPU box ------------------------------------------------------------------------------------------
+
+FIXTURE_CASES = {
+    "ka1": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt"],
+    "ka2_scaling": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt", "--scaling", "1"],
+    "ka3_pamin": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt", "--scaling", "1", "--pa_min", "100"],
+    "ka5_delimit": ["-k", "6", "-d", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/single_kmer_file.txt"],
+    "ka6_defaults": ["{G}/reads.slow5", "{G}/guppy_move.paf", "--file_limit", "50", "{OUT}", "--fastq", "{G}/read_0.fastq"],
+    "margin0_k5_all": ["-k", "5", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--file_limit", "5000", "--kmer_pick_margin", "0", "--scaling", "1"],
+    "print_margin2": ["-k", "5", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--file_limit", "5000", "--kmer_pick_margin", "1", "--scaling", "1", "--margin", "2"],
+    "slice": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt", "--index_start", "10", "--index_end", "40", "-d"],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FIXTURE_CASES))
+def test_fixture_dirs_equal_oracle(tmp_path, name):
+    a, b = tmp_path / "gpu", tmp_path / "cpu"
+    args = FIXTURE_CASES[name]
+    r = cli([x.replace("{G}", G).replace("{OUT}", str(a)) for x in args]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([x.replace("{G}", G).replace("{OUT}", str(b)) for x in args]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,extra", [
+    ("rna004", ["-k", "5", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40", "--file_limit", "1024", "--sample_limit", "30"]),
+    ("rna004", ["-k", "5", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40", "--file_limit", "1024", "--sample_limit", "4", "-d", "--batch_reads", "37"]),
+    ("dna_r10", ["-k", "6", "--scaling", "1", "--file_limit", "4096", "--sample_limit", "12", "--kmer_pick_margin", "1"]),
+    ("dna_r10", ["-k", "9", "--scaling", "1", "--index_start", "1000", "--index_end", "3000", "--sample_limit", "5", "--batch_reads", "50"]),
+])
+def test_synthetic_files_equal_oracle(tmp_path, kind, extra):
+    b = synth.make_batch(160, kind=kind, seed=77, indel_rate=0.02)
+    pre = str(tmp_path / "syn")
+    synth.write_files(b, pre)
+    common = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq"] + extra
+    r = cli(common + [tmp_path / "gpu"]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([x for x in common if x not in ("--batch_reads", "37", "50")] + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+
+
+@pytest.mark.gpu
+def test_print_margin_larger_than_window_start_is_rejected(tmp_path):
+    """--margin > start of an accepted window is undefined behaviour in the reference (unsigned wrap at
+    src/gmove.cpp:928-932); the oracle flags it (exit 70) and the product refuses it (exit 1)."""
+    args = ["-k", "5", f"{G}/reads.slow5", f"{G}/guppy_move.paf", "--fastq", f"{G}/read_0.fastq", "--file_limit", "5000", "--kmer_pick_margin", "0", "--margin", "2"]
+    r = cli(args + [tmp_path / "gpu"]); assert r.returncode == 1 and "margin > start" in r.stderr
+    assert oracle_cli(args + [tmp_path / "cpu"]).returncode == 70
+
+
+@pytest.mark.gpu
+def test_rna_record_without_flag_exits_1(tmp_path):
+    b = synth.make_batch(5, kind="rna004", seed=78)
+    pre = str(tmp_path / "syn"); synth.write_files(b, pre)
+    r = cli(["-k", "5", pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq", tmp_path / "o"])
+    assert r.returncode == 1 and "allow_rna" in r.stderr     # src/gmove.cpp:795-797
+
+
+@pytest.mark.gpu
+def test_blow5_input_equals_ascii_input(tmp_path):
+    """The reference's BLOW5 fixture (zlib + svb-zd) through the CLI == the same reads as ASCII SLOW5 through the oracle."""
+    import ctypes as C
+    h = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
+    b5 = os.path.join(ROOT, "tests", "golden", "blow5", "example.blow5")
+    rng = np.random.default_rng(3)
+    with open(tmp_path / "r.slow5", "w") as s5, open(tmp_path / "r.paf", "w") as paf, open(tmp_path / "r.fastq", "w") as fq:
+        s5.write("#slow5_version\t0.2.0\n#num_read_groups\t1\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
+        for i in range(1, 6):
+            dor = np.zeros(3); raw = np.zeros(100000, np.int16)
+            n = h.pgt_slow5_get(b5.encode(), f"r{i}".encode(), dor.ctypes.data, raw.ctypes.data, 100000)
+            s5.write(f"r{i}\t0\t{dor[0]:.17g}\t{dor[1]:.17g}\t{dor[2]:.17g}\t4000\t{n}\t" + ",".join(map(str, raw[:n].tolist())) + "\n")
+            nb = 900
+            d = rng.integers(5, 60, nb); d[-1] += 0
+            seq = "".join("ACGT"[x] for x in rng.integers(0, 4, nb))
+            fq.write(f"@r{i}\n{seq}\n+\n{'I' * nb}\n")
+            paf.write(f"r{i}\t{n}\t100\t{n}\t+\tr{i}\t{nb}\t0\t{nb}\t{nb}\t{nb}\t255\tss:Z:" + "".join(f"{x}," for x in d) + "\n")
+    extra = ["-k", "5", "--scaling", "1", "--file_limit", "1024", "--sample_limit", "6", "--pa_min", "60", "--pa_max", "140"]
+    r = cli([b5, tmp_path / "r.paf", "--fastq", tmp_path / "r.fastq", tmp_path / "gpu"] + extra); assert r.returncode == 0, r.stderr
+    o = oracle_cli([tmp_path / "r.slow5", tmp_path / "r.paf", "--fastq", tmp_path / "r.fastq", tmp_path / "cpu"] + extra); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")

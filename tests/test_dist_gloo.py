@@ -1,0 +1,81 @@
+"""The N>1 path on CPU: two `gloo` ranks run poregen_amd.dist.sharded_step on contiguous PAF-order shards.
+The GPU engine is replaced by a stand-in with the same count/collect contract built on the CPU oracle (this
+is a test of the exchange logic, not of the kernels), and the rank-ordered concatenation must equal a single
+sequential oracle run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """count(): accepted events per slot of the shard, uncapped. collect(base): keep the events whose global
+    rank base+local is < sample_limit. Same contract as GmoveEngine.count/collect (include/pgmove.h)."""
+
+    def __init__(self, kmers, p):
+        from helpers import oracle_for
+        self.kmers, self.p = kmers, p
+        self.n_slots = len(kmers)
+        big = dict(p); big["sample_limit"] = 2 ** 31 - 1
+        self.o = oracle_for(kmers, **big)
+
+    def count(self, shard):
+        self.o.run_batch(shard)
+        return self.o.counts().astype(np.uint64)
+
+    def collect(self, base):
+        lim = self.p["sample_limit"]
+        self.kept = []
+        for s in range(self.n_slots):
+            room = max(0, lim - int(base[s]))
+            lens = self.o.event_lens(s)[:room]
+            self.kept.append(self.o.values(s)[: int(lens.sum())])
+
+    def sync(self):
+        pass
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from poregen_amd import dist as pgdist
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    tdist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    b = synth.make_batch(120, kind="rna004", seed=21, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=9)
+    kmers = generate_kmers(5, rna=True)
+    lo, hi = pgdist.shard_bounds(b.n_reads, world, rank)
+    eng = OracleEngine(kmers, p)
+    total = pgdist.sharded_step(eng, b.slice_reads(lo, hi))
+    freq = pgdist.merged_freq(total, p["sample_limit"]).numpy()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), freq=freq, sizes=np.array([v.size for v in eng.kept]),
+             flat=np.concatenate(eng.kept) if eng.kept else np.zeros(0))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_sequential_oracle(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from helpers import oracle_for
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    b = synth.make_batch(120, kind="rna004", seed=21, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=9)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
+    assert np.array_equal(r[0]["freq"], r[1]["freq"])
+    assert np.array_equal(r[0]["freq"].astype(np.uint64), o.counts())
+    offs = [np.concatenate([[0], np.cumsum(x["sizes"])]) for x in r]
+    for s in range(len(kmers)):
+        cat = np.concatenate([r[i]["flat"][offs[i][s]:offs[i][s + 1]] for i in range(2)])
+        assert np.array_equal(cat.view(np.uint64), o.values(s).view(np.uint64)), s

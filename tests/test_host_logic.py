@@ -1,0 +1,58 @@
+"""Host-side logic of the Python layer (no GPU): k-mer list, slice reconciliation, generator, shard bounds,
+dump text assembly."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+from poregen_amd import dist, synth
+from poregen_amd.engine import Result, generate_kmers, reconcile_slice
+
+
+def test_generate_kmers_matches_oracle():
+    for k, rna in ((1, False), (3, True), (5, False)):
+        L = orc.lib()
+        L.orc_generate_kmers.restype = C.POINTER(C.c_char_p); L.orc_generate_kmers.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        n = C.c_size_t()
+        arr = L.orc_generate_kmers(k, int(rna), C.byref(n))
+        ref = [arr[i].decode() for i in range(n.value)]
+        assert generate_kmers(k, rna) == ref and len(ref) == 4 ** k
+
+
+def test_reconcile_slice():
+    assert reconcile_slice(1024, 1, 5000, 5000) == (1, 1024)      # --file_limit 5000 at k=5 (README)
+    assert reconcile_slice(262144, 1, 500, 500) == (1, 500)       # defaults at k=9
+    assert reconcile_slice(300, 51, 250, 200) == (51, 250)        # config 4 slice
+    assert reconcile_slice(53, 1, 500, 500) == (1, 53)            # kmer_file with 53 lines, defaults
+
+
+def test_generators_are_deterministic_and_well_formed():
+    a = synth.make_batch(40, kind="rna004", seed=3, indel_rate=0.02)
+    b = synth.make_batch(40, kind="rna004", seed=3, indel_rate=0.02)
+    for name in ("sig", "op_n", "op_t", "seq", "sig_off", "op_off", "seq_off"):
+        assert np.array_equal(getattr(a, name), getattr(b, name))
+    for r in range(a.n_reads):
+        ops_n = a.op_n[int(a.op_off[r]):int(a.op_off[r + 1])]; ops_t = a.op_t[int(a.op_off[r]):int(a.op_off[r + 1])]
+        assert int(ops_n[ops_t != 2].sum()) == int(a.sig_off[r + 1] - a.sig_off[r])          # matches + insertions cover the signal
+        assert int((ops_t == 0).sum() + ops_n[ops_t == 2].sum()) == int(a.seq_off[r + 1] - a.seq_off[r])  # matches + deleted bases = sequence
+        assert a.target_start[r] > a.target_end[r] == 0
+    f = synth.make_batch_fast(300, kind="dna_r10", seed=4)
+    assert f.n_samples == 300 * 4000 and np.all(f.target_start == 0)
+    assert int(f.op_n.sum()) == f.n_samples
+
+
+def test_shard_bounds_cover_in_order():
+    for n, w in ((10, 3), (400000, 8), (7, 8)):
+        b = [dist.shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_slot_text_delimiters():
+    # two slots, three reads; slot 0 closes (sample_limit 2) during read 1, slot 1 never fills; read 2 is skipped
+    res = Result(counts=np.array([2, 1], np.uint64), ev_off=np.array([0, 2, 3], np.uint64), ev_len=np.array([1, 2, 1], np.uint32),
+                 ev_read=np.array([0, 1, 1], np.uint32), samp_off=np.array([0, 1, 3, 4], np.uint64),
+                 samples=np.array([1.0, 2.5, -0.125, 100.123456789]), read_skipped=np.array([0, 0, 1], np.uint8), n_reads=3)
+    assert res.slot_text(0) == "1.00000000;2.50000000,-0.12500000;"
+    assert res.slot_text(0, delimit=True, sample_limit=2) == "1.00000000;:2.50000000,-0.12500000;"
+    assert res.slot_text(1, delimit=True, sample_limit=2) == ":100.12345679;:"

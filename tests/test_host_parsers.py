@@ -1,0 +1,128 @@
+"""Host-side C++ of the CLI (poregen_amd/csrc/host), exercised without a GPU through the host test shim:
+SLOW5/BLOW5 reader, FASTQ fetch with faidx clamping, PAF + ss tokeniser, exact %.8f formatting."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden", "single_read")
+B5 = os.path.join(ROOT, "tests", "golden", "blow5")
+
+
+@pytest.fixture(scope="module")
+def h():
+    lib = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    lib.pgt_format_f8.argtypes = [C.c_double, C.c_char_p]; lib.pgt_format_f8.restype = C.c_size_t
+    lib.pgt_tokenize_ss.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; lib.pgt_tokenize_ss.restype = C.c_long
+    lib.pgt_fastx_fetch.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long, C.c_char_p, C.c_size_t]; lib.pgt_fastx_fetch.restype = C.c_long
+    lib.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; lib.pgt_slow5_get.restype = C.c_long
+    lib.pgt_slow5_count.argtypes = [C.c_char_p]; lib.pgt_slow5_count.restype = C.c_long
+    lib.pgt_parse_paf.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]; lib.pgt_parse_paf.restype = C.c_int
+    return lib
+
+
+def test_format_f8_equals_printf(h):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([
+        rng.normal(0, 2, 20000), rng.uniform(40, 180, 20000), rng.normal(0, 1e-6, 2000), rng.normal(0, 1e5, 2000),
+        np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0 ** -9, 3 * 2.0 ** -9, -(2.0 ** -9), 0.001953125, 1e-9, -1e-9, 4.9e-9, 5e-9, 5.1e-9,
+                  123456.123456785, 0.000000005, 0.000000015, 99999999.99999999, 1e15]),
+        (rng.integers(-10 ** 12, 10 ** 12, 5000) + 0.5) / 1e8,   # decimal ties at the 9th digit (not exactly representable)
+        rng.integers(-2 ** 20, 2 ** 20, 3000) / 2.0 ** 12,       # exactly representable, some with exact binary ties
+    ])
+    buf = C.create_string_buffer(400)
+    for v in vals:
+        n = h.pgt_format_f8(float(v), buf)
+        assert buf.raw[:n].decode() == "%.8f" % float(v), v
+
+
+def test_tokenize_ss(h):
+    n = np.zeros(64, np.uint32); t = np.zeros(64, np.uint8)
+    assert h.pgt_tokenize_ss(b"10,5,3D12,40I7,", n.ctypes.data, t.ctypes.data, 64) == 6
+    assert n[:6].tolist() == [10, 5, 3, 12, 40, 7] and t[:6].tolist() == [0, 0, 2, 0, 1, 0]
+    assert h.pgt_tokenize_ss(b"", n.ctypes.data, t.ctypes.data, 64) == 0
+    for bad in (b",5,", b"5,,3,", b"5x3,", b"12345678901,", b"-5,", b"4294967295,"):   # the reference's "Bad ss" exits
+        assert h.pgt_tokenize_ss(bad, n.ctypes.data, t.ctypes.data, 64) == -1, bad
+    assert h.pgt_tokenize_ss(b"0,2147483647I", n.ctypes.data, t.ctypes.data, 64) == 2
+
+
+def test_fastx_fetch_clamping(h):
+    fq = os.path.join(G, "read_0.fastq").encode()
+    rid = b"2babd419-2e01-454a-b7f4-08ad9d4e2a9e"
+    buf = C.create_string_buffer(1000)
+    full = open(os.path.join(G, "read_0.fastq")).read().splitlines()[1]
+    assert len(full) == 481
+    assert h.pgt_fastx_fetch(fq, rid, 0, 480, buf, 1000) == 481 and buf.value.decode() == full
+    assert h.pgt_fastx_fetch(fq, rid, 3, 9, buf, 1000) == 7 and buf.value.decode() == full[3:10]
+    assert h.pgt_fastx_fetch(fq, rid, 470, 10 ** 6, buf, 1000) == 11 and buf.value.decode() == full[470:]   # end clamps to len-1
+    assert h.pgt_fastx_fetch(fq, rid, 5, 4, buf, 1000) == 1 and buf.value.decode() == full[4]                 # end < beg: beg = end
+    assert h.pgt_fastx_fetch(fq, rid, 0, -1, buf, 1000) == 1 and buf.value.decode() == full[0]                # empty target range
+    assert h.pgt_fastx_fetch(fq, rid, 600, 700, buf, 1000) == 0
+    assert h.pgt_fastx_fetch(fq, b"nope", 0, 10, buf, 1000) == -2
+
+
+def test_fastx_multiline_fasta_and_fastq(h, tmp_path):
+    p = tmp_path / "x.fa"
+    p.write_text(">a desc\nACGTAC\nGTACGT\nAC\n>b\nTTTT\n")
+    buf = C.create_string_buffer(100)
+    assert h.pgt_fastx_fetch(str(p).encode(), b"a", 4, 9, buf, 100) == 6 and buf.value == b"ACGTAC"
+    assert h.pgt_fastx_fetch(str(p).encode(), b"b", 0, 100, buf, 100) == 4 and buf.value == b"TTTT"
+    q = tmp_path / "x.fq"
+    q.write_text("@r1 x\nACGT\n+\n@@@@\n@r2\nGGCC\n+r2\nIIII\n")   # quality line starting with '@'
+    assert h.pgt_fastx_fetch(str(q).encode(), b"r2", 1, 2, buf, 100) == 2 and buf.value == b"GC"
+    assert h.pgt_fastx_fetch(str(q).encode(), b"@@@", 0, 2, buf, 100) == -2
+
+
+def test_ascii_slow5_fixture(h):
+    dor = np.zeros(3); raw = np.zeros(7000, np.int16)
+    n = h.pgt_slow5_get(os.path.join(G, "reads.slow5").encode(), b"2babd419-2e01-454a-b7f4-08ad9d4e2a9e", dor.ctypes.data, raw.ctypes.data, 7000)
+    assert n == 6020 and dor.tolist() == [2048.0, -101.0, 281.345551]
+    line = [l for l in open(os.path.join(G, "reads.slow5")) if not l.startswith(("#", "@"))][0].split("\t")
+    assert raw[:n].tolist() == [int(x) for x in line[7].split(",")]
+    assert h.pgt_slow5_get(os.path.join(G, "reads.slow5").encode(), b"missing", dor.ctypes.data, raw.ctypes.data, 7000) == -1
+
+
+def test_blow5_zlib_svbzd_means_match_reference_fixture(h):
+    """test/example.blow5 (zlib + svb-zd) -> mean pA per read == test/example.exp (the reference's subtool0 golden)."""
+    path = os.path.join(B5, "example.blow5").encode()
+    assert h.pgt_slow5_count(path) == 5
+    for line in open(os.path.join(B5, "example.exp")):
+        rid, mean = line.split()
+        dor = np.zeros(3); raw = np.zeros(100000, np.int16)
+        n = h.pgt_slow5_get(path, rid.encode(), dor.ctypes.data, raw.ctypes.data, 100000)
+        assert n > 50000
+        pa = (raw[:n].astype(np.float64) + dor[1]) * (dor[2] / dor[0])     # TO_PICOAMPS, src/poregen.h:30
+        assert "%.6f" % pa.mean() == mean
+
+
+def test_blow5_uncompressed_roundtrip(h, tmp_path):
+    """Our own uncompressed BLOW5 (record none / signal none) with two reads."""
+    p = tmp_path / "t.blow5"
+    hdr = b"#slow5_version\t0.2.0\n#num_read_groups\t1\n#char*\tuint32_t\n#read_id\tread_group\n"
+    with open(p, "wb") as f:
+        f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([0]) + struct.pack("<I", 1) + bytes([0]) + bytes(64 - 15))
+        f.write(struct.pack("<I", len(hdr)) + hdr)
+        for rid, sig in ((b"a", [1, -2, 3]), (b"bb", [7] * 10)):
+            body = struct.pack("<H", len(rid)) + rid + struct.pack("<I", 0) + struct.pack("<dddd", 2048.0, -5.0, 300.0, 4000.0)
+            body += struct.pack("<Q", len(sig)) + np.array(sig, np.int16).tobytes()
+            f.write(struct.pack("<Q", len(body)) + body)
+        f.write(b"5WOLB")
+    dor = np.zeros(3); raw = np.zeros(16, np.int16)
+    assert h.pgt_slow5_count(str(p).encode()) == 2
+    assert h.pgt_slow5_get(str(p).encode(), b"a", dor.ctypes.data, raw.ctypes.data, 16) == 3 and raw[:3].tolist() == [1, -2, 3]
+    assert h.pgt_slow5_get(str(p).encode(), b"bb", dor.ctypes.data, raw.ctypes.data, 16) == 10 and dor.tolist() == [2048.0, -5.0, 300.0]
+
+
+def test_parse_paf_fixture(h):
+    line = open(os.path.join(G, "guppy_move.paf")).read()
+    cols = (C.c_int32 * 6)(); rid = C.create_string_buffer(256); tid = C.create_string_buffer(256); ss = C.create_string_buffer(1 << 16)
+    buf = C.create_string_buffer(line.encode())
+    assert h.pgt_parse_paf(buf, cols, rid, tid, ss, 1 << 16) == 0
+    assert list(cols) == [6020, 0, 6020, 481, 0, 481] and rid.value == tid.value == b"2babd419-2e01-454a-b7f4-08ad9d4e2a9e"
+    ops = ss.value.decode()
+    assert ops.count(",") == 481 and sum(int(x) for x in ops.split(",") if x) == 6020
+    assert h.pgt_parse_paf(C.create_string_buffer(b"a\t1\t2\n"), cols, rid, tid, ss, 1 << 16) == 1
+    assert h.pgt_parse_paf(C.create_string_buffer(b"r\t10\t0\t10\t+\tt\t5\t0\t5\t5\t5\t255\tsc:f:1\n"), cols, rid, tid, ss, 1 << 16) == 2

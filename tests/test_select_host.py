@@ -1,0 +1,76 @@
+"""The shared host/device selection arithmetic (poregen_amd/csrc/pg_select.h, compiled for the host) against
+the oracle's order statistics on the doubles the reference would build (src/gmove.cpp:754-771, 142-184)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim():
+    h = ctypes.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h.pgt_medmad.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_double] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3
+    h.pgt_plan.argtypes = [ctypes.c_double] * 5 + [ctypes.c_void_p]
+    return h
+
+
+def ref_medmad(raw, dig, off, rg, pmin, pmax):
+    L = orc.lib()
+    pa = (raw.astype(np.float64) + off) * (rg / dig)
+    x = np.where((pa < pmin) | (pa > pmax), 0.0, pa)
+    med = L.orc_median(x.ctypes.data, x.size)
+    return med, L.orc_madf(x.ctypes.data, x.size, med)
+
+
+def shim_medmad(h, raw, dig, off, rg, pmin, pmax):
+    med, mad, mr = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    rc = h.pgt_medmad(raw.ctypes.data, raw.size, dig, off, rg, pmin, pmax, ctypes.byref(med), ctypes.byref(mad), ctypes.byref(mr))
+    return rc, med.value, mad.value, mr.value
+
+
+@pytest.mark.parametrize("mode", range(8))
+def test_fuzz_bit_exact(shim, mode):
+    rng = np.random.default_rng(100 + mode)
+    for trial in range(250):
+        n = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 100, 1000, 4000]))
+        dig = float(rng.choice([2048.0, 8192.0])); rg = float(rng.uniform(200, 1500))
+        off = float(rng.integers(-300, 300)) if mode != 5 else float(rng.uniform(-300, 300))
+        raw = np.clip(np.rint(rng.normal(rng.uniform(300, 1500), rng.choice([1, 5, 50, 300, 3000]), n)), -32768, 32767).astype(np.int16)
+        pmin, pmax = 40.0, 180.0
+        if mode == 1: raw[rng.random(n) < 0.3] = rng.integers(-32768, 32767)
+        if mode == 2: raw[:] = raw[0]
+        if mode == 3: pmin = 100.0
+        if mode == 4: pmin, pmax = -50.0, 60.0          # zero-filled samples sort into the middle of the values
+        if mode == 6: pmin, pmax, off = float(rng.uniform(-100, 100)), float(rng.uniform(100, 400)), float(rng.integers(-3000, -500))
+        if mode == 7: pmin, pmax = 0.0, 0.0
+        rc, med, mad, mad_raw = shim_medmad(shim, raw, dig, off, rg, pmin, pmax)
+        rm, rd = ref_medmad(raw, dig, off, rg, pmin, pmax)
+        assert rc == 0
+        assert np.float64(med).tobytes() == np.float64(rm).tobytes(), (mode, trial, n)
+        assert np.float64(mad_raw * 1.4826).tobytes() == np.float64(rd).tobytes(), (mode, trial, n)
+        assert mad == (rd if rd > 1.0 else 1.0)
+
+
+def test_fixture_read_known_answers(shim):
+    G = os.path.join(ROOT, "tests", "golden", "single_read")
+    raw = np.array([int(x) for x in [l for l in open(os.path.join(G, "reads.slow5")) if not l.startswith(("#", "@"))][0].split("\t")[7].split(",")], np.int16)
+    rc, med, mad, _ = shim_medmad(shim, raw, 2048.0, -101.0, 281.345551, 40.0, 180.0)
+    assert rc == 0 and abs(med - 111.5491149473) < 5e-11 and abs(mad - 20.1636564831) < 5e-11   # KA-2
+    rc, med, mad, _ = shim_medmad(shim, raw, 2048.0, -101.0, 281.345551, 100.0, 180.0)
+    assert rc == 0 and abs(med - 111.5491149473) < 5e-11 and abs(mad - 21.1820229721) < 5e-11   # KA-3
+
+
+def test_plan_rejects_non_positive_scale(shim):
+    out = (ctypes.c_int32 * 4)()
+    assert shim.pgt_plan(2048.0, 0.0, -5.0, 40.0, 180.0, out) == -1
+    assert shim.pgt_plan(0.0, 0.0, 5.0, 40.0, 180.0, out) == -1
+    assert shim.pgt_plan(2048.0, -101.0, 281.345551, 40.0, 180.0, out) == 0
+    c_lo, span = out[0], out[1]
+    scale = 281.345551 / 2048.0
+    assert (c_lo - 101.0) * scale >= 40.0 > (c_lo - 1 - 101.0) * scale
+    assert (c_lo + span - 1 - 101.0) * scale <= 180.0 < (c_lo + span - 101.0) * scale
