@@ -50,11 +50,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    backend = os.environ.get("PG_BENCH_BACKEND", "nccl")  # "gloo": rehearse N>1 on fewer GPUs (ranks share devices)
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     rna = args.kind == "rna004"
     p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy)
@@ -95,7 +101,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -135,6 +141,7 @@ def main():
                         f"k={args.k}, scaling med-MAD, sample_limit={args.sample_limit}" + (", min/max_dur 20/40, --rna" if rna else ""),
             "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
             "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
+            "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if world > 1 else None,
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples,
         },
         "roofline": roofline,

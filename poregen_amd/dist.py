@@ -44,12 +44,17 @@ def sharded_step(engine, shard, group=None, counts_buf=None):
     """count -> exchange -> collect for one shard. Device-resident shards exchange on the GPU (RCCL); host
     shards exchange CPU tensors (gloo). Returns the job-wide accepted counts."""
     import torch
+    import torch.distributed as dist
     if shard.on_device:
         if counts_buf is None:
             counts_buf = torch.empty(engine.n_slots, dtype=torch.int64, device=shard.sig.device)
         engine.count(shard, out=counts_buf)
         engine.sync()  # the library works on its own stream; RCCL runs on torch's
-        base, total = exchange_bases(counts_buf, group)
+        if dist.get_backend(group) == "gloo":  # rehearsal without RCCL: exchange through the host
+            base, total = exchange_bases(counts_buf.cpu(), group)
+            base = base.to(counts_buf.device)
+        else:
+            base, total = exchange_bases(counts_buf, group)
         torch.cuda.current_stream().synchronize()
         engine.collect(base.contiguous())
     else:

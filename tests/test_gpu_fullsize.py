@@ -1,0 +1,87 @@
+"""Full-size runs (BASELINE.json shapes) checked through size-independent properties and through the oracle on
+the prefix of the job that decides the output (the reference stops reading once every k-mer is complete)."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import assert_result_equals_oracle, oracle_for
+from poregen_amd import synth
+from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def check_invariants(res, sample_limit, n_reads):
+    assert np.all(res.counts <= sample_limit)
+    assert np.array_equal(np.diff(res.ev_off.astype(np.int64)), res.counts.astype(np.int64))
+    assert np.array_equal(np.diff(res.samp_off.astype(np.int64)), res.ev_len.astype(np.int64))
+    assert res.samples.size == int(res.samp_off[-1]) and np.all(np.isfinite(res.samples))
+    assert res.ev_read.size == 0 or int(res.ev_read.max()) < n_reads
+    for s in np.flatnonzero(res.counts > 1)[:200]:   # PAF-line order inside every k-mer file
+        r = res.ev_read[int(res.ev_off[s]):int(res.ev_off[s + 1])]
+        assert np.all(np.diff(r.astype(np.int64)) >= 0)
+
+
+def test_config1_full_size_rna_k5():
+    """50 000 reads x 4 000 samples, k=5, --rna --scaling 1, dur 20/40, sample_limit 100, all 1024 k-mers."""
+    b = synth.make_batch_fast(50000, kind="rna004", seed=20251003 + 1)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=100)
+    kmers = generate_kmers(5, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    check_invariants(res, 100, b.n_reads)
+    assert int(res.counts.sum()) == 1024 * 100 and eng.all_slots_full()
+    # the oracle stops (like the reference, gmove.cpp:733-735) once all k-mers are complete: its output over the
+    # prefix it reads is the output of the whole job
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(b.slice_reads(0, 12000))
+    assert rcs[-1] == orc.ORC_STOPPED
+    assert_result_equals_oracle(res, o, check_text_slots=4, sample_limit=100)
+    # same job in three uneven batches, and with lazy statistics: identical bits
+    eng.reset()
+    for lo, hi in ((0, 700), (700, 21000), (21000, 50000)):
+        eng.submit(b.slice_reads(lo, hi))
+    res2 = eng.finish()
+    assert np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64)) and np.array_equal(res2.ev_off, res.ev_off)
+    eng.close()
+    lz = GmoveEngine(GmoveParams(kmers=kmers, lazy_stats=True, **p))
+    lz.submit(b)
+    res3 = lz.finish()
+    assert np.array_equal(res3.samples.view(np.uint64), res.samples.view(np.uint64))
+    lz.close()
+
+
+def test_config3_dna_k9_all_slots():
+    """DNA, k=9 (262 144 slots: generic radix-sort ranking), sample_limit 1000, homopolymer-rich reads."""
+    b = synth.make_batch(3000, kind="dna_r10", seed=20251003 + 3, homopolymer_frac=0.1)
+    p = dict(kmer_size=9, scaling=1, sample_limit=1000)
+    kmers = generate_kmers(9)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b.slice_reads(0, 1234)); eng.submit(b.slice_reads(1234, 3000))
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 1000, b.n_reads)
+    oc = o.counts()
+    assert np.array_equal(res.counts, oc)
+    hot = np.argsort(oc)[-40:]
+    for s in list(hot) + list(np.flatnonzero(oc)[:200]):
+        assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64))
+
+
+def test_config3_full_size_properties():
+    """50 000 DNA reads, k=9: properties only at full size (counts vs limit, ordering, batch-split invariance)."""
+    b = synth.make_batch_fast(50000, kind="dna_r10", seed=20251003 + 3)
+    p = dict(kmer_size=9, scaling=1, sample_limit=1000)
+    kmers = generate_kmers(9)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    check_invariants(res, 1000, b.n_reads)
+    eng.reset()
+    eng.submit(b.slice_reads(0, 20000)); eng.submit(b.slice_reads(20000, 50000))
+    res2 = eng.finish()
+    assert np.array_equal(res2.counts, res.counts) and np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
+    eng.close()
