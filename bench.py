@@ -77,11 +77,16 @@ def main():
 
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
     counts_buf = torch.empty(len(kmers), dtype=torch.int64, device=dev)
+    stream_ordered = world > 1 and backend == "nccl"
+    if stream_ordered:  # count -> RCCL all_gather -> collect ordered on one stream, no host sync inside a step
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(side)
+        eng.use_torch_stream(side)
 
     def step():
         eng.reset()
         if world > 1:
-            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf)
+            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered)
             pgdist.merged_freq(total, args.sample_limit)
         else:
             eng.submit(shard)

@@ -29,6 +29,8 @@
  * pg_finish                        the bytes the fprintf calls would have produced, as binary
  *                                                                         src/gmove.cpp:938-950
  * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
+ * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
+ * pg_last_batch_device / pg_kernel_stats*
  */
 #ifndef PGMOVE_H
 #define PGMOVE_H
@@ -174,6 +176,10 @@ pg_status pg_count(pg_ctx *ctx, const pg_batch *batch, uint64_t *counts_out, int
 pg_status pg_collect(pg_ctx *ctx, const uint64_t *base, int32_t base_location);
 
 pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work of the context */
+/* Run the context's main chain on a caller-owned HIP stream (hipStream_t passed as void*), e.g. PyTorch's current
+ * stream, so that collectives issued by the caller between pg_count and pg_collect are ordered without host
+ * synchronisation. NULL restores the context's own stream. */
+pg_status pg_set_stream(pg_ctx *ctx, void *hip_stream);
 pg_status pg_finish(pg_ctx *ctx, pg_result *out);    /* sync, copy results to host, merge batches */
 int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events */
 

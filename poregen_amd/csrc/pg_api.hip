@@ -51,7 +51,7 @@ struct ProfEntry { const char *name; hipEvent_t a, b; };
 struct pg_ctx {
     pg_params prm{};
     int device = 0;
-    hipStream_t st = nullptr, st2 = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr, own_st = nullptr;
     hipEvent_t ev_join = nullptr, ev_fork = nullptr;
     std::string err;
     uint32_t n_codes = 0, key_bits = 1;
@@ -200,7 +200,7 @@ void pg_destroy(pg_ctx *c) {
     if (c->h_max_span) (void)hipHostFree(c->h_max_span);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->own_st) (void)hipStreamDestroy(c->own_st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     delete c;
 }
@@ -228,7 +228,8 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     c->key_bits = 1; while ((1ull << c->key_bits) < (uint64_t)p->n_slots) c->key_bits++;
     auto bail = [&](pg_status s) { g_create_error = c->err; pg_destroy(c); return s; };
 #define CTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(PG_ERR_HIP); } } while (0)
-    CTRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    CTRY(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
+    c->st = c->own_st;
     CTRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     CTRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -592,6 +593,15 @@ pg_status pg_sync(pg_ctx *c) {
     HIP_TRY(c, hipStreamSynchronize(c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st2));
     return settle_batch(c);
+}
+
+pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
+    return PG_OK;
 }
 
 int32_t pg_all_slots_full(pg_ctx *c) {

@@ -40,22 +40,27 @@ def merged_freq(total_counts, sample_limit: int):
     return torch.clamp(total_counts, max=sample_limit)
 
 
-def sharded_step(engine, shard, group=None, counts_buf=None):
+def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=False):
     """count -> exchange -> collect for one shard. Device-resident shards exchange on the GPU (RCCL); host
-    shards exchange CPU tensors (gloo). Returns the job-wide accepted counts."""
+    shards exchange CPU tensors (gloo). Returns the job-wide accepted counts.
+    stream_ordered: the engine runs on torch's current stream (GmoveEngine.use_torch_stream), so the
+    collective is ordered by the stream and no host synchronisation is needed."""
     import torch
     import torch.distributed as dist
     if shard.on_device:
         if counts_buf is None:
             counts_buf = torch.empty(engine.n_slots, dtype=torch.int64, device=shard.sig.device)
         engine.count(shard, out=counts_buf)
-        engine.sync()  # the library works on its own stream; RCCL runs on torch's
-        if dist.get_backend(group) == "gloo":  # rehearsal without RCCL: exchange through the host
+        gloo = dist.get_backend(group) == "gloo"
+        if gloo or not stream_ordered:
+            engine.sync()  # the library works on its own stream; the collective runs on torch's
+        if gloo:  # rehearsal without RCCL: exchange through the host
             base, total = exchange_bases(counts_buf.cpu(), group)
             base = base.to(counts_buf.device)
         else:
             base, total = exchange_bases(counts_buf, group)
-        torch.cuda.current_stream().synchronize()
+        if gloo or not stream_ordered:
+            torch.cuda.current_stream().synchronize()
         engine.collect(base.contiguous())
     else:
         c = engine.count(shard)

@@ -252,6 +252,16 @@ class GmoveEngine:
     def sync(self):
         self._check(self._lib.pg_sync(self._h))
 
+    def use_torch_stream(self, stream=None):
+        """Run the main chain on a torch CUDA stream (default: the current one) so that torch collectives
+        between count() and collect() are ordered on the device, without host synchronisation."""
+        import torch
+        s = torch.cuda.current_stream() if stream is None else stream
+        if not s.cuda_stream:
+            raise ValueError("use a non-default torch stream (torch.cuda.Stream() + torch.cuda.set_stream): handle 0 means "
+                             "'the context's own stream' in pg_set_stream")
+        self._check(self._lib.pg_set_stream(self._h, C.c_void_p(s.cuda_stream)))
+
     def reset(self):
         self._check(self._lib.pg_reset(self._h))
 

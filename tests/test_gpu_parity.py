@@ -133,3 +133,32 @@ def test_error_paths():
         eng.sync()  # per-read errors surface at the next synchronisation point
     assert ei.value.status == -4
     eng.close()
+
+
+def test_stream_ordered_count_collect_on_torch_stream():
+    """pg_set_stream: count -> torch op on the counts -> collect, all ordered on one torch stream, no host sync."""
+    import torch
+    b = synth.make_batch(300, kind="rna004", seed=17)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=12)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+        eng.use_torch_stream(side)
+        shards = [b.slice_reads(0, 120).to_device(dev), b.slice_reads(120, 300).to_device(dev)]
+        cnt = torch.empty(len(kmers), dtype=torch.int64, device=dev)
+        base = torch.zeros(len(kmers), dtype=torch.int64, device=dev)
+        results = []
+        for sh in shards:
+            eng.count(sh, out=cnt)
+            eng.collect(base.clone())      # device-side base, produced by torch ops on the same stream
+            base = base + cnt
+            results.append(eng.finish())
+            eng.reset()
+        eng.close()
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in results])
+        assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
