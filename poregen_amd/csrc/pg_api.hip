@@ -60,11 +60,12 @@ struct pg_ctx {
     // staged copy of a host batch
     DevBuf s_sig, s_sig_off, s_dig, s_off, s_range, s_qs, s_ts, s_te, s_seq, s_seq_off, s_op_n, s_op_t, s_op_off;
     // per-batch work buffers
-    DevBuf m_start, m_len, m_base, p_int, ev_slot, n_match, status, errflag;
+    DevBuf m_start, m_len, m_base, p_int, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan, stat_status, stat_err;
-    DevBuf n_indel, tile_read;
+    DevBuf m_read, meta;
+    bool zero_running = false;
     int32_t *h_max_span = nullptr; // pinned
     bool stats_in_flight = false, totals_known = false;
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
@@ -190,10 +191,10 @@ void pg_destroy(pg_ctx *c) {
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     DevBuf *bufs[] = {&c->table_t, &c->table_u, &c->s_sig, &c->s_sig_off, &c->s_dig, &c->s_off, &c->s_range, &c->s_qs, &c->s_ts,
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
-                      &c->p_int, &c->ev_slot, &c->n_match, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
+                      &c->p_int, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->n_indel, &c->tile_read};
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->m_read, &c->meta};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -259,9 +260,8 @@ pg_status pg_reset(pg_ctx *c) {
         HIP_TRY(c, hipStreamSynchronize(c->st2));
         prof_drain(c);
     }
-    // stream order is enough: the next batch's work is queued behind everything already submitted, and its
-    // statistics stream waits on an event recorded after this memset
-    HIP_TRY(c, hipMemsetAsync(c->running.p, 0, c->prm.n_slots * 8ull, c->st));
+    // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
+    c->zero_running = true;
     c->batches.clear();
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->cur_n_kept = c->cur_n_samples = 0;
@@ -345,18 +345,18 @@ static pg_status check_read_errors(pg_ctx *c) {
 static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
     const uint32_t n = c->B.n_reads;
     HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull));
-    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull)); HIP_TRY(c, c->stat_status.ensure((n + 1) * 4ull));
-    HIP_TRY(c, hipMemsetAsync(c->stat_status.p, 0, (n + 1) * 4ull, st));
+    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull));
     prof_begin(c, "k_read_plan", st);
-    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p, c->stat_err.as<int32_t>() + 1);
+    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p);
     prof_end(c, st);
     prof_begin(c, "k_read_stats", st);
+    const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>());
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
     pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>());
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win);
     prof_end(c, st);
     return PG_OK;
 }
@@ -366,8 +366,8 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
     W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
-    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>(); O.n_match = c->n_match.as<uint32_t>();
-    O.n_indel = c->n_indel.as<uint32_t>(); O.tile_read = c->tile_read.as<uint32_t>();
+    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>();
+    O.m_read = c->m_read.as<uint32_t>(); O.meta = c->meta.as<PgReadMeta>();
     O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
 }
 
@@ -413,8 +413,9 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     const uint64_t Nn = N ? N : 1;
     const bool direct = c->prm.n_slots <= PG_DIRECT_MAX_SLOTS;
     HIP_TRY(c, c->m_start.ensure(Nn * 4)); HIP_TRY(c, c->m_len.ensure(Nn * 4)); HIP_TRY(c, c->m_base.ensure(Nn));
-    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4)); HIP_TRY(c, c->tile_read.ensure((Nn / 256 + 2) * 4));
-    HIP_TRY(c, c->n_match.ensure((n + 1) * 4ull)); HIP_TRY(c, c->n_indel.ensure((n + 1) * 4ull)); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4)); HIP_TRY(c, c->m_read.ensure(Nn * 4));
+    HIP_TRY(c, c->meta.ensure((n + 1) * sizeof(PgReadMeta))); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->read_needed.ensure(n + 2ull)); HIP_TRY(c, c->stat_status.ensure((n + 2) * 4ull));
     const uint32_t n_tiles = (uint32_t)((Nn + PG_SORT_TILE - 1) / PG_SORT_TILE);
     uint32_t ndig;
     if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
@@ -426,9 +427,9 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16));
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
-    const int32_t errinit[2] = {INT_MAX, 0};
-    HIP_TRY(c, hipMemcpyAsync(c->errflag.p, errinit, 8, hipMemcpyHostToDevice, c->st));
-    HIP_TRY(c, hipMemcpyAsync(c->stat_err.p, errinit, 8, hipMemcpyHostToDevice, c->st));
+    pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->stat_err.as<int32_t>(), c->read_needed.as<uint8_t>(),
+                         c->stat_status.as<int32_t>(), c->running.as<uint64_t>(), c->prm.n_slots, c->zero_running ? 1 : 0);
+    c->zero_running = false;
     const bool eager_stats = c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS);
     const bool overlap = !(c->prm.flags & PG_FLAG_NO_OVERLAP);
     if (eager_stats && overlap) { // the second stream may start once the batch is resident
@@ -489,7 +490,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t ns = c->prm.n_slots, n = c->B.n_reads;
+    const uint32_t ns = c->prm.n_slots;
     const uint64_t N = c->B.n_ops;
     const bool direct = ns <= PG_DIRECT_MAX_SLOTS;
     const uint64_t *d_base = c->running.as<uint64_t>();
@@ -511,8 +512,6 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     const uint64_t samp_cap = ke_cap * win_cap;
     HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
     HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 2) * 8));
-    HIP_TRY(c, c->read_needed.ensure(n + 1ull));
-    HIP_TRY(c, hipMemsetAsync(c->read_needed.p, 0, n + 1ull, c->st));
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);

@@ -40,15 +40,24 @@ enum {
     PGR_ERR_WIDE = -9         // pa window spans more than PG_STATS_BINS codes (not implemented yet)
 };
 
+// per-read summary written by k_walk, read by k_events / k_rank_emit with two 16-byte loads
+struct __attribute__((aligned(16))) PgReadMeta {
+    uint64_t o0;     // op_off[r]
+    uint32_t n;      // matched bases (fastq_len after refinement, gmove.cpp:872); 0 for skipped / failed reads
+    uint32_t m;      // number of I/D ops
+    int32_t st_k, end_k; // min / max of the PAF target columns (gmove.cpp:792-794)
+    uint32_t L;      // len_raw_signal
+    uint32_t rna;    // target_start > target_end
+};
+
 struct PgWalkOut {
     uint32_t *m_start; // [n_ops] window start of match j of read r at op_off[r]+j  (end_raw_idx in the reference)
     uint32_t *m_len;   // [n_ops] window length
     uint8_t *m_base;   // [n_ops] 2-bit base code of the matched base, 4 = not ACGT/U
     int32_t *p_int;    // [n_ops] matched-base count at each I/D op (interior of indel_pos, gmove.cpp:843,845)
     uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
-    uint32_t *n_match; // [n_reads] matched bases (fastq_len after refinement, gmove.cpp:872); 0 for skipped/failed reads
-    uint32_t *n_indel; // [n_reads] number of I/D ops
-    uint32_t *tile_read; // [ceil(n_ops/256)] read that owns op index 256*t
+    uint32_t *m_read;  // [n_ops] read that owns op index g
+    PgReadMeta *meta;  // [n_reads]
     int32_t *status;   // [n_reads]
     int32_t *err;      // [2] err[0] = lowest read index with an error (init INT32_MAX), err[1] = its code
 };
@@ -83,6 +92,10 @@ struct PgKeptOut {
     uint32_t *ev_start;   // [n_kept] window start inside the read
     uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
 };
+// resets the per-batch flags in one launch: err words, stat_err words, read_needed[n], stat_status[n], and (if
+// zero_running) the context's running per-slot counts
+void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, int32_t *stat_err, uint8_t *read_needed,
+                          int32_t *stat_status, uint64_t *running, uint32_t n_slots, int zero_running);
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
@@ -105,11 +118,12 @@ void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t
                          uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+1 uint64
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
-// plan_buf: 16 bytes per read. max_span (device int32) receives the widest in-range code interval of the batch.
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *max_span);
+// plan_buf: 16 bytes per read
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf);
 // bins: LDS histogram size of this launch (1024 or PG_STATS_BINS); reads with a wider interval are flagged PGR_ERR_WIDE
+// win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err);
+                          double *med, double *mad, int32_t *status, int32_t *err, int win);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

@@ -97,14 +97,19 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
     const int32_t ts = B.tstart[r], te = B.tend[r], qs = B.qstart[r];
     const uint32_t k = W.k;
 
-    // k_events finds the read of an op index through the read that owns the first op of its 256-op tile
-    if (nops) for (uint64_t t = (o0 + 255) >> 8; (t << 8) < o0 + nops; t += 1) { if (lane == 0) O.tile_read[t] = r; }
-    if (lane == 0) { O.n_match[r] = 0; O.n_indel[r] = 0; O.status[r] = PGR_OK; }
+    // k_events / k_rank_emit find the read of an op index through m_read
+    for (uint32_t i = lane; i < nops; i += WAVE) O.m_read[o0 + i] = r;
+    const bool rna = ts > te;                                          // gmove.cpp:793
+    auto put_meta = [&](uint32_t n_, uint32_t m_) {
+        PgReadMeta mt; mt.o0 = o0; mt.n = n_; mt.m = m_; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
+        mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.rna = rna ? 1u : 0u;
+        O.meta[r] = mt;
+    };
+    if (lane == 0) { put_meta(0, 0); O.status[r] = PGR_OK; }
 
     int status = PGR_OK;
     // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
     if (qs < 0 || ts < 0 || te < 0 || (uint64_t)qs >= L || L > 0x7fffffffull) status = PGR_ERR_NEG;
-    const bool rna = ts > te;                                          // gmove.cpp:793
     if (status == PGR_OK && rna && !W.allow_rna) status = PGR_ERR_RNA; // gmove.cpp:795-798
     if (status == PGR_OK && slen < k) status = PGR_SKIPPED;            // gmove.cpp:806-808
     if (status != PGR_OK) {
@@ -164,14 +169,7 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
         return;
     }
     if (match_carry < k) { if (lane == 0) report_error(O, r, PGR_ERR_SHORT); return; } // unsigned wrap at gmove.cpp:891
-    if (lane == 0) { O.n_match[r] = match_carry; O.n_indel[r] = indel_carry; }
-}
-
-// the read that owns op index g
-__device__ __forceinline__ uint32_t find_read(const PgDevBatch &B, const uint32_t *__restrict__ tile_read, uint64_t g) {
-    uint32_t r = tile_read[g >> 8];
-    while (B.op_off[r + 1] <= g) ++r;
-    return r;
+    if (lane == 0) put_meta(match_carry, indel_carry);
 }
 
 // =====================================================================================================
@@ -180,42 +178,48 @@ __device__ __forceinline__ uint32_t find_read(const PgDevBatch &B, const uint32_
 __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= B.n_ops) return;
-    const uint32_t r = find_read(B, O.tile_read, g);
-    uint32_t out = PG_INVALID_SLOT;
     const uint32_t k = W.k;
-    const uint32_t n = O.n_match[r]; // 0 for skipped / failed reads
-    const uint64_t o0 = B.op_off[r];
-    const uint32_t i = (uint32_t)(g - o0);
+    // round trip 1: the owning read; round trip 2: its summary and everything that only depends on g
+    const uint32_t r = O.m_read[g];
+    const uint64_t last = B.n_ops - 1;
+    // k-mer of matched bases [g, g+k): forward code (first base most significant) and its mirror, which is
+    // what the reference reads on RNA-oriented records (gmove.cpp:883, 899)
+    uint32_t fwd = 0, rev = 0; bool bad = false;
+#pragma unroll
+    for (uint32_t t = 0; t < 13; ++t) if (t < k) {
+        const uint64_t a = g + t;
+        const uint8_t b = O.m_base[a > last ? last : a];
+        bad |= b > 3;
+        fwd = (fwd << 2) | (b & 3u);
+        rev |= (uint32_t)(b & 3u) << (2 * t);
+    }
+    const uint64_t ge = g + W.sig_move_offset > last ? last : g + W.sig_move_offset;
+    const uint32_t len = O.m_len[ge], start = O.m_start[ge];
+    const PgReadMeta mt = O.meta[r];
+    uint32_t out = PG_INVALID_SLOT;
+    const uint32_t n = mt.n; // 0 for skipped / failed reads
+    const uint32_t i = (uint32_t)(g - mt.o0);
     const uint32_t e = i + W.sig_move_offset;
     if (n >= k && i <= n - k && e < n) { // e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
-        const int32_t ts = B.tstart[r], te = B.tend[r];
-        const bool rna = ts > te;
-        const int32_t st_k = rna ? te : ts, end_k = rna ? ts : te;
-        const uint32_t m = O.n_indel[r];
-        // k-mer of matched bases [i, i+k); RNA reads it reversed (gmove.cpp:883, 899)
-        uint32_t code = 0; bool bad = false;
-        for (uint32_t t = 0; t < k; ++t) {
-            const uint8_t b = O.m_base[o0 + (rna ? i + k - 1 - t : i + t)];
-            bad |= b > 3;
-            code = (code << 2) | (b & 3u);
-        }
-        const uint32_t len = O.m_len[o0 + e];
-        const uint32_t start = O.m_start[o0 + e];
+        const bool rna = mt.rna != 0;
+        const uint32_t m = mt.m;
+        const uint32_t code = rna ? rev : fwd;
         const int32_t slot = bad ? -1 : (rna ? W.table_u : W.table_t)[code];
         // pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M]
         const int32_t M = W.pick_margin;
         const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
         const int32_t X = left + (int32_t)k + M, Y = left - M;
+        const uint64_t o0 = mt.o0;
         auto interior = [&](uint32_t u) -> int32_t { // sorted ascending in both orientations (gmove.cpp:877-882)
             return rna ? (int32_t)n - O.p_int[o0 + (m - 1 - u)] : O.p_int[o0 + u];
         };
         uint32_t lo = 0, hi = m; // first u with interior(u) >= X
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (interior(mid) >= X) hi = mid; else lo = mid + 1; }
-        const int32_t prev = lo == 0 ? -st_k : interior(lo - 1);
-        const bool pick = (lo < m) ? (prev <= Y) : (X <= end_k + M && prev <= Y);
+        const int32_t prev = lo == 0 ? -mt.st_k : interior(lo - 1);
+        const bool pick = (lo < m) ? (prev <= Y) : (X <= mt.end_k + M && prev <= Y);
         if (pick && slot >= 0 && len <= W.max_dur && len >= W.min_dur) { // gmove.cpp:916-924
             // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
-            const uint64_t L = B.sig_off[r + 1] - B.sig_off[r];
+            const uint64_t L = mt.L;
             const uint64_t wend = (uint64_t)start + len + W.print_margin > L ? L : (uint64_t)start + len + W.print_margin;
             if (W.print_margin > start || wend <= (uint64_t)(start - W.print_margin)) report_error(O, r, PGR_ERR_WINDOW);
             else out = (uint32_t)slot;
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
 }
 
 // exclusive prefix over tiles, one wave per digit; totals[d] = number of keys with that digit
-__global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals) {
+__global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
+                                                  uint64_t *__restrict__ acc_cnt, uint32_t n_slots) {
     const uint32_t d = blockIdx.x;
     const int lane = lane_id();
     uint32_t run = 0;
@@ -293,14 +298,10 @@ __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, u
         if (i < n_tiles) hist[(uint64_t)d * n_tiles + i] = run + inc - v;
         run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
     }
-    if (lane == 0) totals[d] = run;
-}
-
-// direct mode: totals[slot] are the accepted-event counts of the batch
-__global__ __launch_bounds__(256) void k_totals_to_counts(const uint32_t *__restrict__ totals, uint32_t n_slots,
-                                                          uint64_t *__restrict__ acc_cnt) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s < n_slots) acc_cnt[s] = totals[s];
+    if (lane == 0) {
+        totals[d] = run;
+        if (acc_cnt && d < n_slots) acc_cnt[d] = run; // direct mode: digit == slot, so this is the batch's accepted-event count
+    }
 }
 
 // generic mode: exclusive prefix over the digits (<= 1024) -> first output index of each digit
@@ -361,10 +362,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t *__restrict
 // window of a kept event (gmove.cpp:928-937) and its bookkeeping
 __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K,
                                            uint64_t e, uint64_t g) {
-    const uint32_t rd = find_read(B, O.tile_read, g);
+    const uint32_t rd = O.m_read[g];
     const uint64_t gm = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
     const uint32_t start = O.m_start[gm], len = O.m_len[gm];
-    const uint64_t L = B.sig_off[rd + 1] - B.sig_off[rd];
+    const uint64_t L = O.meta[rd].L;
     const uint32_t ws = start - W.print_margin; // validated in k_events
     const uint64_t we64 = (uint64_t)start + len + W.print_margin;
     const uint32_t we = (uint32_t)(we64 > L ? L : we64);
@@ -546,13 +547,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
-__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
-                                                   int32_t *__restrict__ max_span) {
+__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= B.n_reads) return;
     const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
     plan[r] = p;
-    if (p.status == 0) atomicMax(max_span, p.span);
 }
 
 // prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
@@ -569,11 +568,12 @@ template <int LOG_BPL> struct PaddedPre {
 template <int BINS, int LOW> // handles reads with LOW < span <= BINS; the BINS == PG_STATS_BINS launch flags wider ones
 __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan,
                                                    const uint8_t *__restrict__ needed, double *__restrict__ med,
-                                                   double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err) {
+                                                   double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
+                                                   int win) {
     constexpr int BPL = BINS / WAVE;                  // bins per lane in the scan
     constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
     constexpr int TRASH = BINS + WAVE;                // padded size of the real bins
-    __shared__ uint32_t hist[TRASH + 32];
+    __shared__ uint32_t hist[TRASH + 32 + 4];         // + 32 dummy bins (padded) for out-of-range samples
     const uint32_t r = blockIdx.x;
     const int lane = lane_id();
     const PgReadPlan pl = plan[r];
@@ -587,14 +587,17 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
         }
         return;
     }
-    for (int i = lane; i < TRASH + 32; i += WAVE) hist[i] = 0;
+    for (int i = lane; i < TRASH + 32 + 4; i += WAVE) hist[i] = 0;
 
     const int c_lo = pl.c_lo;
     const uint32_t span = (uint32_t)pl.span;
-    const uint32_t trash = TRASH + (lane & 31u); // out-of-range samples: spread over 32 dummy bins
+    // out-of-range samples (idx wraps to a huge unsigned value) are clamped onto 32 dummy bins behind the real
+    // ones, one per lane pair, so the inner loop is branch-free: sub, min, shift, add-shift, ds_add
+    const uint32_t cap = BINS + (lane & 31u);
+    (void)span;
     auto bin = [&](int code) {
-        const uint32_t idx = (uint32_t)(code - c_lo);
-        atomicAdd(&hist[idx < span ? idx + (idx >> LOG_BPL) : trash], 1u);
+        const uint32_t idx = min((uint32_t)(code - c_lo), cap);
+        atomicAdd(&hist[idx + (idx >> LOG_BPL)], 1u);
     };
     auto bin8 = [&](const int4 &q) {
         bin((int)(short)(q.x & 0xffff)); bin(q.x >> 16);
@@ -645,13 +648,48 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
     double best = INFINITY;
     if (sel.L > 1) {
         sel.begin_mad();
+        // 1. narrow each side with an integer-only model of the predicate (prefix lookups, no FP64)
+        sel.begin_approx();
+        const int aU = wave_first_true(sel.nU, [&](int tt) { return sel.approx_pred(true, tt); });
+        const int aD = wave_first_true(sel.nD, [&](int tt) { return sel.approx_pred(false, tt); });
+        // 2. ONE exact round: lanes 0..30 test U candidates around aU, lanes 32..62 D candidates around aD,
+        //    lane 31 the zero-filled class. The exact predicate decides; the model only placed the window.
+        const bool up = lane < 32;
+        const int sub = lane & 31, n_side = up ? sel.nU : sel.nD;
+        const int t = (up ? aU : aD) - win + sub;
+        const bool cand = sub < 2 * win + 1 && sub < 31 && t >= 0 && t < n_side;
+        double v = INFINITY; int hU = -1, hD = -1; bool act = cand;
+        if (cand) { v = sel.dev(up, t); if (up) hU = t + 1; else hD = t + 1; }
+        if (lane == 31 && sel.nZ > 0) { v = sel.dZ; act = true; }
+        const bool ok = act && sel.N(v, hU, hD) >= sel.need; // one pass of the exact predicate for all 63 candidates
+        const uint64_t okm = __ballot(ok), cm = __ballot(cand);
+        bool certain[2];
         for (int side = 0; side < 2; ++side) {
-            const bool up = side == 0;
-            const int n = up ? sel.nU : sel.nD;
-            const int t = wave_first_true(n, [&](int tt) { return sel.mad_pred(up, tt); });
-            if (t < n) { const double v = sel.dev(up, t); if (v < best) best = v; }
+            const uint64_t lanes = side == 0 ? 0x7fffffffull : (0x7fffffffull << 32);
+            const uint64_t o = okm & lanes, c = cm & lanes;
+            const int n = side == 0 ? sel.nU : sel.nD, a = side == 0 ? aU : aD;
+            if (n == 0) { certain[side] = true; continue; }
+            if (o) {
+                const int fl = __ffsll((long long)o) - 1;           // first lane whose candidate qualifies
+                const int ft = a - win + (fl & 31);
+                const bool prev_tested = fl > (__ffsll((long long)c) - 1); // the candidate before it was tested (and failed)
+                certain[side] = ft == 0 || prev_tested;
+                if (certain[side]) { const double vv = __shfl(v, fl, WAVE); if (vv < best) best = vv; }
+            } else {
+                // no candidate in the window qualifies: conclusive only if the window reached the last code
+                const int last_t = c ? a - win + ((63 - __clzll((long long)c)) & 31) : -1;
+                certain[side] = last_t == n - 1;
+            }
         }
-        if (sel.z_ok() && sel.dZ < best) best = sel.dZ;
+        // 3. fall back to the full exact search for a side the window could not decide (rare)
+        for (int side = 0; side < 2; ++side) {
+            if (certain[side]) continue;
+            const bool u2 = side == 0;
+            const int n = u2 ? sel.nU : sel.nD;
+            const int tt = wave_first_true(n, [&](int x) { return sel.mad_pred(u2, x); });
+            if (tt < n) { const double vv = sel.dev(u2, tt); if (vv < best) best = vv; }
+        }
+        if ((okm >> 31) & 1) { const double vz = sel.dZ; if (vz < best) best = vz; }
     }
     const PgMedMad mm = sel.finish(best);
     if (lane == 0) { med[r] = mm.med; mad[r] = mm.mad; }
@@ -665,15 +703,16 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
                                                 double *__restrict__ samples) {
-    const int lane = lane_id();
+    // 16 lanes per kept event (windows are a few tens of samples): 16 events per workgroup
+    const uint32_t sub = threadIdx.x & 15u;
     const uint64_t n_kept = *n_kept_ptr;
-    const uint64_t stride = (uint64_t)gridDim.x * 4;
-    for (uint64_t e = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); e < n_kept; e += stride) {
+    const uint64_t stride = (uint64_t)gridDim.x * 16;
+    for (uint64_t e = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); e < n_kept; e += stride) {
         const uint32_t rd = ev_read[e], len = ev_len[e];
         const uint64_t src = B.sig_off[rd] + ev_start[e], dst = samp_off[e];
         const double offset = B.off[rd], scale = B.range[rd] / B.dig[rd];
         const double md = scaling ? med[rd] : 0.0, ma = scaling ? mad[rd] : 1.0;
-        for (uint32_t t = lane; t < len; t += WAVE) {
+        for (uint32_t t = sub; t < len; t += 16) {
             const double pA = ((double)B.sig[src + t] + offset) * scale; // TO_PICOAMPS, poregen.h:30
             double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;          // gmove.cpp:756-759
             if (scaling) x = (x - md) / ma;                              // gmove.cpp:774
@@ -682,9 +721,25 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
     }
 }
 
+__global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, int32_t *__restrict__ stat_err,
+                                                    uint8_t *__restrict__ read_needed, int32_t *__restrict__ stat_status,
+                                                    uint64_t *__restrict__ running, uint32_t n_slots, int zero_running) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { err[0] = INT_MAX; err[1] = 0; stat_err[0] = INT_MAX; stat_err[1] = 0; }
+    if (i <= n_reads) { read_needed[i] = 0; stat_status[i] = 0; }
+    if (zero_running && i < n_slots) running[i] = 0;
+}
+
 // =====================================================================================================
 // launchers
 // =====================================================================================================
+
+void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, int32_t *stat_err, uint8_t *read_needed,
+                          int32_t *stat_status, uint64_t *running, uint32_t n_slots, int zero_running) {
+    const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
+    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, stat_err, read_needed, stat_status, running,
+                       n_slots, zero_running);
+}
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_reads == 0) return;
@@ -705,9 +760,8 @@ void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64
     if (n_tiles) {
         hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, (const uint32_t *)nullptr, 0u, nbits,
                            n_tiles, S.hist, S.wcnt);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals);
-    } else (void)hipMemsetAsync(S.totals, 0, sizeof(uint32_t) << nbits, st);
-    hipLaunchKernelGGL(k_totals_to_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, (const uint32_t *)S.totals, n_slots, acc_cnt);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots);
+    } else (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
 }
 
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
@@ -733,7 +787,7 @@ int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, u
         const int nbits = (int)((key_bits - shift) < per ? (key_bits - shift) : per);
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u);
         hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
@@ -775,28 +829,27 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
     hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)scratch, out);
 }
 
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *max_span) {
-    (void)hipMemsetAsync(max_span, 0, sizeof(int32_t), st);
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf) {
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max,
-                       reinterpret_cast<PgReadPlan *>(plan_buf), max_span);
+                       reinterpret_cast<PgReadPlan *>(plan_buf));
 }
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err) {
+                          double *med, double *mad, int32_t *status, int32_t *err, int win) {
     if (B.n_reads == 0) return;
     const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
     if (bins <= 1024)
-        hipLaunchKernelGGL((k_read_stats<1024, -1>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err);
+        hipLaunchKernelGGL((k_read_stats<1024, -1>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
     else
-        hipLaunchKernelGGL((k_read_stats<PG_STATS_BINS, 1024>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err);
+        hipLaunchKernelGGL((k_read_stats<PG_STATS_BINS, 1024>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
 }
 
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples) {
     if (n_kept_cap == 0) return;
-    uint64_t blocks = (n_kept_cap + 3) / 4;
+    uint64_t blocks = (n_kept_cap + 15) / 16;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
     hipLaunchKernelGGL(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_start, samp_off, scaling,
                        pa_min, pa_max, med, mad, samples);

@@ -148,6 +148,26 @@ struct PgSel {
         return N(v, up ? t + 1 : -1, up ? -1 : t + 1) >= need;
     }
     PG_HD bool z_ok() const { return nZ > 0 && N(dZ) >= need; }
+
+    // ---- integer-only approximation of mad_pred, used to NARROW the search (never to decide it) -------------
+    // deviations on both sides are spaced ~scale apart: U(t) ~ u0 + t*scale, D(t) ~ d0 + t*scale
+    int aShiftU, aShiftD, aZU, aZD; // other-side code count offset for a U / D candidate; first t whose value reaches dZ
+    PG_HD void begin_approx() {
+        const double u0 = nU > 0 ? U(0) : 0.0, d0 = nD > 0 ? D(0) : 0.0;
+        const double q = (u0 - d0) * inv;
+        aShiftU = (int)floor(q) + 1;   // D codes with d0 + t'*s <= u0 + t*s  <=>  t' <= t + q
+        aShiftD = (int)floor(-q) + 1;
+        const double zu = (dZ - u0) * inv, zd = (dZ - d0) * inv;
+        aZU = zu <= 0.0 ? 0 : (zu >= 4096.0 ? 4096 : (int)ceil(zu));
+        aZD = zd <= 0.0 ? 0 : (zd >= 4096.0 ? 4096 : (int)ceil(zd));
+    }
+    PG_HD bool approx_pred(bool up, int t) const {
+        int o = t + (up ? aShiftU : aShiftD);
+        const int no = up ? nD : nU;
+        o = o < 0 ? 0 : (o > no ? no : o);
+        const uint64_t own = up ? CU(t + 1) : CD(t + 1), other = up ? CD(o) : CU(o);
+        return own + other + (t >= (up ? aZU : aZD) ? nZ : 0) >= need;
+    }
     PG_HD PgMedMad finish(double best) const {
         PgMedMad out;
         out.med = med;

@@ -162,3 +162,17 @@ def test_stream_ordered_count_collect_on_torch_stream():
     for s in range(len(kmers)):
         vals = np.concatenate([r.slot_values(s) for r in results])
         assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
+
+
+@pytest.mark.parametrize("pa", [(40.0, 180.0), (100.0, 180.0), (-50.0, 95.0)])
+def test_mad_fallback_search_path(pa):
+    """debug_narrow shrinks the exact MAD candidate window to one code, so the full 64-lane search runs for
+    most reads; both paths must give the same bits as the oracle (also with zero-filled samples mid-range)."""
+    b = synth.make_batch(300, kind="rna004", seed=18)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=15, pa_min=pa[0], pa_max=pa[1])
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    for narrow in (False, True):
+        res = run_engine([b], kmers=kmers, debug_narrow=narrow, **p)
+        assert_result_equals_oracle(res, o, sample_limit=15)
