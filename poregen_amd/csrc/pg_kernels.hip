@@ -63,6 +63,34 @@ template <class Pred> __device__ __forceinline__ int wave_first_true(int n, Pred
     return n;
 }
 
+// two independent searches at once: lanes 0..31 look for the first true t of side 0 in [0,n0), lanes 32..63
+// of side 1 in [0,n1); 32 candidates per side and round (two rounds cover 1024)
+template <class Pred> __device__ __forceinline__ void wave_first_true_pair(int n0, int n1, Pred pred, int &r0, int &r1) {
+    const int lane = lane_id(), half = lane >> 5, sub = lane & 31;
+    const int n = half ? n1 : n0;
+    int lo = 0, len = n, res = n;
+    bool done = n == 0;
+    for (int round = 0; round < 4; ++round) {
+        const int step = (len + 31) / 32;
+        int t = lo + (sub + 1) * step - 1;
+        if (t > lo + len - 1) t = lo + len - 1;
+        const bool p = !done && pred(half, t);
+        const uint64_t m = __ballot(p);
+        const uint32_t mh = half ? (uint32_t)(m >> 32) : (uint32_t)m;
+        if (!done) {
+            if (mh == 0) { res = n; done = true; } // only possible in the first round
+            else {
+                const int l = __ffs((int)mh) - 1;
+                if (step == 1) { res = lo + l; done = true; }
+                else { lo += l * step; len = (lo + step > n) ? n - lo : step; }
+            }
+        }
+        if (__ballot(!done) == 0) break;
+    }
+    r0 = __builtin_amdgcn_readlane(res, 0);
+    r1 = __builtin_amdgcn_readlane(res, 32);
+}
+
 // =====================================================================================================
 // k_walk: the ss walk (gmove.cpp:831-871), one wave per read, four reads per workgroup.
 // =====================================================================================================
@@ -562,7 +590,7 @@ template <int LOG_BPL> struct PaddedPre {
 };
 
 // One WAVE per read (64-thread workgroups): no barriers, no idle waves. The signal is streamed once with
-// 16-byte loads (8 int16 per lane, 4 loads in flight per lane) and binned by raw code into an LDS
+// 16-byte loads (8 int16 per lane, up to 8 loads in flight per lane) and binned by raw code into an LDS
 // histogram of the in-range code interval [c_lo, c_lo+span); an inclusive prefix sum of the histogram
 // then yields both order statistics (pg_select.h) without touching the signal again.
 template <int BINS, int LOW> // handles reads with LOW < span <= BINS; the BINS == PG_STATS_BINS launch flags wider ones
@@ -573,7 +601,7 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
     constexpr int BPL = BINS / WAVE;                  // bins per lane in the scan
     constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
     constexpr int TRASH = BINS + WAVE;                // padded size of the real bins
-    __shared__ uint32_t hist[TRASH + 32 + 4];         // + 32 dummy bins (padded) for out-of-range samples
+    __shared__ __attribute__((aligned(16))) uint32_t hist[TRASH + 32 + 4]; // + 32 dummy bins (padded) for out-of-range samples
     const uint32_t r = blockIdx.x;
     const int lane = lane_id();
     const PgReadPlan pl = plan[r];
@@ -587,7 +615,10 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
         }
         return;
     }
-    for (int i = lane; i < TRASH + 32 + 4; i += WAVE) hist[i] = 0;
+    {
+        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+        for (int i = lane; i < (TRASH + 32 + 4) / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
+    }
 
     const int c_lo = pl.c_lo;
     const uint32_t span = (uint32_t)pl.span;
@@ -612,15 +643,13 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
         for (uint64_t s = beg + lane; s < (va << 3); s += WAVE) bin((int)sig[s]);
         for (uint64_t s = (vb << 3) + lane; s < end; s += WAVE) bin((int)sig[s]);
         const int4 *__restrict__ vec = reinterpret_cast<const int4 *>(sig);
-        uint64_t v = va + lane;
-        for (; v + 3 * WAVE < vb; v += 4 * WAVE) { // 4 independent 16-byte loads in flight per lane
-            int4 q[4];
+        for (uint64_t v = va + lane; v < vb; v += 8 * WAVE) { // up to 8 independent 16-byte loads in flight per lane
+            int4 q[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) q[u] = vec[v + u * WAVE];
+            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) q[u] = vec[v + u * WAVE];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bin8(q[u]);
+            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) bin8(q[u]);
         }
-        for (; v < vb; v += WAVE) bin8(vec[v]);
     } else {
         for (uint64_t s = beg + lane; s < end; s += WAVE) bin((int)sig[s]);
     }
@@ -650,8 +679,8 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
         sel.begin_mad();
         // 1. narrow each side with an integer-only model of the predicate (prefix lookups, no FP64)
         sel.begin_approx();
-        const int aU = wave_first_true(sel.nU, [&](int tt) { return sel.approx_pred(true, tt); });
-        const int aD = wave_first_true(sel.nD, [&](int tt) { return sel.approx_pred(false, tt); });
+        int aU, aD;
+        wave_first_true_pair(sel.nU, sel.nD, [&](int side, int tt) { return sel.approx_pred(side == 0, tt); }, aU, aD);
         // 2. ONE exact round: lanes 0..30 test U candidates around aU, lanes 32..62 D candidates around aD,
         //    lane 31 the zero-filled class. The exact predicate decides; the model only placed the window.
         const bool up = lane < 32;

@@ -70,32 +70,32 @@ template <class PrePtr>
 struct PgSel {
     PrePtr pre;
     int span, c_lo, z0;
-    uint64_t L;
+    uint64_t L; // < 2^31 (enforced by the callers), so sample counts fit 32 bits
     double offset, scale;
     // begin()
-    uint64_t nV, nZ, cb, k, jmed;
+    uint32_t nV, nZ, cb, k, jmed;
     bool zmed;
     // set_median()
     double med;
     // begin_mad()
     int sp, nU, nD;
-    uint64_t base, need;
+    uint32_t base, need;
     double dZ, inv;
 
-    PG_HD uint64_t P(int b) const { return (b < 0 || span == 0) ? 0 : (uint64_t)pre[b >= span ? span - 1 : b]; }
+    PG_HD uint32_t P(int b) const { return (b < 0 || span == 0) ? 0u : (uint32_t)pre[b >= span ? span - 1 : b]; }
 
     PG_HD void begin() {
-        nV = span > 0 ? (uint64_t)pre[span - 1] : 0;
-        nZ = L - nV;
+        nV = span > 0 ? (uint32_t)pre[span - 1] : 0u;
+        nZ = (uint32_t)L - nV;
         cb = P(z0 - 1);
-        k = L / 2; // upper median: ks_ksmall(n, copy, n/2), gmove.cpp:146
+        k = (uint32_t)(L / 2); // upper median: ks_ksmall(n, copy, n/2), gmove.cpp:146
         zmed = false; jmed = 0;
         if (k < cb) jmed = k;
         else if (k < cb + nZ) zmed = true;
         else jmed = k - nZ;
     }
     // smallest b with med_pred(b) is the bin of the median (only when !zmed)
-    PG_HD bool med_pred(int b) const { return (uint64_t)pre[b] > jmed; }
+    PG_HD bool med_pred(int b) const { return (uint32_t)pre[b] > jmed; }
     PG_HD void set_median(int bm) { med = zmed ? 0.0 : pg_pa(c_lo + bm, offset, scale); sp = zmed ? z0 : bm; }
 
     PG_HD void begin_mad() {
@@ -128,7 +128,8 @@ struct PgSel {
         }
         int guard = 0;
         while (c < n && dev(up, c) <= v) { ++c; if (++guard > 8) break; }
-        while (guard <= 8 && c > 0 && dev(up, c - 1) > v) { --c; if (++guard > 8) break; }
+        if (hint < 0) // with a hint, code hint-1 is known to qualify: nothing to walk back over
+            while (guard <= 8 && c > 0 && dev(up, c - 1) > v) { --c; if (++guard > 8) break; }
         if (guard > 8) { // spacing assumption failed: plain binary search (first t with dev(t) > v)
             int lo = 0, hi = n;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (dev(up, mid) > v) hi = mid; else lo = mid + 1; }
@@ -136,11 +137,11 @@ struct PgSel {
         }
         return c;
     }
-    PG_HD uint64_t CU(int t) const { return t <= 0 ? 0 : P(sp + t - 1) - base; }
-    PG_HD uint64_t CD(int t) const { return t <= 0 ? 0 : base - P(sp - t - 1); }
+    PG_HD uint32_t CU(int t) const { return t <= 0 ? 0u : P(sp + t - 1) - base; }
+    PG_HD uint32_t CD(int t) const { return t <= 0 ? 0u : base - P(sp - t - 1); }
     // number of samples with |x - med| <= v
-    PG_HD uint64_t N(double v, int hintU = -1, int hintD = -1) const {
-        return CU(count_leq(true, v, hintU)) + CD(count_leq(false, v, hintD)) + (dZ <= v ? nZ : 0);
+    PG_HD uint32_t N(double v, int hintU = -1, int hintD = -1) const {
+        return CU(count_leq(true, v, hintU)) + CD(count_leq(false, v, hintD)) + (dZ <= v ? nZ : 0u);
     }
     // monotone in t: does the t-th code of this side already cover the k-th smallest deviation?
     PG_HD bool mad_pred(bool up, int t) const {
@@ -165,8 +166,8 @@ struct PgSel {
         int o = t + (up ? aShiftU : aShiftD);
         const int no = up ? nD : nU;
         o = o < 0 ? 0 : (o > no ? no : o);
-        const uint64_t own = up ? CU(t + 1) : CD(t + 1), other = up ? CD(o) : CU(o);
-        return own + other + (t >= (up ? aZU : aZD) ? nZ : 0) >= need;
+        const uint32_t own = up ? CU(t + 1) : CD(t + 1), other = up ? CD(o) : CU(o);
+        return own + other + (t >= (up ? aZU : aZD) ? nZ : 0u) >= need;
     }
     PG_HD PgMedMad finish(double best) const {
         PgMedMad out;
