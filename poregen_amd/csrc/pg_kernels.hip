@@ -293,14 +293,13 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
         const uint64_t idx = base + (uint64_t)row * WAVE + lane;
         kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
     }
+    // counts are order-free, so plain LDS atomics do (the stable in-row rank is only needed when placing)
 #pragma unroll
     for (int row = 0; row < PG_SORT_ROWS; ++row) {
         const uint32_t key = kv[row];
-        const bool valid = key != PG_INVALID_SLOT;
-        const uint32_t d = (key >> shift) & mask;
-        const uint64_t peers = match_digit(d, valid, nbits);
-        if (valid && lane == __ffsll((long long)peers) - 1) cnt[w][d] += (uint32_t)__popcll(peers);
+        if (key != PG_INVALID_SLOT) atomicAdd(&cnt[w][(key >> shift) & mask], 1u);
     }
+    (void)lane;
     __syncthreads();
     for (uint32_t d = tid; d < ndig; d += 256) {
         uint32_t sum = 0;
@@ -405,7 +404,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 
 // direct mode: rank = (events of the same slot in earlier tiles / waves / rows) + in-row rank; events with
 // rank < keep[slot] are the first sample_limit ones in (read, event) order (gmove.cpp:925-927)
-__global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
+__global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
                                                    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ wcnt,
                                                    const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off,
                                                    PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K) {
@@ -413,11 +412,13 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
+    int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
     for (uint32_t d = tid; d < ndig; d += 256) {
         uint32_t b = hist[(uint64_t)d * n_tiles + tile];
+        if (d < n_slots && (uint64_t)b < keep[d]) any = 1;
         for (uint32_t ww = 0; ww < 4; ++ww) { wbase[ww][d] = b; b += wcnt[((uint64_t)tile * 4 + ww) * ndig + d]; }
     }
-    __syncthreads();
+    if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
     uint32_t kv[PG_SORT_ROWS];
@@ -799,7 +800,7 @@ void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = tiles_for(n);
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, (const uint32_t *)S.hist,
+    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
                        (const uint32_t *)S.wcnt, keep, ev_off, B, W, O, K);
 }
 
