@@ -64,7 +64,7 @@ struct pg_ctx {
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan, stat_status, stat_err;
-    DevBuf m_read, meta;
+    DevBuf m_read, meta, wide_list;
     bool zero_running = false;
     int32_t *h_max_span = nullptr; // pinned
     bool stats_in_flight = false, totals_known = false;
@@ -194,7 +194,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->p_int, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->m_read, &c->meta};
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->m_read, &c->meta, &c->wide_list};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -345,18 +345,18 @@ static pg_status check_read_errors(pg_ctx *c) {
 static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
     const uint32_t n = c->B.n_reads;
     HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull));
-    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull));
+    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list.ensure((n + 1) * 4ull));
     prof_begin(c, "k_read_plan", st);
-    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p);
+    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
     prof_end(c, st);
     prof_begin(c, "k_read_stats", st);
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win);
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
     pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win);
+                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
     prof_end(c, st);
     return PG_OK;
 }
@@ -502,7 +502,8 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     uint64_t *totals = c->plan_totals.as<uint64_t>();
     prof_begin(c, "k_slot_plan", c->st);
     pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
-                        c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals);
+                        c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
+                        (uint32_t)(((N ? N : 1) + PG_SORT_TILE - 1) / PG_SORT_TILE));
     prof_end(c, c->st);
 
     // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
@@ -522,7 +523,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
         PgSortBufs S{};
         fill_sort(c, S, 0);
         prof_begin(c, "k_rank_emit", c->st);
-        pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
+        pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K);
         prof_end(c, c->st);
     } else {
         prof_begin(c, "k_kept_meta", c->st);

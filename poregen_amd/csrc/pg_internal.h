@@ -102,8 +102,8 @@ void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt);
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                const uint64_t *keep, const uint64_t *ev_off, const PgDevBatch &B, const PgWalkParams &W,
-                                const PgWalkOut &O, const PgKeptOut &K);
+                                const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
+                                const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
 // generic ranking: stable LSD radix sort of (ev_slot, index) pairs by slot, dropping PG_INVALID_SLOT; result in
 // S.keys[out]/S.vals[out], number of sorted pairs in S.count[0]. Returns `out`.
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S);
@@ -114,16 +114,21 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
                          const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
 // keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
 // totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] = base[s] + cnt[s]
+// hist/n_tiles (direct mode, else nullptr): also computes totals[3] = last tile that can still place an event
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
-                         uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals);
+                         uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals,
+                         const uint32_t *hist, uint32_t n_tiles);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+1 uint64
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
 // plan_buf: 16 bytes per read
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf);
+// wide_list/wide_count: reads whose in-range interval needs the PG_STATS_BINS histogram (count zeroed by batch_init)
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
+                         int32_t *wide_count);
 // bins: LDS histogram size of this launch (1024 or PG_STATS_BINS); reads with a wider interval are flagged PGR_ERR_WIDE
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win);
+                          double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
+                          const int32_t *wide_count);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

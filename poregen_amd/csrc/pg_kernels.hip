@@ -407,11 +407,13 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
                                                    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ wcnt,
                                                    const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off,
-                                                   PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K) {
+                                                   const uint64_t *__restrict__ totals, PgDevBatch B, PgWalkParams W, PgWalkOut O,
+                                                   PgKeptOut K) {
     __shared__ uint32_t wbase[4][PG_RANK_MAX_DIGITS];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
+    if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
     for (uint32_t d = tid; d < ndig; d += 256) {
         uint32_t b = hist[(uint64_t)d * n_tiles + tile];
@@ -421,7 +423,8 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
-    uint32_t kv[PG_SORT_ROWS];
+    // phase 0: everything the ordered loop needs from global memory, all rows in flight at once
+    uint32_t kv[PG_SORT_ROWS], kp[PG_SORT_ROWS], eo[PG_SORT_ROWS];
 #pragma unroll
     for (int row = 0; row < PG_SORT_ROWS; ++row) {
         const uint64_t idx = base + (uint64_t)row * WAVE + lane;
@@ -429,7 +432,14 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     }
 #pragma unroll
     for (int row = 0; row < PG_SORT_ROWS; ++row) {
-        const uint64_t idx = base + (uint64_t)row * WAVE + lane;
+        const bool valid = kv[row] != PG_INVALID_SLOT;
+        kp[row] = valid ? (uint32_t)keep[kv[row]] : 0u;   // <= sample_limit
+        eo[row] = valid ? (uint32_t)ev_off[kv[row]] : 0u; // < number of kept events of the batch (< 2^32)
+    }
+    // phase 1: the ordered part -- LDS and ALU only: rank = tile prefix + earlier waves + earlier rows + in-row rank
+    uint32_t dst[PG_SORT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
         const uint32_t key = kv[row];
         const bool valid = key != PG_INVALID_SLOT;
         const uint32_t d = key & (ndig - 1u);
@@ -439,11 +449,13 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
         __builtin_amdgcn_wave_barrier();
         if (valid && lane == __ffsll((long long)peers) - 1) mybase[d] = b + (uint32_t)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const uint64_t rank = (uint64_t)b + (uint32_t)__popcll(peers & lanemask_lt());
-            if (rank < keep[key]) write_kept(B, W, O, K, ev_off[key] + rank, idx);
-        }
+        const uint32_t rank = b + (uint32_t)__popcll(peers & lanemask_lt());
+        dst[row] = (valid && rank < kp[row]) ? eo[row] + rank : 0xFFFFFFFFu;
     }
+    // phase 2: the kept events' windows (independent global round trips, pipelined across rows)
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row)
+        if (dst[row] != 0xFFFFFFFFu) write_kept(B, W, O, K, dst[row], base + (uint64_t)row * WAVE + lane);
 }
 
 // =====================================================================================================
@@ -469,9 +481,11 @@ __global__ __launch_bounds__(256) void k_slot_counts(const uint32_t *__restrict_
 // single workgroup: the sample_limit cut (gmove.cpp:925-927, 945-950) and the output offsets
 __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running,
                                                     uint32_t limit, uint32_t n_slots, uint64_t *__restrict__ keep,
-                                                    uint64_t *__restrict__ ev_off, uint64_t *__restrict__ totals) {
+                                                    uint64_t *__restrict__ ev_off, uint64_t *__restrict__ totals,
+                                                    const uint32_t *__restrict__ hist, uint32_t n_tiles) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t wfull[16];
+    (void)hist; (void)n_tiles;
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     uint64_t carry = 0, full = 0;
@@ -496,7 +510,29 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
         carry += tot; full += ftot;
         __syncthreads();
     }
-    if (tid == 0) { ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full; }
+    __syncthreads();
+    if (tid == 0) { ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full; totals[3] = hist ? ~0ull : ~0ull >> 1; } // ~0 = -1: k_tile_max raises it
+}
+
+// direct mode: totals[3] = last tile that can still place an event = max over slots of the last tile whose exclusive
+// prefix is below keep[slot]. One wave per slot, coalesced over the slot's row of tile prefixes.
+__global__ __launch_bounds__(64) void k_tile_max(const uint32_t *__restrict__ hist, uint32_t n_tiles, const uint64_t *__restrict__ keep,
+                                                 uint64_t *__restrict__ totals) {
+    const uint32_t s = blockIdx.x;
+    const uint64_t kp = keep[s];
+    if (kp == 0) return;
+    const int lane = lane_id();
+    int last = -1;
+    for (uint32_t c = 0; c < n_tiles; c += WAVE) {
+        const uint32_t t = c + lane;
+        const bool below = t < n_tiles && (uint64_t)hist[(uint64_t)s * n_tiles + t] < kp;
+        const uint64_t m = __ballot(below);
+        if (m) last = (int)c + 63 - __clzll((long long)m);
+        if (m != ~0ull) break; // prefixes are non-decreasing: nothing further is below
+    }
+    // ~1000 waves would serialise on one atomic (~12 ns each): only the few that can raise the maximum issue it
+    if (lane == 0 && last > (long long)__hip_atomic_load(reinterpret_cast<long long *>(&totals[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<long long *>(&totals[3]), (long long)last);
 }
 
 __global__ __launch_bounds__(256) void k_kept_meta(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
@@ -576,11 +612,14 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
-__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan) {
+__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
+                                                   uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= B.n_reads) return;
     const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
     plan[r] = p;
+    // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launch
+    if (p.status == 0 && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
 }
 
 // prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
@@ -594,23 +633,25 @@ template <int LOG_BPL> struct PaddedPre {
 // 16-byte loads (8 int16 per lane, up to 8 loads in flight per lane) and binned by raw code into an LDS
 // histogram of the in-range code interval [c_lo, c_lo+span); an inclusive prefix sum of the histogram
 // then yields both order statistics (pg_select.h) without touching the signal again.
-template <int BINS, int LOW> // handles reads with LOW < span <= BINS; the BINS == PG_STATS_BINS launch flags wider ones
-__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan,
-                                                   const uint8_t *__restrict__ needed, double *__restrict__ med,
-                                                   double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
-                                                   int win) {
-    constexpr int BPL = BINS / WAVE;                  // bins per lane in the scan
-    constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
-    constexpr int TRASH = BINS + WAVE;                // padded size of the real bins
-    __shared__ __attribute__((aligned(16))) uint32_t hist[TRASH + 32 + 4]; // + 32 dummy bins (padded) for out-of-range samples
-    const uint32_t r = blockIdx.x;
+template <int BINS> struct StatsGeom {
+    static constexpr int BPL = BINS / WAVE;           // bins per lane in the scan
+    static constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
+    static constexpr int TRASH = BINS + WAVE;         // padded size of the real bins
+    static constexpr int LDS_WORDS = TRASH + 32 + 4;  // + 32 dummy bins (padded) for out-of-range samples
+};
+
+template <int BINS>
+__device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgReadPlan *__restrict__ plan,
+                                               const uint8_t *__restrict__ needed, double *__restrict__ med, double *__restrict__ mad,
+                                               int32_t *__restrict__ status, int32_t *__restrict__ err, int win) {
+    constexpr int BPL = StatsGeom<BINS>::BPL, LOG_BPL = StatsGeom<BINS>::LOG_BPL;
     const int lane = lane_id();
     const PgReadPlan pl = plan[r];
     const uint64_t beg = B.sig_off[r], end = B.sig_off[r + 1];
     const bool skip = (needed && !needed[r]) || end == beg;
-    if (!skip && pl.status == 0 && pl.span <= LOW) return; // belongs to the narrower launch
+    if (BINS == 1024 && !skip && pl.status == 0 && pl.span > BINS) return; // on the wide list
     if (skip || pl.status != 0 || pl.span > BINS) {
-        if (BINS == PG_STATS_BINS && lane == 0) { // the widest launch owns the bookkeeping of unprocessed reads
+        if (lane == 0) {
             med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
             if (!skip) { status[r] = pl.status != 0 ? PGR_ERR_SCALE : PGR_ERR_WIDE; atomicMin(&err[0], (int)r); }
         }
@@ -618,7 +659,7 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
     }
     {
         uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-        for (int i = lane; i < (TRASH + 32 + 4) / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < StatsGeom<BINS>::LDS_WORDS / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
     }
 
     const int c_lo = pl.c_lo;
@@ -725,6 +766,29 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPla
     if (lane == 0) { med[r] = mm.med; mad[r] = mm.mad; }
 }
 
+// one workgroup (= one wave) per read of the batch
+__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
+                                                   double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
+                                                   int32_t *__restrict__ err, int win) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<1024>::LDS_WORDS];
+    stats_one_read<1024>(hist, B, blockIdx.x, plan, needed, med, mad, status, err, win);
+}
+
+// reads whose in-range interval needs the PG_STATS_BINS histogram: usually none, so a small grid strides over the list
+__global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
+                                                        double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
+                                                        int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
+                                                        const int32_t *__restrict__ wide_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
+    const uint32_t n_list = (uint32_t)*wide_count;
+    for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
+        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, needed, med, mad, status, err, win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
+    }
+}
+
+
 // =====================================================================================================
 // k_gather: one wave per kept event (gmove.cpp:773-775, 938-944)
 // =====================================================================================================
@@ -795,13 +859,13 @@ void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64
 }
 
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                const uint64_t *keep, const uint64_t *ev_off, const PgDevBatch &B, const PgWalkParams &W,
+                                const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W,
                                 const PgWalkOut &O, const PgKeptOut &K) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = tiles_for(n);
     if (!n_tiles) return;
     hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
-                       (const uint32_t *)S.wcnt, keep, ev_off, B, W, O, K);
+                       (const uint32_t *)S.wcnt, keep, ev_off, totals, B, W, O, K);
 }
 
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S) {
@@ -839,8 +903,9 @@ void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t 
 }
 
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
-                         uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals) {
-    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals);
+                         uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles) {
+    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles);
+    if (hist && n_tiles) hipLaunchKernelGGL(k_tile_max, dim3(n_slots), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, totals);
 }
 
 void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
@@ -859,20 +924,25 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
     hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)scratch, out);
 }
 
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf) {
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
+                         int32_t *wide_count) {
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max,
-                       reinterpret_cast<PgReadPlan *>(plan_buf));
+                       reinterpret_cast<PgReadPlan *>(plan_buf), wide_list, wide_count);
 }
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win) {
+                          double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
+                          const int32_t *wide_count) {
     if (B.n_reads == 0) return;
     const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
     if (bins <= 1024)
-        hipLaunchKernelGGL((k_read_stats<1024, -1>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
-    else
-        hipLaunchKernelGGL((k_read_stats<PG_STATS_BINS, 1024>), dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
+        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
+    else { // the wide list is usually empty: a small persistent grid
+        const uint32_t grid = B.n_reads < 2048 ? B.n_reads : 2048;
+        hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
+                           wide_count);
+    }
 }
 
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
