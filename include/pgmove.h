@@ -62,7 +62,8 @@ enum {
                                      (legal: event acceptance is signal-independent in the PAF path);
                                      default is to touch every read's signal like the reference does */
     PG_FLAG_PROFILE = 1u << 1,    /* record HIP events around every kernel (pg_kernel_stats) */
-    PG_FLAG_NO_OVERLAP = 1u << 2, /* run the statistics kernel on the main stream instead of next to the sort chain */
+    PG_FLAG_OVERLAP = 1u << 2,    /* run the statistics kernels on a second stream next to the walk/rank chain (measured: no gain
+                                     on MI355X, both sides are occupancy-bound; default is one stream) */
     PG_FLAG_DEBUG_NARROW = 1u << 3 /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
 };
 

@@ -17,7 +17,7 @@ PG_LOC_HOST = 0
 PG_LOC_DEVICE = 1
 PG_FLAG_LAZY_STATS = 1
 PG_FLAG_PROFILE = 2
-PG_FLAG_NO_OVERLAP = 4
+PG_FLAG_OVERLAP = 4
 PG_FLAG_DEBUG_NARROW = 8
 
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)

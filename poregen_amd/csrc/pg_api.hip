@@ -52,7 +52,11 @@ struct pg_ctx {
     pg_params prm{};
     int device = 0;
     hipStream_t st = nullptr, st2 = nullptr, own_st = nullptr;
-    hipEvent_t ev_join = nullptr, ev_fork = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}; // per statistics slot
+    bool slot_used[2] = {false, false};
+    int slot = 0; // statistics buffers are double-buffered so that batch i+1's statistics overlap batch i's tail
+    bool user_stream = false, batch_is_host = false;
     std::string err;
     uint32_t n_codes = 0, key_bits = 1;
 
@@ -63,10 +67,10 @@ struct pg_ctx {
     DevBuf m_start, m_len, m_base, p_int, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
-    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples, med, mad, read_plan, stat_status, stat_err;
-    DevBuf m_read, meta, wide_list;
+    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
+    DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
+    DevBuf m_read, meta;
     bool zero_running = false;
-    int32_t *h_max_span = nullptr; // pinned
     bool stats_in_flight = false, totals_known = false;
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
 
@@ -194,12 +198,12 @@ void pg_destroy(pg_ctx *c) {
                       &c->p_int, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med, &c->mad, &c->read_plan, &c->stat_status, &c->stat_err, &c->m_read, &c->meta, &c->wide_list};
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    if (c->h_max_span) (void)hipHostFree(c->h_max_span);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; i++) { if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); if (c->ev_gathered[i]) (void)hipEventDestroy(c->ev_gathered[i]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
@@ -229,10 +233,15 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     c->key_bits = 1; while ((1ull << c->key_bits) < (uint64_t)p->n_slots) c->key_bits++;
     auto bail = [&](pg_status s) { g_create_error = c->err; pg_destroy(c); return s; };
 #define CTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(PG_ERR_HIP); } } while (0)
-    CTRY(hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking));
+    // The main chain is a sequence of short, latency-bound kernels; the statistics kernel is one long throughput-bound
+    // launch. Give the chain the higher dispatch priority so that its workgroups get wave slots as soon as they are
+    // ready instead of queueing behind the statistics kernel's 50 000 workgroups.
+    int prio_low = 0, prio_high = 0;
+    CTRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)); // "least" and "greatest" priority (numerically high / low)
+    CTRY(hipStreamCreateWithPriority(&c->own_st, hipStreamNonBlocking, prio_high));
     c->st = c->own_st;
-    CTRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
-    CTRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
+    for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
     CTRY(c->table_t.ensure(tb)); CTRY(c->table_u.ensure(tb));
@@ -244,8 +253,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull));
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
-    CTRY(c->stat_err.ensure(16));
-    CTRY(hipHostMalloc((void **)&c->h_max_span, 64));
+    CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
 #undef CTRY
     *out = c;
@@ -329,12 +337,13 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 static pg_status check_read_errors(pg_ctx *c) {
     int32_t errv[2] = {INT_MAX, 0}, errs[2] = {INT_MAX, 0};
     HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(errs, c->stat_err.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 4, hipMemcpyDeviceToHost));
+    if (c->prm.scaling != 1) errs[0] = INT_MAX;
     if (errv[0] == INT_MAX && errs[0] == INT_MAX) return PG_OK;
     const bool walk = errv[0] <= errs[0];
     const int32_t idx = walk ? errv[0] : errs[0];
     int32_t code = 0;
-    HIP_TRY(c, hipMemcpy(&code, (walk ? c->status.as<int32_t>() : c->stat_status.as<int32_t>()) + idx, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&code, (walk ? c->status.as<int32_t>() : c->stat_status[c->slot].as<int32_t>()) + idx, 4, hipMemcpyDeviceToHost));
     pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : PG_ERR_INPUT);
     return fail(c, s, "read %llu of the batch (global read %llu): %s", (unsigned long long)idx,
                 (unsigned long long)(c->reads_before + idx), read_status_text(code));
@@ -344,19 +353,23 @@ static pg_status check_read_errors(pg_ctx *c) {
 // handles the reads whose in-range code interval fits it (no host decision, no sync)
 static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
     const uint32_t n = c->B.n_reads;
-    HIP_TRY(c, c->med.ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad.ensure((n + 1) * 8ull));
-    HIP_TRY(c, c->read_plan.ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list.ensure((n + 1) * 4ull));
+    const int sl = c->slot;
+    HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
+    HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull));
+    int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] length of the wide list
     prof_begin(c, "k_read_plan", st);
-    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan.p, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
+    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
+                        c->stat_status[sl].as<int32_t>());
     prof_end(c, st);
-    prof_begin(c, "k_read_stats", st);
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
-    pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
+    prof_begin(c, "k_read_stats", st);
+    pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
-    pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan.p, c->med.as<double>(), c->mad.as<double>(),
-                         c->stat_status.as<int32_t>(), c->stat_err.as<int32_t>(), win, c->wide_list.as<uint32_t>(), c->stat_err.as<int32_t>() + 1);
+    pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1);
     prof_end(c, st);
     return PG_OK;
 }
@@ -388,6 +401,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     c->have_count = false;
     const uint32_t n = b->n_reads;
 
+    c->batch_is_host = b->location == PG_LOC_HOST;
     if (b->location == PG_LOC_HOST) {
         s = stage_host_batch(c, b);
         if (s != PG_OK) return s;
@@ -412,10 +426,11 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // work buffers
     const uint64_t Nn = N ? N : 1;
     const bool direct = c->prm.n_slots <= PG_DIRECT_MAX_SLOTS;
-    HIP_TRY(c, c->m_start.ensure(Nn * 4)); HIP_TRY(c, c->m_len.ensure(Nn * 4)); HIP_TRY(c, c->m_base.ensure(Nn));
-    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure(Nn * 4)); HIP_TRY(c, c->m_read.ensure(Nn * 4));
+    // +32 entries: k_events reads/writes these per-op arrays with 16-byte vectors that may overrun n_ops
+    HIP_TRY(c, c->m_start.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_len.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_base.ensure(Nn + 32));
+    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_read.ensure((Nn + 32) * 4));
     HIP_TRY(c, c->meta.ensure((n + 1) * sizeof(PgReadMeta))); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
-    HIP_TRY(c, c->read_needed.ensure(n + 2ull)); HIP_TRY(c, c->stat_status.ensure((n + 2) * 4ull));
+    HIP_TRY(c, c->read_needed.ensure(n + 2ull));
     const uint32_t n_tiles = (uint32_t)((Nn + PG_SORT_TILE - 1) / PG_SORT_TILE);
     uint32_t ndig;
     if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
@@ -427,15 +442,24 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16));
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
-    pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->stat_err.as<int32_t>(), c->read_needed.as<uint8_t>(),
-                         c->stat_status.as<int32_t>(), c->running.as<uint64_t>(), c->prm.n_slots, c->zero_running ? 1 : 0);
-    c->zero_running = false;
+    c->slot ^= 1; // this batch's statistics buffers
     const bool eager_stats = c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS);
-    const bool overlap = !(c->prm.flags & PG_FLAG_NO_OVERLAP);
-    if (eager_stats && overlap) { // the second stream may start once the batch is resident
-        HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
-        HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+    const bool overlap = (c->prm.flags & PG_FLAG_OVERLAP) != 0;
+    if (eager_stats && overlap) {
+        // The statistics stream only needs the batch to be resident: after the staging copies of a host batch, or
+        // after the producer of a device batch when the caller drives us on its own stream. A device batch on the
+        // context's own stream must be complete when pg_count is called, so nothing on `st` has to be awaited and
+        // the statistics of this batch overlap the tail (plan/emit/scan/gather) of the previous one.
+        if (c->batch_is_host || c->user_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+            HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        }
+        // ... and the buffers of this slot to be free: the gather of the batch that used them two batches ago
+        if (c->slot_used[c->slot]) HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_gathered[c->slot], 0));
     }
+    pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
+                         c->zero_running ? 1 : 0);
+    c->zero_running = false;
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
@@ -470,7 +494,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         hipStream_t ss = overlap ? c->st2 : c->st;
         pg_status s2 = launch_stats(c, ss, nullptr);
         if (s2 != PG_OK) return s2;
-        if (overlap) HIP_TRY(c, hipEventRecord(c->ev_join, c->st2));
+        if (overlap) HIP_TRY(c, hipEventRecord(c->ev_join[c->slot], c->st2));
         c->stats_in_flight = overlap;
     }
 
@@ -554,12 +578,14 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
             gather_cap = tot[0];
         }
     }
-    if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join, 0)); c->stats_in_flight = false; }
+    if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", c->st);
     pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
-                     c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med.as<double>(), c->mad.as<double>(),
+                     c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>());
     prof_end(c, c->st);
+    HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], c->st));
+    c->slot_used[c->slot] = true;
     c->have_count = false; c->have_batch_result = true; c->downloaded = false; c->totals_known = false;
     return PG_OK;
 }
@@ -601,6 +627,7 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
     HIP_TRY(c, hipStreamSynchronize(c->st));
     HIP_TRY(c, hipStreamSynchronize(c->st2));
     c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
+    c->user_stream = hip_stream != nullptr;
     return PG_OK;
 }
 
@@ -617,7 +644,7 @@ pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
     v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
     v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off.as<uint64_t>(); v->d_samples = c->samples.as<double>();
-    v->d_med = c->prm.scaling == 1 ? c->med.as<double>() : nullptr; v->d_mad = c->prm.scaling == 1 ? c->mad.as<double>() : nullptr;
+    v->d_med = c->prm.scaling == 1 ? c->med[c->slot].as<double>() : nullptr; v->d_mad = c->prm.scaling == 1 ? c->mad[c->slot].as<double>() : nullptr;
     return PG_OK;
 }
 

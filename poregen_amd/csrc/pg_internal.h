@@ -92,10 +92,10 @@ struct PgKeptOut {
     uint32_t *ev_start;   // [n_kept] window start inside the read
     uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
 };
-// resets the per-batch flags in one launch: err words, stat_err words, read_needed[n], stat_status[n], and (if
-// zero_running) the context's running per-slot counts
-void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, int32_t *stat_err, uint8_t *read_needed,
-                          int32_t *stat_status, uint64_t *running, uint32_t n_slots, int zero_running);
+// resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
+// context's running per-slot counts
+void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+                          int zero_running);
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
@@ -121,9 +121,10 @@ void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+1 uint64
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
 // plan_buf: 16 bytes per read
-// wide_list/wide_count: reads whose in-range interval needs the PG_STATS_BINS histogram (count zeroed by batch_init)
+// flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
+// in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
-                         int32_t *wide_count);
+                         int32_t *flags, int32_t *stat_status);
 // bins: LDS histogram size of this launch (1024 or PG_STATS_BINS); reads with a wider interval are flagged PGR_ERR_WIDE
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,

@@ -150,45 +150,62 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
     uint64_t del_carry = 0;              // num_deletion
     uint32_t indel_carry = 0;            // entries pushed to indel_pos so far (interior only)
     int err = 0;
-    // software pipeline: the ops of chunk c+1 are in flight while chunk c is scanned
-    uint32_t n_nx = lane < nops ? B.op_n[o0 + lane] : 0u;
-    uint32_t t_nx = lane < nops ? (uint32_t)B.op_t[o0 + lane] : 3u;
-    for (uint32_t c = 0; c < nops; c += WAVE) {
-        const uint32_t i = c + lane;
-        const bool act = i < nops;
-        const uint32_t n = n_nx, t = t_nx;
-        {
-            const uint32_t i2 = i + WAVE;
-            n_nx = i2 < nops ? B.op_n[o0 + i2] : 0u;
-            t_nx = i2 < nops ? (uint32_t)B.op_t[o0 + i2] : 3u;
+    // Four chunks of 64 ops per trip: all their op loads are in flight together, then the (ALU-only) wave scans run
+    // chunk after chunk, then all sequence loads, then the stores -- three dependent round trips per 256 ops.
+    constexpr int U = 4;
+    for (uint32_t c = 0; c < nops; c += U * WAVE) {
+        uint32_t nn[U], tt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = c + u * WAVE + lane;
+            nn[u] = i < nops ? B.op_n[o0 + i] : 0u;
+            tt[u] = i < nops ? (uint32_t)B.op_t[o0 + i] : 3u;
         }
-        const bool is_m = act && t == 0, is_i = act && t == 1, is_d = act && t == 2;
-        if (act && t > 2) err = PGR_ERR_OP;
-        if (n >= (1u << 25)) err = PGR_ERR_RANGE; // keeps the 32-bit chunk scans below exact (64 ops x 2^25 < 2^31)
-        const uint64_t mm = __ballot(is_m), mi = __ballot(is_i || is_d);
-        const uint32_t j = match_carry + (uint32_t)__popcll(mm & lanemask_lt());
-        const uint32_t tix = indel_carry + (uint32_t)__popcll(mi & lanemask_lt());
-        const uint32_t radv = (is_m || is_i) ? (n & 0x1ffffffu) : 0u;
-        const uint32_t dadv = is_d ? (n & 0x1ffffffu) : 0u;
-        const uint32_t rinc = wave_incl_scan_u32(radv);
-        const uint32_t dinc = __ballot(is_d) ? wave_incl_scan_u32(dadv) : 0u; // most chunks hold no deletion
-        const uint64_t start = raw_carry + rinc - radv;
-        if (is_m) {
-            const uint64_t ik = (uint64_t)j + del_carry + dinc - dadv; // i_k at this op
-            if (ik >= slen) err = PGR_ERR_SEQ_OVERRUN;
-            else if (start + n > 0x7fffffffull) err = PGR_ERR_RANGE;
-            else {
-                const uint64_t src = rna ? (uint64_t)slen - 1 - ik : ik; // gmove.cpp:849-853
-                O.m_start[o0 + j] = (uint32_t)start;                     // end_raw_idx[i_k_raw]
-                O.m_len[o0 + j] = n;                                     // st_raw_idx - end_raw_idx
-                O.m_base[o0 + j] = base_code(B.seq[s0 + src], rna);
+        uint32_t jj[U], tix[U], st32[U]; uint64_t ik[U]; bool ism[U], isid[U], okm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = c + u * WAVE + lane;
+            const bool act = i < nops;
+            const uint32_t n = nn[u], t = tt[u];
+            const bool is_m = act && t == 0, is_i = act && t == 1, is_d = act && t == 2;
+            if (act && t > 2) err = PGR_ERR_OP;
+            if (n >= (1u << 25)) err = PGR_ERR_RANGE; // keeps the 32-bit chunk scans below exact (64 ops x 2^25 < 2^31)
+            const uint64_t mm = __ballot(is_m), mi = __ballot(is_i || is_d);
+            jj[u] = match_carry + (uint32_t)__popcll(mm & lanemask_lt());
+            tix[u] = indel_carry + (uint32_t)__popcll(mi & lanemask_lt());
+            const uint32_t radv = (is_m || is_i) ? (n & 0x1ffffffu) : 0u;
+            const uint32_t dadv = is_d ? (n & 0x1ffffffu) : 0u;
+            const uint32_t rinc = wave_incl_scan_u32(radv);
+            const uint32_t dinc = __ballot(is_d) ? wave_incl_scan_u32(dadv) : 0u; // most chunks hold no deletion
+            const uint64_t start = raw_carry + rinc - radv;
+            ik[u] = (uint64_t)jj[u] + del_carry + dinc - dadv; // i_k at this op
+            ism[u] = is_m; isid[u] = is_i || is_d; okm[u] = false;
+            if (is_m) {
+                if (ik[u] >= slen) err = PGR_ERR_SEQ_OVERRUN;
+                else if (start + n > 0x7fffffffull) err = PGR_ERR_RANGE;
+                else okm[u] = true;
             }
+            st32[u] = (uint32_t)start;
+            raw_carry += (uint32_t)__builtin_amdgcn_readlane((int)rinc, WAVE - 1);
+            del_carry += (uint32_t)__builtin_amdgcn_readlane((int)dinc, WAVE - 1);
+            match_carry += (uint32_t)__popcll(mm);
+            indel_carry += (uint32_t)__popcll(mi);
         }
-        if (is_i || is_d) O.p_int[o0 + tix] = (int32_t)j;                // i_k - num_deletion == matched bases so far
-        raw_carry += (uint32_t)__builtin_amdgcn_readlane((int)rinc, WAVE - 1);
-        del_carry += (uint32_t)__builtin_amdgcn_readlane((int)dinc, WAVE - 1);
-        match_carry += (uint32_t)__popcll(mm);
-        indel_carry += (uint32_t)__popcll(mi);
+        uint8_t bc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t src = rna ? (uint64_t)slen - 1 - ik[u] : ik[u]; // gmove.cpp:849-853
+            bc[u] = okm[u] ? base_code(B.seq[s0 + src], rna) : (uint8_t)4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (okm[u]) {
+                O.m_start[o0 + jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
+                O.m_len[o0 + jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
+                O.m_base[o0 + jj[u]] = bc[u];
+            }
+            if (isid[u]) O.p_int[o0 + tix[u]] = (int32_t)jj[u]; // i_k - num_deletion == matched bases so far
+        }
     }
     const uint64_t bm = __ballot(err != 0);
     if (bm) { // lowest failing lane decides the code
@@ -203,57 +220,86 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
 // =====================================================================================================
 // k_events: the event loop (gmove.cpp:891-927), one thread per (read, event index) = per op index
 // =====================================================================================================
+#define PG_EV_PER_THREAD 4 // four consecutive op indices per thread: 16-byte loads instead of four 4-byte ones
+
+// The kernel issues ~12 vector-memory instructions per event when written one event per thread and is bound by
+// that instruction rate, not by bytes; with four consecutive events per thread the per-op arrays are read with one
+// 16-byte load each (buffers are padded by 16 bytes so the last vector may overrun n_ops).
 __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= B.n_ops) return;
+    constexpr int E = PG_EV_PER_THREAD;
     const uint32_t k = W.k;
-    // round trip 1: the owning read; round trip 2: its summary and everything that only depends on g
-    const uint32_t r = O.m_read[g];
+    const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
+    if (g0 >= B.n_ops) return;
     const uint64_t last = B.n_ops - 1;
-    // k-mer of matched bases [g, g+k): forward code (first base most significant) and its mirror, which is
-    // what the reference reads on RNA-oriented records (gmove.cpp:883, 899)
-    uint32_t fwd = 0, rev = 0; bool bad = false;
+    // round trip 1: owning reads, the 16 base codes starting at g0, window lengths and starts of matches g0+off..
+    const uint4 rv = *reinterpret_cast<const uint4 *>(O.m_read + g0);
+    const uint32_t r[E] = {rv.x, rv.y, rv.z, rv.w};
+    const uint4 bv = *reinterpret_cast<const uint4 *>(O.m_base + g0); // bases g0 .. g0+15 (k <= 13 needs g0 .. g0+15)
+    const uint64_t blo = (uint64_t)bv.x | ((uint64_t)bv.y << 32), bhi = (uint64_t)bv.z | ((uint64_t)bv.w << 32);
+    uint32_t len[E], start[E];
+    if (W.sig_move_offset == 0) {
+        const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0), sv = *reinterpret_cast<const uint4 *>(O.m_start + g0);
+        len[0] = lv.x; len[1] = lv.y; len[2] = lv.z; len[3] = lv.w;
+        start[0] = sv.x; start[1] = sv.y; start[2] = sv.z; start[3] = sv.w;
+    } else {
 #pragma unroll
-    for (uint32_t t = 0; t < 13; ++t) if (t < k) {
-        const uint64_t a = g + t;
-        const uint8_t b = O.m_base[a > last ? last : a];
-        bad |= b > 3;
-        fwd = (fwd << 2) | (b & 3u);
-        rev |= (uint32_t)(b & 3u) << (2 * t);
+        for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; start[j] = O.m_start[ge > last ? last : ge]; }
     }
-    const uint64_t ge = g + W.sig_move_offset > last ? last : g + W.sig_move_offset;
-    const uint32_t len = O.m_len[ge], start = O.m_start[ge];
-    const PgReadMeta mt = O.meta[r];
-    uint32_t out = PG_INVALID_SLOT;
-    const uint32_t n = mt.n; // 0 for skipped / failed reads
-    const uint32_t i = (uint32_t)(g - mt.o0);
-    const uint32_t e = i + W.sig_move_offset;
-    if (n >= k && i <= n - k && e < n) { // e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
-        const bool rna = mt.rna != 0;
-        const uint32_t m = mt.m;
-        const uint32_t code = rna ? rev : fwd;
-        const int32_t slot = bad ? -1 : (rna ? W.table_u : W.table_t)[code];
-        // pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M]
-        const int32_t M = W.pick_margin;
-        const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
-        const int32_t X = left + (int32_t)k + M, Y = left - M;
-        const uint64_t o0 = mt.o0;
-        auto interior = [&](uint32_t u) -> int32_t { // sorted ascending in both orientations (gmove.cpp:877-882)
-            return rna ? (int32_t)n - O.p_int[o0 + (m - 1 - u)] : O.p_int[o0 + u];
-        };
-        uint32_t lo = 0, hi = m; // first u with interior(u) >= X
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (interior(mid) >= X) hi = mid; else lo = mid + 1; }
-        const int32_t prev = lo == 0 ? -mt.st_k : interior(lo - 1);
-        const bool pick = (lo < m) ? (prev <= Y) : (X <= mt.end_k + M && prev <= Y);
-        if (pick && slot >= 0 && len <= W.max_dur && len >= W.min_dur) { // gmove.cpp:916-924
-            // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
-            const uint64_t L = mt.L;
-            const uint64_t wend = (uint64_t)start + len + W.print_margin > L ? L : (uint64_t)start + len + W.print_margin;
-            if (W.print_margin > start || wend <= (uint64_t)(start - W.print_margin)) report_error(O, r, PGR_ERR_WINDOW);
-            else out = (uint32_t)slot;
+    // round trip 2: the reads' summaries (one load when the four events belong to one read)
+    PgReadMeta mt[E];
+    mt[0] = O.meta[r[0]];
+#pragma unroll
+    for (int j = 1; j < E; ++j) { mt[j] = mt[0]; if (g0 + j <= last && r[j] != r[0]) mt[j] = O.meta[r[j]]; }
+    // round trip 3: the slot of the k-mer of matched bases [g, g+k): forward code (first base most significant) or its
+    // mirror, which is what the reference reads on RNA-oriented records (gmove.cpp:883, 899)
+    int32_t slot[E]; bool cand[E]; uint32_t idx[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        uint32_t fwd = 0, rev = 0; bool bad = false;
+#pragma unroll
+        for (uint32_t t = 0; t < 13; ++t) if (t < k) {
+            const uint32_t pos = j + t; // byte pos of the 16-byte window
+            const uint32_t b = (uint32_t)((pos < 8 ? blo >> (8 * pos) : bhi >> (8 * (pos - 8))) & 0xff);
+            bad |= b > 3;
+            fwd = (fwd << 2) | (b & 3u);
+            rev |= (b & 3u) << (2 * t);
+        }
+        const uint32_t n = mt[j].n; // 0 for skipped / failed reads
+        idx[j] = (uint32_t)(g0 + j - mt[j].o0);
+        const uint32_t e = idx[j] + W.sig_move_offset;
+        cand[j] = g0 + j <= last && n >= k && idx[j] <= n - k && e < n; // e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
+        const uint32_t code = mt[j].rna ? rev : fwd;
+        slot[j] = (cand[j] && !bad) ? (mt[j].rna ? W.table_u : W.table_t)[code] : -1;
+    }
+    uint32_t out[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        out[j] = PG_INVALID_SLOT;
+        if (cand[j]) {
+            const bool rna = mt[j].rna != 0;
+            const uint32_t n = mt[j].n, m = mt[j].m, i = idx[j];
+            // pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M]
+            const int32_t M = W.pick_margin;
+            const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
+            const int32_t X = left + (int32_t)k + M, Y = left - M;
+            const uint64_t o0 = mt[j].o0;
+            auto interior = [&](uint32_t u) -> int32_t { // sorted ascending in both orientations (gmove.cpp:877-882)
+                return rna ? (int32_t)n - O.p_int[o0 + (m - 1 - u)] : O.p_int[o0 + u];
+            };
+            uint32_t lo = 0, hi = m; // first u with interior(u) >= X
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (interior(mid) >= X) hi = mid; else lo = mid + 1; }
+            const int32_t prev = lo == 0 ? -mt[j].st_k : interior(lo - 1);
+            const bool pick = (lo < m) ? (prev <= Y) : (X <= mt[j].end_k + M && prev <= Y);
+            if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) { // gmove.cpp:916-924
+                // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
+                const uint64_t L = mt[j].L;
+                const uint64_t wend = (uint64_t)start[j] + len[j] + W.print_margin > L ? L : (uint64_t)start[j] + len[j] + W.print_margin;
+                if (W.print_margin > start[j] || wend <= (uint64_t)(start[j] - W.print_margin)) report_error(O, r[j], PGR_ERR_WINDOW);
+                else out[j] = (uint32_t)slot[j];
+            }
         }
     }
-    O.ev_slot[g] = out;
+    *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]); // entries past n_ops are padding
 }
 
 // =====================================================================================================
@@ -612,12 +658,16 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
+__global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; }
+
 __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
-                                                   uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count) {
+                                                   uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count,
+                                                   int32_t *__restrict__ stat_status) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= B.n_reads) return;
     const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
     plan[r] = p;
+    stat_status[r] = 0;
     // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launch
     if (p.status == 0 && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
 }
@@ -815,12 +865,11 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
     }
 }
 
-__global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, int32_t *__restrict__ stat_err,
-                                                    uint8_t *__restrict__ read_needed, int32_t *__restrict__ stat_status,
+__global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, uint8_t *__restrict__ read_needed,
                                                     uint64_t *__restrict__ running, uint32_t n_slots, int zero_running) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { err[0] = INT_MAX; err[1] = 0; stat_err[0] = INT_MAX; stat_err[1] = 0; }
-    if (i <= n_reads) { read_needed[i] = 0; stat_status[i] = 0; }
+    if (i == 0) { err[0] = INT_MAX; err[1] = 0; }
+    if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
 }
 
@@ -828,11 +877,10 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
 // launchers
 // =====================================================================================================
 
-void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, int32_t *stat_err, uint8_t *read_needed,
-                          int32_t *stat_status, uint64_t *running, uint32_t n_slots, int zero_running) {
+void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+                          int zero_running) {
     const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
-    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, stat_err, read_needed, stat_status, running,
-                       n_slots, zero_running);
+    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running);
 }
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
@@ -842,7 +890,7 @@ void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, 
 
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_ops == 0) return;
-    hipLaunchKernelGGL(k_events, dim3((uint32_t)((B.n_ops + 255) / 256)), dim3(256), 0, st, B, W, O);
+    hipLaunchKernelGGL(k_events, dim3((uint32_t)((B.n_ops + 256 * PG_EV_PER_THREAD - 1) / (256 * PG_EV_PER_THREAD))), dim3(256), 0, st, B, W, O);
 }
 
 static uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + PG_SORT_TILE - 1) / PG_SORT_TILE); }
@@ -925,10 +973,11 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 }
 
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
-                         int32_t *wide_count) {
+                         int32_t *flags, int32_t *stat_status) {
+    hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max,
-                       reinterpret_cast<PgReadPlan *>(plan_buf), wide_list, wide_count);
+                       reinterpret_cast<PgReadPlan *>(plan_buf), wide_list, flags + 1, stat_status);
 }
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
