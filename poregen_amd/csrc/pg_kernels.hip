@@ -498,10 +498,33 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
         const uint32_t rank = b + (uint32_t)__popcll(peers & lanemask_lt());
         dst[row] = (valid && rank < kp[row]) ? eo[row] + rank : 0xFFFFFFFFu;
     }
-    // phase 2: the kept events' windows (independent global round trips, pipelined across rows)
+    // phase 2: the kept events' windows (gmove.cpp:928-937). Staged across rows so that every stage is one set of
+    // independent loads: owning read + window of match i+off, then the read's length, then the stores.
+    uint32_t rd[PG_SORT_ROWS], ws[PG_SORT_ROWS], wl[PG_SORT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row)
-        if (dst[row] != 0xFFFFFFFFu) write_kept(B, W, O, K, dst[row], base + (uint64_t)row * WAVE + lane);
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+        rd[row] = 0; ws[row] = 0; wl[row] = 0;
+        if (dst[row] != 0xFFFFFFFFu) {
+            const uint64_t g = base + (uint64_t)row * WAVE + lane;
+            rd[row] = O.m_read[g];
+            ws[row] = O.m_start[g + W.sig_move_offset]; // the event's window is that of match i + sig_move_offset
+            wl[row] = O.m_len[g + W.sig_move_offset];
+        }
+    }
+    uint32_t Lr[PG_SORT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) Lr[row] = dst[row] != 0xFFFFFFFFu ? O.meta[rd[row]].L : 0u;
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+        if (dst[row] == 0xFFFFFFFFu) continue;
+        const uint32_t start = ws[row] - W.print_margin; // validated in k_events
+        const uint64_t we64 = (uint64_t)ws[row] + wl[row] + W.print_margin;
+        const uint32_t we = (uint32_t)(we64 > Lr[row] ? Lr[row] : we64);
+        K.ev_len[dst[row]] = we - start;
+        K.ev_start[dst[row]] = start;
+        K.ev_read[dst[row]] = rd[row];
+        if (K.read_needed) K.read_needed[rd[row]] = 1;
+    }
 }
 
 // =====================================================================================================
