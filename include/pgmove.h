@@ -64,6 +64,9 @@ enum {
     PG_FLAG_PROFILE = 1u << 1,    /* record HIP events around every kernel (pg_kernel_stats) */
     PG_FLAG_OVERLAP = 1u << 2,    /* run the statistics kernels on a second stream next to the walk/rank chain (measured: no gain
                                      on MI355X, both sides are occupancy-bound; default is one stream) */
+    PG_FLAG_SHORT_READS_OK = 1u << 4, /* a read with fewer than k matched bases simply has no events (move-table front-end,
+                                        where that is well defined); default: PG_ERR_INPUT, because the PAF path of the
+                                        reference has undefined behaviour there (src/gmove.cpp:891) */
     PG_FLAG_DEBUG_NARROW = 1u << 3 /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
 };
 

@@ -19,6 +19,7 @@ PG_FLAG_LAZY_STATS = 1
 PG_FLAG_PROFILE = 2
 PG_FLAG_OVERLAP = 4
 PG_FLAG_DEBUG_NARROW = 8
+PG_FLAG_SHORT_READS_OK = 16
 
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [

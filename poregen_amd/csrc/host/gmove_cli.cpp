@@ -186,13 +186,16 @@ int gmove_main(int argc, char **argv) {
 
     const std::string mt(move_table); // src/gmove.cpp:505-521
     const std::string ext = mt.size() >= 4 ? mt.substr(mt.size() - 4) : "";
-    if (ext != ".paf") {
-        fprintf(stderr, "this build implements the .paf (ss:Z:) front-end of gmove; move-table and SAM/BAM inputs are not implemented\n");
+    const bool is_paf = ext == ".paf";
+    if (ext == ".bam" || ext == ".sam") {
+        fprintf(stderr, "this build implements the .paf (ss:Z:) and move-table front-ends of gmove; SAM/BAM input (gmove.cpp:1061-1266) is not implemented\n");
         return EXIT_FAILURE;
     }
-    if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return EXIT_FAILURE; } // gmove.cpp:510-513
     pgh::FastxIndex fai;
-    if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return EXIT_FAILURE; }
+    if (is_paf) {
+        if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return EXIT_FAILURE; } // gmove.cpp:510-513
+        if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return EXIT_FAILURE; }
+    }
     FILE *paf_fp = fopen(move_table, "r");
     if (!paf_fp) { fprintf(stderr, "Error in opening file %s\n", move_table); return EXIT_FAILURE; }
 
@@ -208,8 +211,11 @@ int gmove_main(int argc, char **argv) {
     pg_params prm; pg_default_params(&prm);
     prm.kmer_size = opt.kmer_size; prm.sig_move_offset = opt.sig_move_offset; prm.signal_print_margin = opt.signal_print_margin;
     prm.sample_limit = opt.sample_limit; prm.max_dur = opt.max_dur; prm.min_dur = opt.min_dur; prm.kmer_pick_margin = (int32_t)opt.kmer_pick_margin;
+    if (!is_paf) { // the move-table front-end has no indel logic and resolves -m / -s on the host (gmove.cpp:620-639)
+        prm.kmer_pick_margin = 0; prm.sig_move_offset = 0;
+    }
     prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
-    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = lazy ? PG_FLAG_LAZY_STATS : 0; prm.device = device;
+    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK); prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     pg_ctx *ctx = nullptr;
     if (pg_create(&prm, &ctx) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(nullptr)); return EXIT_FAILURE; }
@@ -237,24 +243,69 @@ int gmove_main(int argc, char **argv) {
         return true;
     };
     while (!stop && (got = getline(&line, &cap, paf_fp)) != -1) {
-        pgh::PafRec paf;
-        int pr = pgh::parse_paf_line(line, (size_t)got, paf);
-        if (pr == 1) { fprintf(stderr, "malformed PAF record (fewer than 12 columns)\n"); status = EXIT_FAILURE; break; }
-        if (pr == 2) { fprintf(stderr, "ss:Z: tag not found in paf record for %s\n", paf.rid.c_str()); status = EXIT_FAILURE; break; } // gmove.cpp:1046-1049
-        if (!s5.get(paf.rid, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }              // gmove.cpp:745-749
-        const size_t ops_before = hb.op_n.size();
-        if (!pgh::tokenize_ss(paf.ss, paf.ss_len, hb.op_n, hb.op_t, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; break; }
-        (void)ops_before;
-        // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
-        const int64_t a = paf.target_start, b2 = paf.target_end;
-        const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
-        fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), seq); // absent name: empty sequence -> the read is skipped on the device
-        hb.sig.insert(hb.sig.end(), rec.raw.begin(), rec.raw.end()); hb.sig_off.push_back(hb.sig.size());
+        if (is_paf) {
+            pgh::PafRec paf;
+            int pr = pgh::parse_paf_line(line, (size_t)got, paf);
+            if (pr == 1) { fprintf(stderr, "malformed PAF record (fewer than 12 columns)\n"); status = EXIT_FAILURE; break; }
+            if (pr == 2) { fprintf(stderr, "ss:Z: tag not found in paf record for %s\n", paf.rid.c_str()); status = EXIT_FAILURE; break; } // gmove.cpp:1046-1049
+            if (!s5.get(paf.rid, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }              // gmove.cpp:745-749
+            if (!pgh::tokenize_ss(paf.ss, paf.ss_len, hb.op_n, hb.op_t, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; break; }
+            // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
+            const int64_t a = paf.target_start, b2 = paf.target_end;
+            const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
+            fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), seq); // absent name: empty sequence -> the read is skipped on the device
+            hb.sig.insert(hb.sig.end(), rec.raw.begin(), rec.raw.end());
+            hb.qs.push_back(paf.query_start); hb.ts.push_back(paf.target_start); hb.te.push_back(paf.target_end);
+            total_samples += rec.raw.size();
+        } else {
+            // move table (gmove.cpp:557-700): read_id, fastq_len, fastq_seq, stride, moves, signal_len, trim_offset.
+            // Host work: resolve -m (first window starts at the (m+1)-th '1') and -s (first k-mer starts at base s),
+            // turn every closed move segment into a match op of (gap x stride) samples, drop the trimmed prefix of
+            // the signal. The device then runs the same collector with kmer_pick_margin 0 and no indels.
+            char *col[7]; int nc = 0;
+            for (char *p = line, *e = line + got; p < e && nc < 7;) {
+                char *t = (char *)memchr(p, '\t', (size_t)(e - p)); if (!t) t = e;
+                col[nc++] = p; *t = 0; p = t + 1;
+            }
+            if (nc < 7) { fprintf(stderr, "malformed move-table record (fewer than 7 columns)\n"); status = EXIT_FAILURE; break; }
+            const int fastq_len = atoi(col[1]); const std::string fseq(col[2]); const int stride = atoi(col[3]);
+            const char *moves = col[4]; const size_t move_len = strlen(moves);
+            const uint64_t signal_len = strtoull(col[5], nullptr, 10); const int trim = atoi(col[6]);
+            if (!s5.get(col[0], rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }  // gmove.cpp:582-586
+            if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
+                fprintf(stderr, "move-table record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", col[0]); status = EXIT_FAILURE; break;
+            }
+            hb.sig.insert(hb.sig.end(), rec.raw.begin() + trim, rec.raw.end()); // gmove.cpp:591-598: only the trimmed signal is used
+            total_samples += rec.raw.size();
+            seq.clear();
+            uint32_t qstart = 0;
+            if (fastq_len >= 10) { // gmove.cpp:616-619: shorter reads are skipped (no events, no ':')
+                size_t idx = 0, start_idx = 0; uint32_t ones = 0;
+                while (ones < opt.sig_move_offset + 1 && idx < move_len) { if (moves[idx] == '1') { ones++; start_idx = idx; } idx++; } // gmove.cpp:623-629
+                if (ones < opt.sig_move_offset + 1) { fprintf(stderr, "move string of %s has fewer than %u moves\n", col[0], opt.sig_move_offset + 1); status = EXIT_FAILURE; break; }
+                if (opt.kmer_start_offset > fseq.size()) { fprintf(stderr, "kmer start offset beyond the sequence of %s\n", col[0]); status = EXIT_FAILURE; break; }
+                seq = fseq.substr(opt.kmer_start_offset);
+                qstart = (uint32_t)(start_idx * (size_t)stride);
+                size_t n_seg = 0, prev = start_idx;
+                for (size_t i = start_idx + 1; i < move_len; i++) // the last move is never closed (moves[move_len] is NUL, gmove.cpp:632)
+                    if (moves[i] == '1') {
+                        if (n_seg < seq.size()) { hb.op_n.push_back((uint32_t)((i - prev) * (size_t)stride)); hb.op_t.push_back(0); }
+                        n_seg++; prev = i;
+                    }
+                // event j pairs segment j with the k-mer at base j even when fewer than k segments follow it: pad with
+                // zero-length matches (never used as windows) so that the collector sees k matched bases for it
+                const size_t real = n_seg < seq.size() ? n_seg : seq.size();
+                size_t pad = seq.size() > n_seg ? seq.size() - n_seg : 0; if (pad > opt.kmer_size - 1) pad = opt.kmer_size - 1;
+                for (size_t i = 0; i < pad; i++) { hb.op_n.push_back(0); hb.op_t.push_back(0); }
+                seq.resize(real + pad);
+                if (seq.size() < opt.kmer_size) seq.append(opt.kmer_size - seq.size(), 'N'); // not "skipped": the read still gets its ':' with -d
+            }
+            hb.qs.push_back((int32_t)qstart); hb.ts.push_back(0); hb.te.push_back((int32_t)seq.size());
+        }
+        hb.sig_off.push_back(hb.sig.size());
         hb.dig.push_back(rec.digitisation); hb.off.push_back(rec.offset); hb.range.push_back(rec.range);
-        hb.qs.push_back(paf.query_start); hb.ts.push_back(paf.target_start); hb.te.push_back(paf.target_end);
         hb.seq.insert(hb.seq.end(), seq.begin(), seq.end()); hb.seq_off.push_back(hb.seq.size());
         hb.op_off.push_back(hb.op_n.size());
-        total_samples += rec.raw.size();
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
         if (hb.n() >= batch_reads || hb.sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
     }

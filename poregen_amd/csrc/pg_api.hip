@@ -377,6 +377,7 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
 static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
     W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
+    W.short_ok = (c->prm.flags & PG_FLAG_SHORT_READS_OK) ? 1 : 0;
     W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
     O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>();

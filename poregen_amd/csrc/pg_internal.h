@@ -20,7 +20,7 @@ struct PgDevBatch {
 
 struct PgWalkParams {
     uint32_t k, sig_move_offset, print_margin, max_dur, min_dur;
-    int32_t pick_margin, allow_rna;
+    int32_t pick_margin, allow_rna, short_ok;
     uint32_t n_codes; // 4^k
     const int32_t *table_t, *table_u;
 };

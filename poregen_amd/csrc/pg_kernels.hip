@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
         if (lane == 0) report_error(O, r, code);
         return;
     }
-    if (match_carry < k) { if (lane == 0) report_error(O, r, PGR_ERR_SHORT); return; } // unsigned wrap at gmove.cpp:891
+    if (match_carry < k) { // unsigned wrap at gmove.cpp:891 in the PAF path; simply no events for the move-table front-end
+        if (lane == 0 && !W.short_ok) report_error(O, r, PGR_ERR_SHORT);
+        return;
+    }
     if (lane == 0) put_meta(match_carry, indel_carry);
 }
 

@@ -196,3 +196,24 @@ def write_files(b: Batch, prefix: str):
         for r in range(b.n_reads):
             L = int(b.sig_off[r + 1] - b.sig_off[r]); ns = int(b.seq_off[r + 1] - b.seq_off[r])
             f.write(f"r{r}\t{L}\t{int(b.query_start[r])}\t{L}\t+\tr{r}\t{ns}\t{int(b.target_start[r])}\t{int(b.target_end[r])}\t{ns}\t{ns}\t255\tss:Z:{ss_string(b, r)}\n")
+
+
+def write_table_files(b: Batch, prefix: str, stride: int = 5, trim: int = 0, seed: int = 1):
+    """ASCII SLOW5 + 7-column move table (read_id, fastq_len, seq, stride, moves, signal_len, trim_offset) for a
+    DNA-oriented, match-only batch whose dwells are multiples of `stride` (format: src/gmove.cpp:570-577). With
+    trim > 0 every read gets `trim` extra leading samples that the table tells gmove to ignore."""
+    rng = np.random.default_rng(seed)
+    assert np.all(b.op_t == 0) and np.all(b.target_start == 0)
+    with open(prefix + ".slow5", "w") as f, open(prefix + ".table", "w") as t:
+        f.write("#slow5_version\t0.2.0\n#num_read_groups\t1\n")
+        f.write("#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
+        for r in range(b.n_reads):
+            s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+            lead = rng.integers(300, 1500, trim).astype(np.int16)
+            full = np.concatenate([lead, s])
+            f.write(f"r{r}\t0\t{b.digitisation[r]:.17g}\t{b.offset[r]:.17g}\t{b.range[r]:.17g}\t4000\t{len(full)}\t" + ",".join(map(str, full.tolist())) + "\n")
+            d = b.op_n[int(b.op_off[r]):int(b.op_off[r + 1])]
+            assert np.all(d % stride == 0) and np.all(d > 0)
+            moves = "".join("1" + "0" * (int(x) // stride - 1) for x in d)
+            seq = seq_string(b, r)
+            t.write(f"r{r}\t{len(seq)}\t{seq}\t{stride}\t{moves}\t{len(full)}\t{trim}\n")

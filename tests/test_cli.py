@@ -101,6 +101,52 @@ def test_synthetic_files_equal_oracle(tmp_path, kind, extra):
     assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
 
 
+TABLE_CASES = {
+    "t02_defaults": ["{G}/reads.slow5", "{G}/guppy_move", "--file_limit", "50", "{OUT}"],                                         # test_gmove.sh 0.2
+    "t04_kmer_file": ["-k", "6", "-m", "0", "{G}/reads.slow5", "{G}/guppy_move", "--kmer_file", "{G}/kmer_file.txt", "{OUT}"],   # 0.4 / 2.1
+    "t11_single": ["-k", "6", "-m", "0", "{G}/reads.slow5", "{G}/guppy_move", "--kmer_file", "{G}/single_kmer_file.txt", "{OUT}"],  # 1.1 (KA-4)
+    "t_k5_all_scaled": ["-k", "5", "{G}/reads.slow5", "{G}/guppy_move", "--file_limit", "5000", "--scaling", "1", "-d", "{OUT}"],
+    "t_offsets": ["-k", "5", "-m", "2", "-s", "3", "{G}/reads.slow5", "{G}/guppy_move", "--file_limit", "5000", "--scaling", "1", "--margin", "4", "{OUT}"],
+    "t_k9_slice": ["{G}/reads.slow5", "{G}/guppy_move", "--index_start", "50000", "--index_end", "60000", "--scaling", "1", "{OUT}"],
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(TABLE_CASES))
+def test_table_front_end_fixture_equals_oracle(tmp_path, name):
+    """Move-table front-end (src/gmove.cpp:539-706) on the reference's fixture; t11_single is KA-4."""
+    a, b = tmp_path / "gpu", tmp_path / "cpu"
+    args = TABLE_CASES[name]
+    r = cli([x.replace("{G}", G).replace("{OUT}", str(a)) for x in args]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([x.replace("{G}", G).replace("{OUT}", str(b)) for x in args]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(a, b)
+    if name == "t11_single":
+        assert open(a / "dump" / "ATGTTG").read() == "143.00816337,118.41790281,115.53301191,119.24215736,114.43400585,117.18152100,113.33499979,115.53301191,128.44633310,162.51552091;"
+
+
+@pytest.mark.gpu
+def test_reference_invariant_table_equals_paf_on_gpu(tmp_path):
+    """test_gmove.sh 2.1 == 2.2 through the product (valid at --kmer_pick_margin 0)."""
+    t, p = tmp_path / "t", tmp_path / "p"
+    assert cli(["-k", "6", "-m", "0", f"{G}/reads.slow5", f"{G}/guppy_move", "--kmer_file", f"{G}/kmer_file.txt", t]).returncode == 0
+    assert cli(["-k", "6", f"{G}/reads.slow5", f"{G}/guppy_move.paf", "--fastq", f"{G}/read_0.fastq", "--kmer_file", f"{G}/kmer_file.txt",
+                "--kmer_pick_margin", "0", p]).returncode == 0
+    assert_same_dirs(t, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trim,extra", [(0, ["-k", "5", "--file_limit", "1024", "--scaling", "1", "--sample_limit", "25"]),
+                                        (37, ["-k", "6", "--file_limit", "4096", "--scaling", "1", "--sample_limit", "7", "-d", "-m", "1", "--batch_reads", "33"])])
+def test_table_front_end_synthetic_equals_oracle(tmp_path, trim, extra):
+    b = synth.make_batch(120, kind="dna_r10", seed=79)
+    pre = str(tmp_path / "syn")
+    synth.write_table_files(b, pre, trim=trim)
+    common = [pre + ".slow5", pre + ".table"] + extra
+    r = cli(common + [tmp_path / "gpu"]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([x for x in common if x not in ("--batch_reads", "33")] + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+
+
 @pytest.mark.gpu
 def test_print_margin_larger_than_window_start_is_rejected(tmp_path):
     """--margin > start of an accepted window is undefined behaviour in the reference (unsigned wrap at
