@@ -69,7 +69,7 @@ struct pg_ctx {
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
-    DevBuf m_read, meta;
+    DevBuf m_read, meta, huge_scratch;
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
@@ -114,7 +114,7 @@ static const char *read_status_text(int code) {
         case PGR_ERR_WINDOW: return "an accepted event has an empty/out-of-signal window or margin > start (undefined in the reference, gmove.cpp:928-941)";
         case PGR_ERR_RANGE: return "sample index exceeds INT32_MAX";
         case PGR_ERR_SCALE: return "range/digitisation is not a positive finite number";
-        case PGR_ERR_WIDE: return "[pa_min, pa_max] spans more than 2048 raw codes for this read (wide statistics path not implemented)";
+        case PGR_ERR_WIDE: return "internal: statistics histogram too narrow for this read";
         default: return "unknown";
     }
 }
@@ -199,7 +199,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
-                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta};
+                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -356,7 +356,7 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
     const int sl = c->slot;
     HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
     HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
-    HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull));
+    HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull)); HIP_TRY(c, c->huge_scratch.ensure(PG_HUGE_SCRATCH_WORDS * 4));
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] length of the wide list
     prof_begin(c, "k_read_plan", st);
     pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
@@ -365,11 +365,13 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1);
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
     pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1);
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr);
+    pg_launch_read_stats(st, c->B, 65536, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>());
     prof_end(c, st);
     return PG_OK;
 }

@@ -83,7 +83,9 @@ struct PgSortBufs {
 };
 
 // ---- stats ---------------------------------------------------------------------------------------
-#define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global path
+#define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global-memory path
+#define PG_HUGE_BLOCKS 64   // workgroups (and 65600-word scratch histograms) of the global-memory path
+#define PG_HUGE_SCRATCH_WORDS ((size_t)PG_HUGE_BLOCKS * (65536 + 64))
 
 // ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
 struct PgKeptOut {
@@ -125,11 +127,11 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
                          int32_t *flags, int32_t *stat_status);
-// bins: LDS histogram size of this launch (1024 or PG_STATS_BINS); reads with a wider interval are flagged PGR_ERR_WIDE
+// bins: 1024 (one workgroup per read), PG_STATS_BINS (LDS, wide list) or 65536 (global-memory histograms, huge list)
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count);
+                          const int32_t *wide_count, uint32_t *huge_scratch);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

@@ -13,6 +13,7 @@
 #include "pg_internal.h"
 #include "pg_select.h"
 #include <limits.h>
+#include <type_traits>
 
 #define WAVE 64
 
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
-__global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; }
+__global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; flags[2] = 0; }
 
 __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
                                                    uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count,
@@ -694,8 +695,10 @@ __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, 
     const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
     plan[r] = p;
     stat_status[r] = 0;
-    // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launch
-    if (p.status == 0 && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
+    // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launches: the list is
+    // filled from the front (<= PG_STATS_BINS codes, LDS) and from the back (more: global-memory histogram)
+    if (p.status == 0 && p.span > PG_STATS_BINS) wide_list[B.n_reads - 1 - (uint32_t)atomicAdd(wide_count + 1, 1)] = r;
+    else if (p.status == 0 && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
 }
 
 // prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
@@ -709,6 +712,16 @@ template <int LOG_BPL> struct PaddedPre {
 // 16-byte loads (8 int16 per lane, up to 8 loads in flight per lane) and binned by raw code into an LDS
 // histogram of the in-range code interval [c_lo, c_lo+span); an inclusive prefix sum of the histogram
 // then yields both order statistics (pg_select.h) without touching the signal again.
+// prefix accessor over a global-memory histogram (reads served by L2: the wave's own atomics/stores are visible there)
+struct GlobalPre {
+    const uint32_t *h;
+    __device__ __forceinline__ uint32_t operator[](int b) const {
+        return __hip_atomic_load(h + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+#define PG_HUGE_BINS 65536 // every int16 code: the global-memory fallback for very wide [pa_min, pa_max]
+#define PG_HUGE_WORDS (PG_HUGE_BINS + 64)
+
 template <int BINS> struct StatsGeom {
     static constexpr int BPL = BINS / WAVE;           // bins per lane in the scan
     static constexpr int LOG_BPL = BPL == 16 ? 4 : (BPL == 32 ? 5 : 6);
@@ -716,16 +729,19 @@ template <int BINS> struct StatsGeom {
     static constexpr int LDS_WORDS = TRASH + 32 + 4;  // + 32 dummy bins (padded) for out-of-range samples
 };
 
+// BINS == 1024 / PG_STATS_BINS: padded LDS histogram; BINS == PG_HUGE_BINS: global-memory histogram (one per block)
 template <int BINS>
 __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgReadPlan *__restrict__ plan,
                                                const uint8_t *__restrict__ needed, double *__restrict__ med, double *__restrict__ mad,
                                                int32_t *__restrict__ status, int32_t *__restrict__ err, int win) {
-    constexpr int BPL = StatsGeom<BINS>::BPL, LOG_BPL = StatsGeom<BINS>::LOG_BPL;
+    constexpr bool GLOBAL = BINS == PG_HUGE_BINS;
+    constexpr int BPL = GLOBAL ? 1 : BINS / WAVE, LOG_BPL = GLOBAL ? 31 : (BPL == 16 ? 4 : (BPL == 32 ? 5 : 6));
+    constexpr int WORDS = GLOBAL ? PG_HUGE_WORDS : BINS + WAVE + 32 + 4;
     const int lane = lane_id();
     const PgReadPlan pl = plan[r];
     const uint64_t beg = B.sig_off[r], end = B.sig_off[r + 1];
     const bool skip = (needed && !needed[r]) || end == beg;
-    if (BINS == 1024 && !skip && pl.status == 0 && pl.span > BINS) return; // on the wide list
+    if (!GLOBAL && !skip && pl.status == 0 && pl.span > BINS) return; // on the list of a wider launch
     if (skip || pl.status != 0 || pl.span > BINS) {
         if (lane == 0) {
             med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
@@ -735,7 +751,8 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
     }
     {
         uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-        for (int i = lane; i < StatsGeom<BINS>::LDS_WORDS / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < WORDS / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
+        if (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
     }
 
     const int c_lo = pl.c_lo;
@@ -743,10 +760,9 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
     // out-of-range samples (idx wraps to a huge unsigned value) are clamped onto 32 dummy bins behind the real
     // ones, one per lane pair, so the inner loop is branch-free: sub, min, shift, add-shift, ds_add
     const uint32_t cap = BINS + (lane & 31u);
-    (void)span;
     auto bin = [&](int code) {
         const uint32_t idx = min((uint32_t)(code - c_lo), cap);
-        atomicAdd(&hist[idx + (idx >> LOG_BPL)], 1u);
+        atomicAdd(&hist[GLOBAL ? idx : idx + (idx >> LOG_BPL)], 1u);
     };
     auto bin8 = [&](const int4 &q) {
         bin((int)(short)(q.x & 0xffff)); bin(q.x >> 16);
@@ -771,22 +787,37 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
     } else {
         for (uint64_t s = beg + lane; s < end; s += WAVE) bin((int)sig[s]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // inclusive prefix over the bins: lane l owns bins [l*BPL, (l+1)*BPL) at padded address l*(BPL+1)+i
-    uint32_t ssum = 0;
+    if constexpr (GLOBAL) {
+        // inclusive prefix over the in-range bins, 64 at a time with a running carry
+        uint32_t carry = 0;
+        for (uint32_t c = 0; c < span; c += WAVE) {
+            const uint32_t b = c + lane;
+            const uint32_t v = b < span ? __hip_atomic_load(hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const uint32_t inc = wave_incl_scan_u32(v);
+            if (b < span) __hip_atomic_store(hist + b, carry + inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
+    } else {
+        // inclusive prefix over the bins: lane l owns bins [l*BPL, (l+1)*BPL) at padded address l*(BPL+1)+i
+        uint32_t ssum = 0;
 #pragma unroll
-    for (int i = 0; i < BPL; ++i) ssum += hist[lane * (BPL + 1) + i];
-    uint32_t run = wave_incl_scan_u32(ssum) - ssum;
+        for (int i = 0; i < BPL; ++i) ssum += hist[lane * (BPL + 1) + i];
+        uint32_t run = wave_incl_scan_u32(ssum) - ssum;
 #pragma unroll 8
-    for (int i = 0; i < BPL; ++i) { run += hist[lane * (BPL + 1) + i]; hist[lane * (BPL + 1) + i] = run; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int i = 0; i < BPL; ++i) { run += hist[lane * (BPL + 1) + i]; hist[lane * (BPL + 1) + i] = run; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
     __builtin_amdgcn_wave_barrier();
 
     // order statistics: every search step tests 64 candidates (pg_select.h holds the arithmetic)
-    PgSel<PaddedPre<LOG_BPL>> sel;
-    sel.pre = PaddedPre<LOG_BPL>{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = end - beg;
+    using Pre = typename std::conditional<GLOBAL, GlobalPre, PaddedPre<LOG_BPL>>::type;
+    PgSel<Pre> sel;
+    sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = end - beg;
     sel.offset = B.off[r]; sel.scale = B.range[r] / B.dig[r];
     sel.begin();
     int bm = 0;
@@ -864,6 +895,20 @@ __global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgRe
     }
 }
 
+// reads whose in-range interval exceeds PG_STATS_BINS codes (very wide --pa_min/--pa_max): same algorithm on a
+// 65536-bin histogram in global memory, one scratch histogram per workgroup
+__global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
+                                                        double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
+                                                        int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
+                                                        const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch) {
+    const uint32_t n_list = (uint32_t)wide_count[1];
+    uint32_t *hist = scratch + (size_t)blockIdx.x * PG_HUGE_WORDS;
+    for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
+        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, needed, med, mad, status, err, win);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 // =====================================================================================================
 // k_gather: one wave per kept event (gmove.cpp:773-775, 938-944)
@@ -1008,15 +1053,19 @@ void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, dou
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count) {
+                          const int32_t *wide_count, uint32_t *huge_scratch) {
     if (B.n_reads == 0) return;
     const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
     if (bins <= 1024)
         hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
-    else { // the wide list is usually empty: a small persistent grid
+    else if (bins <= PG_STATS_BINS) { // the wide list is usually empty: a small persistent grid
         const uint32_t grid = B.n_reads < 2048 ? B.n_reads : 2048;
         hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
                            wide_count);
+    } else {
+        const uint32_t grid = B.n_reads < PG_HUGE_BLOCKS ? B.n_reads : PG_HUGE_BLOCKS;
+        hipLaunchKernelGGL(k_read_stats_huge, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
+                           wide_count, huge_scratch);
     }
 }
 

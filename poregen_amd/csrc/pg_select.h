@@ -159,8 +159,8 @@ struct PgSel {
         aShiftU = (int)floor(q) + 1;   // D codes with d0 + t'*s <= u0 + t*s  <=>  t' <= t + q
         aShiftD = (int)floor(-q) + 1;
         const double zu = (dZ - u0) * inv, zd = (dZ - d0) * inv;
-        aZU = zu <= 0.0 ? 0 : (zu >= 4096.0 ? 4096 : (int)ceil(zu));
-        aZD = zd <= 0.0 ? 0 : (zd >= 4096.0 ? 4096 : (int)ceil(zd));
+        aZU = zu <= 0.0 ? 0 : (zu >= 65536.0 ? 65536 : (int)ceil(zu));
+        aZD = zd <= 0.0 ? 0 : (zd >= 65536.0 ? 65536 : (int)ceil(zd));
     }
     PG_HD bool approx_pred(bool up, int t) const {
         int o = t + (up ? aShiftU : aShiftD);

@@ -176,3 +176,15 @@ def test_mad_fallback_search_path(pa):
     for narrow in (False, True):
         res = run_engine([b], kmers=kmers, debug_narrow=narrow, **p)
         assert_result_equals_oracle(res, o, sample_limit=15)
+
+
+@pytest.mark.parametrize("pa", [(0.0, 250.0), (-300.0, 1000.0), (-5000.0, 5000.0)])
+def test_wide_pa_windows_use_the_wider_histograms(pa):
+    """[pa_min, pa_max] wider than 1024 raw codes: 2048-bin LDS histogram, then the 65536-bin global-memory one."""
+    b = synth.make_batch(120, kind="rna004", seed=19, spike_rate=0.05)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=8, pa_min=pa[0], pa_max=pa[1])
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    res = run_engine([b], kmers=kmers, **p)
+    assert_result_equals_oracle(res, o, sample_limit=8)
