@@ -129,12 +129,40 @@ def main():
     # algorithmic bytes of the statistics kernels per launch: every int16 sample once, the three
     # doubles + two offsets of each read in, median + MAD out
     stats_bytes = 2 * n_samples + (24 + 16 + 16) * host.n_reads
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950
+    # note of MI355X_MICROARCH.md): measured offline on this exact workload and committed under profiles/
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+        "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
         "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
     }
     kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
+
+    # the same job with statistics only for the reads that own a kept event (legal: acceptance is signal-independent in
+    # the PAF path); reported next to `value`, never as `value`
+    lazy_info = None
+    if world == 1 and not args.lazy:
+        lz = GmoveEngine(GmoveParams(kmers=kmers, **dict(p, lazy_stats=True)))
+        for _ in range(args.warmup):
+            lz.reset(); lz.submit(shard)
+        lz.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lz.reset(); lz.submit(shard)
+        lz.sync(); torch.cuda.synchronize()
+        ldt = (time.perf_counter() - t0) / args.steps
+        lres = lz.finish()
+        touched = int(np.unique(lres.ev_read).size)
+        lazy_info = {"value": n_samples / ldt, "ms_per_step": ldt * 1e3, "reads_with_statistics": touched,
+                     "samples_touched": int(touched * args.read_len)}
+        lz.close()
 
     out = {
         "metric": "signal samples/sec aggregated into k-mer buckets", "value": value, "unit": "samples/s",
@@ -151,6 +179,7 @@ def main():
         },
         "roofline": roofline,
         "kernels_ms_per_step": kernels_ms,
+        "lazy_statistics_mode": lazy_info,
         "gen_seconds": gen_s,
     }
 
