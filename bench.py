@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--sample-limit", type=int, default=100)
     ap.add_argument("--lazy", action="store_true", help="statistics only for reads that own a kept event")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -148,7 +149,7 @@ def main():
     # the same job with statistics only for the reads that own a kept event (legal: acceptance is signal-independent in
     # the PAF path); reported next to `value`, never as `value`
     lazy_info = None
-    if world == 1 and not args.lazy:
+    if world == 1 and not args.lazy and not args.no_lazy_extra:
         lz = GmoveEngine(GmoveParams(kmers=kmers, **dict(p, lazy_stats=True)))
         for _ in range(args.warmup):
             lz.reset(); lz.submit(shard)

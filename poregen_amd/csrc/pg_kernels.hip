@@ -588,24 +588,46 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
 }
 
 // direct mode: totals[3] = last tile that can still place an event = max over slots of the last tile whose exclusive
-// prefix is below keep[slot]. One wave per slot, coalesced over the slot's row of tile prefixes.
+// prefix in the slot's row is below keep[slot]. One thread per slot, spread over many small workgroups (the probes are
+// scattered loads: a single workgroup would serialise them on one CU).
 __global__ __launch_bounds__(64) void k_tile_max(const uint32_t *__restrict__ hist, uint32_t n_tiles, const uint64_t *__restrict__ keep,
-                                                 uint64_t *__restrict__ totals) {
-    const uint32_t s = blockIdx.x;
-    const uint64_t kp = keep[s];
-    if (kp == 0) return;
-    const int lane = lane_id();
+                                                 uint32_t n_slots, uint64_t *__restrict__ totals) {
+    const uint32_t s = blockIdx.x * 64 + threadIdx.x;
     int last = -1;
-    for (uint32_t c = 0; c < n_tiles; c += WAVE) {
-        const uint32_t t = c + lane;
-        const bool below = t < n_tiles && (uint64_t)hist[(uint64_t)s * n_tiles + t] < kp;
-        const uint64_t m = __ballot(below);
-        if (m) last = (int)c + 63 - __clzll((long long)m);
-        if (m != ~0ull) break; // prefixes are non-decreasing: nothing further is below
+    if (s < n_slots) {
+        const uint64_t kp = keep[s];
+        if (kp > 0) {
+            // the row is non-decreasing: bracket the crossing with 12 independent probes at 2^j, then narrow 8 ways per
+            // round (three dependent round trips instead of a binary search's eleven)
+            const uint32_t *row = hist + (uint64_t)s * n_tiles;
+            uint32_t pv[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) { const uint32_t p = 1u << j; pv[j] = row[p < n_tiles ? p : n_tiles - 1]; }
+            uint32_t lo = 0, hi = n_tiles; // row[lo] < kp (row[0] == 0), row[hi] >= kp or hi == n_tiles
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const uint32_t p = 1u << j;
+                if (p < n_tiles) { if ((uint64_t)pv[j] < kp) lo = p; else if (p < hi) hi = p; }
+            }
+            while (hi - lo > 1) {
+                const uint32_t step = (hi - lo + 8) / 9;
+                uint32_t qv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const uint32_t p = lo + (i + 1) * step; qv[i] = row[p < hi ? p : lo]; }
+                uint32_t nlo = lo, nhi = hi;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t p = lo + (i + 1) * step;
+                    if (p < hi) { if ((uint64_t)qv[i] < kp) nlo = p; else if (p < nhi) nhi = p; }
+                }
+                lo = nlo; hi = nhi;
+            }
+            last = (int)lo;
+        }
     }
-    // ~1000 waves would serialise on one atomic (~12 ns each): only the few that can raise the maximum issue it
-    if (lane == 0 && last > (long long)__hip_atomic_load(reinterpret_cast<long long *>(&totals[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<long long *>(&totals[3]), (long long)last);
+    // one atomic per wave
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(last, d, WAVE); last = o > last ? o : last; }
+    if (threadIdx.x == 0 && last >= 0) atomicMax(reinterpret_cast<long long *>(&totals[3]), (long long)last);
 }
 
 __global__ __launch_bounds__(256) void k_kept_meta(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
@@ -1024,7 +1046,7 @@ void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t 
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                          uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles) {
     hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles);
-    if (hist && n_tiles) hipLaunchKernelGGL(k_tile_max, dim3(n_slots), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, totals);
+    if (hist && n_tiles) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
 }
 
 void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
