@@ -67,6 +67,9 @@ enum {
     PG_FLAG_SHORT_READS_OK = 1u << 4, /* a read with fewer than k matched bases simply has no events (move-table front-end,
                                         where that is well defined); default: PG_ERR_INPUT, because the PAF path of the
                                         reference has undefined behaviour there (src/gmove.cpp:891) */
+    PG_FLAG_SKIP_OUT_OF_RANGE = 1u << 5, /* a read with ANY sample outside [pa_min, pa_max] is skipped as a whole instead of
+                                           zero-filling the sample: the SAM/BAM front-end (src/gmove.cpp:1149-1160). Event
+                                           acceptance then depends on the signal, so the statistics pass runs first. */
     PG_FLAG_DEBUG_NARROW = 1u << 3 /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
 };
 

@@ -434,6 +434,75 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* SAM/BAM path: one loop iteration of process_move_table_bam (gmove.cpp:1080-1261)            */
+
+int orc_bam_read(orc_state_t *st, const int16_t *raw, uint64_t len_total,
+                 double digitisation, double offset, double range,
+                 int32_t fastq_len, const char *fastq_seq, int32_t stride,
+                 const int8_t *moves, uint32_t n_moves, uint64_t signal_len, uint64_t trim_offset) {
+    const orc_opt_t *o = &st->opt;
+    if (st->num_kmers_complete == st->n_kmers) return ORC_STOPPED;                       /* gmove.cpp:1081-1083 */
+    if (len_total != signal_len) return ORC_ERR_ASSERT;                                  /* gmove.cpp:1146 */
+    if (!(trim_offset < len_total)) return ORC_ERR_ASSERT;                               /* gmove.cpp:1147 */
+    st->reads_seen++; st->total_samples += len_total;
+    uint64_t len_raw_signal = len_total - trim_offset;                                   /* gmove.cpp:1148 */
+    double *x = (double *)calloc(len_total ? len_total : 1, sizeof(double));
+    int rc = ORC_OK;
+    /* gmove.cpp:1149-1160: ANY out-of-range sample skips the whole read (no zero-fill on this path) */
+    for (uint64_t i = 0; i < len_raw_signal; i++) {
+        double pA = (raw[i + trim_offset] + offset) * (range / digitisation);
+        if (pA < o->pa_min || pA > o->pa_max) { rc = ORC_SKIPPED; goto done; }
+        x[i] = pA;
+    }
+    if (o->scaling == 1) {                                                               /* gmove.cpp:1162-1176 */
+        double med = orc_median(x, len_raw_signal);
+        double mad = orc_madf(x, len_raw_signal, med);
+        mad = (mad > 1.0) ? mad : 1.0;
+        for (uint64_t i = 0; i < len_raw_signal; i++) x[i] = (x[i] - med) / mad;
+        st->last_med = med; st->last_mad = mad;
+    }
+    if (fastq_len < 10) { rc = ORC_SKIPPED; goto done; }                                 /* gmove.cpp:1178-1181 */
+    {
+        /* bam_auxB2i(mv_array, q + 1) is moves[q] for q < n_moves and 0 beyond the array (htslib 1.17 sam.c) */
+        const size_t move_len = (size_t)n_moves + 1;                                     /* bam_auxB_len includes the stride */
+        size_t seq_size = strlen(fastq_seq);
+        uint32_t move_count = 0; size_t move_idx = 0, start_move_idx = 0;
+        while (move_count < o->sig_move_offset + 1) {                                    /* gmove.cpp:1185-1192 */
+            if (move_idx >= n_moves) { rc = ORC_ERR_UNDEFINED; goto done; }              /* would spin forever on zeros */
+            if (moves[move_idx] == 1) { move_count++; start_move_idx = move_idx; }
+            move_idx++;
+        }
+        move_idx = start_move_idx + 1;
+        size_t seq_start = o->kmer_start_offset;
+        char kmer[64];
+        if (o->kmer_size >= sizeof kmer) { rc = ORC_ERR_UNDEFINED; goto done; }
+        for (; move_idx <= move_len; move_idx++) {                                       /* gmove.cpp:1195 */
+            int8_t value = move_idx < n_moves ? moves[move_idx] : 0;
+            if (value != 1) continue;
+            if (seq_start > seq_size) { rc = ORC_ERR_UNDEFINED; goto done; }             /* substr would throw */
+            size_t kl = seq_size - seq_start < o->kmer_size ? seq_size - seq_start : o->kmer_size;
+            memcpy(kmer, fastq_seq + seq_start, kl); kmer[kl] = 0;                       /* gmove.cpp:1198 */
+            uint32_t raw_start_local = (uint32_t)(start_move_idx * (size_t)stride);      /* gmove.cpp:1199-1202 */
+            uint32_t raw_end_local = (uint32_t)(move_idx * (size_t)stride);
+            start_move_idx = move_idx;
+            seq_start++;
+            if (raw_end_local - raw_start_local > o->max_dur) continue;
+            if (raw_end_local - raw_start_local < o->min_dur) continue;
+            orc_slot_t *s = find_slot(st, kmer);
+            if (!s) continue;
+            if (s->count == o->sample_limit) continue;
+            rc = emit_event(st, s, x, len_raw_signal, raw_start_local, raw_end_local);
+            if (rc != ORC_OK) goto done;
+            if (seq_start + o->kmer_size > seq_size) break;                              /* gmove.cpp:1248-1250 */
+        }
+    }
+    if (o->delimit_files == 1) delimit(st);                                              /* gmove.cpp:1253-1255 */
+done:
+    free(x);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* accessors and output                                                                       */
 
 size_t orc_n_slots(const orc_state_t *st) { return st->n_slots; }

@@ -15,7 +15,8 @@
  *       own input fixtures (copied as data under tests/golden/single_read/),
  *   (2) the reference tests' cross-format invariant (table path == PAF path at --kmer_pick_margin 0,
  *       test/test_gmove.sh:79-80,95-96), and
- *   (3) the reference tests' exit-status expectations (test_gmove.sh:50,58,66).
+ *   (3) the reference tests' exit-status expectations (test_gmove.sh:50,58,66);
+ *   (4) for the SAM/BAM path only the invariant BAM == table (test_gmove.sh:85-86,101-102): no known answers exist.
  * No reference-held golden output exists, so by the rules of this build: "parity unpinned" with
  * respect to reference-owned expected values; see DESIGN.md.
  */
@@ -91,6 +92,15 @@ int orc_table_read(orc_state_t *st,
                    double digitisation, double offset, double range,
                    int32_t fastq_len, const char *fastq_seq, int32_t stride,
                    const char *move_seq, uint64_t signal_len, int32_t trim_offset);
+
+/* One iteration of the while(sam_read1) loop of process_move_table_bam (gmove.cpp:1080-1261).
+ * moves[0..n_moves) are the mv:B:c values AFTER the leading stride element (bam_auxB_len - 1 of them);
+ * fastq_seq is the record's SEQ with every non-ACGT letter already mapped to 'N' (gmove.cpp:1128-1134). */
+int orc_bam_read(orc_state_t *st,
+                 const int16_t *raw, uint64_t len_raw_signal,
+                 double digitisation, double offset, double range,
+                 int32_t fastq_len, const char *fastq_seq, int32_t stride,
+                 const int8_t *moves, uint32_t n_moves, uint64_t signal_len, uint64_t trim_offset);
 
 /* results (slot = index into the slice, 0-based: slot i is kmers[index_start-1+i]) */
 size_t      orc_n_slots(const orc_state_t *st);

@@ -4,7 +4,7 @@
  * handling and set-up (src/gmove.cpp:213-537) around gmove_oracle.c, with its own minimal readers
  * for ASCII SLOW5, FASTQ/FASTA, PAF and the 7-column move table, so that the product CLI (which has
  * independent parsers) can be diffed against it byte-for-byte on whole output directories.
- * BAM/SAM input (gmove.cpp:1061-1266) is not restated (needs htslib; unpinned) -> exit status 3.
+ * SAM text input (gmove.cpp:1061-1266) is parsed here; binary BAM is not (exit status 3: convert with samtools view).
  */
 #define _GNU_SOURCE
 #include "gmove_oracle.h"
@@ -175,8 +175,8 @@ int main(int argc, char **argv) {
 
     size_t ml = strlen(move_table);                                      /* gmove.cpp:505-521 */
     const char *ext = ml >= 4 ? move_table + ml - 4 : "";
-    int is_paf = strcmp(ext, ".paf") == 0, is_bam = strcmp(ext, ".bam") == 0 || strcmp(ext, ".sam") == 0;
-    if (is_bam) { fprintf(stderr, "BAM/SAM input is not restated by the oracle\n"); return 3; }
+    int is_paf = strcmp(ext, ".paf") == 0, is_bam = strcmp(ext, ".bam") == 0, is_sam = strcmp(ext, ".sam") == 0;
+    if (is_bam) { fprintf(stderr, "binary BAM input is not read by the oracle (use the SAM text of the same records)\n"); return 3; }
     fq_t fq = {0, 0, 0};
     if (is_paf) {
         if (!fastq) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return 1; } /* gmove.cpp:510-513 */
@@ -200,6 +200,32 @@ int main(int argc, char **argv) {
             fq_rec_t *t = fq_get(&fq, col[5]);
             rc = orc_paf_read(st, r->raw, r->len, r->dig, r->off, r->range, atoi(col[2]), atoi(col[7]), atoi(col[8]),
                               t ? t->seq : NULL, t ? t->len : 0, ss);
+        } else if (is_sam) {                                             /* sam_read1 + tags ns, ts, mv (gmove.cpp:1080-1134) */
+            if (line[0] == '@') continue;
+            char *col[11]; int nc = 0; char *mv = NULL; long long ns = -1, ts = -1;
+            for (char *p = strtok_r(line, "\t\r\n", &save); p; p = strtok_r(NULL, "\t\r\n", &save)) {
+                if (nc < 11) col[nc++] = p;
+                else if (strncmp(p, "mv:B:c,", 7) == 0) mv = p + 7;
+                else if (strncmp(p, "ns:i:", 5) == 0) ns = atoll(p + 5);
+                else if (strncmp(p, "ts:i:", 5) == 0) ts = atoll(p + 5);
+            }
+            if (nc < 11) { status = 1; break; }
+            if (ns < 0 || ts < 0 || !mv) { fprintf(stderr, "tag ns/ts/mv is not found\n"); status = 1; break; }  /* gmove.cpp:1086-1105 */
+            size_t cap2 = strlen(mv) / 2 + 2, nm = 0;
+            int8_t *vals = (int8_t *)malloc(cap2);
+            for (char *q = mv; *q;) { vals[nm++] = (int8_t)strtol(q, &q, 10); if (*q == ',') q++; }
+            if (nm == 0) { status = 1; free(vals); break; }
+            int stride = vals[0];
+            size_t sl = strlen(col[9]);
+            char *seq = (char *)malloc(sl + 1);
+            for (size_t i = 0; i < sl; i++) { char ch = col[9][i]; if (ch >= 'a' && ch <= 'z') ch -= 32; seq[i] = (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? ch : 'N'; }
+            seq[sl] = 0;
+            if (sl == 1 && col[9][0] == '*') { seq[0] = 0; sl = 0; }
+            s5_rec_t *r = s5_get(&s5, col[0]);
+            if (!r) { fprintf(stderr, "Error in when fetching the read\n"); status = 1; free(vals); free(seq); break; }
+            rc = orc_bam_read(st, r->raw, r->len, r->dig, r->off, r->range, (int32_t)sl, seq, stride, vals + 1, (uint32_t)(nm - 1),
+                              (uint64_t)ns, (uint64_t)ts);
+            free(vals); free(seq);
         } else {                                                         /* gmove.cpp:570-577 */
             char *col[7]; int nc = 0;
             for (char *p = strtok_r(line, "\t", &save); p && nc < 7; p = strtok_r(NULL, "\t", &save)) col[nc++] = p;

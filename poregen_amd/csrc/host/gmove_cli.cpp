@@ -186,12 +186,10 @@ int gmove_main(int argc, char **argv) {
 
     const std::string mt(move_table); // src/gmove.cpp:505-521
     const std::string ext = mt.size() >= 4 ? mt.substr(mt.size() - 4) : "";
-    const bool is_paf = ext == ".paf";
-    if (ext == ".bam" || ext == ".sam") {
-        fprintf(stderr, "this build implements the .paf (ss:Z:) and move-table front-ends of gmove; SAM/BAM input (gmove.cpp:1061-1266) is not implemented\n");
-        return EXIT_FAILURE;
-    }
+    const bool is_paf = ext == ".paf", is_bam = ext == ".bam" || ext == ".sam";
     pgh::FastxIndex fai;
+    pgh::SamBamReader sam;
+    if (is_bam && !sam.open(move_table, err)) { fprintf(stderr, "[gmove] %s\n", err.c_str()); return EXIT_FAILURE; } // F_CHK(bam_fp), gmove.cpp:1067-1068
     if (is_paf) {
         if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return EXIT_FAILURE; } // gmove.cpp:510-513
         if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return EXIT_FAILURE; }
@@ -215,7 +213,8 @@ int gmove_main(int argc, char **argv) {
         prm.kmer_pick_margin = 0; prm.sig_move_offset = 0;
     }
     prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
-    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK); prm.device = device;
+    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
+    prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     pg_ctx *ctx = nullptr;
     if (pg_create(&prm, &ctx) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(nullptr)); return EXIT_FAILURE; }
@@ -242,8 +241,60 @@ int gmove_main(int argc, char **argv) {
         if (pg_all_slots_full(ctx)) stop = true; // every file is closed: nothing later can be written (gmove.cpp:733-735)
         return true;
     };
-    while (!stop && (got = getline(&line, &cap, paf_fp)) != -1) {
-        if (is_paf) {
+    // Move-table style records (table file and SAM/BAM, gmove.cpp:557-700 / 1080-1261): resolve -m (first window starts
+    // at the (m+1)-th move) and -s (first k-mer starts at base s) on the host, turn every closed move segment into a match
+    // op of (gap x stride) samples, drop the trimmed prefix of the signal. The device then runs the same collector with
+    // kmer_pick_margin 0 and no indels.
+    std::vector<uint8_t> is_one;
+    auto add_move_record = [&](const char *read_id, int fastq_len, const std::string &fseq, int stride, uint64_t signal_len, long long trim) -> bool {
+        if (!s5.get(read_id, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; return false; }  // gmove.cpp:582-586
+        if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
+            fprintf(stderr, "move record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", read_id); status = EXIT_FAILURE; return false;
+        }
+        hb.sig.insert(hb.sig.end(), rec.raw.begin() + trim, rec.raw.end()); // gmove.cpp:591-598: only the trimmed signal is used
+        total_samples += rec.raw.size();
+        seq.clear();
+        uint32_t qstart = 0;
+        const size_t move_len = is_one.size();
+        if (fastq_len >= 10) { // gmove.cpp:616-619: shorter reads are skipped (no events, no ':')
+            size_t idx = 0, start_idx = 0; uint32_t ones = 0;
+            while (ones < opt.sig_move_offset + 1 && idx < move_len) { if (is_one[idx]) { ones++; start_idx = idx; } idx++; } // gmove.cpp:623-629
+            if (ones < opt.sig_move_offset + 1) { fprintf(stderr, "move array of %s has fewer than %u moves\n", read_id, opt.sig_move_offset + 1); status = EXIT_FAILURE; return false; }
+            if (opt.kmer_start_offset > fseq.size()) { fprintf(stderr, "kmer start offset beyond the sequence of %s\n", read_id); status = EXIT_FAILURE; return false; }
+            seq = fseq.substr(opt.kmer_start_offset);
+            qstart = (uint32_t)(start_idx * (size_t)stride);
+            size_t n_seg = 0, prev = start_idx;
+            for (size_t i = start_idx + 1; i < move_len; i++) // the last move is never closed (gmove.cpp:632, 1195)
+                if (is_one[i]) {
+                    if (n_seg < seq.size()) { hb.op_n.push_back((uint32_t)((i - prev) * (size_t)stride)); hb.op_t.push_back(0); }
+                    n_seg++; prev = i;
+                }
+            // event j pairs segment j with the k-mer at base j even when fewer than k segments follow it: pad with
+            // zero-length matches (never used as windows) so that the collector sees k matched bases for it
+            const size_t real = n_seg < seq.size() ? n_seg : seq.size();
+            size_t pad = seq.size() > n_seg ? seq.size() - n_seg : 0; if (pad > opt.kmer_size - 1) pad = opt.kmer_size - 1;
+            for (size_t i = 0; i < pad; i++) { hb.op_n.push_back(0); hb.op_t.push_back(0); }
+            seq.resize(real + pad);
+            if (seq.size() < opt.kmer_size) seq.append(opt.kmer_size - seq.size(), 'N'); // not "skipped": the read still gets its ':' with -d
+        }
+        hb.qs.push_back((int32_t)qstart); hb.ts.push_back(0); hb.te.push_back((int32_t)seq.size());
+        return true;
+    };
+    for (;;) {
+        if (stop) break;
+        pgh::MoveRec mrec;
+        if (is_bam) {
+            const int nr = sam.next(mrec, err);
+            if (nr == 0) break;
+            if (nr < 0) { fprintf(stderr, "[gmove] %s\n", err.c_str()); status = EXIT_FAILURE; break; }
+            if (!mrec.has_ns) { fprintf(stderr, "tag 'ns' is not found. Please check your SAM/BAM file: \n"); status = EXIT_FAILURE; break; }   // gmove.cpp:1086-1089
+            if (!mrec.has_ts) { fprintf(stderr, "tag 'ts' is not found. Please check your SAM/BAM file: \n"); status = EXIT_FAILURE; break; }   // gmove.cpp:1094-1097
+            if (!mrec.has_mv) { fprintf(stderr, "NULL returned for tag mv: \n"); status = EXIT_FAILURE; break; }                               // gmove.cpp:1102-1105
+            if (!mrec.mv_is_Bc) { fprintf(stderr, "tag 'mv' specification is incorrect\n"); status = EXIT_FAILURE; break; }                    // gmove.cpp:1120-1123
+            is_one.swap(mrec.is_one);
+            if (!add_move_record(mrec.qname.c_str(), (int)mrec.seq.size(), mrec.seq, mrec.stride, mrec.ns, (long long)mrec.ts)) break;
+        } else if ((got = getline(&line, &cap, paf_fp)) == -1) break;
+        else if (is_paf) {
             pgh::PafRec paf;
             int pr = pgh::parse_paf_line(line, (size_t)got, paf);
             if (pr == 1) { fprintf(stderr, "malformed PAF record (fewer than 12 columns)\n"); status = EXIT_FAILURE; break; }
@@ -258,49 +309,17 @@ int gmove_main(int argc, char **argv) {
             hb.qs.push_back(paf.query_start); hb.ts.push_back(paf.target_start); hb.te.push_back(paf.target_end);
             total_samples += rec.raw.size();
         } else {
-            // move table (gmove.cpp:557-700): read_id, fastq_len, fastq_seq, stride, moves, signal_len, trim_offset.
-            // Host work: resolve -m (first window starts at the (m+1)-th '1') and -s (first k-mer starts at base s),
-            // turn every closed move segment into a match op of (gap x stride) samples, drop the trimmed prefix of
-            // the signal. The device then runs the same collector with kmer_pick_margin 0 and no indels.
+            // move table (gmove.cpp:557-700): read_id, fastq_len, fastq_seq, stride, moves, signal_len, trim_offset
             char *col[7]; int nc = 0;
             for (char *p = line, *e = line + got; p < e && nc < 7;) {
                 char *t = (char *)memchr(p, '\t', (size_t)(e - p)); if (!t) t = e;
                 col[nc++] = p; *t = 0; p = t + 1;
             }
             if (nc < 7) { fprintf(stderr, "malformed move-table record (fewer than 7 columns)\n"); status = EXIT_FAILURE; break; }
-            const int fastq_len = atoi(col[1]); const std::string fseq(col[2]); const int stride = atoi(col[3]);
             const char *moves = col[4]; const size_t move_len = strlen(moves);
-            const uint64_t signal_len = strtoull(col[5], nullptr, 10); const int trim = atoi(col[6]);
-            if (!s5.get(col[0], rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }  // gmove.cpp:582-586
-            if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
-                fprintf(stderr, "move-table record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", col[0]); status = EXIT_FAILURE; break;
-            }
-            hb.sig.insert(hb.sig.end(), rec.raw.begin() + trim, rec.raw.end()); // gmove.cpp:591-598: only the trimmed signal is used
-            total_samples += rec.raw.size();
-            seq.clear();
-            uint32_t qstart = 0;
-            if (fastq_len >= 10) { // gmove.cpp:616-619: shorter reads are skipped (no events, no ':')
-                size_t idx = 0, start_idx = 0; uint32_t ones = 0;
-                while (ones < opt.sig_move_offset + 1 && idx < move_len) { if (moves[idx] == '1') { ones++; start_idx = idx; } idx++; } // gmove.cpp:623-629
-                if (ones < opt.sig_move_offset + 1) { fprintf(stderr, "move string of %s has fewer than %u moves\n", col[0], opt.sig_move_offset + 1); status = EXIT_FAILURE; break; }
-                if (opt.kmer_start_offset > fseq.size()) { fprintf(stderr, "kmer start offset beyond the sequence of %s\n", col[0]); status = EXIT_FAILURE; break; }
-                seq = fseq.substr(opt.kmer_start_offset);
-                qstart = (uint32_t)(start_idx * (size_t)stride);
-                size_t n_seg = 0, prev = start_idx;
-                for (size_t i = start_idx + 1; i < move_len; i++) // the last move is never closed (moves[move_len] is NUL, gmove.cpp:632)
-                    if (moves[i] == '1') {
-                        if (n_seg < seq.size()) { hb.op_n.push_back((uint32_t)((i - prev) * (size_t)stride)); hb.op_t.push_back(0); }
-                        n_seg++; prev = i;
-                    }
-                // event j pairs segment j with the k-mer at base j even when fewer than k segments follow it: pad with
-                // zero-length matches (never used as windows) so that the collector sees k matched bases for it
-                const size_t real = n_seg < seq.size() ? n_seg : seq.size();
-                size_t pad = seq.size() > n_seg ? seq.size() - n_seg : 0; if (pad > opt.kmer_size - 1) pad = opt.kmer_size - 1;
-                for (size_t i = 0; i < pad; i++) { hb.op_n.push_back(0); hb.op_t.push_back(0); }
-                seq.resize(real + pad);
-                if (seq.size() < opt.kmer_size) seq.append(opt.kmer_size - seq.size(), 'N'); // not "skipped": the read still gets its ':' with -d
-            }
-            hb.qs.push_back((int32_t)qstart); hb.ts.push_back(0); hb.te.push_back((int32_t)seq.size());
+            is_one.resize(move_len);
+            for (size_t i = 0; i < move_len; i++) is_one[i] = moves[i] == '1';
+            if (!add_move_record(col[0], atoi(col[1]), col[2], atoi(col[3]), strtoull(col[5], nullptr, 10), atoll(col[6]))) break;
         }
         hb.sig_off.push_back(hb.sig.size());
         hb.dig.push_back(rec.digitisation); hb.off.push_back(rec.offset); hb.range.push_back(rec.range);

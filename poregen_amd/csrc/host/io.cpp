@@ -323,4 +323,166 @@ bool tokenize_ss(const char *ss, size_t len, std::vector<uint32_t> &op_n, std::v
     return true;
 }
 
+// ======================================================================================================
+// SAM / BAM
+// ======================================================================================================
+
+static char seq_letter(char c) { // gmove.cpp:1128-1134: alphabet "NACNGNNNT" over htslib's 4-bit codes
+    if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N';
+}
+
+bool SamBamReader::open(const std::string &path, std::string &err) {
+    if (!f_.open(path)) { err = "cannot open " + path; return false; }
+    bam_ = f_.size >= 4 && (unsigned char)f_.data[0] == 0x1f && (unsigned char)f_.data[1] == 0x8b;
+    pos_ = 0; buf_.clear(); bpos_ = 0;
+    if (!bam_) return true;
+    // BAM header: magic, l_text, text, n_ref, references
+    if (!fill(12, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
+    if (memcmp(buf_.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return false; }
+    int32_t l_text; memcpy(&l_text, buf_.data() + 4, 4);
+    if (!fill(12 + (size_t)l_text, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
+    bpos_ = 8 + (size_t)l_text;
+    int32_t n_ref; memcpy(&n_ref, buf_.data() + bpos_, 4); bpos_ += 4;
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (!fill(bpos_ + 4, err)) return false;
+        int32_t l_name; memcpy(&l_name, buf_.data() + bpos_, 4);
+        if (!fill(bpos_ + 8 + (size_t)l_name, err)) return false;
+        bpos_ += 4 + (size_t)l_name + 4;
+    }
+    return true;
+}
+
+// make at least `need` inflated bytes available in buf_ (from offset 0); false at end of data
+bool SamBamReader::fill(size_t need, std::string &err) {
+    while (buf_.size() < need) {
+        if (pos_ + 18 > f_.size) return false;
+        const unsigned char *b = (const unsigned char *)f_.data + pos_;
+        if (b[0] != 0x1f || b[1] != 0x8b || !(b[3] & 4)) { err = "corrupt BGZF block"; return false; }
+        uint16_t xlen; memcpy(&xlen, b + 10, 2);
+        uint32_t bsize = 0; bool found = false;
+        for (size_t o = 12; o + 4 <= 12u + xlen;) { // extra subfields: SI1 SI2 SLEN data
+            uint16_t slen; memcpy(&slen, b + o + 2, 2);
+            if (b[o] == 'B' && b[o + 1] == 'C' && slen == 2) { uint16_t v; memcpy(&v, b + o + 4, 2); bsize = (uint32_t)v + 1; found = true; }
+            o += 4u + slen;
+        }
+        if (!found || pos_ + bsize > f_.size) { err = "corrupt BGZF block"; return false; }
+        const size_t hdr = 12u + xlen, clen = bsize - hdr - 8;
+        uint32_t isize; memcpy(&isize, b + bsize - 4, 4);
+        const size_t old = buf_.size();
+        buf_.resize(old + isize);
+        if (isize) {
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { err = "zlib init failed"; return false; }
+            zs.next_in = (Bytef *)(b + hdr); zs.avail_in = (uInt)clen; zs.next_out = buf_.data() + old; zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END) { err = "zlib error in BGZF block"; return false; }
+        }
+        pos_ += bsize;
+    }
+    return true;
+}
+
+int SamBamReader::next(MoveRec &out, std::string &err) {
+    out = MoveRec();
+    if (!bam_) {
+        const char *e = f_.data + f_.size;
+        while (pos_ < f_.size) {
+            const char *p = f_.data + pos_;
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+            const char *le = nl ? nl : e;
+            pos_ = (size_t)((nl ? nl + 1 : e) - f_.data);
+            if (le == p || *p == '@') continue; // header / blank line
+            int col = 0;
+            while (p <= le) {
+                const char *t = (const char *)memchr(p, '\t', (size_t)(le - p)); if (!t) t = le;
+                if (col == 0) out.qname.assign(p, t);
+                else if (col == 9) { out.seq.assign(p, t); if (out.seq == "*") out.seq.clear(); for (auto &ch : out.seq) ch = seq_letter(ch); }
+                else if (col >= 11 && t - p >= 5) {
+                    if (memcmp(p, "ns:i:", 5) == 0) { out.ns = strtoull(std::string(p + 5, t).c_str(), nullptr, 10); out.has_ns = true; }
+                    else if (memcmp(p, "ts:i:", 5) == 0) { out.ts = strtoull(std::string(p + 5, t).c_str(), nullptr, 10); out.has_ts = true; }
+                    else if (memcmp(p, "mv:", 3) == 0) {
+                        out.has_mv = true;
+                        out.mv_is_Bc = t - p >= 7 && memcmp(p, "mv:B:c", 6) == 0;
+                        if (out.mv_is_Bc) {
+                            const char *q = p + 6; bool first = true;
+                            while (q < t) {
+                                if (*q == ',') q++;
+                                char *endp; const long v = strtol(q, &endp, 10);
+                                if (endp == q) break;
+                                if (first) { out.stride = (int)v; first = false; } else out.is_one.push_back(v == 1);
+                                q = endp;
+                            }
+                        }
+                    }
+                }
+                col++;
+                if (t >= le) break;
+                p = t + 1;
+            }
+            if (col < 11) { err = "malformed SAM record"; return -1; }
+            return 1;
+        }
+        return 0;
+    }
+    // BAM record
+    // drop consumed bytes now and then
+    if (bpos_ > (1u << 20)) { buf_.erase(buf_.begin(), buf_.begin() + (long)bpos_); bpos_ = 0; }
+    if (!fill(bpos_ + 4, err)) return err.empty() ? 0 : -1;
+    int32_t block_size; memcpy(&block_size, buf_.data() + bpos_, 4);
+    if (block_size < 32 || !fill(bpos_ + 4 + (size_t)block_size, err)) { if (err.empty()) err = "truncated BAM record"; return -1; }
+    const unsigned char *r = buf_.data() + bpos_ + 4, *rend = r + block_size;
+    bpos_ += 4 + (size_t)block_size;
+    const uint8_t l_read_name = r[8];
+    uint16_t n_cigar; memcpy(&n_cigar, r + 12, 2);
+    int32_t l_seq; memcpy(&l_seq, r + 16, 4);
+    const unsigned char *p = r + 32;
+    if (p + l_read_name > rend) { err = "corrupt BAM record"; return -1; }
+    out.qname.assign((const char *)p, l_read_name ? l_read_name - 1 : 0); p += l_read_name;
+    p += 4u * n_cigar;
+    if (p + (l_seq + 1) / 2 + l_seq > rend) { err = "corrupt BAM record"; return -1; }
+    static const char code[] = "=ACMGRSVTWYHKDBN";
+    out.seq.resize((size_t)l_seq);
+    for (int32_t i = 0; i < l_seq; i++) out.seq[(size_t)i] = seq_letter(code[(p[i >> 1] >> ((~i & 1) << 2)) & 15]);
+    p += (l_seq + 1) / 2 + l_seq;
+    while (p + 3 <= rend) { // tags
+        const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
+        p += 3;
+        int64_t iv = 0; bool is_int = false; size_t adv = 0;
+        switch (ty) {
+            case 'A': adv = 1; break;
+            case 'c': iv = (int8_t)p[0]; is_int = true; adv = 1; break;
+            case 'C': iv = p[0]; is_int = true; adv = 1; break;
+            case 's': { int16_t v; memcpy(&v, p, 2); iv = v; is_int = true; adv = 2; break; }
+            case 'S': { uint16_t v; memcpy(&v, p, 2); iv = v; is_int = true; adv = 2; break; }
+            case 'i': { int32_t v; memcpy(&v, p, 4); iv = v; is_int = true; adv = 4; break; }
+            case 'I': { uint32_t v; memcpy(&v, p, 4); iv = v; is_int = true; adv = 4; break; }
+            case 'f': adv = 4; break;
+            case 'Z': case 'H': { const unsigned char *z = (const unsigned char *)memchr(p, 0, (size_t)(rend - p)); if (!z) { err = "corrupt BAM tag"; return -1; } adv = (size_t)(z - p) + 1; break; }
+            case 'B': {
+                if (p + 5 > rend) { err = "corrupt BAM tag"; return -1; }
+                const char sub = (char)p[0]; int32_t cnt; memcpy(&cnt, p + 1, 4);
+                const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if (p + 5 + esz * (size_t)cnt > rend) { err = "corrupt BAM tag"; return -1; }
+                if (t0 == 'm' && t1 == 'v') {
+                    out.has_mv = true; out.mv_is_Bc = sub == 'c';
+                    if (out.mv_is_Bc && cnt > 0) {
+                        out.stride = (int8_t)p[5];
+                        out.is_one.resize((size_t)cnt - 1);
+                        for (int32_t i = 1; i < cnt; i++) out.is_one[(size_t)i - 1] = (int8_t)p[5 + i] == 1;
+                    }
+                }
+                adv = 5 + esz * (size_t)cnt; break;
+            }
+            default: err = "unknown BAM tag type"; return -1;
+        }
+        if (p + adv > rend) { err = "corrupt BAM tag"; return -1; }
+        if (is_int && t0 == 'n' && t1 == 's') { out.ns = (uint64_t)iv; out.has_ns = true; }
+        if (is_int && t0 == 't' && t1 == 's') { out.ts = (uint64_t)iv; out.has_ts = true; }
+        p += adv;
+    }
+    return 1;
+}
+
 } // namespace pgh

@@ -68,6 +68,27 @@ int parse_paf_line(char *line, size_t len, PafRec &out);
 // tokenises "<n>," "<n>I" "<n>D" (src/gmove.cpp:831-871); returns false on the reference's "Bad ss" exits
 bool tokenize_ss(const char *ss, size_t len, std::vector<uint32_t> &op_n, std::vector<uint8_t> &op_t, std::string &err);
 
+// ---- SAM / BAM records with the move table tags (replaces sam_open/sam_read1/bam_aux_get, src/gmove.cpp:1067-1134) --
+struct MoveRec {
+    std::string qname, seq;        // SEQ with every letter outside ACGT mapped to 'N' (gmove.cpp:1128-1134)
+    int stride = 0;                // mv[0]
+    std::vector<uint8_t> is_one;   // mv[1..]: 1 where the value is 1
+    uint64_t ns = 0, ts = 0;       // signal length / trim offset tags
+    bool has_ns = false, has_ts = false, has_mv = false, mv_is_Bc = false;
+};
+class SamBamReader {
+public:
+    bool open(const std::string &path, std::string &err); // SAM text or BGZF-compressed BAM, detected by content
+    int next(MoveRec &out, std::string &err);              // 1 = record, 0 = end of file, -1 = error
+private:
+    MappedFile f_;
+    bool bam_ = false;
+    size_t pos_ = 0;                 // SAM: offset into the file; BAM: offset of the next BGZF block
+    std::vector<unsigned char> buf_; // BAM: inflated bytes not yet consumed
+    size_t bpos_ = 0;
+    bool fill(size_t need, std::string &err);
+};
+
 // ---- k-mer list (src/poregen.cpp:248-267, src/gmove.cpp:394-426) ----------------------------------------
 void generate_kmers(int k, bool rna, std::vector<std::string> &out);
 // returns 0 ok, 1 cannot open, 2 a line does not have exactly k characters + '\n'

@@ -69,7 +69,7 @@ struct pg_ctx {
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
-    DevBuf m_read, meta, huge_scratch;
+    DevBuf m_read, meta, huge_scratch, oor;
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
@@ -199,7 +199,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
-                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch};
+                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -338,7 +338,7 @@ static pg_status check_read_errors(pg_ctx *c) {
     int32_t errv[2] = {INT_MAX, 0}, errs[2] = {INT_MAX, 0};
     HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 4, hipMemcpyDeviceToHost));
-    if (c->prm.scaling != 1) errs[0] = INT_MAX;
+    if (c->prm.scaling != 1 && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) errs[0] = INT_MAX;
     if (errv[0] == INT_MAX && errs[0] == INT_MAX) return PG_OK;
     const bool walk = errv[0] <= errs[0];
     const int32_t idx = walk ? errv[0] : errs[0];
@@ -354,6 +354,10 @@ static pg_status check_read_errors(pg_ctx *c) {
 static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
     const uint32_t n = c->B.n_reads;
     const int sl = c->slot;
+    const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0;
+    uint8_t *oor = nullptr;
+    if (skip_oor) { HIP_TRY(c, c->oor.ensure(n + 1ull)); oor = c->oor.as<uint8_t>(); }
+    const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
     HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
     HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
     HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull)); HIP_TRY(c, c->huge_scratch.ensure(PG_HUGE_SCRATCH_WORDS * 4));
@@ -365,13 +369,13 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr);
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
     pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr);
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
     pg_launch_read_stats(st, c->B, 65536, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>());
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only);
     prof_end(c, st);
     return PG_OK;
 }
@@ -385,6 +389,7 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>();
     O.m_read = c->m_read.as<uint32_t>(); O.meta = c->meta.as<PgReadMeta>();
     O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
+    O.oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) ? c->oor.as<uint8_t>() : nullptr;
 }
 
 static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
@@ -446,8 +451,9 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
     c->slot ^= 1; // this batch's statistics buffers
-    const bool eager_stats = c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS);
-    const bool overlap = (c->prm.flags & PG_FLAG_OVERLAP) != 0;
+    const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0; // statistics first: the walk needs their verdict
+    const bool eager_stats = skip_oor || (c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS));
+    const bool overlap = !skip_oor && (c->prm.flags & PG_FLAG_OVERLAP) != 0;
     if (eager_stats && overlap) {
         // The statistics stream only needs the batch to be resident: after the staging copies of a host batch, or
         // after the producer of a device batch when the caller drives us on its own stream. A device batch on the
@@ -464,6 +470,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
                          c->zero_running ? 1 : 0);
     c->zero_running = false;
 
+    if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr); if (s2 != PG_OK) return s2; }
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     prof_begin(c, "k_walk", c->st);
@@ -493,7 +500,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // Statistics only need the signal: in eager mode they run on the second stream, overlapping the
     // latency-bound walk/rank chain above; pg_collect joins the two streams before the gather.
     c->stats_in_flight = false;
-    if (eager_stats) {
+    if (eager_stats && !skip_oor) {
         hipStream_t ss = overlap ? c->st2 : c->st;
         pg_status s2 = launch_stats(c, ss, nullptr);
         if (s2 != PG_OK) return s2;
@@ -560,7 +567,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     }
 
     // lazy statistics: only the reads that own a kept event (flags written above)
-    const bool lazy = c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS);
+    const bool lazy = c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE);
     if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>()); if (s2 != PG_OK) return s2; }
 
     prof_begin(c, "scan_ev_len", c->st);

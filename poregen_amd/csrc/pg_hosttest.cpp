@@ -77,3 +77,18 @@ extern "C" int pgt_parse_paf(char *line, int32_t *cols6, char *rid, char *tid, c
     if (p.ss_len < cap) { memcpy(ss, p.ss, p.ss_len); ss[p.ss_len] = 0; }
     return 0;
 }
+
+// first record of a SAM/BAM file: returns number of moves (mv entries after the stride) or -1; seq/qname copied
+extern "C" long pgt_sam_first(const char *path, char *qname, char *seq, size_t cap, long long *stride_ns_ts, uint8_t *is_one, size_t mcap) {
+    pgh::SamBamReader r; std::string err;
+    if (!r.open(path, err)) return -1;
+    pgh::MoveRec m;
+    if (r.next(m, err) != 1) return -1;
+    snprintf(qname, cap, "%s", m.qname.c_str()); snprintf(seq, cap, "%s", m.seq.c_str());
+    stride_ns_ts[0] = m.stride; stride_ns_ts[1] = m.has_ns ? (long long)m.ns : -1; stride_ns_ts[2] = m.has_ts ? (long long)m.ts : -1;
+    const long n_moves = (long)m.is_one.size();
+    for (size_t i = 0; i < m.is_one.size() && i < mcap; i++) is_one[i] = m.is_one[i];
+    pgh::MoveRec m2;
+    if (r.next(m2, err) != 0) return -2; // the fixtures hold exactly one record
+    return n_moves;
+}

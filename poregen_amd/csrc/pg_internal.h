@@ -58,6 +58,7 @@ struct PgWalkOut {
     uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
     uint32_t *m_read;  // [n_ops] read that owns op index g
     PgReadMeta *meta;  // [n_reads]
+    const uint8_t *oor; // [n_reads] or nullptr: 1 = the read holds an out-of-range sample and the caller wants such reads skipped
     int32_t *status;   // [n_reads]
     int32_t *err;      // [2] err[0] = lowest read index with an error (init INT32_MAX), err[1] = its code
 };
@@ -131,7 +132,7 @@ void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, dou
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count, uint32_t *huge_scratch);
+                          const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWa
     if (qs < 0 || ts < 0 || te < 0 || (uint64_t)qs >= L || L > 0x7fffffffull) status = PGR_ERR_NEG;
     if (status == PGR_OK && rna && !W.allow_rna) status = PGR_ERR_RNA; // gmove.cpp:795-798
     if (status == PGR_OK && slen < k) status = PGR_SKIPPED;            // gmove.cpp:806-808
+    if (status == PGR_OK && O.oor && O.oor[r]) status = PGR_SKIPPED;   // SAM/BAM front-end: out-of-range sample (gmove.cpp:1158-1160)
     if (status != PGR_OK) {
         if (lane == 0) { if (status < 0) report_error(O, r, status); else O.status[r] = status; }
         return;
@@ -755,7 +756,8 @@ template <int BINS> struct StatsGeom {
 template <int BINS>
 __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgReadPlan *__restrict__ plan,
                                                const uint8_t *__restrict__ needed, double *__restrict__ med, double *__restrict__ mad,
-                                               int32_t *__restrict__ status, int32_t *__restrict__ err, int win) {
+                                               int32_t *__restrict__ status, int32_t *__restrict__ err, int win,
+                                               uint8_t *__restrict__ oor, int range_only) {
     constexpr bool GLOBAL = BINS == PG_HUGE_BINS;
     constexpr int BPL = GLOBAL ? 1 : BINS / WAVE, LOG_BPL = GLOBAL ? 31 : (BPL == 16 ? 4 : (BPL == 32 ? 5 : 6));
     constexpr int WORDS = GLOBAL ? PG_HUGE_WORDS : BINS + WAVE + 32 + 4;
@@ -836,8 +838,13 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
     }
     __builtin_amdgcn_wave_barrier();
 
-    // order statistics: every search step tests 64 candidates (pg_select.h holds the arithmetic)
     using Pre = typename std::conditional<GLOBAL, GlobalPre, PaddedPre<LOG_BPL>>::type;
+    if (oor) { // SAM/BAM front-end: a read with ANY out-of-range sample is skipped as a whole (gmove.cpp:1149-1160)
+        const uint32_t in_range = span ? Pre{hist}[(int)span - 1] : 0u;
+        if (lane == 0) oor[r] = in_range != (uint32_t)(end - beg);
+    }
+    if (range_only) return;
+    // order statistics: every search step tests 64 candidates (pg_select.h holds the arithmetic)
     PgSel<Pre> sel;
     sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = end - beg;
     sel.offset = B.off[r]; sel.scale = B.range[r] / B.dig[r];
@@ -898,20 +905,20 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 // one workgroup (= one wave) per read of the batch
 __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
                                                    double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
-                                                   int32_t *__restrict__ err, int win) {
+                                                   int32_t *__restrict__ err, int win, uint8_t *__restrict__ oor, int range_only) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<1024>::LDS_WORDS];
-    stats_one_read<1024>(hist, B, blockIdx.x, plan, needed, med, mad, status, err, win);
+    stats_one_read<1024>(hist, B, blockIdx.x, plan, needed, med, mad, status, err, win, oor, range_only);
 }
 
 // reads whose in-range interval needs the PG_STATS_BINS histogram: usually none, so a small grid strides over the list
 __global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
                                                         double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
-                                                        const int32_t *__restrict__ wide_count) {
+                                                        const int32_t *__restrict__ wide_count, uint8_t *__restrict__ oor, int range_only) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
     const uint32_t n_list = (uint32_t)*wide_count;
     for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, needed, med, mad, status, err, win);
+        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, needed, med, mad, status, err, win, oor, range_only);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
     }
@@ -922,11 +929,12 @@ __global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgRe
 __global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
                                                         double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
-                                                        const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch) {
+                                                        const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch,
+                                                        uint8_t *__restrict__ oor, int range_only) {
     const uint32_t n_list = (uint32_t)wide_count[1];
     uint32_t *hist = scratch + (size_t)blockIdx.x * PG_HUGE_WORDS;
     for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, needed, med, mad, status, err, win);
+        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, needed, med, mad, status, err, win, oor, range_only);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
     }
@@ -1075,19 +1083,19 @@ void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, dou
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count, uint32_t *huge_scratch) {
+                          const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only) {
     if (B.n_reads == 0) return;
     const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
     if (bins <= 1024)
-        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win);
+        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, oor, range_only);
     else if (bins <= PG_STATS_BINS) { // the wide list is usually empty: a small persistent grid
         const uint32_t grid = B.n_reads < 2048 ? B.n_reads : 2048;
         hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
-                           wide_count);
+                           wide_count, oor, range_only);
     } else {
         const uint32_t grid = B.n_reads < PG_HUGE_BLOCKS ? B.n_reads : PG_HUGE_BLOCKS;
         hipLaunchKernelGGL(k_read_stats_huge, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
-                           wide_count, huge_scratch);
+                           wide_count, huge_scratch, oor, range_only);
     }
 }
 

@@ -217,3 +217,12 @@ def write_table_files(b: Batch, prefix: str, stride: int = 5, trim: int = 0, see
             moves = "".join("1" + "0" * (int(x) // stride - 1) for x in d)
             seq = seq_string(b, r)
             t.write(f"r{r}\t{len(seq)}\t{seq}\t{stride}\t{moves}\t{len(full)}\t{trim}\n")
+    # the same records as unaligned SAM with the basecaller's move tags (mv:B:c,<stride>,<moves>; ns; ts)
+    with open(prefix + ".sam", "w") as f:
+        f.write("@HD\tVN:1.6\tSO:unknown\n@PG\tID:synthetic\n")
+        for r in range(b.n_reads):
+            d = b.op_n[int(b.op_off[r]):int(b.op_off[r + 1])]
+            mv = ",".join("1" + ",0" * (int(x) // stride - 1) for x in d)
+            seq = seq_string(b, r)
+            L = int(b.sig_off[r + 1] - b.sig_off[r]) + trim
+            f.write(f"r{r}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*\tmv:B:c,{stride},{mv}\tqs:i:10\tns:i:{L}\tts:i:{trim}\n")

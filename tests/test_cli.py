@@ -148,6 +148,48 @@ def test_table_front_end_synthetic_equals_oracle(tmp_path, trim, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kf", ["single_kmer_file.txt", "kmer_file.txt"])
+def test_sam_bam_front_end_fixture(tmp_path, kf):
+    """SAM/BAM front-end (src/gmove.cpp:1061-1266): test_gmove.sh 1.3 / 2.3 -- BAM == table -- plus BAM == SAM == oracle(SAM)."""
+    outs = {}
+    for name, args in {"bam": ["-k", "6", f"{G}/reads.slow5", f"{G}/guppy_move.bam"], "sam": ["-k", "6", f"{G}/reads.slow5", f"{G}/guppy_move.sam"],
+                       "table": ["-k", "6", "-m", "0", f"{G}/reads.slow5", f"{G}/guppy_move"]}.items():
+        outs[name] = tmp_path / name
+        r = cli(args + ["--kmer_file", f"{G}/{kf}", outs[name]]); assert r.returncode == 0, r.stderr
+    o = oracle_cli(["-k", "6", f"{G}/reads.slow5", f"{G}/guppy_move.sam", "--kmer_file", f"{G}/{kf}", tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(outs["bam"], outs["table"])      # the reference's own invariant
+    assert_same_dirs(outs["bam"], outs["sam"])
+    assert_same_dirs(outs["sam"], tmp_path / "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["-k", "5", "--file_limit", "1024", "--scaling", "1", "--sample_limit", "25"],
+                                   ["-k", "6", "--file_limit", "4096", "--sample_limit", "9", "-d", "-m", "1", "--batch_reads", "29"],
+                                   ["-k", "5", "--file_limit", "1024", "--scaling", "1", "--pa_min", "60", "--pa_max", "170", "-d"]])
+def test_sam_front_end_synthetic_skips_out_of_range_reads(tmp_path, extra):
+    """On the SAM/BAM path a read with ANY out-of-range sample is skipped (gmove.cpp:1149-1160): with 0.05 % spikes about
+    one read in eight survives, which also makes event acceptance signal-dependent."""
+    b = synth.make_batch(160, kind="dna_r10", seed=80, spike_rate=0.0005)
+    pre = str(tmp_path / "syn")
+    synth.write_table_files(b, pre, trim=11)
+    common = [pre + ".slow5", pre + ".sam"] + extra
+    r = cli(common + [tmp_path / "gpu"]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([x for x in common if x not in ("--batch_reads", "29")] + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+    freq = [int(l.split()[1]) for l in open(tmp_path / "cpu" / "freq.txt")]
+    assert 0 < sum(freq)     # some reads survive, and (below) not all of them
+    t = cli([pre + ".slow5", pre + ".table"] + [x for x in extra if x not in ("--batch_reads", "29")] + [tmp_path / "tab"]); assert t.returncode == 0
+    assert open(tmp_path / "tab" / "freq.txt").read() != open(tmp_path / "gpu" / "freq.txt").read()   # the table path zero-fills instead
+
+
+@pytest.mark.gpu
+def test_sam_missing_tags_exit_1(tmp_path):
+    p = tmp_path / "x.sam"
+    p.write_text("r0\t4\t*\t0\t0\t*\t*\t0\t0\tACGTACGTACGT\t*\tmv:B:c,5,1,0,1\tts:i:0\n")
+    r = cli([f"{G}/reads.slow5", p, tmp_path / "o"]); assert r.returncode == 1 and "tag 'ns' is not found" in r.stderr
+
+
+@pytest.mark.gpu
 def test_print_margin_larger_than_window_start_is_rejected(tmp_path):
     """--margin > start of an accepted window is undefined behaviour in the reference (unsigned wrap at
     src/gmove.cpp:928-932); the oracle flags it (exit 70) and the product refuses it (exit 1)."""

@@ -20,6 +20,7 @@ def h():
     lib.pgt_fastx_fetch.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long, C.c_char_p, C.c_size_t]; lib.pgt_fastx_fetch.restype = C.c_long
     lib.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; lib.pgt_slow5_get.restype = C.c_long
     lib.pgt_slow5_count.argtypes = [C.c_char_p]; lib.pgt_slow5_count.restype = C.c_long
+    lib.pgt_sam_first.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]; lib.pgt_sam_first.restype = C.c_long
     lib.pgt_parse_paf.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]; lib.pgt_parse_paf.restype = C.c_int
     return lib
 
@@ -126,3 +127,18 @@ def test_parse_paf_fixture(h):
     assert ops.count(",") == 481 and sum(int(x) for x in ops.split(",") if x) == 6020
     assert h.pgt_parse_paf(C.create_string_buffer(b"a\t1\t2\n"), cols, rid, tid, ss, 1 << 16) == 1
     assert h.pgt_parse_paf(C.create_string_buffer(b"r\t10\t0\t10\t+\tt\t5\t0\t5\t5\t5\t255\tsc:f:1\n"), cols, rid, tid, ss, 1 << 16) == 2
+
+
+def test_sam_and_bam_readers_agree_on_fixture(h):
+    """guppy_move.sam (text) and guppy_move.bam (BGZF + binary records) hold the same record; the move tags agree
+    with the move table fixture (481 moves = one per base, stride 5, ns 6020, ts 0)."""
+    got = {}
+    for ext in ("sam", "bam"):
+        q = C.create_string_buffer(256); s = C.create_string_buffer(4096); v = (C.c_longlong * 3)(); mv = np.zeros(4096, np.uint8)
+        n = h.pgt_sam_first(os.path.join(G, f"guppy_move.{ext}").encode(), q, s, 4096, v, mv.ctypes.data, 4096)
+        got[ext] = (n, q.value, s.value, list(v), mv[:max(n, 0)].tolist())
+    assert got["sam"] == got["bam"]
+    n, q, s, v, mv = got["bam"]
+    table = open(os.path.join(G, "guppy_move")).read().split("\t")
+    assert q.decode() == table[0] and s.decode() == table[2] and v == [5, 6020, 0]
+    assert "".join(map(str, mv)) == table[4] and n == len(table[4])
