@@ -1,0 +1,110 @@
+"""Edge cases through the C ABI: empty and ragged batches, long reads, degenerate parameters."""
+import numpy as np
+import pytest
+
+from helpers import assert_result_equals_oracle, oracle_for
+from poregen_amd import synth
+from poregen_amd.engine import Batch, GmoveEngine, GmoveParams, PgError, generate_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def concat(batches):
+    def cat(name): return np.concatenate([getattr(b, name) for b in batches])
+    def offs(name):
+        out = [np.zeros(1, np.uint64)]; base = np.uint64(0)
+        for b in batches:
+            o = getattr(b, name); out.append(o[1:] + base); base = base + o[-1]
+        return np.concatenate(out)
+    return Batch(n_reads=sum(b.n_reads for b in batches), sig=cat("sig"), sig_off=offs("sig_off"), digitisation=cat("digitisation"),
+                 offset=cat("offset"), range=cat("range"), query_start=cat("query_start"), target_start=cat("target_start"),
+                 target_end=cat("target_end"), seq=cat("seq"), seq_off=offs("seq_off"), op_n=cat("op_n"), op_t=cat("op_t"), op_off=offs("op_off"))
+
+
+def run(batches, kmers, **p):
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    for b in batches:
+        eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    return res
+
+
+def test_empty_batch_and_empty_between_batches():
+    kmers = generate_kmers(5)
+    p = dict(kmer_size=5, scaling=1, sample_limit=10)
+    empty = synth.make_batch(0, kind="dna_r10")
+    res = run([empty], kmers, **p)
+    assert res.counts.sum() == 0 and res.samples.size == 0 and res.n_reads == 0
+    b = synth.make_batch(60, kind="dna_r10", seed=31)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    res = run([b.slice_reads(0, 20), empty, b.slice_reads(20, 60), empty], kmers, **p)
+    assert_result_equals_oracle(res, o, sample_limit=10)
+
+
+def test_ragged_lengths_long_read_and_unaligned_signal_starts():
+    """Reads of 41 ... 250 000 samples back to back (signal starts are not 16-byte aligned), one read with ~50 000 ops."""
+    parts = [synth.make_batch(1, read_len=L, kind="dna_r10", seed=40 + i) for i, L in enumerate([41, 4000, 250000, 77, 1234, 9999, 16, 100003])]
+    b = concat(parts)
+    assert any(int(x) % 8 for x in b.sig_off[1:-1])
+    kmers = generate_kmers(5)
+    for p in (dict(kmer_size=5, scaling=1, sample_limit=1000), dict(kmer_size=5, scaling=0, sample_limit=3, margin=2, kmer_pick_margin=3)):
+        o = oracle_for(kmers, **p); rcs = o.run_batch(b)
+        assert set(rcs) <= {0, 1, 2}   # 2: every k-mer complete, the reference stops reading
+        assert_result_equals_oracle(run([b], kmers, **p), o, sample_limit=p["sample_limit"])
+
+
+def test_all_reads_skipped_and_short_sequences():
+    b = synth.make_batch(30, kind="rna004", seed=50)
+    # fetched sequence shorter than k for every read: target range of 3 bases
+    b.target_start[:] = 3; b.target_end[:] = 0
+    seq = np.concatenate([b.seq[int(b.seq_off[r]):int(b.seq_off[r]) + 3] for r in range(b.n_reads)])
+    b = Batch(**{**b.__dict__, "seq": seq, "seq_off": (np.arange(b.n_reads + 1, dtype=np.uint64) * np.uint64(3))})
+    kmers = generate_kmers(5, rna=True)
+    res = run([b], kmers, kmer_size=5, rna=True, scaling=1)
+    assert res.counts.sum() == 0 and np.all(res.read_skipped == 1)
+
+
+@pytest.mark.parametrize("p", [
+    dict(kmer_size=1, scaling=1, sample_limit=50, kmer_pick_margin=0),
+    dict(kmer_size=12, scaling=0, sample_limit=2),
+    dict(kmer_size=5, scaling=1, sample_limit=0),
+    dict(kmer_size=5, scaling=1, sample_limit=10 ** 9),
+    dict(kmer_size=5, scaling=1, sample_limit=4, min_dur=0, max_dur=10 ** 6),
+])
+def test_degenerate_parameters(p):
+    b = synth.make_batch(80, kind="dna_r10", seed=60)
+    k = p["kmer_size"]
+    kmers = generate_kmers(k) if k < 12 else sorted({synth.seq_string(b, r)[i:i + k] for r in range(b.n_reads) for i in range(0, 200, 7)})
+    o = oracle_for(kmers, **p); rcs = o.run_batch(b)
+    assert set(rcs) <= {0, 1, 2}
+    assert_result_equals_oracle(run([b], kmers, **p), o, sample_limit=p["sample_limit"])
+
+
+def test_single_slot_and_whitelist_of_absent_kmers():
+    b = synth.make_batch(100, kind="dna_r10", seed=61)
+    for kmers in (["ACGTA"], ["NNNNN", "ACGUA", "ACGTA"]):   # k-mers that can never match get (empty) slots
+        p = dict(kmer_size=5, scaling=1, sample_limit=7)
+        o = oracle_for(kmers, **p); o.run_batch(b)
+        assert_result_equals_oracle(run([b], kmers, **p), o, sample_limit=7)
+
+
+def test_inputs_outside_the_references_defined_behaviour_are_errors():
+    b = synth.make_batch(10, kind="dna_r10", seed=62)
+    kmers = generate_kmers(5)
+    bad = Batch(**{**b.__dict__, "query_start": b.query_start.copy()}); bad.query_start[4] = -1
+    eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5))
+    with pytest.raises(PgError) as ei:
+        eng.submit(bad); eng.sync()
+    assert ei.value.status == -3 and "read 4" in ei.value.text          # assert(query_start < len), gmove.cpp:752
+    eng.close()
+    ops = b.op_t.copy(); ops[int(b.op_off[2]) + 1] = 7                  # not ',', 'I' or 'D'
+    eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5))
+    with pytest.raises(PgError) as ei:
+        eng.submit(Batch(**{**b.__dict__, "op_t": ops})); eng.sync()
+    assert ei.value.status == -3 and "read 2" in ei.value.text
+    eng.close()
+    with pytest.raises(PgError):
+        GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, kmer_pick_margin=-1))
+    with pytest.raises(PgError):
+        GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, sig_move_offset=6))
