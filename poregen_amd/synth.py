@@ -226,3 +226,35 @@ def write_table_files(b: Batch, prefix: str, stride: int = 5, trim: int = 0, see
             seq = seq_string(b, r)
             L = int(b.sig_off[r + 1] - b.sig_off[r]) + trim
             f.write(f"r{r}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*\tmv:B:c,{stride},{mv}\tqs:i:10\tns:i:{L}\tts:i:{trim}\n")
+
+
+def write_blow5(b: Batch, path: str):
+    """Uncompressed BLOW5 (record compression none, signal compression none; layout: SURVEY.md 8f-1) for the batch;
+    read ids are r<index>. Meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate."""
+    import struct
+    hdr = (b"#slow5_version\t0.2.0\n#num_read_groups\t1\n@asic_id\tsynthetic\n"
+           b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
+           b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
+    with open(path, "wb") as f:
+        f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([0]) + struct.pack("<I", 1) + bytes([0]) + bytes(64 - 15))
+        f.write(struct.pack("<I", len(hdr)) + hdr)
+        for r in range(b.n_reads):
+            rid = f"r{r}".encode()
+            sig = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+            body = (struct.pack("<H", len(rid)) + rid + struct.pack("<I", 0)
+                    + struct.pack("<dddd", b.digitisation[r], b.offset[r], b.range[r], 4000.0) + struct.pack("<Q", sig.size))
+            f.write(struct.pack("<Q", len(body) + sig.size * 2) + body)
+            f.write(sig.tobytes())
+        f.write(b"5WOLB")
+
+
+def write_paf_fastq(b: Batch, prefix: str):
+    """PAF(ss) + FASTQ of the batch without the (slow) ASCII SLOW5."""
+    with open(prefix + ".fastq", "w") as f:
+        for r in range(b.n_reads):
+            s = seq_string(b, r)
+            f.write(f"@r{r} synthetic\n{s}\n+\n{'I' * len(s)}\n")
+    with open(prefix + ".paf", "w") as f:
+        for r in range(b.n_reads):
+            L = int(b.sig_off[r + 1] - b.sig_off[r]); ns = int(b.seq_off[r + 1] - b.seq_off[r])
+            f.write(f"r{r}\t{L}\t{int(b.query_start[r])}\t{L}\t+\tr{r}\t{ns}\t{int(b.target_start[r])}\t{int(b.target_end[r])}\t{ns}\t{ns}\t255\tss:Z:{ss_string(b, r)}\n")
