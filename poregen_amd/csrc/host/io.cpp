@@ -412,6 +412,7 @@ int SamBamReader::next(MoveRec &out, std::string &err) {
                                 char *endp; const long v = strtol(q, &endp, 10);
                                 if (endp == q) break;
                                 if (first) { out.stride = (int)v; first = false; } else out.is_one.push_back(v == 1);
+                                out.mv_len++;
                                 q = endp;
                             }
                         }
@@ -466,7 +467,7 @@ int SamBamReader::next(MoveRec &out, std::string &err) {
                 const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 if (p + 5 + esz * (size_t)cnt > rend) { err = "corrupt BAM tag"; return -1; }
                 if (t0 == 'm' && t1 == 'v') {
-                    out.has_mv = true; out.mv_is_Bc = sub == 'c';
+                    out.has_mv = true; out.mv_is_Bc = sub == 'c'; out.mv_len = (uint32_t)cnt;
                     if (out.mv_is_Bc && cnt > 0) {
                         out.stride = (int8_t)p[5];
                         out.is_one.resize((size_t)cnt - 1);

@@ -1,4 +1,4 @@
-// main.cpp -- `poregen` dispatcher (src/main.c:64-103): only the gmove subtool is implemented here.
+// main.cpp -- `poregen` dispatcher (src/main.c:64-103): the gmove subtool (device path) and reform (host-only).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -6,13 +6,14 @@
 #include <sys/time.h>
 
 int gmove_main(int argc, char **argv);
+int reform_main(int argc, char **argv);
 
 static double realtime() { struct timeval tp; gettimeofday(&tp, nullptr); return tp.tv_sec + tp.tv_usec * 1e-6; }
 static double cputime() { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec); }
 static long peakrss() { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_maxrss * 1024; }
 
 static int usage(FILE *fp, int code) {
-    fprintf(fp, "Usage: poregen <command> [options]\n\ncommand:\n         gmove      move k-mer signal samples into k-mer buckets (MI355X implementation)\n");
+    fprintf(fp, "Usage: poregen <command> [options]\n\ncommand:\n         gmove      move k-mer signal samples into k-mer buckets (MI355X implementation)\n         reform     rewrite a SAM/BAM move table as TSV or as PAF with ss:Z:\n");
     return code;
 }
 
@@ -21,6 +22,7 @@ int main(int argc, char **argv) {
     if (argc < 2) return usage(stderr, 1);
     int ret;
     if (strcmp(argv[1], "gmove") == 0) ret = gmove_main(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "reform") == 0) ret = reform_main(argc - 1, argv + 1);
     else if (strcmp(argv[1], "--version") == 0 || strcmp(argv[1], "-V") == 0) { fprintf(stdout, "poregen 0.1.0 (pgmove, gfx950)\n"); return 0; }
     else if (strcmp(argv[1], "--help") == 0 || strcmp(argv[1], "-h") == 0) return usage(stdout, 0);
     else { fprintf(stderr, "[poregen] Unrecognised command %s\n", argv[1]); return usage(stderr, 1); }

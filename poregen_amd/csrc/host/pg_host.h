@@ -72,6 +72,7 @@ bool tokenize_ss(const char *ss, size_t len, std::vector<uint32_t> &op_n, std::v
 struct MoveRec {
     std::string qname, seq;        // SEQ with every letter outside ACGT mapped to 'N' (gmove.cpp:1128-1134)
     int stride = 0;                // mv[0]
+    uint32_t mv_len = 0;           // bam_auxB_len of mv (stride element included)
     std::vector<uint8_t> is_one;   // mv[1..]: 1 where the value is 1
     uint64_t ns = 0, ts = 0;       // signal length / trim offset tags
     bool has_ns = false, has_ts = false, has_mv = false, mv_is_Bc = false;

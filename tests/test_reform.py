@@ -1,0 +1,115 @@
+"""`poregen reform` against the reference's OWN expected files (test/test_reform.sh testcases 1-18; inputs and
+expected outputs copied as data under tests/golden/reform/, the two 1.6 MB TSVs gzip-compressed). Host-only: runs on
+any box. This is the one sub-tool for which the reference holds golden outputs, so parity here is pinned, byte for
+byte, by reference-owned vectors."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin", "poregen")
+R = os.path.join(ROOT, "tests", "golden", "reform")
+
+
+def reform(*args):
+    return subprocess.run([BIN, "reform"] + [str(a) for a in args], capture_output=True)
+
+
+def golden(name):
+    p = os.path.join(R, name)
+    if os.path.exists(p):
+        return open(p, "rb").read()
+    return gzip.open(p + ".gz", "rb").read()
+
+
+def test_usage_and_rejected_options():
+    assert reform().returncode != 0                                              # testcase 1
+    assert reform("-k0", "-m1", "-c", f"{R}/guppy_one_read.bam").returncode != 0  # testcase 2
+    assert reform("-k0", "-m0", "-c", f"{R}/guppy_one_read.bam").returncode != 0  # testcase 3
+    assert reform("-k9", "-m10", "-c", f"{R}/guppy_one_read.bam").returncode != 0  # testcase 4
+    r = reform("-h"); assert r.returncode == 0 and b"Usage: poregen reform" in r.stdout
+
+
+@pytest.mark.parametrize("k,m", [(1, 0), (9, 0), (9, 1), (9, 6), (9, 8)])
+@pytest.mark.parametrize("fmt", ["paf", "tsv"])
+def test_guppy_one_read(k, m, fmt):                                              # testcases 5-14
+    args = [f"-k{k}", f"-m{m}"] + (["-c"] if fmt == "paf" else []) + [f"{R}/guppy_one_read.bam"]
+    r = reform(*args)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == golden(f"r1k{k}m{m}.{fmt}")
+
+
+@pytest.mark.parametrize("k,m", [(9, 8), (1, 0)])
+@pytest.mark.parametrize("fmt", ["paf", "tsv"])
+def test_dorado_sam(k, m, fmt):                                                  # testcases 15-18
+    args = [f"-k{k}", f"-m{m}"] + (["-c"] if fmt == "paf" else []) + [f"{R}/slow5-dorado.sam"]
+    r = reform(*args)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == golden(f"dr2k{k}m{m}.{fmt}")
+
+
+def test_output_file_option(tmp_path):
+    out = tmp_path / "o.paf"
+    r = reform("-k9", "-m0", "-c", "-o", out, f"{R}/guppy_one_read.bam")
+    assert r.returncode == 0 and r.stdout == b""
+    assert out.read_bytes() == golden("r1k9m0.paf")
+
+
+def test_missing_tags_are_errors():
+    # buttery_eel.sam carries mv but neither ns nor ts: reform returns -1 (src/reform.cpp:212-215)
+    r = reform("-k9", "-m0", "-c", f"{R}/buttery_eel.sam")
+    assert r.returncode != 0 and b"tag 'ns' is not found" in r.stderr and r.stdout == b""
+
+
+def test_two_reads_bam_paf_and_tsv_agree():
+    """No golden for guppy_two_reads.bam: check the two output formats against each other (each ss duration is the
+    width of the matching TSV row; columns 3/4 are the first start / last end)."""
+    paf = reform("-k9", "-m0", "-c", f"{R}/guppy_two_reads.bam"); tsv = reform("-k9", "-m0", f"{R}/guppy_two_reads.bam")
+    assert paf.returncode == 0 and tsv.returncode == 0
+    rows = {}
+    for line in tsv.stdout.decode().splitlines():
+        rid, idx, s, e = line.split("\t")
+        rows.setdefault(rid, []).append((int(idx), int(s), int(e)))
+    lines = paf.stdout.decode().splitlines()
+    assert len(lines) == len(rows) == 2
+    for line in lines:
+        c = line.split("\t")
+        durs = [int(x) for x in c[12][5:].rstrip(",").split(",")]
+        rr = rows[c[0]]
+        assert [i for i, _, _ in rr] == list(range(len(rr))) and len(rr) == int(c[6]) == len(durs)
+        assert durs == [e - s for _, s, e in rr]
+        assert int(c[2]) == rr[0][1] and int(c[3]) == rr[-1][2]
+
+
+def test_reform_reproduces_the_gmove_fixture_ss():
+    """The reference's gmove fixture guppy_move.paf (test/data/raw/gmove/single_read) holds the ss string of the
+    same read's BAM move table: `reform -k1 -m0 -c` of guppy_move.bam must reproduce it and columns 1-11."""
+    G = os.path.join(ROOT, "tests", "golden", "single_read")
+    for f in ("guppy_move.bam", "guppy_move.sam"):
+        r = reform("-k1", "-m0", "-c", f"{G}/{f}")
+        assert r.returncode == 0
+        mine = r.stdout.decode().rstrip("\n").split("\t")
+        ref = open(f"{G}/guppy_move.paf").read().rstrip("\n").split("\t")
+        assert mine[:11] == ref[:11]
+        assert mine[12] == [c for c in ref if c.startswith("ss:Z:")][0]
+
+
+@pytest.mark.gpu
+def test_reform_then_gmove_equals_fixture_paf(tmp_path):
+    """reform -c | gmove --paf == gmove on the fixture PAF (device path, whole dump directory)."""
+    import filecmp
+    G = os.path.join(ROOT, "tests", "golden", "single_read")
+    paf = tmp_path / "re.paf"
+    assert reform("-k1", "-m0", "-c", "-o", paf, f"{G}/guppy_move.bam").returncode == 0
+    outs = []
+    for name, p in (("a", paf), ("b", f"{G}/guppy_move.paf")):
+        out = tmp_path / name
+        r = subprocess.run([BIN, "gmove", "-k", "6", f"{G}/reads.slow5", str(p), "--fastq", f"{G}/read_0.fastq", str(out)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(out)
+    assert (outs[0] / "freq.txt").read_bytes() == (outs[1] / "freq.txt").read_bytes()
+    names = sorted(os.listdir(outs[0] / "dump"))
+    _, mismatch, errors = filecmp.cmpfiles(outs[0] / "dump", outs[1] / "dump", names, shallow=False)
+    assert not mismatch and not errors
