@@ -359,22 +359,22 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
     if (skip_oor) { HIP_TRY(c, c->oor.ensure(n + 1ull)); oor = c->oor.as<uint8_t>(); }
     const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
     HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
-    HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * 16ull)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * (size_t)PG_STAT_REC_BYTES)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
     HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull)); HIP_TRY(c, c->huge_scratch.ensure(PG_HUGE_SCRATCH_WORDS * 4));
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] length of the wide list
     prof_begin(c, "k_read_plan", st);
-    pg_launch_read_plan(st, c->B, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
+    pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
                         c->stat_status[sl].as<int32_t>());
     prof_end(c, st);
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
-    pg_launch_read_stats(st, c->B, 1024, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+    pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
     prof_end(c, st);
     prof_begin(c, "k_read_stats_wide", st);
-    pg_launch_read_stats(st, c->B, PG_STATS_BINS, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+    pg_launch_read_stats(st, c->B, PG_STATS_BINS, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
-    pg_launch_read_stats(st, c->B, 65536, needed, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+    pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only);
     prof_end(c, st);
     return PG_OK;

@@ -86,6 +86,16 @@ struct PgSortBufs {
 // ---- stats ---------------------------------------------------------------------------------------
 #define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global-memory path
 #define PG_HUGE_BLOCKS 64   // workgroups (and 65600-word scratch histograms) of the global-memory path
+// per-read record written by k_read_plan (pg_select.h's PgReadPlan + the read's sample range and calibration)
+struct PgStatRec {
+    uint64_t beg, end;   // sig_off[r], sig_off[r+1]
+    int32_t c_lo, span, z0;
+    int32_t mode;        // PG_STAT_*
+    double offset, scale;
+    uint64_t pad[2];
+};
+enum { PG_STAT_RUN = 0, PG_STAT_SKIP = 1, PG_STAT_BAD = 2 };
+#define PG_STAT_REC_BYTES 64
 #define PG_HUGE_SCRATCH_WORDS ((size_t)PG_HUGE_BLOCKS * (65536 + 64))
 
 // ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
@@ -123,14 +133,14 @@ void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t
                          const uint32_t *hist, uint32_t n_tiles);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+1 uint64
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
-// plan_buf: 16 bytes per read
+// plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
-                         int32_t *flags, int32_t *stat_status);
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
+                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status);
 // bins: 1024 (one workgroup per read), PG_STATS_BINS (LDS, wide list) or 65536 (global-memory histograms, huge list)
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
+void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
                           const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,

@@ -710,18 +710,25 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 
 __global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; flags[2] = 0; }
 
-__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, double pa_min, double pa_max, PgReadPlan *__restrict__ plan,
-                                                   uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count,
-                                                   int32_t *__restrict__ stat_status) {
+__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
+                                                   PgStatRec *__restrict__ rec, uint32_t *__restrict__ wide_list,
+                                                   int32_t *__restrict__ wide_count, int32_t *__restrict__ stat_status) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
     if (r >= B.n_reads) return;
-    const PgReadPlan p = pg_make_plan(B.dig[r], B.off[r], B.range[r], pa_min, pa_max);
-    plan[r] = p;
+    const double offset = B.off[r], scale = B.range[r] / B.dig[r];
+    const PgReadPlan p = pg_make_plan(B.dig[r], offset, B.range[r], pa_min, pa_max);
+    PgStatRec o;
+    o.beg = B.sig_off[r]; o.end = B.sig_off[r + 1];
+    o.c_lo = p.c_lo; o.span = p.span; o.z0 = p.z0;
+    const bool skip = (needed && !needed[r]) || o.end == o.beg;
+    o.mode = skip ? PG_STAT_SKIP : (p.status != 0 ? PG_STAT_BAD : PG_STAT_RUN);
+    o.offset = offset; o.scale = scale; o.pad[0] = o.pad[1] = 0;
+    rec[r] = o;
     stat_status[r] = 0;
     // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launches: the list is
     // filled from the front (<= PG_STATS_BINS codes, LDS) and from the back (more: global-memory histogram)
-    if (p.status == 0 && p.span > PG_STATS_BINS) wide_list[B.n_reads - 1 - (uint32_t)atomicAdd(wide_count + 1, 1)] = r;
-    else if (p.status == 0 && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
+    if (o.mode == PG_STAT_RUN && p.span > PG_STATS_BINS) wide_list[B.n_reads - 1 - (uint32_t)atomicAdd(wide_count + 1, 1)] = r;
+    else if (o.mode == PG_STAT_RUN && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
 }
 
 // prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
@@ -752,71 +759,72 @@ template <int BINS> struct StatsGeom {
     static constexpr int LDS_WORDS = TRASH + 32 + 4;  // + 32 dummy bins (padded) for out-of-range samples
 };
 
+// ---- pieces shared by the three statistics kernels -----------------------------------------------------------------
 // BINS == 1024 / PG_STATS_BINS: padded LDS histogram; BINS == PG_HUGE_BINS: global-memory histogram (one per block)
-template <int BINS>
-__device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgReadPlan *__restrict__ plan,
-                                               const uint8_t *__restrict__ needed, double *__restrict__ med, double *__restrict__ mad,
-                                               int32_t *__restrict__ status, int32_t *__restrict__ err, int win,
-                                               uint8_t *__restrict__ oor, int range_only) {
-    constexpr bool GLOBAL = BINS == PG_HUGE_BINS;
-    constexpr int BPL = GLOBAL ? 1 : BINS / WAVE, LOG_BPL = GLOBAL ? 31 : (BPL == 16 ? 4 : (BPL == 32 ? 5 : 6));
-    constexpr int WORDS = GLOBAL ? PG_HUGE_WORDS : BINS + WAVE + 32 + 4;
-    const int lane = lane_id();
-    const PgReadPlan pl = plan[r];
-    const uint64_t beg = B.sig_off[r], end = B.sig_off[r + 1];
-    const bool skip = (needed && !needed[r]) || end == beg;
-    if (!GLOBAL && !skip && pl.status == 0 && pl.span > BINS) return; // on the list of a wider launch
-    if (skip || pl.status != 0 || pl.span > BINS) {
-        if (lane == 0) {
-            med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
-            if (!skip) { status[r] = pl.status != 0 ? PGR_ERR_SCALE : PGR_ERR_WIDE; atomicMin(&err[0], (int)r); }
-        }
-        return;
-    }
-    {
-        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-        for (int i = lane; i < WORDS / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
-        if (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
-    }
+template <int BINS> struct StatsCfg {
+    static constexpr bool GLOBAL = BINS == PG_HUGE_BINS;
+    static constexpr int BPL = GLOBAL ? 1 : BINS / WAVE;
+    static constexpr int LOG_BPL = GLOBAL ? 31 : (BPL == 16 ? 4 : (BPL == 32 ? 5 : 6));
+    static constexpr int WORDS = GLOBAL ? PG_HUGE_WORDS : BINS + WAVE + 32 + 4;
+    using Pre = typename std::conditional<GLOBAL, GlobalPre, PaddedPre<LOG_BPL>>::type;
+};
 
-    const int c_lo = pl.c_lo;
-    const uint32_t span = (uint32_t)pl.span;
-    // out-of-range samples (idx wraps to a huge unsigned value) are clamped onto 32 dummy bins behind the real
-    // ones, one per lane pair, so the inner loop is branch-free: sub, min, shift, add-shift, ds_add
-    const uint32_t cap = BINS + (lane & 31u);
-    auto bin = [&](int code) {
-        const uint32_t idx = min((uint32_t)(code - c_lo), cap);
-        atomicAdd(&hist[GLOBAL ? idx : idx + (idx >> LOG_BPL)], 1u);
-    };
-    auto bin8 = [&](const int4 &q) {
-        bin((int)(short)(q.x & 0xffff)); bin(q.x >> 16);
-        bin((int)(short)(q.y & 0xffff)); bin(q.y >> 16);
-        bin((int)(short)(q.z & 0xffff)); bin(q.z >> 16);
-        bin((int)(short)(q.w & 0xffff)); bin(q.w >> 16);
-    };
-    const int16_t *__restrict__ sig = B.sig;
-    // 16-byte vectors fully inside [beg, end): [va, vb); ragged head and tail handled element-wise
-    const uint64_t va = (beg + 7) >> 3, vb = end >> 3;
-    if (va < vb) {
-        for (uint64_t s = beg + lane; s < (va << 3); s += WAVE) bin((int)sig[s]);
-        for (uint64_t s = (vb << 3) + lane; s < end; s += WAVE) bin((int)sig[s]);
-        const int4 *__restrict__ vec = reinterpret_cast<const int4 *>(sig);
-        for (uint64_t v = va + lane; v < vb; v += 8 * WAVE) { // up to 8 independent 16-byte loads in flight per lane
-            int4 q[8];
+template <int BINS> __device__ __forceinline__ void stats_zero(uint32_t *hist, int lane) {
+    using C = StatsCfg<BINS>;
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+    for (int i = lane; i < C::WORDS / 4; i += WAVE) h4[i] = make_uint4(0, 0, 0, 0);
+    if (C::GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
+}
+
+// one sample into the histogram: out-of-range samples (idx wraps to a huge unsigned value) are clamped onto 32
+// dummy bins behind the real ones, one per lane pair, so the path is branch-free
+template <int BINS> __device__ __forceinline__ void stats_bin1(uint32_t *hist, int code, int c_lo, int lane) {
+    using C = StatsCfg<BINS>;
+    const uint32_t idx = min((uint32_t)(code - c_lo), (uint32_t)BINS + (lane & 31u));
+    atomicAdd(&hist[C::GLOBAL ? idx : idx + (idx >> C::LOG_BPL)], 1u);
+}
+
+typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
+
+// eight samples (one 16-byte vector) into the LDS histogram with packed 16-bit arithmetic: per PAIR of samples
+// v_pk_sub_u16, v_pk_min_u16, v_pk_lshrrev_b16, v_pk_add_u16, v_pk_lshlrev_b16 + two extracts = 3.5 VALU per sample.
+// code - c_lo is taken modulo 2^16: an out-of-range code wraps to a value >= span (c_lo + span <= 32768), so it
+// lands on a bin the selection never reads or, through the min, on this lane's dummy bin.
+template <int BINS> __device__ __forceinline__ void stats_bin8(uint32_t *hist, const int4 &q, uint32_t c2, uint32_t cap2) {
+    using C = StatsCfg<BINS>;
+    static_assert(!C::GLOBAL, "packed binning is for the LDS histograms");
+    const pg_us2 cv = __builtin_bit_cast(pg_us2, c2), capv = __builtin_bit_cast(pg_us2, cap2);
+    // the four pairs side by side: dependent packed ops of one pair are never back to back (no hazard wait states)
+    const int w[4] = {q.x, q.y, q.z, q.w};
+    pg_us2 d[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) q[u] = vec[v + u * WAVE];
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(pg_us2, w[i]) - cv;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) bin8(q[u]);
-        }
-    } else {
-        for (uint64_t s = beg + lane; s < end; s += WAVE) bin((int)sig[s]);
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_elementwise_min(d[i], capv);
+    pg_us2 t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = d[i] >> (unsigned short)C::LOG_BPL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = d[i] + t[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = d[i] << (unsigned short)2;
+    char *hb = reinterpret_cast<char *>(hist);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t aw = __builtin_bit_cast(uint32_t, d[i]);
+        atomicAdd(reinterpret_cast<uint32_t *>(hb + (aw & 0xffffu)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t *>(hb + (aw >> 16)), 1u);
     }
-    if (GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
+}
+
+// inclusive prefix over the bins, in place
+template <int BINS> __device__ __forceinline__ void stats_prefix(uint32_t *hist, int lane, uint32_t span) {
+    using C = StatsCfg<BINS>;
+    if (C::GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-
-    if constexpr (GLOBAL) {
-        // inclusive prefix over the in-range bins, 64 at a time with a running carry
+    if constexpr (C::GLOBAL) {
+        // 64 bins at a time with a running carry
         uint32_t carry = 0;
         for (uint32_t c = 0; c < span; c += WAVE) {
             const uint32_t b = c + lane;
@@ -827,7 +835,8 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
     } else {
-        // inclusive prefix over the bins: lane l owns bins [l*BPL, (l+1)*BPL) at padded address l*(BPL+1)+i
+        // lane l owns bins [l*BPL, (l+1)*BPL) at padded address l*(BPL+1)+i
+        constexpr int BPL = C::BPL;
         uint32_t ssum = 0;
 #pragma unroll
         for (int i = 0; i < BPL; ++i) ssum += hist[lane * (BPL + 1) + i];
@@ -837,17 +846,16 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     __builtin_amdgcn_wave_barrier();
+}
 
-    using Pre = typename std::conditional<GLOBAL, GlobalPre, PaddedPre<LOG_BPL>>::type;
-    if (oor) { // SAM/BAM front-end: a read with ANY out-of-range sample is skipped as a whole (gmove.cpp:1149-1160)
-        const uint32_t in_range = span ? Pre{hist}[(int)span - 1] : 0u;
-        if (lane == 0) oor[r] = in_range != (uint32_t)(end - beg);
-    }
-    if (range_only) return;
-    // order statistics: every search step tests 64 candidates (pg_select.h holds the arithmetic)
+// order statistics from the prefix sums: every search step tests 64 candidates (pg_select.h holds the arithmetic)
+template <int BINS>
+__device__ __forceinline__ void stats_select(const uint32_t *hist, int lane, const PgReadPlan &pl, uint64_t L, double offset, double scale,
+                                             int win, double &med_out, double &mad_out) {
+    using Pre = typename StatsCfg<BINS>::Pre;
     PgSel<Pre> sel;
-    sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = end - beg;
-    sel.offset = B.off[r]; sel.scale = B.range[r] / B.dig[r];
+    sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = L;
+    sel.offset = offset; sel.scale = scale;
     sel.begin();
     int bm = 0;
     if (!sel.zmed) bm = wave_first_true(sel.span, [&](int b) { return sel.med_pred(b); });
@@ -899,26 +907,208 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
         if ((okm >> 31) & 1) { const double vz = sel.dZ; if (vz < best) best = vz; }
     }
     const PgMedMad mm = sel.finish(best);
-    if (lane == 0) { med[r] = mm.med; mad[r] = mm.mad; }
+    med_out = mm.med; mad_out = mm.mad;
 }
 
-// one workgroup (= one wave) per read of the batch
-__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
-                                                   double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
-                                                   int32_t *__restrict__ err, int win, uint8_t *__restrict__ oor, int range_only) {
+// The usual case in ~1/3 of the instructions of stats_select: same median search and integer model, but the exact round
+// counts the codes on each side of a candidate with PgSel::count_chk (a guessed count verified by three evaluations)
+// instead of searching for it. Every decision still rests on the exact predicate; whenever a verification fails (ties
+// between adjacent codes, a model that is off) it returns false and the caller runs stats_select.
+template <int BINS>
+__device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane, const PgReadPlan &pl, uint64_t L, double offset,
+                                                  double scale, double &med_out, double &mad_out) {
+    using Pre = typename StatsCfg<BINS>::Pre;
+    PgSel<Pre> sel;
+    sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = L;
+    sel.offset = offset; sel.scale = scale;
+    sel.begin();
+    int bm = 0;
+    if (!sel.zmed) bm = wave_first_true(sel.span, [&](int b) { return sel.med_pred(b); });
+    sel.set_median(bm);
+    if (!sel.zmed && sel.sp > 0 && pg_pa(sel.c_lo + sel.sp - 1, offset, scale) >= sel.med) return false; // equal neighbours
+    double best = INFINITY;
+    if (L > 1) {
+        sel.nU = sel.span - sel.sp; sel.nD = sel.sp;
+        sel.base = sel.P(sel.sp - 1);
+        sel.dZ = fabs(0.0 - sel.med);
+        sel.inv = 1.0 / scale;
+        sel.need = sel.k + 1;
+        sel.begin_approx();
+        int aU, aD;
+        wave_first_true_pair(sel.nU, sel.nD, [&](int side, int tt) { return sel.approx_pred(side == 0, tt); }, aU, aD);
+        // model of "codes of the other side at or below a candidate": t' <= t + q for a U candidate t, t' <= t - q for D
+        auto to_int = [](double x) { return x != x ? 0 : (x < -70000.0 ? -70000 : (x > 70000.0 ? 70000 : (int)rint(x))); };
+        const bool two_sided = sel.nU > 0 && sel.nD > 0;
+        const int rq = two_sided ? to_int((sel.U(0) - sel.D(0)) * sel.inv) : 0;
+        const bool up = lane < 32;
+        const int sub = lane & 31, n_side = up ? sel.nU : sel.nD;
+        const int t = (up ? aU : aD) - 15 + sub;
+        const bool cand = sub < 31 && t >= 0 && t < n_side;
+        const bool zlane = lane == 31 && sel.nZ > 0;
+        double v = INFINITY; int mU = 0, mD = 0;
+        if (cand) { v = sel.dev(up, t); mU = up ? t : t - rq; mD = up ? t + rq : t; }
+        if (zlane) {
+            v = sel.dZ;
+            mU = sel.nU > 0 ? to_int((sel.dZ - sel.U(0)) * sel.inv) : 0;
+            mD = sel.nD > 0 ? to_int((sel.dZ - sel.D(0)) * sel.inv) : 0;
+        }
+        bool okU, okD;
+        const int cntU = sel.count_chk(true, v, mU, okU), cntD = sel.count_chk(false, v, mD, okD);
+        const uint32_t N = sel.CU(cntU) + sel.CD(cntD) + (sel.dZ <= v ? sel.nZ : 0u);
+        const bool act = cand || zlane;
+        const uint64_t passm = __ballot(act && N >= sel.need), candm = __ballot(cand), surem = __ballot(okU && okD);
+        for (int side = 0; side < 2; ++side) {
+            const int sh = side * 32, n = side == 0 ? sel.nU : sel.nD, a = side == 0 ? aU : aD;
+            if (n == 0) continue;
+            const uint32_t o = (uint32_t)(passm >> sh) & 0x7fffffffu, c = (uint32_t)(candm >> sh) & 0x7fffffffu;
+            const uint32_t su = (uint32_t)(surem >> sh);
+            if (o) {
+                const int fl = __ffs((int)o) - 1; // first candidate that qualifies: exact if it is code 0 or its predecessor failed for sure
+                if (!((su >> fl) & 1)) return false;
+                const int ft = a - 15 + fl;
+                if (ft != 0 && !(fl > 0 && ((c >> (fl - 1)) & 1) && ((su >> (fl - 1)) & 1))) return false;
+                const double vv = __shfl(v, sh + fl, WAVE);
+                if (vv < best) best = vv;
+            } else { // none qualifies: conclusive only if the side's last code was tested, for sure
+                if (!c) return false;
+                const int ll = 31 - __clz((int)c);
+                if (a - 15 + ll != n - 1 || !((su >> ll) & 1)) return false;
+            }
+        }
+        if (sel.nZ > 0) {
+            if (!((surem >> 31) & 1)) return false;
+            if ((passm >> 31) & 1) { const double vz = sel.dZ; if (vz < best) best = vz; }
+        }
+    }
+    const PgMedMad mm = sel.finish(best);
+    med_out = mm.med; mad_out = mm.mad;
+    return true;
+}
+
+// everything after the histogram is complete: prefix, the out-of-range flag, the selection, the two stores
+template <int BINS>
+__device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t r, const PgStatRec &m, double *__restrict__ med,
+                                             double *__restrict__ mad, int win, uint8_t *__restrict__ oor, int range_only) {
+    using Pre = typename StatsCfg<BINS>::Pre;
+    const uint64_t L = m.end - m.beg;
+    stats_prefix<BINS>(hist, lane, (uint32_t)m.span);
+    if (oor) { // SAM/BAM front-end: a read with ANY out-of-range sample is skipped as a whole (gmove.cpp:1149-1160)
+        const uint32_t in_range = m.span ? Pre{hist}[(int)m.span - 1] : 0u;
+        if (lane == 0) oor[r] = in_range != (uint32_t)L;
+    }
+    if (range_only) return;
+    PgReadPlan pl; pl.c_lo = m.c_lo; pl.span = m.span; pl.z0 = m.z0; pl.status = 0;
+    double m0, m1;
+    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1)) // win == 0: tests of the general path
+        stats_select<BINS>(hist, lane, pl, L, m.offset, m.scale, win, m0, m1);
+    if (lane == 0) { med[r] = m0; mad[r] = m1; }
+}
+
+// a read that gets no statistics: skipped, unusable calibration, or wider than the widest histogram
+__device__ __forceinline__ void stats_no_result(int lane, uint32_t r, int code, double *__restrict__ med, double *__restrict__ mad,
+                                                int32_t *__restrict__ status, int32_t *__restrict__ err) {
+    if (lane == 0) {
+        med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
+        if (code) { status[r] = code; atomicMin(&err[0], (int)r); }
+    }
+}
+
+// One read, start to finish, by one wave (the wide / huge launches: rare reads, no cross-read pipelining).
+template <int BINS>
+__device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgStatRec *__restrict__ rec,
+                                               double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
+                                               int32_t *__restrict__ err, int win, uint8_t *__restrict__ oor, int range_only) {
+    using C = StatsCfg<BINS>;
+    const int lane = lane_id();
+    const PgStatRec m = rec[r];
+    if (m.mode != PG_STAT_RUN) return; // reported by the main launch
+    if (m.span > BINS) { stats_no_result(lane, r, PGR_ERR_WIDE, med, mad, status, err); return; }
+    const uint64_t beg = m.beg, end = m.end;
+    stats_zero<BINS>(hist, lane);
+    const int c_lo = m.c_lo;
+    const int16_t *__restrict__ sig = B.sig;
+    auto bin8 = [&](const int4 &q) {
+        if constexpr (C::GLOBAL) {
+            const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { stats_bin1<BINS>(hist, (int)(short)(w[i] & 0xffff), c_lo, lane); stats_bin1<BINS>(hist, w[i] >> 16, c_lo, lane); }
+        } else {
+            const uint32_t c16 = (uint32_t)c_lo & 0xffffu, cap = (uint32_t)BINS + (lane & 31u);
+            stats_bin8<BINS>(hist, q, c16 | (c16 << 16), cap | (cap << 16));
+        }
+    };
+    // 16-byte vectors fully inside [beg, end): [va, vb); ragged head and tail handled element-wise
+    const uint64_t va = (beg + 7) >> 3, vb = end >> 3;
+    if (va < vb) {
+        for (uint64_t s2 = beg + lane; s2 < (va << 3); s2 += WAVE) stats_bin1<BINS>(hist, (int)sig[s2], c_lo, lane);
+        for (uint64_t s2 = (vb << 3) + lane; s2 < end; s2 += WAVE) stats_bin1<BINS>(hist, (int)sig[s2], c_lo, lane);
+        const int4 *__restrict__ vec = reinterpret_cast<const int4 *>(sig);
+        for (uint64_t v = va + lane; v < vb; v += 8 * WAVE) { // up to 8 independent 16-byte loads in flight per lane
+            int4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) q[u] = vec[v + u * WAVE];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (v + u * WAVE < vb) bin8(q[u]);
+        }
+    } else {
+        for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<BINS>(hist, (int)sig[s2], c_lo, lane);
+    }
+    stats_finish<BINS>(hist, lane, r, m, med, mad, win, oor, range_only);
+}
+
+// ---- the main launch: one workgroup (= one wave) per read -------------------------------------------------------------
+// Measured alternatives (tools/probe/stream_probe.hip): a wave per 8 KB of signal with LDS-atomic binning
+// streams at 5.9 TB/s whether the waves are launched per read or kept persistent with a rolling register prefetch of the
+// next read; the persistent form only added bookkeeping and registers (fewer resident waves), so the hardware
+// dispatcher does the load balancing and the overlap comes from eight resident waves per SIMD.
+__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
+                                                   double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
+                                                   int win, uint8_t *__restrict__ oor, int range_only) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<1024>::LDS_WORDS];
-    stats_one_read<1024>(hist, B, blockIdx.x, plan, needed, med, mad, status, err, win, oor, range_only);
+    const uint32_t r = blockIdx.x;
+    const int lane = lane_id();
+    const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
+    if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, status, err); return; }
+    if (m.span > 1024) return; // on the list of a wider launch
+    stats_zero<1024>(hist, lane);
+    const int16_t *__restrict__ sig = B.sig;
+    const int c_lo = m.c_lo;
+    const uint32_t c16 = (uint32_t)c_lo & 0xffffu, c2 = c16 | (c16 << 16);
+    const uint32_t cap = 1024u + (lane & 31u), cap2 = cap | (cap << 16);
+    // 16-byte vectors fully inside [beg, end): [va, vb); ragged head and tail handled element-wise
+    const uint64_t beg = m.beg, end = m.end, va = (beg + 7) >> 3, vb = end >> 3;
+    if (va < vb) {
+        // passes of eight rows of 64 vectors. The eight 16-byte loads of a pass are UNCONDITIONAL (a lane past the read's
+        // last vector re-reads that vector and does not bin it): straight-line code, all eight in flight per lane
+        const uint64_t n_vec = vb - va;
+        for (uint64_t p = 0; p < n_vec; p += 8 * WAVE) {
+            const int4 *__restrict__ vp = reinterpret_cast<const int4 *>(sig) + (va + p); // uniform base, 32-bit lane offsets
+            const uint32_t last = n_vec - p > 8 * WAVE ? 8 * WAVE - 1 : (uint32_t)(n_vec - p) - 1;
+            int4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if ((uint32_t)(u * WAVE + lane) <= last) stats_bin8<1024>(hist, q[u], c2, cap2);
+        }
+        if ((va << 3) != beg || (vb << 3) != end) {
+            for (uint64_t s2 = beg + lane; s2 < (va << 3); s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
+            for (uint64_t s2 = (vb << 3) + lane; s2 < end; s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
+        }
+    } else {
+        for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
+    }
+    stats_finish<1024>(hist, lane, r, m, med, mad, win, oor, range_only);
 }
 
 // reads whose in-range interval needs the PG_STATS_BINS histogram: usually none, so a small grid strides over the list
-__global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
+__global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgStatRec *__restrict__ plan,
                                                         double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
                                                         const int32_t *__restrict__ wide_count, uint8_t *__restrict__ oor, int range_only) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
     const uint32_t n_list = (uint32_t)*wide_count;
     for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, needed, med, mad, status, err, win, oor, range_only);
+        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, med, mad, status, err, win, oor, range_only);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
     }
@@ -926,7 +1116,7 @@ __global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgRe
 
 // reads whose in-range interval exceeds PG_STATS_BINS codes (very wide --pa_min/--pa_max): same algorithm on a
 // 65536-bin histogram in global memory, one scratch histogram per workgroup
-__global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgReadPlan *__restrict__ plan, const uint8_t *__restrict__ needed,
+__global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgStatRec *__restrict__ plan,
                                                         double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
                                                         int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
                                                         const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch,
@@ -934,7 +1124,7 @@ __global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgRe
     const uint32_t n_list = (uint32_t)wide_count[1];
     uint32_t *hist = scratch + (size_t)blockIdx.x * PG_HUGE_WORDS;
     for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, needed, med, mad, status, err, win, oor, range_only);
+        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, med, mad, status, err, win, oor, range_only);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
     }
@@ -1073,28 +1263,30 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
     hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)scratch, out);
 }
 
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, uint32_t *wide_list,
-                         int32_t *flags, int32_t *stat_status) {
+void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
+                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status) {
     hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
     if (B.n_reads == 0) return;
-    hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, pa_min, pa_max,
-                       reinterpret_cast<PgReadPlan *>(plan_buf), wide_list, flags + 1, stat_status);
+    hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
+                       reinterpret_cast<PgStatRec *>(plan_buf), wide_list, flags + 1, stat_status);
 }
 
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const uint8_t *read_needed, const void *plan_buf,
+void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
                           const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only) {
     if (B.n_reads == 0) return;
-    const PgReadPlan *plan = reinterpret_cast<const PgReadPlan *>(plan_buf);
-    if (bins <= 1024)
-        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, oor, range_only);
+    const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
+    if (bins <= 1024) {
+                const uint32_t grid = B.n_reads;
+        hipLaunchKernelGGL(k_read_stats, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only);
+    }
     else if (bins <= PG_STATS_BINS) { // the wide list is usually empty: a small persistent grid
         const uint32_t grid = B.n_reads < 2048 ? B.n_reads : 2048;
-        hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
+        hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, wide_list,
                            wide_count, oor, range_only);
     } else {
         const uint32_t grid = B.n_reads < PG_HUGE_BLOCKS ? B.n_reads : PG_HUGE_BLOCKS;
-        hipLaunchKernelGGL(k_read_stats_huge, dim3(grid), dim3(64), 0, st, B, plan, read_needed, med, mad, status, err, win, wide_list,
+        hipLaunchKernelGGL(k_read_stats_huge, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, wide_list,
                            wide_count, huge_scratch, oor, range_only);
     }
 }

@@ -137,6 +137,22 @@ struct PgSel {
         }
         return c;
     }
+    // count_leq when a guess m of the answer is at hand: three evaluations, no loop. The result is b + [dev(b) <= v] for
+    // b = clamp(m, -1, n-1); it is exact iff dev(b-1) <= v < dev(b+1) (deviations are monotone in t), which `ok` reports.
+    // Index -1 counts as "<= v", index n as "> v".
+    PG_HD int count_chk(bool up, double v, int m, bool &ok) const {
+        const int n = up ? nU : nD;
+        const int b = m < -1 ? -1 : (m > n - 1 ? n - 1 : m);
+        const int hi = n > 0 ? n - 1 : 0;
+        auto le = [&](int x) {
+            const int xc = x < 0 ? 0 : (x > hi ? hi : x);
+            const bool r = dev(up, xc) <= v;
+            return x < 0 ? true : (x >= n ? false : r);
+        };
+        const bool ea = le(b - 1), eb = le(b), ec = le(b + 1);
+        ok = ea && !ec;
+        return b + (eb ? 1 : 0);
+    }
     PG_HD uint32_t CU(int t) const { return t <= 0 ? 0u : P(sp + t - 1) - base; }
     PG_HD uint32_t CD(int t) const { return t <= 0 ? 0u : base - P(sp - t - 1); }
     // number of samples with |x - med| <= v

@@ -14,6 +14,6 @@ for d in sorted(glob.glob('gpurun_out/pmcs_*/')):
             k=row['Kernel_Name'].split('(')[0]
             acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
         for k,v in acc.items():
-            if 'k_read_stats<1024' in k or 'k_walk' in k or 'k_events' in k or 'k_rank' in k:
+            if k.strip() in ('k_read_stats','k_walk','k_events','k_rank_count','k_rank_emit','k_gather'):
                 print(k[:34], {c: round(sum(x)/len(x)) for c,x in v.items()})
 PY

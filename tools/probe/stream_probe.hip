@@ -1,0 +1,184 @@
+// stream_probe.hip -- how fast can one MI355X READ a 400 MB int16 buffer with the access shapes k_read_stats could use?
+// build: hipcc --offload-arch=gfx950 -O3 -o stream_probe stream_probe.hip ; run: ./stream_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__device__ __forceinline__ uint32_t fold(const int4 &q) { return (uint32_t)(q.x ^ q.y ^ q.z ^ q.w); }
+
+// A: plain grid-stride 16-byte reads, 256-thread blocks
+__global__ __launch_bounds__(256) void k_plain(const int4 *__restrict__ v, size_t n, uint32_t *out) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= fold(v[i]);
+    if (acc == 0x12345678u) out[0] = acc;
+}
+// B: one wave (64-thread block) per 8 KB chunk, all 8 loads issued, then consumed
+__global__ __launch_bounds__(64) void k_chunk(const int4 *__restrict__ v, size_t n, uint32_t *out) {
+    const size_t base = (size_t)blockIdx.x * 512 + threadIdx.x;
+    int4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = v[base + u * 64];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= fold(q[u]);
+    if (acc == 0x12345678u) out[0] = acc;
+}
+// C: persistent waves, chunk c of wave w = w + c*G, rolling refill of 8 slots (DEPTH rows in flight)
+template <int WORK> __global__ __launch_bounds__(64) void k_roll(const int4 *__restrict__ v, size_t n_chunks, uint32_t *out) {
+    const size_t G = gridDim.x;
+    size_t c = blockIdx.x;
+    int4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = v[c * 512 + u * 64 + threadIdx.x];
+    uint32_t acc = 0;
+    for (; c < n_chunks; c += G) {
+        const size_t nc = c + G < n_chunks ? c + G : c;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t f = fold(q[u]);
+#pragma unroll
+            for (int k = 0; k < WORK; ++k) f = f * 1664525u + 1013904223u; // stand-in for the binning ALU work
+            acc ^= f;
+            q[u] = v[nc * 512 + u * 64 + threadIdx.x];
+        }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+// D: like B but each block handles R consecutive chunks one after the other (no prefetch)
+__global__ __launch_bounds__(64) void k_chunk_seq(const int4 *__restrict__ v, size_t n_chunks, int R, uint32_t *out) {
+    uint32_t acc = 0;
+    for (int k = 0; k < R; ++k) {
+        const size_t c = (size_t)blockIdx.x + (size_t)k * gridDim.x;
+        if (c >= n_chunks) break;
+        int4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = v[c * 512 + u * 64 + threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= fold(q[u]);
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bin8(uint32_t *hist, const int4 &q, uint32_t c2, uint32_t cap2) {
+    const us2 cv = __builtin_bit_cast(us2, c2), capv = __builtin_bit_cast(us2, cap2);
+    const int w[4] = {q.x, q.y, q.z, q.w};
+    us2 d[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(us2, w[i]) - cv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = __builtin_elementwise_min(d[i], capv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = d[i] >> (unsigned short)4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = d[i] + t[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = d[i] << (unsigned short)2;
+    char *hb = reinterpret_cast<char *>(hist);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t aw = __builtin_bit_cast(uint32_t, d[i]);
+        atomicAdd(reinterpret_cast<uint32_t *>(hb + (aw & 0xffffu)), 1u);
+        atomicAdd(reinterpret_cast<uint32_t *>(hb + (aw >> 16)), 1u);
+    }
+}
+#define HWORDS (1024 + 64 + 32 + 4)
+// E: wave per chunk; MODE bit0: chunk offset comes from a table (dependent scalar load); bit1: zero an LDS histogram;
+// bit2: bin all samples into it with LDS atomics
+template <int MODE> __global__ __launch_bounds__(64) void k_chunk_x(const int4 *__restrict__ v, const uint64_t *__restrict__ tab, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HWORDS];
+    const int lane = threadIdx.x;
+    if (MODE & 2) { uint4 *h4 = (uint4 *)hist; for (int i = lane; i < HWORDS / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0); }
+    const size_t base = ((MODE & 1) ? tab[blockIdx.x] : (size_t)blockIdx.x * 512) + lane;
+    int4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = v[base + u * 64];
+    uint32_t acc = 0;
+    const uint32_t cap = 1024u + (lane & 31u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { if (MODE & 4) bin8(hist, q[u], 0x00640064u, cap | (cap << 16)); else acc ^= fold(q[u]); }
+    if (MODE & 2) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); acc ^= hist[lane * 17]; }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+// F: rolling persistent + LDS binning
+__global__ __launch_bounds__(64) void k_roll_bin(const int4 *__restrict__ v, size_t n_chunks, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HWORDS];
+    const int lane = threadIdx.x;
+    { uint4 *h4 = (uint4 *)hist; for (int i = lane; i < HWORDS / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0); }
+    const size_t G = gridDim.x;
+    size_t c = blockIdx.x;
+    int4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = v[c * 512 + u * 64 + lane];
+    const uint32_t cap = 1024u + (lane & 31u);
+    uint32_t acc = 0;
+    for (; c < n_chunks; c += G) {
+        const size_t nc = c + G < n_chunks ? c + G : c;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bin8(hist, q[u], 0x00640064u, cap | (cap << 16));
+            q[u] = v[nc * 512 + u * 64 + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        acc ^= hist[lane * 17];
+        { uint4 *h4 = (uint4 *)hist; for (int i = lane; i < HWORDS / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0); }
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+// signal-like content: codes 100 + level(event) + noise, events of ~10-30 samples
+__global__ void k_fill(int16_t *s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        uint32_t ev = (uint32_t)(i / 30), h = ev * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        uint32_t g = (uint32_t)i * 2246822519u; g ^= g >> 15; g *= 3266489917u; g ^= g >> 16;
+        // level 70..130 pA at 0.18 pA per code, noise ~ N(0, 17 codes) as the sum of four uniforms (bench.py's signal)
+        int noise = (int)(g & 31) + (int)((g >> 5) & 31) + (int)((g >> 10) & 31) + (int)((g >> 15) & 31) - 62;
+        s[i] = (int16_t)(100 + 390 + (h % 333) + noise);
+    }
+}
+
+int main() {
+    const size_t bytes = 400ull << 20, n = bytes / 16, n_chunks = n / 512;
+    int4 *d; uint32_t *o;
+    CK(hipMalloc(&d, bytes)); CK(hipMalloc(&o, 64)); CK(hipMemset(d, 1, bytes)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (int16_t *)d, bytes / 2); CK(hipDeviceSynchronize());
+    uint64_t *tab; CK(hipMalloc(&tab, n_chunks * 8)); { std::vector<uint64_t> h(n_chunks); for (size_t i = 0; i < n_chunks; ++i) h[i] = i * 512; CK(hipMemcpy(tab, h.data(), n_chunks * 8, hipMemcpyHostToDevice)); }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time = [&](const char *name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(e0); for (int i = 0; i < 20; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+        printf("%-44s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, bytes / (ms * 1e-3) / 1e12); fflush(stdout);
+    };
+    time("A plain grid-stride, 2048 blocks x256", [&] { hipLaunchKernelGGL(k_plain, dim3(2048), dim3(256), 0, 0, d, n, o); });
+    time("A plain grid-stride, 8192 blocks x256", [&] { hipLaunchKernelGGL(k_plain, dim3(8192), dim3(256), 0, 0, d, n, o); });
+    time("A plain, one 16B per thread (n/256 blocks)", [&] { hipLaunchKernelGGL(k_plain, dim3((unsigned)(n / 256)), dim3(256), 0, 0, d, n, o); });
+    time("B wave per 8KB chunk (51200 blocks x64)", [&] { hipLaunchKernelGGL(k_chunk, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, n, o); });
+    for (int g : {2048, 4096, 6144, 8192}) {
+        char nm[96]; snprintf(nm, sizeof nm, "C rolling persistent, %d waves, work 0", g);
+        time(nm, [&] { hipLaunchKernelGGL(k_roll<0>, dim3(g), dim3(64), 0, 0, d, n_chunks, o); });
+    }
+    for (int g : {4096, 6144, 8192}) {
+        char nm[96]; snprintf(nm, sizeof nm, "C rolling persistent, %d waves, work 8", g);
+        time(nm, [&] { hipLaunchKernelGGL(k_roll<8>, dim3(g), dim3(64), 0, 0, d, n_chunks, o); });
+    }
+    for (int g : {4096, 6144, 8192}) {
+        char nm[96]; snprintf(nm, sizeof nm, "C rolling persistent, %d waves, work 32", g);
+        time(nm, [&] { hipLaunchKernelGGL(k_roll<32>, dim3(g), dim3(64), 0, 0, d, n_chunks, o); });
+    }
+    for (int R : {2, 4, 8}) {
+        char nm[96]; snprintf(nm, sizeof nm, "D wave per chunk, %d chunks per block in turn", R);
+        time(nm, [&] { hipLaunchKernelGGL(k_chunk_seq, dim3((unsigned)((n_chunks + R - 1) / R)), dim3(64), 0, 0, d, n_chunks, R, o); });
+    }
+    time("E0 wave per chunk (as B)", [&] { hipLaunchKernelGGL(k_chunk_x<0>, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    time("E1 + chunk offset from a table", [&] { hipLaunchKernelGGL(k_chunk_x<1>, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    time("E3 + table + zeroed LDS histogram", [&] { hipLaunchKernelGGL(k_chunk_x<3>, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    time("E7 + table + zero + LDS-atomic binning", [&] { hipLaunchKernelGGL(k_chunk_x<7>, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    time("E6 zero + binning, no table", [&] { hipLaunchKernelGGL(k_chunk_x<6>, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    for (int g : {4096, 6144, 8192}) {
+        char nm[96]; snprintf(nm, sizeof nm, "F rolling persistent + binning, %d waves", g);
+        time(nm, [&] { hipLaunchKernelGGL(k_roll_bin, dim3(g), dim3(64), 0, 0, d, n_chunks, o); });
+    }
+    return 0;
+}
