@@ -69,6 +69,7 @@ struct pg_ctx {
     DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
+    bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf m_read, meta, huge_scratch, oor;
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
@@ -352,6 +353,8 @@ static pg_status check_read_errors(pg_ctx *c) {
 // statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
 // handles the reads whose in-range code interval fits it (no host decision, no sync)
 static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
+    const bool flags_are_reset = st == c->st && c->stat_flags_reset; // by this batch's k_batch_init, on the same stream
+    c->stat_flags_reset = false;
     const uint32_t n = c->B.n_reads;
     const int sl = c->slot;
     const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0;
@@ -364,16 +367,14 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) 
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] length of the wide list
     prof_begin(c, "k_read_plan", st);
     pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
-                        c->stat_status[sl].as<int32_t>());
+                        c->stat_status[sl].as<int32_t>(), flags_are_reset);
     prof_end(c, st);
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
     prof_end(c, st);
-    prof_begin(c, "k_read_stats_wide", st);
-    pg_launch_read_stats(st, c->B, PG_STATS_BINS, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
+    prof_begin(c, "k_read_stats_rare", st);
     pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only);
     prof_end(c, st);
@@ -467,7 +468,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         if (c->slot_used[c->slot]) HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_gathered[c->slot], 0));
     }
     pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
-                         c->zero_running ? 1 : 0);
+                         c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>());
+    c->stat_flags_reset = !overlap;
     c->zero_running = false;
 
     if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr); if (s2 != PG_OK) return s2; }

@@ -107,8 +107,9 @@ struct PgKeptOut {
 };
 // resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
 // context's running per-slot counts
+// stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch
 void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
-                          int zero_running);
+                          int zero_running, int32_t *stat_flags);
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
@@ -137,8 +138,9 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status);
-// bins: 1024 (one workgroup per read), PG_STATS_BINS (LDS, wide list) or 65536 (global-memory histograms, huge list)
+                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status, bool flags_are_reset);
+// bins: 1024 (one workgroup per read) or anything larger = the rare reads (wide list: PG_STATS_BINS LDS bins; huge list:
+// 65536 bins in global memory), one launch for both lists
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,

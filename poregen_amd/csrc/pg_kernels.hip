@@ -1100,33 +1100,32 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec
     stats_finish<1024>(hist, lane, r, m, med, mad, win, oor, range_only);
 }
 
-// reads whose in-range interval needs the PG_STATS_BINS histogram: usually none, so a small grid strides over the list
-__global__ __launch_bounds__(64) void k_read_stats_wide(PgDevBatch B, const PgStatRec *__restrict__ plan,
-                                                        double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
-                                                        int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
-                                                        const int32_t *__restrict__ wide_count, uint8_t *__restrict__ oor, int range_only) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
-    const uint32_t n_list = (uint32_t)*wide_count;
-    for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, med, mad, status, err, win, oor, range_only);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
-    }
-}
-
-// reads whose in-range interval exceeds PG_STATS_BINS codes (very wide --pa_min/--pa_max): same algorithm on a
-// 65536-bin histogram in global memory, one scratch histogram per workgroup
-__global__ __launch_bounds__(64) void k_read_stats_huge(PgDevBatch B, const PgStatRec *__restrict__ plan,
-                                                        double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
-                                                        int32_t *__restrict__ err, int win, const uint32_t *__restrict__ wide_list,
+// The rare reads: in-range interval wider than 1024 codes. ONE launch covers both lists (usually both are empty, and an
+// empty launch still costs a kernel boundary): blocks [0, gridDim.x - PG_HUGE_BLOCKS) stride over the wide list
+// (<= PG_STATS_BINS codes: LDS histogram), the last PG_HUGE_BLOCKS blocks over the huge list (any interval: a 65536-bin
+// histogram in global memory, one scratch histogram per block).
+__global__ __launch_bounds__(64) void k_read_stats_rare(PgDevBatch B, const PgStatRec *__restrict__ plan, double *__restrict__ med,
+                                                        double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
+                                                        int win, const uint32_t *__restrict__ wide_list,
                                                         const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch,
                                                         uint8_t *__restrict__ oor, int range_only) {
-    const uint32_t n_list = (uint32_t)wide_count[1];
-    uint32_t *hist = scratch + (size_t)blockIdx.x * PG_HUGE_WORDS;
-    for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-        stats_one_read<PG_HUGE_BINS>(hist, B, wide_list[B.n_reads - 1 - it], plan, med, mad, status, err, win, oor, range_only);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
+    const uint32_t n_wide_blocks = gridDim.x - PG_HUGE_BLOCKS;
+    if (blockIdx.x < n_wide_blocks) {
+        const uint32_t n_list = (uint32_t)wide_count[0];
+        for (uint32_t it = blockIdx.x; it < n_list; it += n_wide_blocks) {
+            stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, med, mad, status, err, win, oor, range_only);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
+        }
+    } else {
+        const uint32_t hb = blockIdx.x - n_wide_blocks, n_list = (uint32_t)wide_count[1];
+        uint32_t *gh = scratch + (size_t)hb * PG_HUGE_WORDS;
+        for (uint32_t it = hb; it < n_list; it += PG_HUGE_BLOCKS) {
+            stats_one_read<PG_HUGE_BINS>(gh, B, wide_list[B.n_reads - 1 - it], plan, med, mad, status, err, win, oor, range_only);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -1157,9 +1156,11 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
 }
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, uint8_t *__restrict__ read_needed,
-                                                    uint64_t *__restrict__ running, uint32_t n_slots, int zero_running) {
+                                                    uint64_t *__restrict__ running, uint32_t n_slots, int zero_running,
+                                                    int32_t *__restrict__ stat_flags) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { err[0] = INT_MAX; err[1] = 0; }
+    if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; } // as k_stat_flags_init
     if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
 }
@@ -1169,9 +1170,10 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
 // =====================================================================================================
 
 void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
-                          int zero_running) {
+                          int zero_running, int32_t *stat_flags) {
     const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
-    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running);
+    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running,
+                       stat_flags);
 }
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
@@ -1264,8 +1266,8 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 }
 
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status) {
-    hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
+                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
+    if (!flags_are_reset) hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
                        reinterpret_cast<PgStatRec *>(plan_buf), wide_list, flags + 1, stat_status);
@@ -1277,17 +1279,11 @@ void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const v
     if (B.n_reads == 0) return;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     if (bins <= 1024) {
-                const uint32_t grid = B.n_reads;
-        hipLaunchKernelGGL(k_read_stats, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only);
-    }
-    else if (bins <= PG_STATS_BINS) { // the wide list is usually empty: a small persistent grid
-        const uint32_t grid = B.n_reads < 2048 ? B.n_reads : 2048;
-        hipLaunchKernelGGL(k_read_stats_wide, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, wide_list,
-                           wide_count, oor, range_only);
-    } else {
-        const uint32_t grid = B.n_reads < PG_HUGE_BLOCKS ? B.n_reads : PG_HUGE_BLOCKS;
-        hipLaunchKernelGGL(k_read_stats_huge, dim3(grid), dim3(64), 0, st, B, plan, med, mad, status, err, win, wide_list,
-                           wide_count, huge_scratch, oor, range_only);
+        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only);
+    } else { // the wide and huge lists are usually empty: a small grid strides over them
+        const uint32_t wide_blocks = B.n_reads < 2048 ? B.n_reads : 2048;
+        hipLaunchKernelGGL(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
+                           wide_list, wide_count, huge_scratch, oor, range_only);
     }
 }
 

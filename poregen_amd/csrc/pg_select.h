@@ -42,15 +42,27 @@ template <class Pred> PG_HD int pg_first_code(Pred pred) {
     return lo;
 }
 
+// the same with an estimate x of the answer (pA is linear in the code up to rounding): a few evaluations next to the
+// estimate instead of 17; any estimate is safe, a bad one only costs the plain binary search
+template <class Pred> PG_HD int pg_first_code_near(Pred pred, double x) {
+    if (!(x > -32768.0 && x < 32768.0)) return pg_first_code(pred); // also NaN
+    int g = (int)x;
+    for (int step = 0; step < 4; ++step) {
+        if (pred(g)) { if (g == -32768 || !pred(g - 1)) return g; --g; }
+        else { if (g == 32767) return 32768; ++g; if (pred(g)) return g; }
+    }
+    return pg_first_code(pred);
+}
+
 PG_HD PgReadPlan pg_make_plan(double digitisation, double offset, double range, double pa_min, double pa_max) {
     PgReadPlan p;
     const double scale = range / digitisation;
     p.status = (scale > 0.0 && isfinite(scale) && isfinite(offset)) ? 0 : -1;
     if (p.status != 0) { p.c_lo = 0; p.span = 0; p.z0 = 0; return p; }
     // zero-fill test of the reference: pA < pa_min || pA > pa_max  (gmove.cpp:756)
-    const int c_lo = pg_first_code([&](int c) { return !(pg_pa(c, offset, scale) < pa_min); });
-    const int c_gt = pg_first_code([&](int c) { return pg_pa(c, offset, scale) > pa_max; });
-    const int c_z = pg_first_code([&](int c) { return pg_pa(c, offset, scale) >= 0.0; });
+    const int c_lo = pg_first_code_near([&](int c) { return !(pg_pa(c, offset, scale) < pa_min); }, ceil(pa_min / scale - offset));
+    const int c_gt = pg_first_code_near([&](int c) { return pg_pa(c, offset, scale) > pa_max; }, floor(pa_max / scale - offset) + 1.0);
+    const int c_z = pg_first_code_near([&](int c) { return pg_pa(c, offset, scale) >= 0.0; }, ceil(-offset));
     p.c_lo = c_lo;
     p.span = c_gt > c_lo ? c_gt - c_lo : 0;
     int z0 = c_z - c_lo;

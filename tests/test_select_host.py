@@ -74,3 +74,26 @@ def test_plan_rejects_non_positive_scale(shim):
     scale = 281.345551 / 2048.0
     assert (c_lo - 101.0) * scale >= 40.0 > (c_lo - 1 - 101.0) * scale
     assert (c_lo + span - 1 - 101.0) * scale <= 180.0 < (c_lo + span - 101.0) * scale
+
+
+def test_plan_boundaries_match_brute_force(shim):
+    """pg_make_plan's estimate-guided code search against an exhaustive scan of all 65536 codes, including bounds at or
+    beyond the int16 range, infinite bounds and huge / tiny scales."""
+    rng = np.random.default_rng(7)
+    codes = np.arange(-32768, 32768, dtype=np.float64)
+    cases = [(2048.0, -101.0, 281.345551, 40.0, 180.0), (8192.0, 5.0, 1400.0, -1e300, 1e300), (8192.0, 5.0, 1400.0, float("-inf"), float("inf")),
+             (2048.0, 0.0, 1e-9, 40.0, 180.0), (2048.0, 0.0, 1e12, 40.0, 180.0), (2048.0, -40000.0, 300.0, 0.0, 10.0),
+             (2048.0, 40000.0, 300.0, 0.0, 10.0), (2048.0, 0.0, 300.0, 180.0, 40.0), (8192.0, 0.5, 1000.0, 0.0, 0.0)]
+    for _ in range(300):
+        cases.append((float(rng.choice([2048.0, 8192.0])), float(rng.uniform(-40000, 40000)), float(10 ** rng.uniform(-3, 6)),
+                      float(rng.uniform(-500, 500)), float(rng.uniform(-500, 5000))))
+    for dig, off, rg, pmin, pmax in cases:
+        out = (ctypes.c_int32 * 4)()
+        assert shim.pgt_plan(dig, off, rg, pmin, pmax, out) == 0
+        pa = (codes + off) * (rg / dig)
+        ge_min = np.flatnonzero(~(pa < pmin)); gt_max = np.flatnonzero(pa > pmax); ge0 = np.flatnonzero(pa >= 0.0)
+        c_lo = int(codes[ge_min[0]]) if ge_min.size else 32768
+        c_gt = int(codes[gt_max[0]]) if gt_max.size else 32768
+        c_z = int(codes[ge0[0]]) if ge0.size else 32768
+        span = max(c_gt - c_lo, 0)
+        assert (out[0], out[1], out[2]) == (c_lo, span, min(max(c_z - c_lo, 0), span)), (dig, off, rg, pmin, pmax)
