@@ -548,7 +548,11 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
     HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
-    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 2) * 8));
+    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); {
+        const size_t before = c->scan_scratch.cap;
+        HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 4) * 8));
+        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st)); // chained-scan state
+    }
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);

@@ -704,6 +704,75 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 }
 
+// The same scan in ONE launch (chained scan with decoupled look-back): block b publishes the sum of its 4096 elements,
+// then adds up the published sums (or the first published prefix) of the blocks before it. state[0] = ticket (block
+// order = order of arrival, so a block only ever waits for blocks that already run), state[1] = blocks done,
+// state[2 + b] = (value << 2) | flag, flag 1 = sum of block b, 2 = inclusive prefix up to block b. The block that
+// finishes last clears the state for the next launch (the buffer is zeroed when it is allocated).
+__global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
+                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ state) {
+    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t sh_prefix;
+    __shared__ uint32_t sh_block;
+    const uint64_t n = n_ptr ? *n_ptr : n_scalar;
+    if (threadIdx.x == 0) sh_block = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(state), 1ull);
+    __syncthreads();
+    const uint32_t b = sh_block;
+    const uint64_t base = (uint64_t)b * SCAN_CHUNK + (uint64_t)threadIdx.x * 16;
+    uint32_t v[16];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const uint64_t a = base + i; v[i] = a < n ? in[a] : 0u; s += v[i]; }
+    const uint64_t inc = wave_incl_scan_u64(s);
+    if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    const uint64_t block_sum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint64_t *st = state + 2;
+    if (threadIdx.x < WAVE) { // wave 0: publish, then look back 64 blocks at a time
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(st + b, (block_sum << 2) | (b == 0 ? 2ull : 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t excl = 0;
+        int64_t hi = (int64_t)b - 1; // highest block not yet accounted for
+        while (hi >= 0) {
+            const int64_t j = hi - lane;
+            uint64_t w = 0;
+            // every lane waits for its block's entry; entries only move 0 -> sum -> prefix
+            if (j >= 0) do { w = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w & 3ull) == 0);
+            const uint64_t pm = __ballot(j >= 0 && (w & 3ull) == 2ull);
+            const int stop = pm ? __ffsll((long long)pm) - 1 : WAVE; // nearest block that already holds a prefix
+            uint64_t part = (j >= 0 && lane <= stop) ? (w >> 2) : 0ull;
+            part = wave_incl_scan_u64(part);
+            excl += (uint64_t)__shfl(part, WAVE - 1, WAVE);
+            if (pm) break;
+            hi -= WAVE;
+        }
+        if (lane == 0) {
+            if (b != 0) __hip_atomic_store(st + b, ((excl + block_sum) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_prefix = excl;
+        }
+    }
+    __syncthreads();
+    uint64_t off = sh_prefix;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) off += wsum[w];
+    uint64_t run = off + inc - s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t a = base + i;
+        if (a < n) out[a] = run;
+        run += v[i];
+        if (a + 1 == n) out[n] = run;
+    }
+    if (n == 0 && b == 0 && threadIdx.x == 0) out[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(state + 1), 1ull);
+        sh_block = done + 1 == gridDim.x;
+    }
+    __syncthreads();
+    if (sh_block) // last block out: nobody reads the state any more
+        for (uint32_t i = threadIdx.x; i < gridDim.x + 2; i += 256) __hip_atomic_store(state + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // =====================================================================================================
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
@@ -1259,10 +1328,7 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
     const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    const uint32_t nbl = nb ? nb : 1;
-    hipLaunchKernelGGL(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, scratch);
-    hipLaunchKernelGGL(k_scan_partials_scan, dim3(1), dim3(256), 0, st, scratch, nbl);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)scratch, out);
+    hipLaunchKernelGGL(k_scan_chained, dim3(nb ? nb : 1), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
 }
 
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
