@@ -93,7 +93,7 @@ template <class Pred> __device__ __forceinline__ void wave_first_true_pair(int n
 }
 
 // =====================================================================================================
-// k_walk: the ss walk (gmove.cpp:831-871), one wave per read, four reads per workgroup.
+// k_walk: the ss walk (gmove.cpp:831-871), one wave (= one workgroup) per read.
 // =====================================================================================================
 
 __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
@@ -114,10 +114,9 @@ __device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int
     atomicMin(&O.err[0], (int)r);
 }
 
-__global__ __launch_bounds__(256) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+__global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
     const int lane = lane_id();
-    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (r >= B.n_reads) return; // wave-uniform
+    const uint32_t r = blockIdx.x; // one wave per workgroup: a finished read frees its slot at once
     const uint64_t o0 = B.op_off[r];
     const uint32_t nops = (uint32_t)(B.op_off[r + 1] - o0);
     const uint64_t s0 = B.seq_off[r];
@@ -1247,7 +1246,7 @@ void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_reads == 0) return;
-    hipLaunchKernelGGL(k_walk, dim3((B.n_reads + 3) / 4), dim3(256), 0, st, B, W, O);
+    hipLaunchKernelGGL(k_walk, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
 }
 
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Everything the round's profile artefacts come from, in one GPU call: the GPU test suite, the bench line, the kernel
+# trace of the same command and the HBM-traffic counters of the dominant kernel (separate --pmc passes).
+# usage (from the repo root, on the GPU box): bash tests/round_artifacts.sh <tag>   -> gpurun_out/<tag>/
+set -o pipefail
+tag=${1:-r01}
+out=gpurun_out/$tag; mkdir -p $out
+R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -20 $out/pytest_gpu.txt; exit 1; }
+tail -2 $out/pytest_gpu.txt
+python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+for pass in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$pass -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lazy-extra > /dev/null 2> $out/pmc_$pass.err || { tail -5 $out/pmc_$pass.err; exit 1; }
+done
+python3 - "$out" <<'PY'
+import csv, glob, collections, json, sqlite3, sys
+out = sys.argv[1]
+res = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{out}/pmc_{name}/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name: acc[row["Kernel_Name"].split("(")[0].strip()].append(float(row["Counter_Value"]))
+        res[name] = {k: sum(v) / len(v) for k, v in acc.items()}
+json.dump(res, open(f"{out}/pmc_fetch_write_kb.json", "w"), indent=1)
+db = sqlite3.connect(glob.glob(f"{out}/trace/**/*results.db", recursive=True)[0])
+rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+with open(f"{out}/kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows: w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 2), r[4], r[5]])
+print("k_read_stats FETCH KB", res["FETCH_SIZE"].get("k_read_stats"), "WRITE KB", res["WRITE_SIZE"].get("k_read_stats"))
+PY
+cat $out/bench.json

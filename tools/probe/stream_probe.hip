@@ -139,6 +139,57 @@ __global__ void k_fill(int16_t *s, size_t n) {
     }
 }
 
+// G: as E7 but reads of 500 vectors (8000 bytes, so every other read starts in the middle of a 128-byte line), the
+// last row partial: lanes past the end re-read the last vector and do not bin (the shape of bench.py's reads)
+__global__ __launch_bounds__(64) void k_chunk_500(const int4 *__restrict__ v, const uint64_t *__restrict__ tab, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HWORDS];
+    const int lane = threadIdx.x;
+    { uint4 *h4 = (uint4 *)hist; for (int i = lane; i < HWORDS / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0); }
+    const int4 *vp = v + tab[blockIdx.x];
+    int4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = vp[min(u * 64 + lane, 499)];
+    const uint32_t cap = 1024u + (lane & 31u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (u * 64 + lane <= 499) bin8(hist, q[u], 0x00640064u, cap | (cap << 16));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint32_t acc = hist[lane * 17];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+struct Rec { uint64_t beg, end; int32_t c_lo, span, z0, mode; double offset, scale; uint64_t pad[2]; };
+struct BigArgs { uint32_t n; uint64_t n_ops; const int16_t *sig; const uint64_t *a1; const double *a2, *a3, *a4; const int32_t *a5, *a6, *a7; const uint8_t *a8; const uint64_t *a9; const uint32_t *a10; const uint8_t *a11; const uint64_t *a12; };
+// H: G + everything of the read comes from a 64-byte record (one scalar load), kernel arguments as k_read_stats, a
+// generic pass loop, the edge test
+__global__ __launch_bounds__(64) void k_chunk_rec(BigArgs B, const Rec *__restrict__ rec, double *__restrict__ med, uint32_t *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HWORDS];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    const Rec m = rec[r];
+    if (m.mode != 0) { if (lane == 0) med[r] = 0.0; return; }
+    if (m.span > 1024) return;
+    { uint4 *h4 = (uint4 *)hist; for (int i = lane; i < HWORDS / 4; i += 64) h4[i] = make_uint4(0, 0, 0, 0); }
+    const uint32_t c16 = (uint32_t)m.c_lo & 0xffffu, c2 = c16 | (c16 << 16);
+    const uint32_t cap = 1024u + (lane & 31u), cap2 = cap | (cap << 16);
+    const uint64_t beg = m.beg, end = m.end, va = (beg + 7) >> 3, vb = end >> 3;
+    if (va < vb) {
+        const uint64_t n_vec = vb - va;
+        for (uint64_t p = 0; p < n_vec; p += 512) {
+            const int4 *__restrict__ vp = reinterpret_cast<const int4 *>(B.sig) + (va + p);
+            const uint32_t last = n_vec - p > 512 ? 511 : (uint32_t)(n_vec - p) - 1;
+            int4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = vp[min((uint32_t)(u * 64 + lane), last)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if ((uint32_t)(u * 64 + lane) <= last) bin8(hist, q[u], c2, cap2);
+        }
+        if ((va << 3) != beg || (vb << 3) != end) out[1] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint32_t acc = hist[lane * 17];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
     const size_t bytes = 400ull << 20, n = bytes / 16, n_chunks = n / 512;
     int4 *d; uint32_t *o;
@@ -180,5 +231,12 @@ int main() {
         char nm[96]; snprintf(nm, sizeof nm, "F rolling persistent + binning, %d waves", g);
         time(nm, [&] { hipLaunchKernelGGL(k_roll_bin, dim3(g), dim3(64), 0, 0, d, n_chunks, o); });
     }
+    { std::vector<uint64_t> h(n_chunks); for (size_t i = 0; i < n_chunks; ++i) h[i] = i * 500; CK(hipMemcpy(tab, h.data(), n_chunks * 8, hipMemcpyHostToDevice)); }
+    time("G 500-vector reads at an 8000-byte stride", [&] { hipLaunchKernelGGL(k_chunk_500, dim3((unsigned)n_chunks), dim3(64), 0, 0, d, tab, o); });
+    Rec *rec; CK(hipMalloc(&rec, n_chunks * sizeof(Rec))); double *medb; CK(hipMalloc(&medb, n_chunks * 8));
+    { std::vector<Rec> h(n_chunks); for (size_t i = 0; i < n_chunks; ++i) { Rec x{}; x.beg = i * 4000; x.end = x.beg + 4000; x.c_lo = 100; x.span = 800; x.z0 = 0; x.mode = 0; x.offset = 1; x.scale = 0.2; h[i] = x; }
+      CK(hipMemcpy(rec, h.data(), n_chunks * sizeof(Rec), hipMemcpyHostToDevice)); }
+    BigArgs ba{}; ba.n = (uint32_t)n_chunks; ba.sig = (const int16_t *)d;
+    time("H as G + 64-byte record, big kernarg, pass loop", [&] { hipLaunchKernelGGL(k_chunk_rec, dim3((unsigned)n_chunks), dim3(64), 0, 0, ba, rec, medb, o); });
     return 0;
 }
