@@ -440,7 +440,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_read.ensure((Nn + 32) * 4));
     HIP_TRY(c, c->meta.ensure((n + 1) * sizeof(PgReadMeta))); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
     HIP_TRY(c, c->read_needed.ensure(n + 2ull));
-    const uint32_t n_tiles = (uint32_t)((Nn + PG_SORT_TILE - 1) / PG_SORT_TILE);
+    const uint32_t n_tiles = pg_tiles(Nn, direct);
     uint32_t ndig;
     if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
     else {
@@ -448,7 +448,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         ndig = 1u << ((c->key_bits + passes - 1) / passes);
         for (int i = 0; i < 2; i++) { HIP_TRY(c, c->sk[i].ensure(Nn * 4)); HIP_TRY(c, c->sv[i].ensure(Nn * 4)); }
     }
-    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4)); HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16));
+    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4));
+    if (!direct) HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16)); // per-wave counts: only the radix sort keeps them
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
     c->slot ^= 1; // this batch's statistics buffers
@@ -539,7 +540,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     prof_begin(c, "k_slot_plan", c->st);
     pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
-                        (uint32_t)(((N ? N : 1) + PG_SORT_TILE - 1) / PG_SORT_TILE));
+                        pg_tiles(N ? N : 1, true));
     prof_end(c, c->st);
 
     // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the

@@ -110,6 +110,12 @@ struct PgKeptOut {
 // stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch
 void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags);
+// tiles of PG_SORT_TILE events; in direct mode (n_slots <= PG_DIRECT_MAX_SLOTS) the count is padded to a multiple of 4:
+// k_rank_count_direct handles 4 tiles per workgroup and writes their counts of a slot as one 16-byte store
+static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
+    const uint64_t t = (n_events + PG_SORT_TILE - 1) / PG_SORT_TILE;
+    return (uint32_t)(direct ? (t + 3) & ~3ull : t);
+}
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot

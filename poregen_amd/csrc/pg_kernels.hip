@@ -363,6 +363,30 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
 }
 
 // exclusive prefix over tiles, one wave per digit; totals[d] = number of keys with that digit
+// direct mode (slot == digit): counts per (tile, slot) only -- k_rank_emit recounts per wave for the few tiles it
+// really places events from. Four tiles per workgroup: their counts of one slot leave as ONE 16-byte store into
+// hist[slot][tile0..tile0+3] (n_tiles is a multiple of 4), a quarter of the scattered write transactions.
+__global__ __launch_bounds__(256) void k_rank_count_direct(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
+                                                           uint32_t *__restrict__ hist) {
+    __shared__ uint32_t cnt[4][PG_RANK_MAX_DIGITS];
+    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u;
+    const uint32_t ndig = 1u << nbits, mask = ndig - 1u;
+    for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const uint64_t base = (uint64_t)(tile0 + tt) * PG_SORT_TILE + tid; // counts are order-free: plain coalesced rows
+        uint32_t kv[PG_SORT_TILE / 256];
+#pragma unroll
+        for (int i = 0; i < PG_SORT_TILE / 256; ++i) { const uint64_t idx = base + (uint64_t)i * 256; kv[i] = idx < n ? keys[idx] : PG_INVALID_SLOT; }
+#pragma unroll
+        for (int i = 0; i < PG_SORT_TILE / 256; ++i) if (kv[i] != PG_INVALID_SLOT) atomicAdd(&cnt[tt][kv[i] & mask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < ndig; d += 256)
+        *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
+}
+
 __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
                                                   uint64_t *__restrict__ acc_cnt, uint32_t n_slots) {
     const uint32_t d = blockIdx.x;
@@ -455,7 +479,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 // direct mode: rank = (events of the same slot in earlier tiles / waves / rows) + in-row rank; events with
 // rank < keep[slot] are the first sample_limit ones in (read, event) order (gmove.cpp:925-927)
 __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
-                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ wcnt,
+                                                   const uint32_t *__restrict__ hist,
                                                    const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off,
                                                    const uint64_t *__restrict__ totals, PgDevBatch B, PgWalkParams W, PgWalkOut O,
                                                    PgKeptOut K) {
@@ -466,9 +490,8 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
     for (uint32_t d = tid; d < ndig; d += 256) {
-        uint32_t b = hist[(uint64_t)d * n_tiles + tile];
-        if (d < n_slots && (uint64_t)b < keep[d]) any = 1;
-        for (uint32_t ww = 0; ww < 4; ++ww) { wbase[ww][d] = b; b += wcnt[((uint64_t)tile * 4 + ww) * ndig + d]; }
+        if (d < n_slots && (uint64_t)hist[(uint64_t)d * n_tiles + tile] < keep[d]) any = 1;
+        for (uint32_t ww = 0; ww < 4; ++ww) wbase[ww][d] = 0;
     }
     if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
@@ -486,6 +509,16 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
         kp[row] = valid ? (uint32_t)keep[kv[row]] : 0u;   // <= sample_limit
         eo[row] = valid ? (uint32_t)ev_off[kv[row]] : 0u; // < number of kept events of the batch (< 2^32)
     }
+    // events of each slot in each wave of this tile (k_rank_count_direct keeps only the tile totals), then the rank of
+    // each wave's first event of a slot = tile prefix + earlier waves
+#pragma unroll
+    for (int row = 0; row < PG_SORT_ROWS; ++row) if (kv[row] != PG_INVALID_SLOT) atomicAdd(&wbase[w][kv[row] & (ndig - 1u)], 1u);
+    __syncthreads();
+    for (uint32_t d = tid; d < ndig; d += 256) {
+        uint32_t b = hist[(uint64_t)d * n_tiles + tile];
+        for (uint32_t ww = 0; ww < 4; ++ww) { const uint32_t cw = wbase[ww][d]; wbase[ww][d] = b; b += cw; }
+    }
+    __syncthreads();
     // phase 1: the ordered part -- LDS and ALU only: rank = tile prefix + earlier waves + earlier rows + in-row rank
     uint32_t dst[PG_SORT_ROWS];
 #pragma unroll
@@ -1254,15 +1287,14 @@ void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W
     hipLaunchKernelGGL(k_events, dim3((uint32_t)((B.n_ops + 256 * PG_EV_PER_THREAD - 1) / (256 * PG_EV_PER_THREAD))), dim3(256), 0, st, B, W, O);
 }
 
-static uint32_t tiles_for(uint64_t n) { return (uint32_t)((n + PG_SORT_TILE - 1) / PG_SORT_TILE); }
+static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
-    const uint32_t n_tiles = tiles_for(n);
+    const uint32_t n_tiles = pg_tiles(n, true);
     if (n_tiles) {
-        hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, (const uint32_t *)nullptr, 0u, nbits,
-                           n_tiles, S.hist, S.wcnt);
+        hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
         hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots);
     } else (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
 }
@@ -1271,10 +1303,10 @@ void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W,
                                 const PgWalkOut &O, const PgKeptOut &K) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
-    const uint32_t n_tiles = tiles_for(n);
+    const uint32_t n_tiles = pg_tiles(n, true);
     if (!n_tiles) return;
     hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
-                       (const uint32_t *)S.wcnt, keep, ev_off, totals, B, W, O, K);
+                       keep, ev_off, totals, B, W, O, K);
 }
 
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S) {
