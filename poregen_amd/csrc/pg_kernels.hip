@@ -392,12 +392,18 @@ __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, u
     const uint32_t d = blockIdx.x;
     const int lane = lane_id();
     uint32_t run = 0;
-    for (uint32_t c = 0; c < n_tiles; c += WAVE) {
-        const uint32_t i = c + lane;
-        const uint32_t v = i < n_tiles ? hist[(uint64_t)d * n_tiles + i] : 0u;
-        const uint32_t inc = wave_incl_scan_u32(v);
-        if (i < n_tiles) hist[(uint64_t)d * n_tiles + i] = run + inc - v;
-        run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+    uint32_t *__restrict__ row = hist + (uint64_t)d * n_tiles;
+    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 8 * WAVE) { // eight independent loads in flight, then the (ALU-only) scans
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const uint32_t i = c0 + u * WAVE + lane; v[u] = i < n_tiles ? row[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = c0 + u * WAVE + lane;
+            const uint32_t inc = wave_incl_scan_u32(v[u]);
+            if (i < n_tiles) row[i] = run + inc - v[u];
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        }
     }
     if (lane == 0) {
         totals[d] = run;
@@ -478,33 +484,37 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 
 // direct mode: rank = (events of the same slot in earlier tiles / waves / rows) + in-row rank; events with
 // rank < keep[slot] are the first sample_limit ones in (read, event) order (gmove.cpp:925-927)
-__global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
+// Geometry: only the few tiles in front of the last useful one do any work, so the tile is spread over 16 waves of 4
+// rows (a 1024-thread workgroup): the ordered loop, the one serial part, is 4 steps instead of 16.
+#define PG_EMIT_WAVES 16
+#define PG_EMIT_ROWS (PG_SORT_TILE / (PG_EMIT_WAVES * WAVE))
+__global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
                                                    const uint32_t *__restrict__ hist,
                                                    const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off,
                                                    const uint64_t *__restrict__ totals, PgDevBatch B, PgWalkParams W, PgWalkOut O,
                                                    PgKeptOut K) {
-    __shared__ uint32_t wbase[4][PG_RANK_MAX_DIGITS];
+    __shared__ uint32_t wbase[PG_EMIT_WAVES][PG_RANK_MAX_DIGITS];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
     if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
-    for (uint32_t d = tid; d < ndig; d += 256) {
+    for (uint32_t d = tid; d < ndig; d += PG_EMIT_WAVES * WAVE) {
         if (d < n_slots && (uint64_t)hist[(uint64_t)d * n_tiles + tile] < keep[d]) any = 1;
-        for (uint32_t ww = 0; ww < 4; ++ww) wbase[ww][d] = 0;
+        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) wbase[ww][d] = 0;
     }
     if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
-    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_SORT_ROWS * WAVE;
+    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
     // phase 0: everything the ordered loop needs from global memory, all rows in flight at once
-    uint32_t kv[PG_SORT_ROWS], kp[PG_SORT_ROWS], eo[PG_SORT_ROWS];
+    uint32_t kv[PG_EMIT_ROWS], kp[PG_EMIT_ROWS], eo[PG_EMIT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const uint64_t idx = base + (uint64_t)row * WAVE + lane;
         kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
     }
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const bool valid = kv[row] != PG_INVALID_SLOT;
         kp[row] = valid ? (uint32_t)keep[kv[row]] : 0u;   // <= sample_limit
         eo[row] = valid ? (uint32_t)ev_off[kv[row]] : 0u; // < number of kept events of the batch (< 2^32)
@@ -512,17 +522,17 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     // events of each slot in each wave of this tile (k_rank_count_direct keeps only the tile totals), then the rank of
     // each wave's first event of a slot = tile prefix + earlier waves
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) if (kv[row] != PG_INVALID_SLOT) atomicAdd(&wbase[w][kv[row] & (ndig - 1u)], 1u);
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) if (kv[row] != PG_INVALID_SLOT) atomicAdd(&wbase[w][kv[row] & (ndig - 1u)], 1u);
     __syncthreads();
-    for (uint32_t d = tid; d < ndig; d += 256) {
+    for (uint32_t d = tid; d < ndig; d += PG_EMIT_WAVES * WAVE) {
         uint32_t b = hist[(uint64_t)d * n_tiles + tile];
-        for (uint32_t ww = 0; ww < 4; ++ww) { const uint32_t cw = wbase[ww][d]; wbase[ww][d] = b; b += cw; }
+        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) { const uint32_t cw = wbase[ww][d]; wbase[ww][d] = b; b += cw; }
     }
     __syncthreads();
     // phase 1: the ordered part -- LDS and ALU only: rank = tile prefix + earlier waves + earlier rows + in-row rank
-    uint32_t dst[PG_SORT_ROWS];
+    uint32_t dst[PG_EMIT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const uint32_t key = kv[row];
         const bool valid = key != PG_INVALID_SLOT;
         const uint32_t d = key & (ndig - 1u);
@@ -537,9 +547,9 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
     }
     // phase 2: the kept events' windows (gmove.cpp:928-937). Staged across rows so that every stage is one set of
     // independent loads: owning read + window of match i+off, then the read's length, then the stores.
-    uint32_t rd[PG_SORT_ROWS], ws[PG_SORT_ROWS], wl[PG_SORT_ROWS];
+    uint32_t rd[PG_EMIT_ROWS], ws[PG_EMIT_ROWS], wl[PG_EMIT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         rd[row] = 0; ws[row] = 0; wl[row] = 0;
         if (dst[row] != 0xFFFFFFFFu) {
             const uint64_t g = base + (uint64_t)row * WAVE + lane;
@@ -548,11 +558,11 @@ __global__ __launch_bounds__(256) void k_rank_emit(const uint32_t *__restrict__ 
             wl[row] = O.m_len[g + W.sig_move_offset];
         }
     }
-    uint32_t Lr[PG_SORT_ROWS];
+    uint32_t Lr[PG_EMIT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) Lr[row] = dst[row] != 0xFFFFFFFFu ? O.meta[rd[row]].L : 0u;
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) Lr[row] = dst[row] != 0xFFFFFFFFu ? O.meta[rd[row]].L : 0u;
 #pragma unroll
-    for (int row = 0; row < PG_SORT_ROWS; ++row) {
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         if (dst[row] == 0xFFFFFFFFu) continue;
         const uint32_t start = ws[row] - W.print_margin; // validated in k_events
         const uint64_t we64 = (uint64_t)ws[row] + wl[row] + W.print_margin;
@@ -1305,7 +1315,7 @@ void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (!n_tiles) return;
-    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
+    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(PG_EMIT_WAVES * WAVE), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
                        keep, ev_off, totals, B, W, O, K);
 }
 
