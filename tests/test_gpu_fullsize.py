@@ -85,3 +85,44 @@ def test_config3_full_size_properties():
     res2 = eng.finish()
     assert np.array_equal(res2.counts, res.counts) and np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
     eng.close()
+
+
+def test_config2_large_limit_rank_shards():
+    """BASELINE configs[2] at one GPU's size: 50 000 RNA reads, k=5, nearly every accepted event kept. The 8-rank job
+    reaches sample_limit 5000 with 400 000 reads; 50 000 reads accept 2060-2240 events per k-mer, so the limit is
+    scaled to 2100: about half of the k-mers hit the cap, the others do not. One run versus four contiguous 'rank'
+    shards with the count exchange (pg_count -> bases -> pg_collect): the concatenation of the shards' streams in rank
+    order is the single run, bit for bit."""
+    b = synth.make_batch_fast(50000, kind="rna004", seed=20251003 + 2)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=2100)
+    kmers = generate_kmers(5, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 2100, b.n_reads)
+    assert int(res.counts.max()) == 2100 and int(res.counts.min()) < 2100
+    bounds = [0, 9000, 25000, 25001, 50000]
+    shards = [b.slice_reads(lo, hi) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    engs = [GmoveEngine(GmoveParams(kmers=kmers, **p)) for _ in shards]
+    cnts = [e.count(s) for e, s in zip(engs, shards)]
+    base = np.zeros_like(cnts[0])
+    parts = []
+    for e, c in zip(engs, cnts):
+        e.collect(base.copy())
+        parts.append(e.finish())
+        base += c
+        e.close()
+    assert np.array_equal(np.minimum(base, 2100), res.counts)  # freq.txt of the job = min(sum of accepted, limit)
+    assert sum(int(r.counts.sum()) for r in parts) == int(res.counts.sum())
+    for s in list(range(0, 1024, 37)) + [int(np.argmax(res.counts)), int(np.argmin(res.counts))]:
+        vals = np.concatenate([r.slot_values(s) for r in parts])
+        assert np.array_equal(vals.view(np.uint64), res.slot_values(s).view(np.uint64)), s
+    # the first shard's prefix against the oracle (slots that the oracle completes within that prefix)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b.slice_reads(0, 3000))
+    oc = o.counts()
+    for s in range(0, 1024, 53):
+        n = int(oc[s])
+        ov = o.values(s)
+        assert np.array_equal(res.slot_values(s)[:ov.size].view(np.uint64), ov.view(np.uint64)), s

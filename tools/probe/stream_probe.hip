@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 __device__ __forceinline__ uint32_t fold(const int4 &q) { return (uint32_t)(q.x ^ q.y ^ q.z ^ q.w); }
@@ -190,8 +191,9 @@ __global__ __launch_bounds__(64) void k_chunk_rec(BigArgs B, const Rec *__restri
     if (acc == 0x12345678u) out[0] = acc;
 }
 
-int main() {
-    const size_t bytes = 400ull << 20, n = bytes / 16, n_chunks = n / 512;
+int main(int argc, char **argv) {
+    const size_t mb = argc > 1 ? (size_t)atoll(argv[1]) : 400; // buffer size in MiB (256 MiB of Infinity Cache: try 1600)
+    const size_t bytes = mb << 20, n = bytes / 16, n_chunks = n / 512;
     int4 *d; uint32_t *o;
     CK(hipMalloc(&d, bytes)); CK(hipMalloc(&o, 64)); CK(hipMemset(d, 1, bytes)); hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (int16_t *)d, bytes / 2); CK(hipDeviceSynchronize());
     uint64_t *tab; CK(hipMalloc(&tab, n_chunks * 8)); { std::vector<uint64_t> h(n_chunks); for (size_t i = 0; i < n_chunks; ++i) h[i] = i * 512; CK(hipMemcpy(tab, h.data(), n_chunks * 8, hipMemcpyHostToDevice)); }
@@ -200,7 +202,7 @@ int main() {
         for (int i = 0; i < 3; ++i) launch();
         hipEventRecord(e0); for (int i = 0; i < 20; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
-        printf("%-44s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, bytes / (ms * 1e-3) / 1e12); fflush(stdout);
+        printf("%-50s %8.1f us  %6.2f TB/s\n", name, ms * 1e3, bytes / (ms * 1e-3) / 1e12); fflush(stdout);
     };
     time("A plain grid-stride, 2048 blocks x256", [&] { hipLaunchKernelGGL(k_plain, dim3(2048), dim3(256), 0, 0, d, n, o); });
     time("A plain grid-stride, 8192 blocks x256", [&] { hipLaunchKernelGGL(k_plain, dim3(8192), dim3(256), 0, 0, d, n, o); });
