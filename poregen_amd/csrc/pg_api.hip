@@ -551,7 +551,7 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
     HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); {
         const size_t before = c->scan_scratch.cap;
-        HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 4) * 8));
+        HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 84) * 8));
         if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st)); // chained-scan state
     }
 

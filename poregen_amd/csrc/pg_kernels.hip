@@ -1409,8 +1409,17 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 }
 
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
-    const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK);
-    hipLaunchKernelGGL(k_scan_chained, dim3(nb ? nb : 1), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
+    const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK), nbl = nb ? nb : 1;
+    if (nbl <= 64) { // one look-back round: a single launch wins (11 vs 17 us at 25 blocks)
+        hipLaunchKernelGGL(k_scan_chained, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
+        return;
+    }
+    // long inputs: the look-back chain (one round per 64 blocks) costs more than two extra launches (52 vs 33 us at 523
+    // blocks); the partial sums live behind the chained scan's state, which has to stay zero
+    uint64_t *partial = scratch + 72;
+    hipLaunchKernelGGL(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
+    hipLaunchKernelGGL(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out);
 }
 
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
