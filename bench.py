@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,7 +65,7 @@ def main():
             dist.init_process_group(backend)
 
     rna = args.kind == "rna004"
-    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy)
+    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=args.overlap)
     if rna:
         p.update(min_dur=20, max_dur=40)
     kmers = generate_kmers(args.k, rna=rna)
