@@ -66,7 +66,7 @@ struct pg_ctx {
     // per-batch work buffers
     DevBuf m_start, m_len, m_base, p_int, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
-    DevBuf slot_start, slot_end, acc_cnt, running, keep, ev_off, plan_totals, base_stage;
+    DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
@@ -198,7 +198,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->p_int, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
+                      &c->keep, &c->keep32, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor};
     for (DevBuf *b : bufs) b->release();
@@ -537,23 +537,25 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
         d_base = c->base_stage.as<uint64_t>();
     }
     uint64_t *totals = c->plan_totals.as<uint64_t>();
+    // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
+    // actual counts from device memory, so the batch needs no host round trip
+    const uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
+    {
+        const size_t before = c->scan_scratch.cap;
+        HIP_TRY(c, c->scan_scratch.ensure((std::max<uint64_t>(ke_cap, ns) / 4096 + 84) * 8));
+        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st)); // chained-scan state
+    }
+    if (!direct) HIP_TRY(c, c->keep32.ensure(ns * 4ull));
     prof_begin(c, "k_slot_plan", c->st);
     pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
-                        pg_tiles(N ? N : 1, true));
+                        pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>());
     prof_end(c, c->st);
 
-    // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
-    // actual counts from device memory, so the batch needs no host round trip
-    uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
     HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
-    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8)); {
-        const size_t before = c->scan_scratch.cap;
-        HIP_TRY(c, c->scan_scratch.ensure((ke_cap / 4096 + 84) * 8));
-        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st)); // chained-scan state
-    }
+    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8));
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);

@@ -135,9 +135,11 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 // keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
 // totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] = base[s] + cnt[s]
 // hist/n_tiles (direct mode, else nullptr): also computes totals[3] = last tile that can still place an event
+// keep32 (uint32[n_slots]) + scan_scratch (as pg_launch_scan_u32_u64, >= ceil(n_slots/4096)+80 entries): work space of
+// the many-slot path (n_slots > 4096, sort mode); may be null for small slot counts
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
                          uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals,
-                         const uint32_t *hist, uint32_t n_tiles);
+                         const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
 // entries ZERO before the first use (every launch leaves them zero again)
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);

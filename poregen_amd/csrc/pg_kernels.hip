@@ -630,6 +630,31 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
     if (tid == 0) { ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full; totals[3] = hist ? ~0ull : ~0ull >> 1; } // ~0 = -1: k_tile_max raises it
 }
 
+// Many slots (k = 9: 262 144): the same cut element-wise over a grid, the offsets by the generic scan, the totals by one
+// atomic per workgroup (the single-workgroup loop above needs 256 trips there: 0.6 ms).
+__global__ __launch_bounds__(256) void k_slot_keep(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
+                                                   uint32_t n_slots, uint64_t *__restrict__ keep, uint32_t *__restrict__ keep32,
+                                                   uint64_t *__restrict__ totals) {
+    __shared__ uint32_t wfull[4];
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    bool isfull = false;
+    if (s < n_slots) {
+        const uint64_t cnt = acc_cnt[s], b = base[s];
+        const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
+        const uint64_t kp = cnt < room ? cnt : room;
+        isfull = b + cnt >= limit;
+        if (running) running[s] = b + cnt;
+        keep[s] = kp; keep32[s] = (uint32_t)kp; // <= sample_limit
+    }
+    const uint32_t nfull = (uint32_t)__popcll(__ballot(isfull));
+    if (lane_id() == 0) wfull[threadIdx.x >> 6] = nfull;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&totals[1]), (unsigned long long)(wfull[0] + wfull[1] + wfull[2] + wfull[3]));
+}
+__global__ void k_slot_totals(const uint64_t *__restrict__ ev_off, uint32_t n_slots, uint64_t *__restrict__ totals) {
+    totals[0] = ev_off[n_slots]; totals[3] = ~0ull >> 1;
+}
+
 // direct mode: totals[3] = last tile that can still place an event = max over slots of the last tile whose exclusive
 // prefix in the slot's row is below keep[slot]. One thread per slot, spread over many small workgroups (the probes are
 // scattered loads: a single workgroup would serialise them on one CU).
@@ -1395,7 +1420,15 @@ void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t 
 }
 
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
-                         uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles) {
+                         uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles,
+                         uint32_t *keep32, uint64_t *scan_scratch) {
+    if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
+        (void)hipMemsetAsync(totals, 0, 32, st);
+        hipLaunchKernelGGL(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals);
+        pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch);
+        hipLaunchKernelGGL(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
+        return;
+    }
     hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles);
     if (hist && n_tiles) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
 }
