@@ -1268,42 +1268,44 @@ __global__ __launch_bounds__(64) void k_read_stats_rare(PgDevBatch B, const PgSt
 // =====================================================================================================
 // k_gather: one wave per kept event (gmove.cpp:773-775, 938-944)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const uint32_t *__restrict__ ev_len,
-                                                const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
-                                                const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
-                                                const double *__restrict__ med, const double *__restrict__ mad,
-                                                double *__restrict__ samples) {
-    // 16 lanes per kept event (windows are a few tens of samples): 16 events per workgroup and pass. The kernel is bound by
-    // the NUMBER of vector-memory instructions (PMC: TA busy, waves waiting on memory 83 % of the time), so every stage is
-    // one instruction per lane group: the event's fields are fetched by five lanes at once and the read's calibration and
-    // statistics by twelve (each lane one dword of a different array), then handed round with ds_bpermute; the window
-    // comes in as one 8-byte load per lane (its two samples, whatever the parity of the window start) and leaves as one
-    // 16-byte store. 4 vector-memory instructions per event instead of 14.
+// G lanes per kept event (16: windows of a few tens of samples; 8: short windows, k = 9 DNA): 256 / G events per
+// workgroup and pass. The kernel is bound by the NUMBER of vector-memory instructions at small windows and by FP64
+// division throughput at short ones, so every stage is one instruction per lane group: the event's fields are fetched by
+// five lanes at once and the read's calibration and statistics by six (each lane one 8-byte value of a different
+// array), then handed round with ds_bpermute; the window comes in as one 8-byte load per lane (its two samples,
+// whatever the parity of the window start) and leaves as one 16-byte store.
+template <int G>
+__device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const uint32_t *__restrict__ ev_len,
+                                              const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
+                                              const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+                                              const double *__restrict__ med, const double *__restrict__ mad, double *__restrict__ samples) {
     const int lane = lane_id();
-    const int g0 = lane & ~15;
-    const uint32_t sub = (uint32_t)lane & 15u;
-    const uint64_t n_kept = *n_kept_ptr;
-    const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
-    const uint64_t stride = (uint64_t)gridDim.x * 16;
+    const int g0 = lane & ~(G - 1);
+    const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
+    const uint64_t stride = (uint64_t)gridDim.x * (256 / G);
     const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
     auto pair64 = [&](uint32_t v, int k) { // dwords held by lanes g0+k, g0+k+1 of this group as one 64-bit value
         return (uint64_t)(uint32_t)__shfl((int)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)v, g0 + k + 1, WAVE) << 32);
     };
-    for (uint64_t e = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 4); e < n_kept; e += stride) {
+    auto from = [&](uint64_t v, int k) { // the 64-bit value held by lane g0+k
+        return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
+    };
+    for (uint64_t e = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G); e < n_kept; e += stride) {
         const uint32_t *p1 = sub == 0 ? ev_read + e : (sub == 1 ? ev_len + e : (sub == 2 ? ev_start + e
                              : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub == 3 ? 0 : 1)));
         const uint32_t f = sub < 5 ? *p1 : 0u;
         const uint32_t rd = (uint32_t)__shfl((int)f, g0, WAVE), len = (uint32_t)__shfl((int)f, g0 + 1, WAVE);
         const uint32_t st0 = (uint32_t)__shfl((int)f, g0 + 2, WAVE);
         const uint64_t dst = pair64(f, 3);
-        const void *arr = sub < 2 ? (const void *)(B.sig_off + rd) : (sub < 4 ? (const void *)(B.off + rd) : (sub < 6 ? (const void *)(B.range + rd)
-                          : (sub < 8 ? (const void *)(B.dig + rd) : (sub < 10 ? (const void *)(med + rd) : (const void *)(mad + rd)))));
-        const uint32_t h = sub < (scaling ? 12u : 8u) ? reinterpret_cast<const uint32_t *>(arr)[sub & 1u] : 0u;
-        const uint64_t src = pair64(h, 0) + st0;
-        const double offset = __longlong_as_double((long long)pair64(h, 2));
-        const double scale = __longlong_as_double((long long)pair64(h, 4)) / __longlong_as_double((long long)pair64(h, 6));
-        const double md = scaling ? __longlong_as_double((long long)pair64(h, 8)) : 0.0;
-        const double ma = scaling ? __longlong_as_double((long long)pair64(h, 10)) : 1.0;
+        const uint64_t *arr = sub == 0 ? B.sig_off + rd : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.off + rd)
+                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.range + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(B.dig + rd)
+                              : (sub == 4 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd)))));
+        const uint64_t h = sub < (scaling ? 6u : 4u) ? *arr : 0ull;
+        const uint64_t src = from(h, 0) + st0;
+        const double offset = __longlong_as_double((long long)from(h, 1));
+        const double scale = __longlong_as_double((long long)from(h, 2)) / __longlong_as_double((long long)from(h, 3));
+        const double md = scaling ? __longlong_as_double((long long)from(h, 4)) : 0.0;
+        const double ma = scaling ? __longlong_as_double((long long)from(h, 5)) : 1.0;
         auto conv = [&](int raw) {
             const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
             double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
@@ -1312,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
         };
         const uint32_t odd = (uint32_t)(src & 1u);
         const uint64_t d0 = src >> 1; // dword that holds sample src
-        for (uint32_t t = 2 * sub; t < len; t += 32) { // this lane's two samples t, t+1 = halves of dwords d, d+1
+        for (uint32_t t = 2 * sub; t < len; t += 2 * G) { // this lane's two samples t, t+1 = halves of dwords d, d+1
             const uint64_t d = d0 + (t >> 1);
             int s0, s1;
             if (2 * d + 3 < total) {
@@ -1330,6 +1332,19 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
             } else samples[dst + t] = x0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const uint32_t *__restrict__ ev_len,
+                                                const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
+                                                const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+                                                const double *__restrict__ med, const double *__restrict__ mad,
+                                                double *__restrict__ samples) {
+    const uint64_t n_kept = *n_kept_ptr;
+    if (n_kept == 0) return;
+    const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
+    // mean kept window (from the scan's total): up to 16 samples are one pass of 8 lanes
+    if (samp_off[n_kept] <= 16 * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_start, samp_off, scaling, pa_min, pa_max, med, mad, samples);
+    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_start, samp_off, scaling, pa_min, pa_max, med, mad, samples);
 }
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, uint8_t *__restrict__ read_needed,
