@@ -165,6 +165,8 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
         uint32_t jj[U], tix[U], st32[U]; uint64_t ik[U]; bool ism[U], isid[U], okm[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            jj[u] = 0; tix[u] = 0; st32[u] = 0; ik[u] = 0; ism[u] = isid[u] = okm[u] = false;
+            if (c + u * WAVE >= nops) continue; // wave-uniform: a chunk behind the read's last op costs nothing
             const uint32_t i = c + u * WAVE + lane;
             const bool act = i < nops;
             const uint32_t n = nn[u], t = tt[u];
