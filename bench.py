@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
     args = ap.parse_args()
 
@@ -57,12 +58,17 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_step = world > 1 or args.force_dist
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif args.force_dist:
+        import tempfile
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="pg_rdv_"), rank=0, world_size=1, device_id=dev)
 
     rna = args.kind == "rna004"
     p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=args.overlap)
@@ -79,7 +85,8 @@ def main():
 
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
     counts_buf = torch.empty(len(kmers), dtype=torch.int64, device=dev)
-    stream_ordered = world > 1 and backend == "nccl"
+    gather_buf = torch.empty(world * len(kmers), dtype=torch.int64, device=dev)  # receive buffer of the per-step all_gather
+    stream_ordered = dist_step and backend == "nccl"
     if stream_ordered:  # count -> RCCL all_gather -> collect ordered on one stream, no host sync inside a step
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
@@ -87,8 +94,8 @@ def main():
 
     def step():
         eng.reset()
-        if world > 1:
-            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered)
+        if dist_step:
+            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered, gather_buf=gather_buf)
             pgdist.merged_freq(total, args.sample_limit)
         else:
             eng.submit(shard)
@@ -176,7 +183,7 @@ def main():
                         f"k={args.k}, scaling med-MAD, sample_limit={args.sample_limit}" + (", min/max_dur 20/40, --rna" if rna else ""),
             "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
             "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
-            "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if world > 1 else None,
+            "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if dist_step else None,
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples,
         },
         "roofline": roofline,
@@ -190,7 +197,7 @@ def main():
     eng.close()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist_step:
         dist.destroy_process_group()
 
 

@@ -182,6 +182,11 @@ pg_status pg_count(pg_ctx *ctx, const pg_batch *batch, uint64_t *counts_out, int
  * reference order (earlier batches, lower ranks of a multi-GPU job); NULL = the context's own running
  * count. The batch pointers given to pg_count must still be valid. */
 pg_status pg_collect(pg_ctx *ctx, const uint64_t *base, int32_t base_location);
+/* Phase 2 of a multi-GPU job, straight from the all-gather: all_counts = uint64[world][n_slots] in DEVICE memory, row g =
+ * pg_count's output of rank g (the receive buffer of the all_gather). base = sum of the rows below `rank`, computed on
+ * the device on the context's stream: the step needs no host arithmetic and no extra kernels of the caller.
+ * Replaces nothing in the reference (which is single-process); the order semantics are those of pg_collect. */
+pg_status pg_collect_gathered(pg_ctx *ctx, const uint64_t *all_counts, uint32_t world, uint32_t rank);
 
 pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work of the context */
 /* Run the context's main chain on a caller-owned HIP stream (hipStream_t passed as void*), e.g. PyTorch's current

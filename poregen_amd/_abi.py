@@ -25,7 +25,7 @@ PG_FLAG_SKIP_OUT_OF_RANGE = 32
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
-    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_sync", "pg_finish", "pg_all_slots_full",
+    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_collect_gathered", "pg_sync", "pg_finish", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream",
 ]
 
@@ -118,6 +118,7 @@ def load():
     lib.pg_submit.argtypes = [vp, C.POINTER(PgBatch)]; lib.pg_submit.restype = i32
     lib.pg_count.argtypes = [vp, C.POINTER(PgBatch), u64p, i32]; lib.pg_count.restype = i32
     lib.pg_collect.argtypes = [vp, u64p, i32]; lib.pg_collect.restype = i32
+    lib.pg_collect_gathered.argtypes = [vp, u64p, C.c_uint32, C.c_uint32]; lib.pg_collect_gathered.restype = i32
     lib.pg_sync.argtypes = [vp]; lib.pg_sync.restype = i32
     lib.pg_set_stream.argtypes = [vp, vp]; lib.pg_set_stream.restype = i32
     lib.pg_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_finish.restype = i32

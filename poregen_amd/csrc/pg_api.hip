@@ -523,7 +523,17 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     return PG_OK;
 }
 
-pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
+static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t rank);
+
+pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0); }
+
+pg_status pg_collect_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!all_counts || world == 0 || rank >= world) return fail(c, PG_ERR_INVALID_ARG, "pg_collect_gathered: all_counts / world / rank");
+    return collect_impl(c, nullptr, PG_LOC_DEVICE, all_counts, rank);
+}
+
+static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t rank) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -531,7 +541,10 @@ pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) {
     const uint64_t N = c->B.n_ops;
     const bool direct = ns <= PG_DIRECT_MAX_SLOTS;
     const uint64_t *d_base = c->running.as<uint64_t>();
-    if (base) {
+    if (all_counts) {
+        pg_launch_rank_base(c->st, all_counts, rank, ns, c->base_stage.as<uint64_t>());
+        d_base = c->base_stage.as<uint64_t>();
+    } else if (base) {
         HIP_TRY(c, hipMemcpyAsync(c->base_stage.p, base, ns * 8ull,
                                   base_location == PG_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
         d_base = c->base_stage.as<uint64_t>();

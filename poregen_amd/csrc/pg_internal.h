@@ -116,6 +116,8 @@ static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
     const uint64_t t = (n_events + PG_SORT_TILE - 1) / PG_SORT_TILE;
     return (uint32_t)(direct ? (t + 3) & ~3ull : t);
 }
+// base[s] = sum over g < rank of all_counts[g * n_slots + s]
+void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t rank, uint32_t n_slots, uint64_t *base);
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot

@@ -40,11 +40,14 @@ def merged_freq(total_counts, sample_limit: int):
     return torch.clamp(total_counts, max=sample_limit)
 
 
-def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=False):
+def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=False, gather_buf=None):
     """count -> exchange -> collect for one shard. Device-resident shards exchange on the GPU (RCCL); host
     shards exchange CPU tensors (gloo). Returns the job-wide accepted counts.
     stream_ordered: the engine runs on torch's current stream (GmoveEngine.use_torch_stream), so the
-    collective is ordered by the stream and no host synchronisation is needed."""
+    collective is ordered by the stream and no host synchronisation is needed.
+    gather_buf: optional preallocated int64 tensor [world * n_slots] on the shard's device (receive buffer of the
+    all_gather). With RCCL the buffer goes straight into pg_collect_gathered, which sums the lower ranks' rows on the
+    device: a step is count, ONE collective, collect, and one torch reduction for the job-wide counts."""
     import torch
     import torch.distributed as dist
     if shard.on_device:
@@ -57,11 +60,17 @@ def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=Fals
         if gloo:  # rehearsal without RCCL: exchange through the host
             base, total = exchange_bases(counts_buf.cpu(), group)
             base = base.to(counts_buf.device)
-        else:
-            base, total = exchange_bases(counts_buf, group)
-        if gloo or not stream_ordered:
             torch.cuda.current_stream().synchronize()
-        engine.collect(base.contiguous())
+            engine.collect(base.contiguous())
+        else:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            if gather_buf is None:
+                gather_buf = torch.empty(world * counts_buf.numel(), dtype=counts_buf.dtype, device=counts_buf.device)
+            dist.all_gather_into_tensor(gather_buf, counts_buf.view(-1), group=group)
+            if not stream_ordered:
+                torch.cuda.current_stream().synchronize()
+            engine.collect_gathered(gather_buf, world, rank)
+            total = gather_buf.view(world, -1).sum(dim=0)
     else:
         c = engine.count(shard)
         t = torch.from_numpy(c.view(np.int64).copy())

@@ -250,6 +250,13 @@ class GmoveEngine:
         else:
             self._check(self._lib.pg_collect(self._h, base.data_ptr(), _abi.PG_LOC_DEVICE))
 
+    def collect_gathered(self, all_counts, world: int, rank: int):
+        """Phase 2 of a multi-GPU job: all_counts = the all_gather's receive buffer (torch int64 CUDA tensor,
+        world x n_slots, row g = rank g's count()); the library sums the rows below `rank` on its own stream."""
+        if all_counts.numel() != world * self.n_slots or not all_counts.is_contiguous():
+            raise ValueError("all_counts must be a contiguous world x n_slots tensor")
+        self._check(self._lib.pg_collect_gathered(self._h, all_counts.data_ptr(), world, rank))
+
     def sync(self):
         self._check(self._lib.pg_sync(self._h))
 

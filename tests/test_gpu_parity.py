@@ -164,6 +164,64 @@ def test_stream_ordered_count_collect_on_torch_stream():
         assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
 
 
+def test_collect_gathered_three_ranks_on_one_gpu():
+    """pg_collect_gathered: the all_gather's receive buffer (world x n_slots) goes in as it is and the library sums the
+    rows below its rank on the device. Three 'ranks' (engines) on one GPU reproduce the single run / the oracle."""
+    import torch
+    b = synth.make_batch(450, kind="rna004", seed=23)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=25)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    dev = torch.device("cuda:0")
+    bounds = [0, 140, 141, 450]
+    shards = [b.slice_reads(lo, hi).to_device(dev) for lo, hi in zip(bounds[:-1], bounds[1:])]
+    engs = [GmoveEngine(GmoveParams(kmers=kmers, **p)) for _ in shards]
+    allc = torch.empty(len(shards) * len(kmers), dtype=torch.int64, device=dev)
+    for g, (e, sh) in enumerate(zip(engs, shards)):
+        e.count(sh, out=allc[g * len(kmers):(g + 1) * len(kmers)])
+    for e in engs:
+        e.sync()
+    results = []
+    for g, e in enumerate(engs):
+        e.collect_gathered(allc, len(shards), g)
+        results.append(e.finish())
+        e.close()
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in results])
+        assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
+    with pytest.raises(Exception):
+        GmoveEngine(GmoveParams(kmers=kmers, **p)).collect_gathered(allc, 3, 3)
+
+
+def test_sharded_step_over_rccl_single_rank(tmp_path):
+    """dist.sharded_step on the RCCL ("nccl") backend, stream-ordered as bench.py runs it at N > 1: count ->
+    all_gather_into_tensor -> pg_collect_gathered on one torch stream. A one-rank group is all a one-GPU box allows; it
+    still runs the collective, the receive-buffer hand-over and the stream ordering."""
+    import torch
+    import torch.distributed as dist
+    from poregen_amd import dist as pgdist
+    b = synth.make_batch(300, kind="rna004", seed=29)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=15)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1, device_id=dev)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+            eng.use_torch_stream(side)
+            total = pgdist.sharded_step(eng, b.to_device(dev), stream_ordered=True)
+            res = eng.finish()
+            eng.close()
+        assert np.array_equal(np.minimum(total.cpu().numpy().astype(np.uint64), 15), o.counts())
+        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=15)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("pa", [(40.0, 180.0), (100.0, 180.0), (-50.0, 95.0)])
 def test_mad_fallback_search_path(pa):
     """debug_narrow shrinks the exact MAD candidate window to one code, so the full 64-lane search runs for
