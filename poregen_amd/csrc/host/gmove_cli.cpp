@@ -10,6 +10,9 @@
 #include <getopt.h>
 #include <string>
 #include <thread>
+#include <chrono>
+#include <atomic>
+#include <functional>
 #include <vector>
 
 #define POREGEN_VERSION "0.1.0"
@@ -227,8 +230,13 @@ int gmove_main(int argc, char **argv) {
     int status = EXIT_SUCCESS;
     uint64_t count_reads = 0, total_samples = 0;
     bool stop = false;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    double t_device = 0, t_finish = 0, t_dump = 0;
+    const clk::time_point t_loop0 = clk::now();
     auto flush = [&]() -> bool {
         if (hb.n() == 0) return true;
+        const clk::time_point tf0 = clk::now();
         pg_batch b; memset(&b, 0, sizeof b);
         b.struct_size = sizeof b; b.location = PG_LOC_HOST; b.n_reads = hb.n();
         b.sig = hb.sig.data(); b.sig_off = hb.sig_off.data(); b.digitisation = hb.dig.data(); b.offset = hb.off.data(); b.range = hb.range.data();
@@ -238,6 +246,7 @@ int gmove_main(int argc, char **argv) {
         if (s == PG_OK) s = pg_sync(ctx);
         if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); return false; }
         hb.clear();
+        t_device += secs(tf0, clk::now());
         if (pg_all_slots_full(ctx)) stop = true; // every file is closed: nothing later can be written (gmove.cpp:733-735)
         return true;
     };
@@ -280,6 +289,92 @@ int gmove_main(int argc, char **argv) {
         hb.qs.push_back((int32_t)qstart); hb.ts.push_back(0); hb.te.push_back((int32_t)seq.size());
         return true;
     };
+    // ---- PAF front-end: a batch of lines is read, then every thread of a pool parses / decodes a contiguous run of them
+    // into its own (reused) buffers -- BLOW5 inflate + svb-zd, ss tokenising and sequence fetch are independent per
+    // read -- and the runs are concatenated into the SoA batch. The first failing line in file order decides the
+    // outcome, as in the reference's one-line-at-a-time loop.
+    if (is_paf) {
+        unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16; if (nt < 1) nt = 1;
+        struct Run { HostBatch b; std::string line_buf, seq, e2, msg; pgh::Slow5Rec rec; size_t lo = 0, hi = 0, n_ok = 0; bool bad = false; };
+        std::vector<Run> runs(nt);
+        std::vector<std::string> lines;
+        auto on_threads = [&](const std::function<void(unsigned)> &fn) {
+            if (nt == 1) { fn(0); return; }
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; t++) pool.emplace_back(fn, t);
+            for (auto &th : pool) th.join();
+        };
+        bool eof = false;
+        while (!stop && !eof && status == EXIT_SUCCESS) {
+            size_t n_lines = 0;
+            while (n_lines < batch_reads) {
+                if ((got = getline(&line, &cap, paf_fp)) == -1) { eof = true; break; }
+                if (n_lines == lines.size()) lines.emplace_back();
+                lines[n_lines++].assign(line, (size_t)got);
+            }
+            if (n_lines == 0) break;
+            on_threads([&](unsigned t) {
+                Run &r = runs[t];
+                r.b.clear(); r.bad = false; r.msg.clear();
+                r.lo = n_lines * t / nt; r.hi = n_lines * (t + 1) / nt; r.n_ok = 0;
+                for (size_t i = r.lo; i < r.hi; i++) {
+                    pgh::PafRec paf;
+                    const int pr = pgh::parse_paf_line(&lines[i][0], lines[i].size(), paf);
+                    if (pr == 1) { r.bad = true; r.msg = "malformed PAF record (fewer than 12 columns)"; return; }
+                    if (pr == 2) { r.bad = true; r.msg = "ss:Z: tag not found in paf record for " + paf.rid; return; }    // gmove.cpp:1046-1049
+                    if (!s5.get(paf.rid, r.rec, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read"; return; } // gmove.cpp:745-749
+                    if (!pgh::tokenize_ss(paf.ss, paf.ss_len, r.b.op_n, r.b.op_t, r.e2)) { r.bad = true; r.msg = r.e2; return; }
+                    // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
+                    const int64_t a = paf.target_start, b2 = paf.target_end;
+                    const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
+                    fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), r.seq); // absent name: empty sequence -> the read is skipped on the device
+                    r.b.sig.insert(r.b.sig.end(), r.rec.raw.begin(), r.rec.raw.end());
+                    r.b.sig_off.push_back(r.b.sig.size());
+                    r.b.seq.insert(r.b.seq.end(), r.seq.begin(), r.seq.end()); r.b.seq_off.push_back(r.b.seq.size());
+                    r.b.op_off.push_back(r.b.op_n.size());
+                    r.b.dig.push_back(r.rec.digitisation); r.b.off.push_back(r.rec.offset); r.b.range.push_back(r.rec.range);
+                    r.b.qs.push_back(paf.query_start); r.b.ts.push_back(paf.target_start); r.b.te.push_back(paf.target_end);
+                    r.n_ok++;
+                }
+            });
+            // runs in file order up to the first failing line; one device batch unless that would exceed 2^29 samples
+            unsigned last_run = nt; // first run that stopped early
+            for (unsigned t = 0; t < nt; t++) if (runs[t].bad) { last_run = t; break; }
+            const unsigned n_runs = last_run < nt ? last_run + 1 : nt;
+            uint64_t tot = 0;
+            for (unsigned t = 0; t < n_runs; t++) tot += runs[t].b.sig_off.back();
+            unsigned t0 = 0;
+            while (t0 < n_runs && !stop && status == EXIT_SUCCESS) {
+                const unsigned t1 = tot > ((uint64_t)1 << 29) ? t0 + 1 : n_runs; // too big for one batch: run by run
+                uint64_t ns = 0, nq = 0, no = 0, nb = 0;
+                for (unsigned t = t0; t < t1; t++) { ns += runs[t].b.sig_off.back(); nq += runs[t].b.seq_off.back(); no += runs[t].b.op_off.back(); nb += runs[t].b.n(); }
+                hb.sig.resize(ns); hb.seq.resize(nq); hb.op_n.resize(no); hb.op_t.resize(no);
+                hb.sig_off.resize(nb + 1); hb.seq_off.resize(nb + 1); hb.op_off.resize(nb + 1);
+                hb.dig.resize(nb); hb.off.resize(nb); hb.range.resize(nb); hb.qs.resize(nb); hb.ts.resize(nb); hb.te.resize(nb);
+                std::vector<uint64_t> bs(nt + 1, 0), bq(nt + 1, 0), bo(nt + 1, 0), bn(nt + 1, 0);
+                for (unsigned t = t0; t < t1; t++) { bs[t + 1] = bs[t] + runs[t].b.sig_off.back(); bq[t + 1] = bq[t] + runs[t].b.seq_off.back(); bo[t + 1] = bo[t] + runs[t].b.op_off.back(); bn[t + 1] = bn[t] + runs[t].b.n(); }
+                on_threads([&](unsigned t) {
+                    if (t < t0 || t >= t1) return;
+                    const HostBatch &b = runs[t].b;
+                    const size_t n = b.n();
+                    if (b.sig_off.back()) memcpy(hb.sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t));
+                    if (b.seq_off.back()) memcpy(hb.seq.data() + bq[t], b.seq.data(), b.seq_off.back());
+                    if (b.op_off.back()) { memcpy(hb.op_n.data() + bo[t], b.op_n.data(), b.op_off.back() * sizeof(uint32_t)); memcpy(hb.op_t.data() + bo[t], b.op_t.data(), b.op_off.back()); } // a failed line may have left ops behind op_off.back()
+                    for (size_t k = 0; k < n; k++) {
+                        const size_t g = bn[t] + k;
+                        hb.sig_off[g] = bs[t] + b.sig_off[k]; hb.seq_off[g] = bq[t] + b.seq_off[k]; hb.op_off[g] = bo[t] + b.op_off[k];
+                        hb.dig[g] = b.dig[k]; hb.off[g] = b.off[k]; hb.range[g] = b.range[k]; hb.qs[g] = b.qs[k]; hb.ts[g] = b.ts[k]; hb.te[g] = b.te[k];
+                    }
+                });
+                hb.sig_off[nb] = ns; hb.seq_off[nb] = nq; hb.op_off[nb] = no;
+                total_samples += ns;
+                for (uint64_t k = 0; k < nb; k++) if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
+                if (nb && !flush()) { status = EXIT_FAILURE; break; }
+                t0 = t1;
+            }
+            if (status == EXIT_SUCCESS && !stop && last_run < nt) { fprintf(stderr, "%s\n", runs[last_run].msg.c_str()); status = EXIT_FAILURE; }
+        }
+    } else
     for (;;) {
         if (stop) break;
         pgh::MoveRec mrec;
@@ -331,14 +426,22 @@ int gmove_main(int argc, char **argv) {
     if (status == EXIT_SUCCESS && !flush()) status = EXIT_FAILURE;
     free(line); fclose(paf_fp);
 
+    const double t_loop = secs(t_loop0, clk::now());
     if (status == EXIT_SUCCESS) {
         pg_result res;
-        if (pg_finish(ctx, &res) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+        const clk::time_point tq0 = clk::now();
+        const pg_status fin = pg_finish(ctx, &res);
+        t_finish = secs(tq0, clk::now());
+        if (fin != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
         else {
             pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
+            const clk::time_point td0 = clk::now();
             if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
-            fprintf(stderr, "\n[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
+            t_dump = secs(td0, clk::now());
+            fprintf(stderr, "\n[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
+                    t_loop - t_device, t_device, t_finish, t_dump);
+            fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
                     (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, device);
         }
     }
