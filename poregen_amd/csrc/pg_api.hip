@@ -83,6 +83,7 @@ struct pg_ctx {
     uint64_t full_slots = 0;
 
     std::vector<HostBatchResult> batches;
+    bool single_moved = false; // batches[0]'s arrays currently live in r_* (pg_finish of a one-batch job)
     // merged view
     std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
     std::vector<uint32_t> r_ev_len, r_ev_read;
@@ -271,7 +272,7 @@ pg_status pg_reset(pg_ctx *c) {
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
     c->zero_running = true;
-    c->batches.clear();
+    c->batches.clear(); c->single_moved = false;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
@@ -686,9 +687,28 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     pg_status s = download_last(c);
     if (s != PG_OK) return s;
     const uint32_t ns = c->prm.n_slots;
+    if (c->single_moved && !c->batches.empty()) { // give the first batch its arrays back (see the one-batch path below)
+        HostBatchResult &h = c->batches[0];
+        c->r_ev_off.swap(h.ev_off); c->r_samp_off.swap(h.samp_off); c->r_ev_len.swap(h.ev_len); c->r_ev_read.swap(h.ev_read);
+        c->r_samples.swap(h.samples); c->r_skipped.swap(h.skipped);
+    }
+    c->single_moved = false;
     // merge the batches slot-major, batch-minor: reference order is PAF-line order inside every k-mer file
     uint64_t n_events = 0, n_samples = 0, n_reads = 0;
     for (auto &h : c->batches) { n_events += h.n_events; n_samples += h.n_samples; n_reads += h.n_reads; }
+    if (c->batches.size() == 1) { // one batch: its arrays ARE the result (no per-event copy of up to GBs of samples)
+        HostBatchResult &h = c->batches[0];
+        c->r_counts.resize(ns);
+        for (uint32_t sl = 0; sl < ns; sl++) c->r_counts[sl] = h.ev_off[sl + 1] - h.ev_off[sl];
+        c->r_ev_off.swap(h.ev_off); c->r_samp_off.swap(h.samp_off); c->r_ev_len.swap(h.ev_len); c->r_ev_read.swap(h.ev_read);
+        c->r_samples.swap(h.samples); c->r_skipped.swap(h.skipped);
+        c->single_moved = true; // undone at the top of the next pg_finish (more batches may follow) and by pg_reset
+        out->n_slots = ns; out->reserved = 0; out->n_events = n_events; out->n_samples = n_samples; out->n_reads = n_reads;
+        out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
+        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+        out->read_skipped = c->r_skipped.data();
+        return PG_OK;
+    }
     c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.assign(n_events + 1, 0);
     c->r_ev_len.resize(n_events); c->r_ev_read.resize(n_events); c->r_samples.resize(n_samples);
     c->r_skipped.resize(n_reads);
