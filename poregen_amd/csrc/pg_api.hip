@@ -64,7 +64,7 @@ struct pg_ctx {
     // staged copy of a host batch
     DevBuf s_sig, s_sig_off, s_dig, s_off, s_range, s_qs, s_ts, s_te, s_seq, s_seq_off, s_op_n, s_op_t, s_op_off;
     // per-batch work buffers
-    DevBuf m_start, m_len, m_base, p_int, ev_slot, status, errflag;
+    DevBuf m_start, m_len, m_base, m_tix, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
@@ -197,7 +197,7 @@ void pg_destroy(pg_ctx *c) {
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     DevBuf *bufs[] = {&c->table_t, &c->table_u, &c->s_sig, &c->s_sig_off, &c->s_dig, &c->s_off, &c->s_range, &c->s_qs, &c->s_ts,
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
-                      &c->p_int, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
+                      &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
@@ -388,7 +388,7 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.short_ok = (c->prm.flags & PG_FLAG_SHORT_READS_OK) ? 1 : 0;
     W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
-    O.p_int = c->p_int.as<int32_t>(); O.ev_slot = c->ev_slot.as<uint32_t>();
+    O.m_tix = c->m_tix.as<uint32_t>() + PG_TIX_FRONT(c->prm.kmer_pick_margin); O.ev_slot = c->ev_slot.as<uint32_t>();
     O.m_read = c->m_read.as<uint32_t>(); O.meta = c->meta.as<PgReadMeta>();
     O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
     O.oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) ? c->oor.as<uint8_t>() : nullptr;
@@ -438,7 +438,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     const bool direct = c->prm.n_slots <= PG_DIRECT_MAX_SLOTS;
     // +32 entries: k_events reads/writes these per-op arrays with 16-byte vectors that may overrun n_ops
     HIP_TRY(c, c->m_start.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_len.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_base.ensure(Nn + 32));
-    HIP_TRY(c, c->p_int.ensure(Nn * 4)); HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_read.ensure((Nn + 32) * 4));
+    HIP_TRY(c, c->m_tix.ensure((Nn + 64 + c->prm.kmer_size + 2 * PG_TIX_FRONT(c->prm.kmer_pick_margin)) * 4));
+    HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_read.ensure((Nn + 32) * 4));
     HIP_TRY(c, c->meta.ensure((n + 1) * sizeof(PgReadMeta))); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
     HIP_TRY(c, c->read_needed.ensure(n + 2ull));
     const uint32_t n_tiles = pg_tiles(Nn, direct);

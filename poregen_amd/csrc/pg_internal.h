@@ -54,7 +54,9 @@ struct PgWalkOut {
     uint32_t *m_start; // [n_ops] window start of match j of read r at op_off[r]+j  (end_raw_idx in the reference)
     uint32_t *m_len;   // [n_ops] window length
     uint8_t *m_base;   // [n_ops] 2-bit base code of the matched base, 4 = not ACGT/U
-    int32_t *p_int;    // [n_ops] matched-base count at each I/D op (interior of indel_pos, gmove.cpp:843,845)
+    uint32_t *m_tix;   // [-front .. n_ops + pad) I/D ops in front of match j of read r at op_off[r]+j = #{indel_pos entries <= j}
+                       // (the interior of indel_pos, gmove.cpp:843,845, is never materialised); readable from index
+                       // -kmer_pick_margin: the pointer sits PG_TIX_FRONT entries into its buffer
     uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
     uint32_t *m_read;  // [n_ops] read that owns op index g
     PgReadMeta *meta;  // [n_reads]
@@ -64,6 +66,7 @@ struct PgWalkOut {
 };
 
 #define PG_INVALID_SLOT 0xFFFFFFFFu
+#define PG_TIX_FRONT(margin) (((uint64_t)((margin) > 0 ? (margin) : 0) + 3) & ~3ull)
 
 // ---- radix sort geometry ---------------------------------------------------------------------------
 #define PG_SORT_ROWS 16                       // rows of 64 keys per wave

@@ -206,8 +206,9 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
                 O.m_start[o0 + jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
                 O.m_len[o0 + jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
                 O.m_base[o0 + jj[u]] = bc[u];
+                O.m_tix[o0 + jj[u]] = tix[u];    // I/D ops in front of this match (the indel positions themselves, i_k -
+                                                 // num_deletion at every I/D op, are only needed as these counts)
             }
-            if (isid[u]) O.p_int[o0 + tix[u]] = (int32_t)jj[u]; // i_k - num_deletion == matched bases so far
         }
     }
     const uint64_t bm = __ballot(err != 0);
@@ -251,6 +252,13 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
 #pragma unroll
         for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; start[j] = O.m_start[ge > last ? last : ge]; }
     }
+    // ... and, for pick_this_kmer, the number of I/D ops in front of match i-M and in front of match i+k+M-1 of the event's
+    // read (both orientations need exactly these two)
+    static_assert(E == 4, "one 16-byte load per bound");
+    const uint32_t kM = k + (uint32_t)W.pick_margin;
+    const uint4 txl = *reinterpret_cast<const uint4 *>(O.m_tix + ((int64_t)g0 - (int64_t)W.pick_margin)); // 4-byte aligned; padded front
+    const uint4 txh = *reinterpret_cast<const uint4 *>(O.m_tix + (g0 + kM - 1));                            // padded back
+    const uint32_t tx_lo[E] = {txl.x, txl.y, txl.z, txl.w}, tx_hi[E] = {txh.x, txh.y, txh.z, txh.w};
     // round trip 2: the reads' summaries (one load when the four events belong to one read)
     PgReadMeta mt[E];
     mt[0] = O.meta[r[0]];
@@ -288,14 +296,15 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
             const int32_t M = W.pick_margin;
             const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
             const int32_t X = left + (int32_t)k + M, Y = left - M;
-            const uint64_t o0 = mt[j].o0;
-            auto interior = [&](uint32_t u) -> int32_t { // sorted ascending in both orientations (gmove.cpp:877-882)
-                return rna ? (int32_t)n - O.p_int[o0 + (m - 1 - u)] : O.p_int[o0 + u];
-            };
-            uint32_t lo = 0, hi = m; // first u with interior(u) >= X
-            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (interior(mid) >= X) hi = mid; else lo = mid + 1; }
-            const int32_t prev = lo == 0 ? -mt[j].st_k : interior(lo - 1);
-            const bool pick = (lo < m) ? (prev <= Y) : (X <= mt[j].end_k + M && prev <= Y);
+            // indel_pos is never built: with cp(Z) = #{interior entries p < Z} = I/D ops in front of match Z-1 (0 for Z <= 0,
+            // all m for Z > n), the entries strictly between the event's bounds number cp(i+k+M) - cp(i-M+1) in BOTH
+            // orientations (the RNA list is the mirrored one), and the search result `lo` of the reference's loop is
+            // cp(i+k+M) on DNA-oriented records and m - cp(i-M+1) on RNA-oriented ones.
+            auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
+            const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
+            const uint32_t lo = rna ? m - cA : cB;       // first interior entry >= X
+            const bool prev_ok = lo == 0 ? (-mt[j].st_k <= Y) : (cA == cB); // the entry in front of it is <= Y
+            const bool pick = prev_ok && (lo < m || X <= mt[j].end_k + M);
             if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) { // gmove.cpp:916-924
                 // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
                 const uint64_t L = mt[j].L;
