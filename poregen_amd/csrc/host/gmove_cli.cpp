@@ -389,21 +389,7 @@ int gmove_main(int argc, char **argv) {
             is_one.swap(mrec.is_one);
             if (!add_move_record(mrec.qname.c_str(), (int)mrec.seq.size(), mrec.seq, mrec.stride, mrec.ns, (long long)mrec.ts)) break;
         } else if ((got = getline(&line, &cap, paf_fp)) == -1) break;
-        else if (is_paf) {
-            pgh::PafRec paf;
-            int pr = pgh::parse_paf_line(line, (size_t)got, paf);
-            if (pr == 1) { fprintf(stderr, "malformed PAF record (fewer than 12 columns)\n"); status = EXIT_FAILURE; break; }
-            if (pr == 2) { fprintf(stderr, "ss:Z: tag not found in paf record for %s\n", paf.rid.c_str()); status = EXIT_FAILURE; break; } // gmove.cpp:1046-1049
-            if (!s5.get(paf.rid, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; break; }              // gmove.cpp:745-749
-            if (!pgh::tokenize_ss(paf.ss, paf.ss_len, hb.op_n, hb.op_t, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; break; }
-            // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
-            const int64_t a = paf.target_start, b2 = paf.target_end;
-            const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
-            fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), seq); // absent name: empty sequence -> the read is skipped on the device
-            hb.sig.insert(hb.sig.end(), rec.raw.begin(), rec.raw.end());
-            hb.qs.push_back(paf.query_start); hb.ts.push_back(paf.target_start); hb.te.push_back(paf.target_end);
-            total_samples += rec.raw.size();
-        } else {
+        else {
             // move table (gmove.cpp:557-700): read_id, fastq_len, fastq_seq, stride, moves, signal_len, trim_offset
             char *col[7]; int nc = 0;
             for (char *p = line, *e = line + got; p < e && nc < 7;) {
