@@ -1,0 +1,50 @@
+"""Randomised parity run on the GPU box (not part of the test suite: a few minutes of random small jobs against the CPU
+oracle). usage: python3 tools/fuzz_gpu.py [n_cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import numpy as np
+from helpers import assert_result_equals_oracle, oracle_for
+from poregen_amd import synth
+from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+skipped = 0
+for case in range(n_cases):
+    rna = bool(rng.integers(0, 2))
+    k = int(rng.choice([3, 5, 5, 6, 9]))
+    p = dict(kmer_size=k, rna=rna, scaling=int(rng.integers(0, 2)), sample_limit=int(rng.choice([1, 3, 20, 100, 1000])),
+             kmer_pick_margin=int(rng.integers(0, 4)), sig_move_offset=int(rng.integers(0, k)),
+             min_dur=int(rng.choice([1, 5, 20])), max_dur=int(rng.choice([30, 40, 70, 200])))
+    if rng.random() < 0.3:
+        lo = float(rng.uniform(-60, 100)); p.update(pa_min=lo, pa_max=lo + float(rng.choice([30, 120, 250, 600])))
+    n_reads = int(rng.choice([1, 7, 60, 300]))
+    read_len = int(rng.choice([150, 1000, 4000, 9001]))
+    b = synth.make_batch(n_reads, read_len=read_len, kind="rna004" if rna else "dna_r10", seed=int(rng.integers(1 << 30)),
+                         indel_rate=float(rng.choice([0.0, 0.02, 0.1])), spike_rate=float(rng.choice([0.0, 0.005, 0.2])))
+    kmers = generate_kmers(k, rna=rna)
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(b)
+    if min(rcs) < 0:  # the oracle flags an input on which the reference has undefined behaviour
+        skipped += 1
+        continue
+    eng = GmoveEngine(GmoveParams(kmers=kmers, lazy_stats=bool(rng.integers(0, 2)), **p))
+    try:
+        cut = int(rng.integers(0, n_reads + 1))
+        if cut and cut < n_reads:
+            eng.submit(b.slice_reads(0, cut)); eng.submit(b.slice_reads(cut, n_reads))
+        else:
+            eng.submit(b)
+        res = eng.finish()
+        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=p["sample_limit"])
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("CASE", case, "FAILED:", p, n_reads, read_len, repr(e)[:300], flush=True)
+    finally:
+        eng.close()
+    if case % 20 == 19:
+        print("case", case + 1, "ok so far" if not bad else f"{bad} failures", flush=True)
+print("fuzz done:", n_cases, "cases,", skipped, "outside the reference's defined behaviour (skipped),", bad, "failures")
+sys.exit(1 if bad else 0)
