@@ -2,12 +2,13 @@
 //
 // Pipeline per batch (reference lines are src/gmove.cpp of hiruna72/poregen):
 //   k_walk          ss walk (lines 822-871), one wave per read, prefix sums by DPP wave scans
-//   k_events        event filters (lines 891-927), one thread per (read, event)
+//   k_events        event filters (lines 891-927, 204-211), four consecutive events per thread
 //   k_rank_*        stable ranking of accepted events inside their k-mer slot: the deterministic stand-in for
 //                   "first sample_limit events in PAF-line order, then event order" (lines 732, 891, 925-927);
-//                   direct for <= 1024 slots, LSD radix sort (k_sort_*) beyond
-//   k_slot_plan / k_scan_*   the sample_limit cut and the output offsets
-//   k_read_plan + k_read_stats          pA conversion, zero-fill, exact median and MAD (lines 754-771)
+//                   direct for <= 1024 slots (k_rank_count_direct / k_rank_scan / k_rank_emit), LSD radix sort
+//                   (k_rank_count / k_sort_* / k_kept_meta) beyond
+//   k_slot_plan (+ k_tile_max) or k_slot_keep, k_scan_*   the sample_limit cut and the output offsets
+//   k_read_plan + k_read_stats (+ k_read_stats_rare)     pA conversion, zero-fill, exact median and MAD (lines 754-771)
 //   k_gather        window copy + normalisation of the kept events (lines 773-775, 928-944)
 // All of this is HBM/LDS-bound integer and FP64 work: there is no contraction here, so no MFMA.
 #include "pg_internal.h"
