@@ -1,6 +1,9 @@
 // stream_probe.hip -- how fast can one MI355X READ a 400 MB int16 buffer with the access shapes k_read_stats could use?
 // build: hipcc --offload-arch=gfx950 -O3 -o stream_probe stream_probe.hip ; run: ./stream_probe
 #include <hip/hip_runtime.h>
+#ifdef PROBE_REAL_KERNEL
+#include "../../poregen_amd/csrc/pg_kernels.hip" // the product kernel on the probe's data (hipcc -DPROBE_REAL_KERNEL -I../../include -I../../poregen_amd/csrc)
+#endif
 #include <cstdio>
 #include <cstdint>
 #include <vector>
@@ -239,6 +242,26 @@ int main(int argc, char **argv) {
     { std::vector<Rec> h(n_chunks); for (size_t i = 0; i < n_chunks; ++i) { Rec x{}; x.beg = i * 4000; x.end = x.beg + 4000; x.c_lo = 100; x.span = 800; x.z0 = 0; x.mode = 0; x.offset = 1; x.scale = 0.2; h[i] = x; }
       CK(hipMemcpy(rec, h.data(), n_chunks * sizeof(Rec), hipMemcpyHostToDevice)); }
     BigArgs ba{}; ba.n = (uint32_t)n_chunks; ba.sig = (const int16_t *)d;
+    { // the same kernel timed the way bench.py times k_read_stats: ONE launch between two events, other work in front
+        float tot = 0; const int reps = 10;
+        for (int i = 0; i < reps + 2; ++i) {
+            hipLaunchKernelGGL(k_plain, dim3(2048), dim3(256), 0, 0, d, n / 4, o); // something else ran before
+            hipEventRecord(e0); hipLaunchKernelGGL(k_chunk_rec, dim3((unsigned)n_chunks), dim3(64), 0, 0, ba, rec, medb, o); hipEventRecord(e1);
+            hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (i >= 2) tot += ms;
+        }
+        printf("%-50s %8.1f us  %6.2f TB/s\n", "H timed as ONE launch between two events", tot / reps * 1e3, bytes / (tot / reps * 1e-3) / 1e12);
+    }
+#ifdef PROBE_REAL_KERNEL
+    {
+        PgDevBatch PB{}; PB.n_reads = (uint32_t)n_chunks; PB.sig = (const int16_t *)d;
+        double *madb; CK(hipMalloc(&madb, n_chunks * 8)); int32_t *stb; CK(hipMalloc(&stb, n_chunks * 4 + 64)); CK(hipMemset(stb, 0, n_chunks * 4 + 64));
+        static_assert(sizeof(PgStatRec) == sizeof(Rec), "same record");
+        for (int ro : {1, 0}) {
+            char nm[96]; snprintf(nm, sizeof nm, "k_read_stats (product kernel), range_only=%d", ro);
+            time(nm, [&] { hipLaunchKernelGGL(k_read_stats, dim3((unsigned)n_chunks), dim3(64), 0, 0, PB, (const PgStatRec *)rec, medb, madb, stb, stb + n_chunks, 15, (uint8_t *)nullptr, ro); });
+        }
+    }
+#endif
     time("H as G + 64-byte record, big kernarg, pass loop", [&] { hipLaunchKernelGGL(k_chunk_rec, dim3((unsigned)n_chunks), dim3(64), 0, 0, ba, rec, medb, o); });
     return 0;
 }
