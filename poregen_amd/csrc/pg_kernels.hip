@@ -1092,19 +1092,31 @@ __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane
         const int sub = lane & 31, n_side = up ? sel.nU : sel.nD;
         const int t = (up ? aU : aD) - 15 + sub;
         const bool cand = sub < 31 && t >= 0 && t < n_side;
-        const bool zlane = lane == 31 && sel.nZ > 0;
-        double v = INFINITY; int mU = 0, mD = 0;
-        if (cand) { v = sel.dev(up, t); mU = up ? t : t - rq; mD = up ? t + rq : t; }
+        // Lanes 0..30 / 32..62: candidates of the U / D side. Lanes 31 and 63: the zero-filled class, counted against the U
+        // side by lane 31 and against the D side by lane 63. Every lane verifies ONE guessed count on the side that is
+        // not its own (PgSel::count_chk: three evaluations); a candidate's own side needs one evaluation only: codes
+        // 0..t deviate by <= dev(t) because deviations are monotone, so the count is t+1 unless dev(t+1) ties with it.
+        const bool zlane = sub == 31 && sel.nZ > 0;
+        double v = INFINITY;
+        bool other_up = !up; int m = 0; bool own_tie = false;
+        if (cand) {
+            v = sel.dev(up, t);
+            m = up ? t + rq : t - rq;
+            own_tie = t + 1 < n_side && sel.dev(up, t + 1) <= v;
+        }
         if (zlane) {
             v = sel.dZ;
-            mU = sel.nU > 0 ? to_int((sel.dZ - sel.U(0)) * sel.inv) : 0;
-            mD = sel.nD > 0 ? to_int((sel.dZ - sel.D(0)) * sel.inv) : 0;
+            other_up = up; // lane 31 counts the U side, lane 63 the D side
+            m = n_side > 0 ? to_int((sel.dZ - sel.dev(up, 0)) * sel.inv) : 0;
         }
-        bool okU, okD;
-        const int cntU = sel.count_chk(true, v, mU, okU), cntD = sel.count_chk(false, v, mD, okD);
-        const uint32_t N = sel.CU(cntU) + sel.CD(cntD) + (sel.dZ <= v ? sel.nZ : 0u);
+        bool ok_other;
+        const int cnt_other = sel.count_chk(other_up, v, m, ok_other);
+        const int cU = other_up ? cnt_other : t + 1, cD = other_up ? t + 1 : cnt_other; // candidate lanes (zero lanes: below)
+        const uint32_t part = other_up ? sel.CU(cnt_other) : sel.CD(cnt_other);            // the verified side's samples
+        const uint32_t NZ = (uint32_t)__builtin_amdgcn_readlane((int)part, 31) + (uint32_t)__builtin_amdgcn_readlane((int)part, 63) + sel.nZ;
+        const uint32_t N = zlane ? NZ : sel.CU(cU) + sel.CD(cD) + (sel.dZ <= v ? sel.nZ : 0u);
         const bool act = cand || zlane;
-        const uint64_t passm = __ballot(act && N >= sel.need), candm = __ballot(cand), surem = __ballot(okU && okD);
+        const uint64_t passm = __ballot(act && N >= sel.need), candm = __ballot(cand), surem = __ballot(ok_other && !own_tie);
         for (int side = 0; side < 2; ++side) {
             const int sh = side * 32, n = side == 0 ? sel.nU : sel.nD, a = side == 0 ? aU : aD;
             if (n == 0) continue;
@@ -1124,7 +1136,7 @@ __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane
             }
         }
         if (sel.nZ > 0) {
-            if (!((surem >> 31) & 1)) return false;
+            if (!((surem >> 31) & 1) || !((surem >> 63) & 1)) return false;
             if ((passm >> 31) & 1) { const double vz = sel.dZ; if (vz < best) best = vz; }
         }
     }
