@@ -113,3 +113,44 @@ def test_reform_then_gmove_equals_fixture_paf(tmp_path):
     names = sorted(os.listdir(outs[0] / "dump"))
     _, mismatch, errors = filecmp.cmpfiles(outs[0] / "dump", outs[1] / "dump", names, shallow=False)
     assert not mismatch and not errors
+
+
+def _sam(tmp_path, name, tags, seq="ACGTACGTACGT"):
+    p = tmp_path / name
+    p.write_text("@HD\tVN:1.6\n" + "\t".join(["read1", "4", "*", "0", "0", "*", "*", "0", "0", seq, "*"] + tags) + "\n")
+    return p
+
+
+def test_reform_error_returns(tmp_path):
+    """The reference's `return -1` paths (src/reform.cpp:212-240) and the inputs on which its scans would run past the
+    mv array: all end with a non-zero exit status and no complete record."""
+    mv = "mv:B:c,5,1,0,1,0,0,1,1,0,1,1,0,1,1,1,0,1"
+    cases = [
+        (["ts:i:10", mv], b"tag 'ns' is not found"),
+        (["ns:i:200", mv], b"tag 'ts' is not found"),
+        (["ns:i:200", "ts:i:10"], b"NULL returned for tag mv"),
+        (["ns:i:200", "ts:i:10", "mv:B:C,5,1,0,1"], b"tag 'mv' specification is incorrect"),
+        (["ns:i:200", "ts:i:10", "mv:B:c,6,1,0,1,1,1,1,1,1,1,1"], b"expected stride of 5 is missing"),
+        (["ns:i:200", "ts:i:10", "mv:B:c,5,0,0,0,0"], b"fewer moves than sig_move_offset + 1"),
+    ]
+    for i, (tags, msg) in enumerate(cases):
+        r = reform("-k3", "-m0", "-c", _sam(tmp_path, f"e{i}.sam", tags))
+        assert r.returncode != 0 and msg in r.stderr, (tags, r.stderr)
+
+
+def test_reform_small_hand_checked_record(tmp_path):
+    """12 bases, k=3 -> 10 k-mers; moves at mv indices 1,3,6,7,9,10,12,13,14,16; ts=10, ns=200, stride 5, -m 0.
+    TSV rows: k-mer j spans [ts + (p_j - 1)*5, ts + (p_{j+1} - 1)*5), the last one ends at ns."""
+    p = _sam(tmp_path, "ok.sam", ["ns:i:200", "ts:i:10", "mv:B:c,5,1,0,1,0,0,1,1,0,1,1,0,1,1,1,0,1"])
+    pos = [1, 3, 6, 7, 9, 10, 12, 13, 14, 16]
+    tsv = reform("-k3", "-m0", p)
+    assert tsv.returncode == 0
+    rows = [l.split("\t") for l in tsv.stdout.decode().splitlines()]
+    starts = [10 + (q - 1) * 5 for q in pos]
+    ends = starts[1:] + [200]
+    assert rows == [["read1", str(j), str(starts[j]), str(ends[j])] for j in range(10)]
+    paf = reform("-k3", "-m0", "-c", p)
+    assert paf.returncode == 0
+    c = paf.stdout.decode().rstrip("\n").split("\t")
+    assert c[:12] == ["read1", "200", "10", "200", "+", "read1", "10", "0", "10", "10", "10", "255"]
+    assert c[12] == "ss:Z:" + "".join(f"{e - s}," for s, e in zip(starts, ends))
