@@ -239,19 +239,18 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
     const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
     if (g0 >= B.n_ops) return;
     const uint64_t last = B.n_ops - 1;
-    // round trip 1: owning reads, the 16 base codes starting at g0, window lengths and starts of matches g0+off..
+    // round trip 1: owning reads, the 16 base codes starting at g0, window lengths of matches g0+off..
     const uint4 rv = *reinterpret_cast<const uint4 *>(O.m_read + g0);
     const uint32_t r[E] = {rv.x, rv.y, rv.z, rv.w};
     const uint4 bv = *reinterpret_cast<const uint4 *>(O.m_base + g0); // bases g0 .. g0+15 (k <= 13 needs g0 .. g0+15)
     const uint64_t blo = (uint64_t)bv.x | ((uint64_t)bv.y << 32), bhi = (uint64_t)bv.z | ((uint64_t)bv.w << 32);
-    uint32_t len[E], start[E];
+    uint32_t len[E];
     if (W.sig_move_offset == 0) {
-        const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0), sv = *reinterpret_cast<const uint4 *>(O.m_start + g0);
+        const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0);
         len[0] = lv.x; len[1] = lv.y; len[2] = lv.z; len[3] = lv.w;
-        start[0] = sv.x; start[1] = sv.y; start[2] = sv.z; start[3] = sv.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; start[j] = O.m_start[ge > last ? last : ge]; }
+        for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; }
     }
     // ... and, for pick_this_kmer, the number of I/D ops in front of match i-M and in front of match i+k+M-1 of the event's
     // read (both orientations need exactly these two)
@@ -307,11 +306,10 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
             const bool prev_ok = lo == 0 ? (-mt[j].st_k <= Y) : (cA == cB); // the entry in front of it is <= Y
             const bool pick = prev_ok && (lo < m || X <= mt[j].end_k + M);
             if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) { // gmove.cpp:916-924
-                // the window must be printable (gmove.cpp:928-944 is undefined otherwise)
-                const uint64_t L = mt[j].L;
-                const uint64_t wend = (uint64_t)start[j] + len[j] + W.print_margin > L ? L : (uint64_t)start[j] + len[j] + W.print_margin;
-                if (W.print_margin > start[j] || wend <= (uint64_t)(start[j] - W.print_margin)) report_error(O, r[j], PGR_ERR_WINDOW);
-                else out[j] = (uint32_t)slot[j];
+                // accepted. Whether its window can be printed (gmove.cpp:928-944 is undefined for margin > start or an empty
+                // window) only matters if the event is KEPT: the reference never looks at the window of an event whose k-mer
+                // is already complete. k_rank_emit / k_kept_meta check it there.
+                out[j] = (uint32_t)slot[j];
             }
         }
     }
@@ -485,9 +483,10 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
     const uint64_t gm = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
     const uint32_t start = O.m_start[gm], len = O.m_len[gm];
     const uint64_t L = O.meta[rd].L;
-    const uint32_t ws = start - W.print_margin; // validated in k_events
     const uint64_t we64 = (uint64_t)start + len + W.print_margin;
-    const uint32_t we = (uint32_t)(we64 > L ? L : we64);
+    uint32_t we = (uint32_t)(we64 > L ? L : we64), ws = start - W.print_margin;
+    // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
+    if (W.print_margin > start || we <= ws) { report_error(O, rd, PGR_ERR_WINDOW); ws = we = 0; }
     K.ev_len[e] = we - ws;
     K.ev_start[e] = ws;
     K.ev_read[e] = rd;
@@ -576,9 +575,11 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         if (dst[row] == 0xFFFFFFFFu) continue;
-        const uint32_t start = ws[row] - W.print_margin; // validated in k_events
+        uint32_t start = ws[row] - W.print_margin;
         const uint64_t we64 = (uint64_t)ws[row] + wl[row] + W.print_margin;
-        const uint32_t we = (uint32_t)(we64 > Lr[row] ? Lr[row] : we64);
+        uint32_t we = (uint32_t)(we64 > Lr[row] ? Lr[row] : we64);
+        // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
+        if (W.print_margin > ws[row] || we <= start) { report_error(O, rd[row], PGR_ERR_WINDOW); start = we = 0; }
         K.ev_len[dst[row]] = we - start;
         K.ev_start[dst[row]] = start;
         K.ev_read[dst[row]] = rd[row];

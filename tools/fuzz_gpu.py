@@ -18,6 +18,8 @@ for case in range(n_cases):
     p = dict(kmer_size=k, rna=rna, scaling=int(rng.integers(0, 2)), sample_limit=int(rng.choice([1, 3, 20, 100, 1000])),
              kmer_pick_margin=int(rng.integers(0, 4)), sig_move_offset=int(rng.integers(0, k)),
              min_dur=int(rng.choice([1, 5, 20])), max_dur=int(rng.choice([30, 40, 70, 200])))
+    if rng.random() < 0.25:
+        p.update(margin=int(rng.integers(1, 4)))   # --margin: windows widened on both sides (start < margin is undefined in the reference)
     if rng.random() < 0.3:
         lo = float(rng.uniform(-60, 100)); p.update(pa_min=lo, pa_max=lo + float(rng.choice([30, 120, 250, 600])))
     n_reads = int(rng.choice([1, 7, 60, 300]))
@@ -25,12 +27,18 @@ for case in range(n_cases):
     b = synth.make_batch(n_reads, read_len=read_len, kind="rna004" if rna else "dna_r10", seed=int(rng.integers(1 << 30)),
                          indel_rate=float(rng.choice([0.0, 0.02, 0.1])), spike_rate=float(rng.choice([0.0, 0.005, 0.2])))
     kmers = generate_kmers(k, rna=rna)
-    o = oracle_for(kmers, **p)
+    sl = {}
+    if rng.random() < 0.3 and k <= 6:  # a shuffled whitelist and a slice of it (--kmer_file, --index_start/--index_end)
+        kmers = [kmers[i] for i in rng.permutation(len(kmers))[:int(rng.integers(1, len(kmers) + 1))]]
+        a = int(rng.integers(1, len(kmers) + 1)); b2 = int(rng.integers(a, len(kmers) + 1))
+        sl = dict(index_start=a, index_end=b2)
+    o = oracle_for(kmers, **sl, **p)
     rcs = o.run_batch(b)
     if min(rcs) < 0:  # the oracle flags an input on which the reference has undefined behaviour
         skipped += 1
         continue
-    eng = GmoveEngine(GmoveParams(kmers=kmers, lazy_stats=bool(rng.integers(0, 2)), **p))
+    slice_kmers = kmers[sl["index_start"] - 1:sl["index_end"]] if sl else kmers  # the engine takes the slice itself
+    eng = GmoveEngine(GmoveParams(kmers=slice_kmers, lazy_stats=bool(rng.integers(0, 2)), debug_narrow=bool(rng.random() < 0.15), **p))
     try:
         cut = int(rng.integers(0, n_reads + 1))
         if cut and cut < n_reads:
