@@ -108,3 +108,25 @@ def test_inputs_outside_the_references_defined_behaviour_are_errors():
         GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, kmer_pick_margin=-1))
     with pytest.raises(PgError):
         GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, sig_move_offset=6))
+
+
+def test_margin_beyond_start_only_matters_for_kept_events():
+    """--margin larger than an event's window start is undefined in the reference only where the window is printed
+    (gmove.cpp:928-941), i.e. for an event that is KEPT. An accepted event whose k-mer is already complete is never
+    looked at: with sample_limit 1 every later read starts with such events (window start 0 < margin) and the job is
+    well defined. (Found by tools/fuzz_gpu.py: the check used to sit in front of the sample_limit cut.)"""
+    p = dict(kmer_size=3, rna=True, scaling=1, sample_limit=1, kmer_pick_margin=1, min_dur=20, max_dur=70, margin=3)
+    kmers = generate_kmers(3, rna=True)
+    checked = 0
+    for seed in range(40):
+        b = synth.make_batch(7, read_len=3000, kind="rna004", seed=1000 + seed)
+        o = oracle_for(kmers, **p)
+        if min(o.run_batch(b)) < 0:  # the first read's own first kept event has start < margin: undefined, skip
+            continue
+        eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+        eng.submit(b)
+        res = eng.finish()
+        eng.close()
+        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=1)
+        checked += 1
+    assert checked >= 5
