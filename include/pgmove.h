@@ -70,7 +70,12 @@ enum {
     PG_FLAG_SKIP_OUT_OF_RANGE = 1u << 5, /* a read with ANY sample outside [pa_min, pa_max] is skipped as a whole instead of
                                            zero-filling the sample: the SAM/BAM front-end (src/gmove.cpp:1149-1160). Event
                                            acceptance then depends on the signal, so the statistics pass runs first. */
-    PG_FLAG_DEBUG_NARROW = 1u << 3 /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
+    PG_FLAG_DEBUG_NARROW = 1u << 3, /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
+    PG_FLAG_STOP_WHEN_FULL = 1u << 6 /* the slots are the WHOLE k-mer list: the reference stops reading PAF lines once every k-mer is
+                                     * complete (src/gmove.cpp:733-735), so a read behind the one that completes the last k-mer
+                                     * is never looked at and cannot fail the job. With this flag a per-read input error is
+                                     * reported only if the reference would have reached that read. Without it (a slice of the
+                                     * list: the reference reads every line) every read of every batch counts. */
 };
 
 typedef struct pg_ctx pg_ctx;

@@ -21,6 +21,7 @@ PG_FLAG_OVERLAP = 4
 PG_FLAG_DEBUG_NARROW = 8
 PG_FLAG_SHORT_READS_OK = 16
 PG_FLAG_SKIP_OUT_OF_RANGE = 32
+PG_FLAG_STOP_WHEN_FULL = 64
 
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [

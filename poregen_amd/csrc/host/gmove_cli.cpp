@@ -216,7 +216,8 @@ int gmove_main(int argc, char **argv) {
         prm.kmer_pick_margin = 0; prm.sig_move_offset = 0;
     }
     prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
-    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
+    const bool whole_list = slot_kmers.size() == kmers.size(); // only then can the reference's loop end early (gmove.cpp:733-735)
+    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (whole_list ? PG_FLAG_STOP_WHEN_FULL : 0) | (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     pg_ctx *ctx = nullptr;
@@ -247,7 +248,9 @@ int gmove_main(int argc, char **argv) {
         if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); return false; }
         hb.clear();
         t_device += secs(tf0, clk::now());
-        if (pg_all_slots_full(ctx)) stop = true; // every file is closed: nothing later can be written (gmove.cpp:733-735)
+        // every k-mer of the WHOLE list complete: the reference stops reading (gmove.cpp:733-735). With a slice it reads on
+        // (and would still fail on a malformed later line), so we do too.
+        if (whole_list && pg_all_slots_full(ctx)) stop = true;
         return true;
     };
     // Move-table style records (table file and SAM/BAM, gmove.cpp:557-700 / 1080-1261): resolve -m (first window starts

@@ -81,6 +81,7 @@ struct pg_ctx {
     uint64_t cur_n_kept = 0, cur_n_samples = 0;
     uint64_t reads_before = 0; // reads submitted in earlier batches
     uint64_t full_slots = 0;
+    bool full_before_batch = false; // every slot was full before the current batch was counted
 
     std::vector<HostBatchResult> batches;
     bool single_moved = false; // batches[0]'s arrays currently live in r_* (pg_finish of a one-batch job)
@@ -274,7 +275,7 @@ pg_status pg_reset(pg_ctx *c) {
     c->zero_running = true;
     c->batches.clear(); c->single_moved = false;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
-    c->reads_before = 0; c->full_slots = 0; c->cur_n_kept = c->cur_n_samples = 0;
+    c->reads_before = 0; c->full_slots = 0; c->full_before_batch = false; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
 }
 
@@ -344,6 +345,19 @@ static pg_status check_read_errors(pg_ctx *c) {
     if (errv[0] == INT_MAX && errs[0] == INT_MAX) return PG_OK;
     const bool walk = errv[0] <= errs[0];
     const int32_t idx = walk ? errv[0] : errs[0];
+    if (c->prm.flags & PG_FLAG_STOP_WHEN_FULL) {
+        // would the reference have read this line at all? It stops once every k-mer is complete (gmove.cpp:733-735)
+        if (c->full_before_batch) return PG_OK; // complete before this batch: none of its reads is looked at
+        uint64_t tot[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(tot, c->plan_totals.p, 16, hipMemcpyDeviceToHost));
+        if (tot[1] == c->prm.n_slots && tot[0] > 0) { // complete inside this batch: at the read of its last kept event
+            std::vector<uint32_t> er(tot[0]);
+            HIP_TRY(c, hipMemcpy(er.data(), c->ev_read.p, tot[0] * 4ull, hipMemcpyDeviceToHost));
+            uint32_t last = 0;
+            for (uint32_t v : er) last = v > last ? v : last;
+            if ((uint32_t)idx > last) return PG_OK; // the lowest failing read lies behind it: never reached
+        }
+    }
     int32_t code = 0;
     HIP_TRY(c, hipMemcpy(&code, (walk ? c->status.as<int32_t>() : c->stat_status[c->slot].as<int32_t>()) + idx, 4, hipMemcpyDeviceToHost));
     pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : PG_ERR_INPUT);
@@ -454,6 +468,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     if (!direct) HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16)); // per-wave counts: only the radix sort keeps them
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
+    c->full_before_batch = c->full_slots == c->prm.n_slots && c->prm.n_slots > 0;
     c->slot ^= 1; // this batch's statistics buffers
     const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0; // statistics first: the walk needs their verdict
     const bool eager_stats = skip_oor || (c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS));

@@ -57,6 +57,7 @@ class GmoveParams:
     profile: bool = False
     overlap: bool = False
     debug_narrow: bool = False
+    stop_when_full: bool = False         # kmers is the WHOLE list: errors behind the read that completes the last k-mer do not count
 
 
 _BATCH_FIELDS = [
@@ -190,7 +191,8 @@ class GmoveEngine:
         p.kmer_pick_margin = params.kmer_pick_margin; p.scaling = params.scaling; p.allow_rna = int(params.rna)
         p.pa_min = params.pa_min; p.pa_max = params.pa_max; p.n_slots = self.n_slots
         p.flags = ((_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
-                   | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0))
+                   | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
+                   | (_abi.PG_FLAG_STOP_WHEN_FULL if params.stop_when_full else 0))
         p.device = params.device
         p.table_t = self._table_t.ctypes.data; p.table_u = self._table_u.ctypes.data
         h = C.c_void_p()

@@ -229,3 +229,28 @@ def test_blow5_input_equals_ascii_input(tmp_path):
     r = cli([b5, tmp_path / "r.paf", "--fastq", tmp_path / "r.fastq", tmp_path / "gpu"] + extra); assert r.returncode == 0, r.stderr
     o = oracle_cli([tmp_path / "r.slow5", tmp_path / "r.paf", "--fastq", tmp_path / "r.fastq", tmp_path / "cpu"] + extra); assert o.returncode == 0, o.stderr
     assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+
+
+@pytest.mark.gpu
+def test_malformed_line_behind_the_completing_read(tmp_path):
+    """Whole k-mer list: the reference stops reading once every k-mer is complete (gmove.cpp:733-735), so a malformed
+    PAF line behind that read goes unnoticed -- exit 0, same directory as the oracle CLI. With a slice of the list the
+    reference reads every line and exits on it: both CLIs fail."""
+    b = synth.make_batch(200, read_len=3000, kind="rna004", seed=91)
+    pre = str(tmp_path / "syn")
+    synth.write_files(b, pre)
+    lines = open(pre + ".paf").read().split("\n")
+    cols = lines[180].split("\t")
+    ss = [i for i, c in enumerate(cols) if c.startswith("ss:Z:")][0]
+    cols[ss] = cols[ss].replace(",", "X", 1)                       # "Bad ss": exit(1) in the reference (gmove.cpp:834-867)
+    lines[180] = "\t".join(cols)
+    open(pre + ".paf", "w").write("\n".join(lines))
+    whole = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq", "-k", "3", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40",
+             "--file_limit", "64", "--sample_limit", "5"]
+    r = cli(whole + [tmp_path / "gpu", "--batch_reads", "64"]); assert r.returncode == 0, r.stderr
+    r1 = cli(whole + [tmp_path / "gpu1", "--batch_reads", "1000"]); assert r1.returncode == 0, r1.stderr   # the bad line inside the completing batch
+    o = oracle_cli(whole + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu"); assert_same_dirs(tmp_path / "gpu1", tmp_path / "cpu")
+    sl = [x if x != "64" else "10" for x in whole]                  # --file_limit 10: a slice, the loop never ends early
+    assert cli(sl + [tmp_path / "gpu2"]).returncode == 1
+    assert oracle_cli(sl + [tmp_path / "cpu2"]).returncode != 0

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 
+import orc
 from helpers import assert_result_equals_oracle, oracle_for
 from poregen_amd import synth
 from poregen_amd.engine import Batch, GmoveEngine, GmoveParams, PgError, generate_kmers
@@ -130,3 +131,41 @@ def test_margin_beyond_start_only_matters_for_kept_events():
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=1)
         checked += 1
     assert checked >= 5
+
+
+def test_errors_behind_the_completing_read_do_not_count_for_the_whole_list():
+    """The reference stops reading PAF lines once every k-mer of the WHOLE list is complete (gmove.cpp:733-735): a
+    malformed line behind that point is never looked at. PG_FLAG_STOP_WHEN_FULL (stop_when_full) gives the batch API the
+    same verdict; without it -- the reference's behaviour for a slice of the list, where its loop never ends early --
+    the malformed read fails the job."""
+    b = synth.make_batch(300, read_len=3000, kind="rna004", seed=77)
+    p = dict(kmer_size=3, rna=True, scaling=1, sample_limit=5, min_dur=20, max_dur=40)
+    kmers = generate_kmers(3, rna=True)
+    bad = Batch(**{**b.__dict__, "query_start": b.query_start.copy()}); bad.query_start[250] = -1   # far behind completion
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(bad)
+    assert min(rcs) >= 0 and rcs[-1] == orc.ORC_STOPPED and len(rcs) < 250   # the oracle (whole list) never reaches read 250
+    eng = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    eng.submit(bad)
+    res = eng.finish()
+    assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=5)
+    # the job was complete after that batch: a further batch is not looked at either, whatever it holds
+    eng.submit(bad.slice_reads(240, 260))
+    res2 = eng.finish()
+    assert np.array_equal(res2.counts, res.counts) and np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
+    eng.close()
+    # the same malformed read INSIDE the part the reference reads: an error with or without the flag
+    early = Batch(**{**b.__dict__, "query_start": b.query_start.copy()}); early.query_start[0] = -1
+    for flag in (True, False):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=flag, **p))
+        with pytest.raises(PgError):
+            eng.submit(early); eng.sync()
+        eng.close()
+    # a slice of the list: the reference reads every line, the oracle reports the malformed one, and so does the engine
+    o2 = oracle_for(kmers, index_start=1, index_end=10, **p)
+    assert min(o2.run_batch(bad)) < 0
+    eng = GmoveEngine(GmoveParams(kmers=kmers[:10], **p))
+    with pytest.raises(PgError) as ei:
+        eng.submit(bad); eng.sync()
+    assert "read 250" in ei.value.text
+    eng.close()
