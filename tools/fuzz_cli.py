@@ -1,0 +1,66 @@
+"""Randomised whole-directory comparison of `bin/poregen gmove` with the CPU oracle's CLI on synthetic files: PAF, move-
+table and SAM front-ends, random options. Not part of the test suite. usage: python3 tools/fuzz_cli.py [n_cases] [seed]"""
+import filecmp, os, shutil, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+import numpy as np
+import orc
+from poregen_amd import synth
+
+BIN = os.path.join(ROOT, "bin", "poregen")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = skipped = 0
+for case in range(n_cases):
+    d = tempfile.mkdtemp(prefix="pgfz_")
+    try:
+        front = str(rng.choice(["paf", "paf", "table", "sam"]))
+        k = int(rng.choice([3, 5, 6]))
+        n_reads = int(rng.choice([1, 5, 40, 120]))
+        pre = os.path.join(d, "syn")
+        opts = ["-k", str(k), "--sample_limit", str(int(rng.choice([1, 4, 30, 100]))), "--file_limit", str(4 ** k)]
+        if rng.random() < 0.6: opts += ["--scaling", "1"]
+        if rng.random() < 0.3: opts += ["-d"]
+        if rng.random() < 0.3: opts += ["--min_dur", str(int(rng.choice([1, 10, 20]))), "--max_dur", str(int(rng.choice([25, 40, 100])))]
+        if rng.random() < 0.2: opts += ["--pa_min", str(float(rng.choice([-20.0, 60.0, 100.0]))), "--pa_max", str(float(rng.choice([120.0, 150.0, 400.0])))]
+        if rng.random() < 0.3:
+            a = int(rng.integers(1, 4 ** k + 1)); b2 = int(rng.integers(a, 4 ** k + 1)); opts += ["--index_start", str(a), "--index_end", str(b2)]
+        if front == "paf":
+            rna = bool(rng.integers(0, 2))
+            b = synth.make_batch(n_reads, read_len=int(rng.choice([600, 4000])), kind="rna004" if rna else "dna_r10", seed=int(rng.integers(1 << 30)),
+                                 indel_rate=float(rng.choice([0.0, 0.03])))
+            synth.write_files(b, pre)
+            args = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq"] + opts + (["--rna"] if rna else [])
+            args += ["--kmer_pick_margin", str(int(rng.integers(0, 4)))]
+            if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
+        else:
+            b = synth.make_batch(n_reads, read_len=int(rng.choice([600, 4000])), kind="dna_r10", seed=int(rng.integers(1 << 30)))
+            synth.write_table_files(b, pre, trim=int(rng.choice([0, 0, 23])))
+            args = [pre + ".slow5", pre + (".table" if front == "table" else ".sam")] + opts
+            if front == "table":
+                args += ["-m", str(int(rng.integers(0, min(k, 3)))), "-s", str(int(rng.integers(0, 3)))]
+            if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
+        o = subprocess.run([orc.CLI] + args + [os.path.join(d, "cpu")], capture_output=True, text=True)
+        if o.returncode == 70:  # the oracle flags an input on which the reference has undefined behaviour
+            skipped += 1
+            continue
+        g = subprocess.run([BIN, "gmove"] + args + [os.path.join(d, "gpu"), "--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))], capture_output=True, text=True)
+        ok = (o.returncode == 0) == (g.returncode == 0)
+        if ok and o.returncode == 0:
+            ok = open(os.path.join(d, "gpu", "freq.txt")).read() == open(os.path.join(d, "cpu", "freq.txt")).read()
+            names = sorted(os.listdir(os.path.join(d, "cpu", "dump")))
+            ok = ok and names == sorted(os.listdir(os.path.join(d, "gpu", "dump")))
+            if ok:
+                _, mism, errs = filecmp.cmpfiles(os.path.join(d, "gpu", "dump"), os.path.join(d, "cpu", "dump"), names, shallow=False)
+                ok = not mism and not errs
+        if not ok:
+            bad += 1
+            keep = os.path.join(ROOT, "gpurun_out", f"fuzz_cli_case{case}")
+            os.makedirs(os.path.dirname(keep), exist_ok=True); shutil.copytree(d, keep, dirs_exist_ok=True)
+            print("CASE", case, "DIFFERS:", front, " ".join(args), "| oracle rc", o.returncode, "gpu rc", g.returncode, g.stderr[-300:].replace("\n", " | "), flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    if case % 20 == 19:
+        print("case", case + 1, "ok so far" if not bad else f"{bad} differences", flush=True)
+print("cli fuzz done:", n_cases, "cases,", skipped, "outside the reference's defined behaviour (skipped),", bad, "differences")
+sys.exit(1 if bad else 0)
