@@ -26,6 +26,15 @@ for case in range(n_cases):
     read_len = int(rng.choice([150, 1000, 4000, 9001]))
     b = synth.make_batch(n_reads, read_len=read_len, kind="rna004" if rna else "dna_r10", seed=int(rng.integers(1 << 30)),
                          indel_rate=float(rng.choice([0.0, 0.02, 0.1])), spike_rate=float(rng.choice([0.0, 0.005, 0.2])))
+    if rng.random() < 0.4:  # PAF column 3 (query_start) > 0: the walk starts inside the signal; the last match gives the samples back
+        from poregen_amd.engine import Batch
+        qs = b.query_start.copy(); opn = b.op_n.copy()
+        for r in range(b.n_reads):
+            last = int(b.op_off[r + 1]) - 1
+            q = int(rng.integers(0, 60))
+            if last >= int(b.op_off[r]) and b.op_t[last] == 0 and opn[last] > q:
+                opn[last] -= q; qs[r] = q
+        b = Batch(**{**b.__dict__, "query_start": qs, "op_n": opn})
     kmers = generate_kmers(k, rna=rna)
     sl = {}
     if rng.random() < 0.3 and k <= 6:  # a shuffled whitelist and a slice of it (--kmer_file, --index_start/--index_end)
