@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=4000)
     ap.add_argument("--kind", default="rna004")
@@ -126,7 +126,7 @@ def main():
     for _ in range(2):
         prof.reset(); prof.submit(shard)
     prof.sync(); prof.kernel_stats_reset()
-    n_prof = 10
+    n_prof = 20
     for _ in range(n_prof):
         prof.reset(); prof.submit(shard)
     prof.sync()
