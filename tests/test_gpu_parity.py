@@ -164,6 +164,26 @@ def test_stream_ordered_count_collect_on_torch_stream():
         assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
 
 
+def test_overlap_mode_same_bits():
+    """PG_FLAG_OVERLAP: the statistics kernels of a batch on a second stream (double-buffered med/MAD), joined before
+    the gather. Several batches back to back, host- and device-resident: the same bits as the oracle."""
+    import torch
+    b = synth.make_batch(700, kind="rna004", seed=31, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=60)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    bounds = [0, 90, 91, 300, 520, 700]
+    for on_device in (False, True):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, overlap=True, **p))
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            part = b.slice_reads(lo, hi)
+            eng.submit(part.to_device(torch.device("cuda:0")) if on_device else part)
+        res = eng.finish()
+        eng.close()
+        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=60)
+
+
 def test_collect_gathered_three_ranks_on_one_gpu():
     """pg_collect_gathered: the all_gather's receive buffer (world x n_slots) goes in as it is and the library sums the
     rows below its rank on the device. Three 'ranks' (engines) on one GPU reproduce the single run / the oracle."""
