@@ -591,7 +591,8 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     fill_walk(c, W, O);
     PgKeptOut K{};
     K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_start = c->ev_start.as<uint32_t>();
-    K.read_needed = c->read_needed.as<uint8_t>();
+    // the per-read "owns a kept event" flags are only consumed by the lazy statistics: no scattered byte stores otherwise
+    K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
     if (direct) {
         PgSortBufs S{};
         fill_sort(c, S, 0);
