@@ -228,6 +228,43 @@ def write_table_files(b: Batch, prefix: str, stride: int = 5, trim: int = 0, see
             f.write(f"r{r}\t4\t*\t0\t0\t*\t*\t0\t0\t{seq}\t*\tmv:B:c,{stride},{mv}\tqs:i:10\tns:i:{L}\tts:i:{trim}\n")
 
 
+def write_bam(b: Batch, path: str, stride: int = 5, trim: int = 0, block_bytes: int = 20000):
+    """The records of write_table_files' SAM as a BAM file (BGZF: gzip members with the BC extra field; layout: SAM/BAM
+    specification 4.2) -- unaligned reads, SEQ 4-bit packed, tags mv:B:c, qs:C, ns:I, ts:I. block_bytes < 64 KiB makes
+    records straddle BGZF blocks, which is what a reader has to get right."""
+    import struct
+    import zlib
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.6\tSO:unknown\n@PG\tID:synthetic\n"
+    raw = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", 0))
+    for r in range(b.n_reads):
+        d = b.op_n[int(b.op_off[r]):int(b.op_off[r + 1])]
+        mv = [stride]
+        for x in d:
+            mv += [1] + [0] * (int(x) // stride - 1)
+        seq = seq_string(b, r)
+        L = int(b.sig_off[r + 1] - b.sig_off[r]) + trim
+        name = f"r{r}".encode() + b"\x00"
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= code.get(ch, 15) << (4 if i % 2 == 0 else 0)
+        tags = (b"mvBc" + struct.pack("<i", len(mv)) + struct.pack(f"<{len(mv)}b", *mv) + b"qsC" + struct.pack("<B", 10)
+                + b"nsI" + struct.pack("<I", L) + b"tsI" + struct.pack("<I", trim))
+        body = (struct.pack("<iiBBHHHiiii", -1, -1, len(name), 0, 4680, 0, 4, len(seq), -1, -1, 0) + name + bytes(packed)
+                + b"\xff" * len(seq) + tags)
+        raw += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        def block(data: bytes):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = c.compress(data) + c.flush()
+            bsize = 18 + len(comp) + 8 - 1
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp
+                    + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+        for o in range(0, len(raw), block_bytes):
+            block(bytes(raw[o:o + block_bytes]))
+        block(b"")  # the BGZF end-of-file marker
+
+
 def write_blow5(b: Batch, path: str):
     """Uncompressed BLOW5 (record compression none, signal compression none; layout: SURVEY.md 8f-1) for the batch;
     read ids are r<index>. Meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate."""

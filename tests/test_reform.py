@@ -154,3 +154,19 @@ def test_reform_small_hand_checked_record(tmp_path):
     c = paf.stdout.decode().rstrip("\n").split("\t")
     assert c[:12] == ["read1", "200", "10", "200", "+", "read1", "10", "0", "10", "10", "10", "255"]
     assert c[12] == "ss:Z:" + "".join(f"{e - s}," for s, e in zip(starts, ends))
+
+
+def test_synthetic_bam_with_records_across_bgzf_blocks(tmp_path):
+    """The BGZF/BAM reader on a synthetic file whose blocks are 777 bytes of payload (every record straddles several
+    blocks) gives the same records as the SAM text of the same reads (reform is the CPU-side consumer of that reader)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from poregen_amd import synth
+    b = synth.make_batch(40, kind="dna_r10", seed=5, read_len=3000)
+    pre = str(tmp_path / "s")
+    synth.write_table_files(b, pre, trim=11)
+    for blk in (777, 60000):
+        synth.write_bam(b, pre + ".bam", trim=11, block_bytes=blk)
+        for fmt in (["-c"], []):
+            a = reform("-k5", "-m1", *fmt, pre + ".sam"); c = reform("-k5", "-m1", *fmt, pre + ".bam")
+            assert a.returncode == 0 and c.returncode == 0 and a.stdout == c.stdout and len(a.stdout) > 1000

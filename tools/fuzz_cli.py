@@ -14,7 +14,8 @@ bad = skipped = 0
 for case in range(n_cases):
     d = tempfile.mkdtemp(prefix="pgfz_")
     try:
-        front = str(rng.choice(["paf", "paf", "table", "sam"]))
+        use_bam = False
+        front = str(rng.choice(["paf", "paf", "table", "sam", "sam"]))
         k = int(rng.choice([3, 5, 6]))
         n_reads = int(rng.choice([1, 5, 40, 120]))
         pre = os.path.join(d, "syn")
@@ -35,8 +36,12 @@ for case in range(n_cases):
             if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
         else:
             b = synth.make_batch(n_reads, read_len=int(rng.choice([600, 4000])), kind="dna_r10", seed=int(rng.integers(1 << 30)))
-            synth.write_table_files(b, pre, trim=int(rng.choice([0, 0, 23])))
+            trim = int(rng.choice([0, 0, 23]))
+            synth.write_table_files(b, pre, trim=trim)
             args = [pre + ".slow5", pre + (".table" if front == "table" else ".sam")] + opts
+            use_bam = front == "sam" and rng.random() < 0.6  # the product reads the BAM, the oracle CLI the SAM text of the same records
+            if use_bam:
+                synth.write_bam(b, pre + ".bam", trim=trim, block_bytes=int(rng.choice([300, 5000, 65000])))
             if front == "table":
                 args += ["-m", str(int(rng.integers(0, min(k, 3)))), "-s", str(int(rng.integers(0, 3)))]
             if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
@@ -44,7 +49,8 @@ for case in range(n_cases):
         if o.returncode == 70:  # the oracle flags an input on which the reference has undefined behaviour
             skipped += 1
             continue
-        g = subprocess.run([BIN, "gmove"] + args + [os.path.join(d, "gpu"), "--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))], capture_output=True, text=True)
+        gargs = [a[:-4] + ".bam" if (front == "sam" and use_bam and a.endswith(".sam")) else a for a in args] if front != "paf" else args
+        g = subprocess.run([BIN, "gmove"] + gargs + [os.path.join(d, "gpu"), "--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))], capture_output=True, text=True)
         ok = (o.returncode == 0) == (g.returncode == 0)
         if ok and o.returncode == 0:
             ok = open(os.path.join(d, "gpu", "freq.txt")).read() == open(os.path.join(d, "cpu", "freq.txt")).read()
