@@ -265,10 +265,44 @@ def write_bam(b: Batch, path: str, stride: int = 5, trim: int = 0, block_bytes: 
         block(b"")  # the BGZF end-of-file marker
 
 
-def write_blow5(b: Batch, path: str):
-    """Uncompressed BLOW5 (record compression none, signal compression none; layout: SURVEY.md 8f-1) for the batch;
-    read ids are r<index>. Meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate."""
+def _svb_zd(sig: np.ndarray) -> bytes:
+    """svb-zd block of a signal: u32 count, then streamvbyte (Lemire: ceil(n/4) control bytes of 2 bits per value =
+    byte length - 1, then the values' little-endian bytes) of the zig-zag-coded deltas of the samples."""
     import struct
+    x = sig.astype(np.int64)
+    d = np.diff(x, prepend=0)
+    zz = ((d << 1) ^ (d >> 63)).astype(np.uint32)
+    nb = np.where(zz < (1 << 8), 1, np.where(zz < (1 << 16), 2, np.where(zz < (1 << 24), 3, 4))).astype(np.uint8)
+    n = zz.size
+    codes = np.zeros((n + 3) // 4 * 4, np.uint8); codes[:n] = nb - 1
+    ctrl = (codes[0::4] | (codes[1::4] << 2) | (codes[2::4] << 4) | (codes[3::4] << 6)).astype(np.uint8)
+    le = zz.astype("<u4").view(np.uint8).reshape(-1, 4)
+    data = le[np.arange(4)[None, :] < nb[:, None]]
+    return struct.pack("<I", n) + ctrl.tobytes() + data.tobytes()
+
+
+def write_blow5(b: Batch, path: str, compress: bool = False):
+    """BLOW5 for the batch (layout: SURVEY.md 8f-1); read ids are r<index>. compress=False: record compression none,
+    signal compression none -- meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate.
+    compress=True: zlib records + svb-zd signals, what slow5tools writes by default (as test/example.blow5)."""
+    import struct
+    import zlib
+    if compress:
+        hdr = (b"#slow5_version\t0.2.0\n#num_read_groups\t1\n@asic_id\tsynthetic\n"
+               b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
+               b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
+        with open(path, "wb") as f:
+            f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15))
+            f.write(struct.pack("<I", len(hdr)) + hdr)
+            for r in range(b.n_reads):
+                rid = f"r{r}".encode()
+                blk = _svb_zd(b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])])
+                body = (struct.pack("<H", len(rid)) + rid + struct.pack("<I", 0)
+                        + struct.pack("<dddd", b.digitisation[r], b.offset[r], b.range[r], 4000.0) + struct.pack("<Q", len(blk)) + blk)
+                z = zlib.compress(body)
+                f.write(struct.pack("<Q", len(z)) + z)
+            f.write(b"5WOLB")
+        return
     hdr = (b"#slow5_version\t0.2.0\n#num_read_groups\t1\n@asic_id\tsynthetic\n"
            b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
            b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")

@@ -142,3 +142,25 @@ def test_sam_and_bam_readers_agree_on_fixture(h):
     table = open(os.path.join(G, "guppy_move")).read().split("\t")
     assert q.decode() == table[0] and s.decode() == table[2] and v == [5, 6020, 0]
     assert "".join(map(str, mv)) == table[4] and n == len(table[4])
+
+
+def test_compressed_blow5_round_trip(tmp_path):
+    """zlib records + svb-zd signals written by our own encoder (synth.write_blow5(compress=True)) decode to the same
+    samples and calibration. The decoder itself is pinned by the reference's test/example.blow5 (test above); this adds
+    ragged lengths, spikes (4-byte deltas) and a few hundred reads."""
+    import ctypes as C
+    from poregen_amd import synth
+    h = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
+    b = synth.make_batch(200, kind="rna004", seed=3, read_len=5003, spike_rate=0.05)
+    big = b.sig.copy(); big[::997] = 32767; big[1::997] = -32768            # extreme deltas: 3- and 4-byte codes
+    b = type(b)(**{**b.__dict__, "sig": big})
+    path = str(tmp_path / "c.blow5")
+    for comp in (True, False):
+        synth.write_blow5(b, path, compress=comp)
+        for r in range(0, b.n_reads, 7):
+            dor = np.zeros(3); raw = np.zeros(6000, np.int16)
+            n = h.pgt_slow5_get(path.encode(), f"r{r}".encode(), dor.ctypes.data, raw.ctypes.data, 6000)
+            s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+            assert n == s.size and np.array_equal(raw[:n], s)
+            assert (dor[0], dor[1], dor[2]) == (b.digitisation[r], b.offset[r], b.range[r])

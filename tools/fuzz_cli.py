@@ -14,7 +14,7 @@ bad = skipped = 0
 for case in range(n_cases):
     d = tempfile.mkdtemp(prefix="pgfz_")
     try:
-        use_bam = False
+        use_bam = blow5 = False
         front = str(rng.choice(["paf", "paf", "table", "sam", "sam"]))
         k = int(rng.choice([3, 5, 6]))
         n_reads = int(rng.choice([1, 5, 40, 120]))
@@ -33,6 +33,9 @@ for case in range(n_cases):
             synth.write_files(b, pre)
             args = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq"] + opts + (["--rna"] if rna else [])
             args += ["--kmer_pick_margin", str(int(rng.integers(0, 4)))]
+            blow5 = rng.random() < 0.5  # the product reads a BLOW5 of the same reads (zlib + svb-zd half of the time), the oracle the ASCII SLOW5
+            if blow5:
+                synth.write_blow5(b, pre + ".blow5", compress=bool(rng.integers(0, 2)))
             if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
         else:
             b = synth.make_batch(n_reads, read_len=int(rng.choice([600, 4000])), kind="dna_r10", seed=int(rng.integers(1 << 30)))
@@ -49,7 +52,8 @@ for case in range(n_cases):
         if o.returncode == 70:  # the oracle flags an input on which the reference has undefined behaviour
             skipped += 1
             continue
-        gargs = [a[:-4] + ".bam" if (front == "sam" and use_bam and a.endswith(".sam")) else a for a in args] if front != "paf" else args
+        gargs = [a[:-4] + ".bam" if (front == "sam" and use_bam and a.endswith(".sam")) else a for a in args] if front != "paf" else \
+                [a[:-6] + ".blow5" if (blow5 and a.endswith(".slow5")) else a for a in args]
         g = subprocess.run([BIN, "gmove"] + gargs + [os.path.join(d, "gpu"), "--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))], capture_output=True, text=True)
         ok = (o.returncode == 0) == (g.returncode == 0)
         if ok and o.returncode == 0:
