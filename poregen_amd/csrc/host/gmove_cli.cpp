@@ -185,6 +185,7 @@ int gmove_main(int argc, char **argv) {
     else { print_help(fp_help, opt); return EXIT_FAILURE; }
 
     pgh::Slow5File s5;
+    const std::chrono::steady_clock::time_point t_setup0 = std::chrono::steady_clock::now();
     if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return EXIT_FAILURE; } // gmove.cpp:493-503
 
     const std::string mt(move_table); // src/gmove.cpp:505-521
@@ -221,6 +222,7 @@ int gmove_main(int argc, char **argv) {
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     pg_ctx *ctx = nullptr;
+    const std::chrono::steady_clock::time_point t_setup1 = std::chrono::steady_clock::now();
     if (pg_create(&prm, &ctx) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(nullptr)); return EXIT_FAILURE; }
 
     // ---- the read loop (src/gmove.cpp:732-969), batched ---------------------------------------------------
@@ -428,7 +430,8 @@ int gmove_main(int argc, char **argv) {
             const clk::time_point td0 = clk::now();
             if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
             t_dump = secs(td0, clk::now());
-            fprintf(stderr, "\n[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
+            fprintf(stderr, "\n[gmove] time: file indices + k-mer list %.3f s, device context %.3f s\n", secs(t_setup0, t_setup1), secs(t_setup1, t_loop0));
+            fprintf(stderr, "[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
                     t_loop - t_device, t_device, t_finish, t_dump);
             fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
                     (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, device);

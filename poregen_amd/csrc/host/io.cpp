@@ -86,6 +86,8 @@ bool Slow5File::index_blow5(std::string &err) {
     if (sig_press_ > 1) { err = "BLOW5 signal compression other than none/svb-zd is not supported"; return false; }
     uint32_t hlen; memcpy(&hlen, d + 64, 4);
     uint64_t pos = 68 + (uint64_t)hlen;
+    z_stream zs; bool zs_ready = false; // one inflate state for all record heads (inflateReset is far cheaper than inflateInit)
+    struct ZEnd { z_stream *z; bool *on; ~ZEnd() { if (*on) inflateEnd(z); } } zend{&zs, &zs_ready};
     while (pos + 8 <= f_.size) {
         if (f_.size - pos >= 5 && memcmp(d + pos, "5WOLB", 5) == 0) break;
         uint64_t sz; memcpy(&sz, d + pos, 8);
@@ -98,15 +100,21 @@ bool Slow5File::index_blow5(std::string &err) {
             uint16_t il; memcpy(&il, d + pos, 2);
             id.assign((const char *)d + pos + 2, il);
         } else {
+            // only the first bytes of the record are inflated: u16 id length + id (a first try of 256 bytes covers every
+            // real read id; longer ones get a second, full-size try) -- inflating whole records made indexing a 50 000-read
+            // file take a second
             unsigned char head[2 + 65536];
-            z_stream zs; memset(&zs, 0, sizeof zs);
-            if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
-            zs.next_in = (Bytef *)(d + pos); zs.avail_in = (uInt)sz; zs.next_out = head; zs.avail_out = sizeof head;
-            int rc = inflate(&zs, Z_SYNC_FLUSH);
-            size_t got = sizeof head - zs.avail_out;
-            inflateEnd(&zs);
-            if ((rc != Z_OK && rc != Z_STREAM_END) || got < 2) { err = "zlib error in BLOW5 record"; return false; }
-            uint16_t il; memcpy(&il, head, 2);
+            uint16_t il = 0; size_t got = 0;
+            for (size_t want : {(size_t)256, sizeof head}) {
+                if (!zs_ready) { memset(&zs, 0, sizeof zs); if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; } zs_ready = true; }
+                else if (inflateReset(&zs) != Z_OK) { err = "zlib reset failed"; return false; }
+                zs.next_in = (Bytef *)(d + pos); zs.avail_in = (uInt)sz; zs.next_out = head; zs.avail_out = (uInt)want;
+                const int rc = inflate(&zs, Z_SYNC_FLUSH);
+                got = want - zs.avail_out;
+                if ((rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) || got < 2) { err = "zlib error in BLOW5 record"; return false; }
+                memcpy(&il, head, 2);
+                if ((size_t)il + 2 <= got) break;
+            }
             if ((size_t)il + 2 > got) { err = "corrupt BLOW5 record"; return false; }
             id.assign((const char *)head + 2, il);
         }

@@ -1,12 +1,13 @@
-"""End-to-end `poregen gmove` on BASELINE config 1 as files (uncompressed BLOW5 + PAF + FASTQ): wall time of the whole
+"""End-to-end `poregen gmove` on BASELINE config 1 as files (BLOW5, uncompressed or zlib + svb-zd, + PAF + FASTQ): wall time of the whole
 process (host parsing + PCIe + GPU + %.8f formatting + writing 1024 files), next to the CPU oracle CLI on a prefix."""
 import os, subprocess, sys, time, shutil
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from poregen_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+compress = len(sys.argv) > 2 and sys.argv[2] == "zlib"   # "zlib": zlib records + svb-zd signals (slow5tools' default)
 d = "/tmp/pg_e2e"; shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
 t0 = time.time(); b = synth.make_batch_fast(n, kind="rna004", seed=20251004); print("generated", n, "reads in %.1f s" % (time.time() - t0))
-t0 = time.time(); synth.write_blow5(b, d + "/r.blow5"); synth.write_paf_fastq(b, d + "/r"); print("wrote files in %.1f s" % (time.time() - t0))
+t0 = time.time(); synth.write_blow5(b, d + "/r.blow5", compress=compress); synth.write_paf_fastq(b, d + "/r"); print("wrote files in %.1f s" % (time.time() - t0))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for lim in (100, 5000):
     for rep in range(2):
