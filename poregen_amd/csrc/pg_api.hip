@@ -66,7 +66,7 @@ struct pg_ctx {
     // per-batch work buffers
     DevBuf m_start, m_len, m_base, m_tix, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
-    DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage;
+    DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage, tile_last;
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
@@ -200,7 +200,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->keep32, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
+                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor};
     for (DevBuf *b : bufs) b->release();
@@ -253,7 +253,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     c->prm.table_t = nullptr; c->prm.table_u = nullptr;
     const uint32_t ns = p->n_slots;
     CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
-    CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull));
+    CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull)); CTRY(c->tile_last.ensure(ns * 4ull));
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
     CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
@@ -504,7 +504,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     fill_sort(c, S, n_tiles);
     if (direct) {
         prof_begin(c, "rank_count", c->st);
-        pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>());
+        pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
+                                    c->tile_last.as<int32_t>());
         prof_end(c, c->st);
     } else {
         prof_begin(c, "sort_events", c->st);
@@ -579,7 +580,8 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     prof_begin(c, "k_slot_plan", c->st);
     pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
-                        pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>());
+                        pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
+                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr);
     prof_end(c, c->st);
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;

@@ -125,7 +125,7 @@ void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, 
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt);
+                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last);
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
@@ -144,7 +144,8 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 // the many-slot path (n_slots > 4096, sort mode); may be null for small slot counts
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
                          uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals,
-                         const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch);
+                         const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch,
+                         const int32_t *tile_last /* direct mode, base == running: from pg_launch_rank_direct_count; else null */);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
 // entries ZERO before the first use (every launch leaves them zero again)
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);

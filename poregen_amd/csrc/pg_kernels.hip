@@ -397,11 +397,20 @@ __global__ __launch_bounds__(256) void k_rank_count_direct(const uint32_t *__res
         *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
 }
 
+// running / limit / tile_last (direct mode, may be null): with base = the context's own running counts -- what pg_submit
+// collects with -- the last tile that still places an event of this slot falls out of the same pass: keep = min(cnt,
+// room), room = limit - base; it is the largest tile whose exclusive prefix is < room when cnt >= room, else the last
+// non-empty tile (k_tile_max finds the same by searching the finished prefix rows when the base arrives later).
 __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
-                                                  uint64_t *__restrict__ acc_cnt, uint32_t n_slots) {
+                                                  uint64_t *__restrict__ acc_cnt, uint32_t n_slots, const uint64_t *__restrict__ running,
+                                                  uint32_t limit, int32_t *__restrict__ tile_last) {
     const uint32_t d = blockIdx.x;
     const int lane = lane_id();
     uint32_t run = 0;
+    const bool want_last = tile_last && d < n_slots;
+    const uint64_t base0 = want_last ? running[d] : 0;
+    const uint32_t room = base0 >= limit ? 0u : limit - (uint32_t)base0;
+    int candA = -1, candB = -1;
     uint32_t *__restrict__ row = hist + (uint64_t)d * n_tiles;
     for (uint32_t c0 = 0; c0 < n_tiles; c0 += 8 * WAVE) { // eight independent loads in flight, then the (ALU-only) scans
         uint32_t v[8];
@@ -411,9 +420,20 @@ __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, u
         for (int u = 0; u < 8; ++u) {
             const uint32_t i = c0 + u * WAVE + lane;
             const uint32_t inc = wave_incl_scan_u32(v[u]);
-            if (i < n_tiles) row[i] = run + inc - v[u];
+            const uint32_t excl = run + inc - v[u];
+            if (i < n_tiles) {
+                row[i] = excl;
+                if (excl < room) candA = (int)i; // i grows along the loop: the last assignment is the largest
+                if (v[u] > 0) candB = (int)i;
+            }
             run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
         }
+    }
+    if (want_last) {
+        int last = run >= room ? candA : candB;
+        if (room == 0 || run == 0) last = -1;
+        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(last, o, WAVE); last = t > last ? t : last; }
+        if (lane == 0) tile_last[d] = last;
     }
     if (lane == 0) {
         totals[d] = run;
@@ -611,7 +631,7 @@ __global__ __launch_bounds__(256) void k_slot_counts(const uint32_t *__restrict_
 __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running,
                                                     uint32_t limit, uint32_t n_slots, uint64_t *__restrict__ keep,
                                                     uint64_t *__restrict__ ev_off, uint64_t *__restrict__ totals,
-                                                    const uint32_t *__restrict__ hist, uint32_t n_tiles) {
+                                                    const uint32_t *__restrict__ hist, uint32_t n_tiles, const int32_t *__restrict__ tile_last) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t wfull[16];
     (void)hist; (void)n_tiles;
@@ -640,7 +660,19 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
         __syncthreads();
     }
     __syncthreads();
-    if (tid == 0) { ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full; totals[3] = hist ? ~0ull : ~0ull >> 1; } // ~0 = -1: k_tile_max raises it
+    int last = -1; // direct mode with the last useful tiles already known (k_rank_scan): their maximum
+    if (tile_last) {
+        __shared__ int wlast[16];
+        for (uint32_t s2 = tid; s2 < n_slots; s2 += 1024) { const int t = tile_last[s2]; last = t > last ? t : last; }
+        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(last, o, WAVE); last = t > last ? t : last; }
+        if (lane == 0) wlast[w] = last;
+        __syncthreads();
+        if (tid == 0) for (int ww = 0; ww < 16; ++ww) last = wlast[ww] > last ? wlast[ww] : last;
+    }
+    if (tid == 0) { // totals[3]: read as a signed tile index by k_rank_emit; ~0 = -1: k_tile_max raises it
+        ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full;
+        totals[3] = tile_last ? (uint64_t)(int64_t)last : (hist ? ~0ull : ~0ull >> 1);
+    }
 }
 
 // Many slots (k = 9: 262 144): the same cut element-wise over a grid, the offsets by the generic scan, the totals by one
@@ -1419,13 +1451,16 @@ void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W
 static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt) {
+                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (n_tiles) {
         hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots);
-    } else (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last);
+    } else {
+        (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
+        if (tile_last) (void)hipMemsetAsync(tile_last, 0xff, sizeof(int32_t) * n_slots, st); // -1: nothing to place
+    }
 }
 
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
@@ -1451,7 +1486,8 @@ int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, u
         const int nbits = (int)((key_bits - shift) < per ? (key_bits - shift) : per);
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, (const uint64_t *)nullptr, 0u,
+                           (int32_t *)nullptr);
         hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
@@ -1474,7 +1510,7 @@ void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t 
 
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                          uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles,
-                         uint32_t *keep32, uint64_t *scan_scratch) {
+                         uint32_t *keep32, uint64_t *scan_scratch, const int32_t *tile_last) {
     if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
         (void)hipMemsetAsync(totals, 0, 32, st);
         hipLaunchKernelGGL(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals);
@@ -1482,8 +1518,8 @@ void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t
         hipLaunchKernelGGL(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
         return;
     }
-    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles);
-    if (hist && n_tiles) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
+    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last);
+    if (hist && n_tiles && !tile_last) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
 }
 
 void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
