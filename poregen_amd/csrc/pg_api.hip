@@ -350,6 +350,8 @@ static pg_status check_read_errors(pg_ctx *c) {
         if (c->full_before_batch) return PG_OK; // complete before this batch: none of its reads is looked at
         uint64_t tot[2] = {0, 0};
         HIP_TRY(c, hipMemcpy(tot, c->plan_totals.p, 16, hipMemcpyDeviceToHost));
+        // every slot full and nothing kept here: the bases alone (earlier batches / lower ranks) had completed the job
+        if (tot[1] == c->prm.n_slots && tot[0] == 0) return PG_OK;
         if (tot[1] == c->prm.n_slots && tot[0] > 0) { // complete inside this batch: at the read of its last kept event
             std::vector<uint32_t> er(tot[0]);
             HIP_TRY(c, hipMemcpy(er.data(), c->ev_read.p, tot[0] * 4ull, hipMemcpyDeviceToHost));

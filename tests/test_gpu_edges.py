@@ -154,6 +154,14 @@ def test_errors_behind_the_completing_read_do_not_count_for_the_whole_list():
     res2 = eng.finish()
     assert np.array_equal(res2.counts, res.counts) and np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
     eng.close()
+    # a higher rank of a multi-GPU job whose lower ranks already completed every k-mer: its shard is never read
+    e0 = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    c0 = e0.count(b.slice_reads(0, 200)); e0.collect(np.zeros_like(c0)); assert e0.all_slots_full()
+    e1 = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    e1.count(bad.slice_reads(200, 300)); e1.collect(c0.copy())
+    r1 = e1.finish()
+    assert int(r1.counts.sum()) == 0
+    e0.close(); e1.close()
     # the same malformed read INSIDE the part the reference reads: an error with or without the flag
     early = Batch(**{**b.__dict__, "query_start": b.query_start.copy()}); early.query_start[0] = -1
     for flag in (True, False):
