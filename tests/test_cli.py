@@ -66,6 +66,7 @@ FIXTURE_CASES = {
     "ka1": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt"],
     "ka2_scaling": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt", "--scaling", "1"],
     "ka3_pamin": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/kmer_file.txt", "--scaling", "1", "--pa_min", "100"],
+    "t12_literal": ["-k", "6", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/single_kmer_file.txt"],  # test_gmove.sh 1.2 as written (ka1 is 2.2, ka6_defaults 0.6)
     "ka5_delimit": ["-k", "6", "-d", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--kmer_file", "{G}/single_kmer_file.txt"],
     "ka6_defaults": ["{G}/reads.slow5", "{G}/guppy_move.paf", "--file_limit", "50", "{OUT}", "--fastq", "{G}/read_0.fastq"],
     "margin0_k5_all": ["-k", "5", "{G}/reads.slow5", "{G}/guppy_move.paf", "{OUT}", "--fastq", "{G}/read_0.fastq", "--file_limit", "5000", "--kmer_pick_margin", "0", "--scaling", "1"],
