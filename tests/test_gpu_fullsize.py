@@ -126,3 +126,41 @@ def test_config2_large_limit_rank_shards():
         n = int(oc[s])
         ov = o.values(s)
         assert np.array_equal(res.slot_values(s)[:ov.size].view(np.uint64), ov.view(np.uint64)), s
+
+
+def test_config4_whitelist_slice_indels_rank_shards():
+    """BASELINE configs[4] at one GPU's size: 30 000 RNA reads whose ss strings carry 2 % deletions and 2 % insertions,
+    a shuffled whitelist of 300 5-mers over ACGU of which the slice [51, 250] is dumped, --kmer_pick_margin 2. The
+    reference reads every line here (a slice never completes the whole list), so the oracle runs on a prefix only for
+    the k-mers it fills there; the whole job is checked through the rank-shard identity and the invariants."""
+    rng = np.random.default_rng(4)
+    full = generate_kmers(5, rna=True)
+    wl = [full[i] for i in rng.permutation(len(full))[:300]]
+    b = synth.make_batch(30000, kind="rna004", seed=20251003 + 4, indel_rate=0.04)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, kmer_pick_margin=2, sample_limit=100)
+    kmers = wl[50:250]
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 100, b.n_reads)
+    assert int(res.counts.min()) == 100                     # 30 000 reads fill every whitelisted k-mer
+    # three uneven 'ranks' with the count exchange
+    bounds = [0, 1000, 17000, 30000]
+    engs = [GmoveEngine(GmoveParams(kmers=kmers, **p)) for _ in bounds[1:]]
+    cnts = [e.count(b.slice_reads(lo, hi)) for e, lo, hi in zip(engs, bounds[:-1], bounds[1:])]
+    base = np.zeros_like(cnts[0])
+    parts = []
+    for e, c in zip(engs, cnts):
+        e.collect(base.copy()); parts.append(e.finish()); base += c; e.close()
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in parts])
+        assert np.array_equal(vals.view(np.uint64), res.slot_values(s).view(np.uint64)), s
+    # the oracle on the first 4 000 reads: k-mers it completes there have their final content
+    o = oracle_for(wl, index_start=51, index_end=250, **p)
+    o.run_batch(b.slice_reads(0, 4000))
+    oc = o.counts()
+    done = np.flatnonzero(oc == 100)
+    assert done.size > 20
+    for s in done:
+        assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64)), int(s)
