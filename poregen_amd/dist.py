@@ -79,6 +79,53 @@ def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=Fals
     return total
 
 
+def gather_kept(counts, ev_len, samples, dst: int = 0, group=None):
+    """The single-writer end of a multi-GPU job: every rank sends its kept events to rank `dst` (point-to-point over
+    xGMI with RCCL, or gloo on CPU tensors), which returns the job's per-k-mer streams as the reference writes them --
+    slot-major, and inside a slot the ranks' events in rank order (= PAF-line order).
+    counts: int64[n_slots] kept events of this rank per slot; ev_len: int32[n_events] window lengths in this rank's
+    slot-major order; samples: float64[n_samples] the windows back to back. Returns (counts, ev_len, samples) of the
+    whole job on rank dst, None elsewhere. Output-side step: not part of the timed hot path."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = counts.device
+    sizes = torch.tensor([ev_len.numel(), samples.numel()], dtype=torch.int64, device=dev)
+    all_sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    all_counts = torch.empty(world * counts.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_counts, counts.contiguous().view(-1), group=group)
+    all_sizes = all_sizes.view(world, 2).cpu(); all_counts = all_counts.view(world, -1)
+    if rank != dst:
+        if ev_len.numel(): dist.send(ev_len.contiguous(), dst, group=group)
+        if samples.numel(): dist.send(samples.contiguous(), dst, group=group)
+        return None
+    lens, vals = [], []
+    for r in range(world):
+        ne, nsmp = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+        if r == rank:
+            lens.append(ev_len); vals.append(samples)
+            continue
+        le = torch.empty(ne, dtype=ev_len.dtype, device=dev); va = torch.empty(nsmp, dtype=samples.dtype, device=dev)
+        if ne: dist.recv(le, r, group=group)
+        if nsmp: dist.recv(va, r, group=group)
+        lens.append(le); vals.append(va)
+    n_slots = counts.numel()
+    slots = torch.arange(n_slots, device=dev)
+    ev_slot = torch.cat([torch.repeat_interleave(slots, all_counts[r]) for r in range(world)])  # rank-major
+    order = torch.sort(ev_slot, stable=True).indices                                             # slot-major, rank order kept
+    cat_len = torch.cat(lens).to(torch.int64)
+    starts = torch.cumsum(cat_len, 0) - cat_len          # sample offset of every event in the rank-major concatenation
+    out_len = cat_len[order]
+    out_start = torch.cumsum(out_len, 0) - out_len
+    cat_val = torch.cat(vals)
+    total = int(out_len.sum())
+    # sample i of the output belongs to output event e(i): source index = starts[order[e]] + (i - out_start[e])
+    ev_of = torch.repeat_interleave(torch.arange(order.numel(), device=dev), out_len)
+    src = starts[order][ev_of] + (torch.arange(total, device=dev) - out_start[ev_of])
+    return all_counts.sum(dim=0), out_len.to(ev_len.dtype), cat_val[src]
+
+
 def concat_rank_results(results: List["Result"]):
     """Per-slot concatenation of the ranks' kept events in rank order (what a single writer would dump)."""
     n_slots = results[0].counts.size

@@ -298,6 +298,29 @@ class GmoveEngine:
         self._check(self._lib.pg_last_batch_device(self._h, C.byref(v)))
         return v
 
+    def kept_tensors(self, device=None):
+        """The last collected batch as torch CUDA tensors that alias the library's device buffers (valid until the next
+        submit/collect/reset): (kept events per slot int64[n_slots], window lengths int32[n_events] in slot-major
+        order, samples float64[n_samples]). What dist.gather_kept sends to the writing rank."""
+        import torch
+        v = self.device_view()
+
+        class _Alias:  # zero-copy hand-over through the CUDA array interface
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr or 0), False), "version": 2}
+
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+        def wrap(ptr, n, typestr, dtype):
+            if n == 0 or not ptr:
+                return torch.empty(0, dtype=dtype, device=dev)
+            return torch.as_tensor(_Alias(ptr, n, typestr), device=dev)
+
+        counts = wrap(v.d_keep, self.n_slots, "<i8", torch.int64)
+        ev_len = wrap(v.d_ev_len, v.n_events, "<i4", torch.int32)
+        samples = wrap(v.d_samples, v.n_samples, "<f8", torch.float64)
+        return counts, ev_len, samples
+
     def kernel_stats(self):
         n = C.c_uint32(0)
         buf = (_abi.PgKernelStat * 64)()

@@ -32,10 +32,11 @@ class OracleEngine:
 
     def collect(self, base):
         lim = self.p["sample_limit"]
-        self.kept = []
+        self.kept, self.kept_lens = [], []
         for s in range(self.n_slots):
             room = max(0, lim - int(base[s]))
             lens = self.o.event_lens(s)[:room]
+            self.kept_lens.append(lens.astype(np.int32))
             self.kept.append(self.o.values(s)[: int(lens.sum())])
 
     def sync(self):
@@ -57,6 +58,12 @@ def _worker(rank, world, port, out_dir):
     freq = pgdist.merged_freq(total, p["sample_limit"]).numpy()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), freq=freq, sizes=np.array([v.size for v in eng.kept]),
              flat=np.concatenate(eng.kept) if eng.kept else np.zeros(0))
+    # the single-writer end: every rank's kept events to rank 0, slot-major / rank order inside a slot
+    g = pgdist.gather_kept(torch.tensor([len(x) for x in eng.kept_lens], dtype=torch.int64), torch.from_numpy(np.concatenate(eng.kept_lens)),
+                           torch.from_numpy(np.concatenate(eng.kept)))
+    assert (g is None) == (rank != 0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gathered.npz"), counts=g[0].numpy(), ev_len=g[1].numpy(), samples=g[2].numpy())
     tdist.barrier()
     tdist.destroy_process_group()
 
@@ -79,3 +86,8 @@ def test_two_rank_gloo_equals_sequential_oracle(tmp_path):
     for s in range(len(kmers)):
         cat = np.concatenate([r[i]["flat"][offs[i][s]:offs[i][s + 1]] for i in range(2)])
         assert np.array_equal(cat.view(np.uint64), o.values(s).view(np.uint64)), s
+    # dist.gather_kept on rank 0: the whole job as one writer would dump it
+    g = np.load(tmp_path / "gathered.npz")
+    assert np.array_equal(g["counts"].astype(np.uint64), o.counts())
+    assert np.array_equal(g["ev_len"], np.concatenate([o.event_lens(s) for s in range(len(kmers))]).astype(np.int32))
+    assert np.array_equal(g["samples"].view(np.uint64), np.concatenate([o.values(s) for s in range(len(kmers))]).view(np.uint64))

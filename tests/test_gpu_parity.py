@@ -238,6 +238,15 @@ def test_sharded_step_over_rccl_single_rank(tmp_path):
             eng.close()
         assert np.array_equal(np.minimum(total.cpu().numpy().astype(np.uint64), 15), o.counts())
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=15)
+        # the single-writer end of the job over the same group: device tensors that alias the library's buffers
+        eng2 = GmoveEngine(GmoveParams(kmers=kmers, **p))
+        eng2.submit(b.to_device(dev))
+        counts, ev_len, samples = eng2.kept_tensors()
+        g = pgdist.gather_kept(counts, ev_len, samples)
+        assert np.array_equal(g[0].cpu().numpy().astype(np.uint64), o.counts())
+        assert np.array_equal(g[1].cpu().numpy(), np.concatenate([o.event_lens(s) for s in range(len(kmers))]).astype(np.int32))
+        assert np.array_equal(g[2].cpu().numpy().view(np.uint64), np.concatenate([o.values(s) for s in range(len(kmers))]).view(np.uint64))
+        eng2.close()
     finally:
         dist.destroy_process_group()
 
