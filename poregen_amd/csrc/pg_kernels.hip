@@ -999,7 +999,8 @@ template <int BINS> __device__ __forceinline__ void stats_bin8(uint32_t *hist, c
 }
 
 // inclusive prefix over the bins, in place
-template <int BINS> __device__ __forceinline__ void stats_prefix(uint32_t *hist, int lane, uint32_t span) {
+// returns the inclusive prefix at the last bin this lane owns (LDS variants; 0 for the global-memory histogram)
+template <int BINS> __device__ __forceinline__ uint32_t stats_prefix(uint32_t *hist, int lane, uint32_t span) {
     using C = StatsCfg<BINS>;
     if (C::GLOBAL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0); }
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1025,8 +1026,11 @@ template <int BINS> __device__ __forceinline__ void stats_prefix(uint32_t *hist,
 #pragma unroll 8
         for (int i = 0; i < BPL; ++i) { run += hist[lane * (BPL + 1) + i]; hist[lane * (BPL + 1) + i] = run; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return run;
     }
     __builtin_amdgcn_wave_barrier();
+    return 0;
 }
 
 // order statistics from the prefix sums: every search step tests 64 candidates (pg_select.h holds the arithmetic)
@@ -1097,14 +1101,24 @@ __device__ __forceinline__ void stats_select(const uint32_t *hist, int lane, con
 // between adjacent codes, a model that is off) it returns false and the caller runs stats_select.
 template <int BINS>
 __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane, const PgReadPlan &pl, uint64_t L, double offset,
-                                                  double scale, double &med_out, double &mad_out) {
+                                                  double scale, double &med_out, double &mad_out, uint32_t lane_end) {
     using Pre = typename StatsCfg<BINS>::Pre;
     PgSel<Pre> sel;
     sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = L;
     sel.offset = offset; sel.scale = scale;
     sel.begin();
     int bm = 0;
-    if (!sel.zmed) bm = wave_first_true(sel.span, [&](int b) { return sel.med_pred(b); });
+    if (!sel.zmed) {
+        if constexpr (StatsCfg<BINS>::GLOBAL) bm = wave_first_true(sel.span, [&](int b) { return sel.med_pred(b); });
+        else { // the prefix at the end of every lane's bins is still in a register: the lane, then the bin inside it
+            constexpr int BPL = StatsCfg<BINS>::BPL;
+            const uint64_t lm = __ballot(lane_end > sel.jmed); // jmed < nV <= the last lane's value: never empty
+            const int l0 = __ffsll((long long)lm) - 1;
+            const int b = l0 * BPL + (lane < BPL ? lane : BPL - 1);
+            const uint64_t bmask = __ballot(lane < BPL && sel.pre[b < sel.span ? b : sel.span - 1] > sel.jmed);
+            bm = l0 * BPL + __ffsll((long long)bmask) - 1;
+        }
+    }
     sel.set_median(bm);
     if (!sel.zmed && sel.sp > 0 && pg_pa(sel.c_lo + sel.sp - 1, offset, scale) >= sel.med) return false; // equal neighbours
     double best = INFINITY;
@@ -1184,7 +1198,7 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
                                              double *__restrict__ mad, int win, uint8_t *__restrict__ oor, int range_only) {
     using Pre = typename StatsCfg<BINS>::Pre;
     const uint64_t L = m.end - m.beg;
-    stats_prefix<BINS>(hist, lane, (uint32_t)m.span);
+    const uint32_t lane_end = stats_prefix<BINS>(hist, lane, (uint32_t)m.span);
     if (oor) { // SAM/BAM front-end: a read with ANY out-of-range sample is skipped as a whole (gmove.cpp:1149-1160)
         const uint32_t in_range = m.span ? Pre{hist}[(int)m.span - 1] : 0u;
         if (lane == 0) oor[r] = in_range != (uint32_t)L;
@@ -1192,7 +1206,7 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
     if (range_only) return;
     PgReadPlan pl; pl.c_lo = m.c_lo; pl.span = m.span; pl.z0 = m.z0; pl.status = 0;
     double m0, m1;
-    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1)) // win == 0: tests of the general path
+    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end)) // win == 0: tests of the general path
         stats_select<BINS>(hist, lane, pl, L, m.offset, m.scale, win, m0, m1);
     if (lane == 0) { med[r] = m0; mad[r] = m1; }
 }
