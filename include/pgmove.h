@@ -29,6 +29,9 @@
  * pg_finish                        the bytes the fprintf calls would have produced, as binary
  *                                                                         src/gmove.cpp:938-950
  * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
+ * pg_model / pg_model_format       the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
+ *                                  median / sstdev per k-mer, awk | datamash median of the dwell times
+ *                                                                         scripts/poregen.sh:54-85, 33-52
  * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
  * pg_last_batch_device / pg_kernel_stats*
  */
@@ -214,6 +217,39 @@ typedef struct {
     const double   *d_mad;
 } pg_device_view;
 pg_status pg_last_batch_device(pg_ctx *ctx, pg_device_view *out);
+
+/* Per-k-mer model over everything collected so far, computed on the device from the kept samples: what the
+ * reference's pipeline gets by reading the dump files back as text (scripts/poregen.sh:54-85: `tr ';,' '\n' < file |
+ * tail -n +2 | datamash median 1` and `... | datamash sstdev 1`; :33-52: awk comma counts | datamash median).
+ * The values are those of the "%.8f" TEXT gmove writes (src/gmove.cpp:941-944), i.e. integers of 1e-8 units:
+ *   - the first value of every file is dropped (`tail -n +2`) unless PG_MODEL_KEEP_FIRST is given;
+ *   - median = datamash's: middle value, or the mean of the two middle values;  sstdev = sqrt(sum (x-mean)^2/(n-1));
+ *   - dwell  = median over the file's ';'-separated fields of the number of commas: samples-1 per event, plus one 0
+ *     for the empty field behind the last ';' (files without events have no fields at all).
+ * Calls pg_finish first. Arrays are owned by the context, valid until the next pg_model/pg_reset/pg_destroy.
+ * PG_ERR_UNSUPPORTED (never a wrong number) if a slot holds a non-finite sample or |sample| >= 4e7, more than 2^23
+ * values, or values further than 2^40 units (10995.1 pA) from its first one. */
+enum { PG_MODEL_KEEP_FIRST = 1u << 0 };
+typedef struct {
+    uint32_t n_slots;
+    uint32_t flags;
+    const uint64_t *n_values;     /* [n_slots] values that count (0: the fields below are NaN / 0) */
+    const double   *median;       /* [n_slots] */
+    const double   *sstdev;       /* [n_slots] NaN when n_values < 2 */
+    const int64_t  *mid_lo;       /* [n_slots] the two middle order statistics, exact, in 1e-8 units */
+    const int64_t  *mid_hi;
+    const int64_t  *origin;       /* [n_slots] exact moments of d = value - origin (1e-8 units): */
+    const int64_t  *sum1;         /*           sum d                                              */
+    const uint64_t *sum2_lo;      /*           sum d*d, low and high 64 bits                      */
+    const uint64_t *sum2_hi;
+    const uint64_t *dwell_n;      /* [n_slots] fields awk sees (kept events + 1), 0 for an empty file */
+    const double   *dwell_median; /* [n_slots] */
+} pg_model_result;
+enum { PG_MODEL_TEXT_MEDIAN = 0, PG_MODEL_TEXT_SSTDEV = 1, PG_MODEL_TEXT_DWELL = 2 };
+pg_status pg_model(pg_ctx *ctx, uint32_t flags, pg_model_result *out);
+/* The number as datamash prints it ("%.14Lg" of its long double; "nan" for sstdev of one value; empty string when the
+ * slot has no value at all, like datamash on empty input). Returns the length written (excluding the NUL), 0 on error. */
+size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap);
 
 /* profiling (PG_FLAG_PROFILE): per-kernel launch counts and HIP-event times since the last reset */
 pg_status pg_kernel_stats(pg_ctx *ctx, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out);

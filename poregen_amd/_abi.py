@@ -22,12 +22,14 @@ PG_FLAG_DEBUG_NARROW = 8
 PG_FLAG_SHORT_READS_OK = 16
 PG_FLAG_SKIP_OUT_OF_RANGE = 32
 PG_FLAG_STOP_WHEN_FULL = 64
+PG_MODEL_KEEP_FIRST = 1
+PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_collect_gathered", "pg_sync", "pg_finish", "pg_all_slots_full",
-    "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream",
+    "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_format",
 ]
 
 
@@ -64,6 +66,14 @@ class PgDeviceView(C.Structure):
         ("n_events", C.c_uint64), ("n_samples", C.c_uint64), ("d_keep", C.c_void_p), ("d_ev_off", C.c_void_p),
         ("d_ev_len", C.c_void_p), ("d_ev_read", C.c_void_p), ("d_samp_off", C.c_void_p), ("d_samples", C.c_void_p),
         ("d_med", C.c_void_p), ("d_mad", C.c_void_p),
+    ]
+
+
+class PgModelResult(C.Structure):
+    _fields_ = [
+        ("n_slots", C.c_uint32), ("flags", C.c_uint32), ("n_values", C.c_void_p), ("median", C.c_void_p), ("sstdev", C.c_void_p),
+        ("mid_lo", C.c_void_p), ("mid_hi", C.c_void_p), ("origin", C.c_void_p), ("sum1", C.c_void_p), ("sum2_lo", C.c_void_p),
+        ("sum2_hi", C.c_void_p), ("dwell_n", C.c_void_p), ("dwell_median", C.c_void_p),
     ]
 
 
@@ -127,5 +137,7 @@ def load():
     lib.pg_last_batch_device.argtypes = [vp, C.POINTER(PgDeviceView)]; lib.pg_last_batch_device.restype = i32
     lib.pg_kernel_stats.argtypes = [vp, C.POINTER(PgKernelStat), u32, C.POINTER(u32)]; lib.pg_kernel_stats.restype = i32
     lib.pg_kernel_stats_reset.argtypes = [vp]; lib.pg_kernel_stats_reset.restype = i32
+    lib.pg_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_model.restype = i32
+    lib.pg_model_format.argtypes = [C.POINTER(PgModelResult), u32, i32, C.c_char_p, C.c_size_t]; lib.pg_model_format.restype = C.c_size_t
     _lib = lib
     return lib

@@ -3,6 +3,7 @@
 // parsing into batches, writing the dump directory. The per-read computation runs on the GPU.
 #include "../../../include/pgmove.h"
 #include "pg_host.h"
+#include <algorithm>
 
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,7 @@ struct option long_options[] = {
     {"version", no_argument, 0, 'V'}, {"debug-break", required_argument, 0, 0},
     // extensions of this implementation (not in the reference)
     {"batch_reads", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"lazy_stats", no_argument, 0, 0},
+    {"raw_model", required_argument, 0, 0}, {"stdv_limit", required_argument, 0, 0}, {"dwell_model", required_argument, 0, 0},
     {0, 0, 0, 0}};
 
 void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
@@ -71,6 +73,10 @@ void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
     fprintf(fp, "   --batch_reads INT          reads per GPU batch [20000]\n");
     fprintf(fp, "   --device INT               HIP device [0]\n");
     fprintf(fp, "   --lazy_stats               median/MAD only for reads that contribute a kept event\n");
+    fprintf(fp, "   --raw_model FILE           also write KMER<TAB>median<TAB>stddev of the kept samples per k-mer, computed on the GPU\n");
+    fprintf(fp, "                              (what scripts/poregen.sh calculate_mean_stddev_all derives from the dump files)\n");
+    fprintf(fp, "   --stdv_limit NUM           cap of the stddev column of --raw_model [3.1]\n");
+    fprintf(fp, "   --dwell_model FILE         also write KMER<TAB>median dwell (scripts/poregen.sh calculate_dwell_times_medians)\n");
 }
 
 struct HostBatch {
@@ -96,6 +102,7 @@ int gmove_main(int argc, char **argv) {
     const char *input_kmer_file = nullptr, *input_fastq_file = nullptr;
     FILE *fp_help = stderr;
     uint32_t batch_reads = 20000; int device = 0; bool lazy = false;
+    const char *raw_model_path = nullptr, *dwell_model_path = nullptr, *stdv_limit = "3.1";
     optind = 1;
     while ((c = getopt_long(argc, argv, "k:m:s:d", long_options, &longindex)) >= 0) { // src/gmove.cpp:240-327
         if (c == 'k') { if (atoi(optarg) < 1) { fprintf(stderr, "Kmer length should be larger than 0. You entered %d\n", atoi(optarg)); return EXIT_FAILURE; } opt.kmer_size = atoi(optarg); }
@@ -122,6 +129,9 @@ int gmove_main(int argc, char **argv) {
         else if (c == 0 && longindex == 22) batch_reads = (uint32_t)std::max(1, atoi(optarg));
         else if (c == 0 && longindex == 23) device = atoi(optarg);
         else if (c == 0 && longindex == 24) lazy = true;
+        else if (c == 0 && longindex == 25) raw_model_path = optarg;
+        else if (c == 0 && longindex == 26) stdv_limit = optarg;
+        else if (c == 0 && longindex == 27) dwell_model_path = optarg;
     }
     if (argc - optind != 3 || fp_help == stdout) { // src/gmove.cpp:330-336
         print_help(fp_help, opt);
@@ -129,6 +139,9 @@ int gmove_main(int argc, char **argv) {
     }
     const char *slow5file = argv[optind], *move_table = argv[optind + 1], *output_dir = argv[optind + 2];
     if (opt.kmer_size <= opt.sig_move_offset) fprintf(stderr, "[gmove::WARNING] signal move offset value should be less than the kmer length\n");
+
+    if (raw_model_path && opt.delimit_files) return die("--raw_model cannot be combined with -d: the ':' delimiters are not numbers (datamash stops on them)");
+    { char *end = nullptr; (void)strtold(stdv_limit, &end); if (end == stdv_limit || *end) return die("--stdv_limit must be a number. You entered %s", stdv_limit); }
 
     int rcd = pgh::create_dir(output_dir); // src/gmove.cpp:374-392
     if (rcd == -1) { fprintf(stderr, "Output directory %s is not empty. Please remove it or specify another directory.\n", output_dir); return EXIT_FAILURE; }
@@ -430,6 +443,39 @@ int gmove_main(int argc, char **argv) {
             const clk::time_point td0 = clk::now();
             if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
             t_dump = secs(td0, clk::now());
+            if (status == EXIT_SUCCESS && (raw_model_path || dwell_model_path)) { // scripts/poregen.sh:54-85, 33-52 without the text round trip
+                const clk::time_point tm0 = clk::now();
+                pg_model_result mr;
+                if (pg_model(ctx, 0, &mr) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+                else {
+                    std::vector<uint32_t> order(res.n_slots); // the shell glob lists the dump files sorted by name
+                    for (uint32_t i = 0; i < res.n_slots; i++) order[i] = i;
+                    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return slot_kmers[a] < slot_kmers[b]; });
+                    char a[64], b[64];
+                    if (raw_model_path) {
+                        FILE *fp = fopen(raw_model_path, "w");
+                        if (!fp) { fprintf(stderr, "Could not open %s for writing.\n", raw_model_path); status = EXIT_FAILURE; }
+                        else {
+                            const long double lim = strtold(stdv_limit, nullptr);
+                            for (uint32_t i : order) {
+                                pg_model_format(&mr, i, PG_MODEL_TEXT_MEDIAN, a, sizeof a); pg_model_format(&mr, i, PG_MODEL_TEXT_SSTDEV, b, sizeof b);
+                                const bool capped = b[0] && strcmp(b, "nan") != 0 && strtold(b, nullptr) > lim; // bc -l: "$stddev > $limit"
+                                fprintf(fp, "%s\t%s\t%s\n", slot_kmers[i].c_str(), a, capped ? stdv_limit : b);
+                            }
+                            fclose(fp);
+                        }
+                    }
+                    if (dwell_model_path) {
+                        FILE *fp = fopen(dwell_model_path, "a"); // the script appends to this file
+                        if (!fp) { fprintf(stderr, "Could not open %s for writing.\n", dwell_model_path); status = EXIT_FAILURE; }
+                        else {
+                            for (uint32_t i : order) { pg_model_format(&mr, i, PG_MODEL_TEXT_DWELL, a, sizeof a); fprintf(fp, "%s\t%s\n", slot_kmers[i].c_str(), a); }
+                            fclose(fp);
+                        }
+                    }
+                }
+                fprintf(stderr, "\n[gmove] time: k-mer model on the device %.3f s", secs(tm0, clk::now()));
+            }
             fprintf(stderr, "\n[gmove] time: file indices + k-mer list %.3f s, device context %.3f s\n", secs(t_setup0, t_setup1), secs(t_setup1, t_loop0));
             fprintf(stderr, "[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
                     t_loop - t_device, t_device, t_finish, t_dump);

@@ -4,6 +4,7 @@
 #include "../../include/pgmove.h"
 #include "pg_internal.h"
 #include "pg_select.h"
+#include "pg_model.h"
 
 #include <algorithm>
 #include <climits>
@@ -71,6 +72,7 @@ struct pg_ctx {
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf m_read, meta, huge_scratch, oor;
+    DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
@@ -90,6 +92,12 @@ struct pg_ctx {
     std::vector<uint32_t> r_ev_len, r_ev_read;
     std::vector<double> r_samples;
     std::vector<uint8_t> r_skipped;
+    // pg_model
+    std::vector<PgSlotModel> mo_raw;
+    std::vector<PgSlotDwell> mo_dw;
+    std::vector<uint64_t> mo_n, mo_s2lo, mo_s2hi, mo_dn;
+    std::vector<int64_t> mo_lo, mo_hi, mo_origin, mo_s1;
+    std::vector<double> mo_med, mo_sd, mo_dmed;
 
     std::vector<ProfEntry> prof;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -202,7 +210,8 @@ void pg_destroy(pg_ctx *c) {
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
-                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor};
+                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor,
+                      &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -757,6 +766,78 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
     out->read_skipped = c->r_skipped.data();
     return PG_OK;
+}
+
+pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    pg_result R;
+    pg_status s = pg_finish(c, &R);
+    if (s != PG_OK) return s;
+    const uint32_t ns = c->prm.n_slots;
+    const uint64_t *d_ev_off, *d_samp_off; const uint32_t *d_ev_len; const double *d_samples;
+    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
+        // one batch: its kept events are still on the device, in the same order
+        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off.as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
+    } else { // several batches were merged on the host (slot-major): hand the merged arrays back
+        HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
+        HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4)); HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
+        HIP_TRY(c, hipMemcpyAsync(c->md_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, hipMemcpyAsync(c->md_samp_off.p, R.samp_off, (R.n_events + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        if (R.n_events) HIP_TRY(c, hipMemcpyAsync(c->md_ev_len.p, R.ev_len, R.n_events * 4ull, hipMemcpyHostToDevice, c->st));
+        if (R.n_samples) HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
+        d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
+    }
+    HIP_TRY(c, c->md_out.ensure(ns * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure(ns * sizeof(PgSlotDwell)));
+    prof_begin(c, "k_slot_model", c->st);
+    HIP_TRY(c, pg_launch_slot_model(c->st, ns, R.n_samples, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
+                                    c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
+    prof_end(c, c->st);
+    c->mo_raw.resize(ns); c->mo_dw.resize(ns);
+    HIP_TRY(c, hipMemcpyAsync(c->mo_raw.data(), c->md_out.p, ns * sizeof(PgSlotModel), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipMemcpyAsync(c->mo_dw.data(), c->md_dwell.p, ns * sizeof(PgSlotDwell), hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->mo_n.resize(ns); c->mo_s2lo.resize(ns); c->mo_s2hi.resize(ns); c->mo_dn.resize(ns); c->mo_lo.resize(ns); c->mo_hi.resize(ns);
+    c->mo_origin.resize(ns); c->mo_s1.resize(ns); c->mo_med.resize(ns); c->mo_sd.resize(ns); c->mo_dmed.resize(ns);
+    for (uint32_t i = 0; i < ns; i++) {
+        const PgSlotModel &m = c->mo_raw[i]; const PgSlotDwell &d = c->mo_dw[i];
+        if (d.flags & PG_MODEL_BAD_VALUE) return fail(c, PG_ERR_UNSUPPORTED, "pg_model: slot %u holds a non-finite sample or one with |x| >= 4e7", i);
+        if (d.flags & PG_MODEL_BAD_COUNT) return fail(c, PG_ERR_UNSUPPORTED, "pg_model: slot %u holds more than 2^23 values", i);
+        if (d.flags & PG_MODEL_BAD_SPREAD) return fail(c, PG_ERR_UNSUPPORTED, "pg_model: slot %u holds values further than 2^40 units of 1e-8 from its first one", i);
+        const unsigned __int128 s2 = ((unsigned __int128)m.s2_hh << 40) + ((unsigned __int128)m.s2_hl << 21) + m.s2_ll;
+        c->mo_n[i] = m.n; c->mo_lo[i] = m.mid_lo; c->mo_hi[i] = m.mid_hi; c->mo_origin[i] = m.origin; c->mo_s1[i] = m.s1;
+        c->mo_s2lo[i] = (uint64_t)s2; c->mo_s2hi[i] = (uint64_t)(s2 >> 64);
+        c->mo_med[i] = m.n ? (double)pg_model_median(m) : NAN;
+        c->mo_sd[i] = m.n >= 2 ? (double)(pg_model_sstdev_units(m) / 1e8L) : NAN;
+        c->mo_dn[i] = d.n; c->mo_dmed[i] = d.n ? ((double)d.mid_lo + (double)d.mid_hi) / 2.0 : NAN;
+    }
+    out->n_slots = ns; out->flags = flags; out->n_values = c->mo_n.data(); out->median = c->mo_med.data(); out->sstdev = c->mo_sd.data();
+    out->mid_lo = c->mo_lo.data(); out->mid_hi = c->mo_hi.data(); out->origin = c->mo_origin.data(); out->sum1 = c->mo_s1.data();
+    out->sum2_lo = c->mo_s2lo.data(); out->sum2_hi = c->mo_s2hi.data(); out->dwell_n = c->mo_dn.data(); out->dwell_median = c->mo_dmed.data();
+    return PG_OK;
+}
+
+size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap) {
+    if (!m || !buf || cap == 0 || slot >= m->n_slots) return 0;
+    int w = 0;
+    buf[0] = 0;
+    if (which == PG_MODEL_TEXT_DWELL) {
+        if (m->dwell_n[slot] == 0) return 0;
+        w = snprintf(buf, cap, "%.14Lg", (long double)m->dwell_median[slot]); // integers or halves: exact
+    } else if (which == PG_MODEL_TEXT_MEDIAN || which == PG_MODEL_TEXT_SSTDEV) {
+        if (m->n_values[slot] == 0) return 0; // datamash prints nothing for empty input
+        PgSlotModel r{};
+        r.n = m->n_values[slot]; r.mid_lo = m->mid_lo[slot]; r.mid_hi = m->mid_hi[slot]; r.s1 = m->sum1[slot];
+        if (which == PG_MODEL_TEXT_MEDIAN) w = snprintf(buf, cap, "%.14Lg", pg_model_median(r));
+        else if (r.n < 2) w = snprintf(buf, cap, "nan"); // 0/0 in datamash's sample variance
+        else {
+            const unsigned __int128 s2 = ((unsigned __int128)m->sum2_hi[slot] << 64) | m->sum2_lo[slot];
+            const __int128 s1 = r.s1;
+            const unsigned __int128 num = (unsigned __int128)r.n * s2 - (unsigned __int128)(s1 * s1);
+            const long double sd = sqrtl((long double)num / ((long double)r.n * (long double)(r.n - 1))) / 1e8L;
+            w = snprintf(buf, cap, "%.14Lg", sd);
+        }
+    } else return 0;
+    return (w < 0 || (size_t)w >= cap) ? 0 : (size_t)w;
 }
 
 pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out) {

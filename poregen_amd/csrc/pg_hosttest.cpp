@@ -92,3 +92,26 @@ extern "C" long pgt_sam_first(const char *path, char *qname, char *seq, size_t c
     if (r.next(m2, err) != 0) return -2; // the fixtures hold exactly one record
     return n_moves;
 }
+
+// pg_model.h: the fixed-point view of a "%.8f" print-out, and the host-side finishing arithmetic on hand-made moments
+#include "pg_model.h"
+#include <algorithm>
+#include <cstdio>
+extern "C" long long pgt_fixed8(double x, int *bad) { bool b = false; const long long v = pg_fixed8(x, b); *bad = b; return v; }
+// values given as 1e-8 units: median text and sstdev text the library would print (same arithmetic as pg_model_format)
+extern "C" void pgt_model_texts(const long long *units, size_t n, char *med, char *sd, size_t cap) {
+    std::vector<long long> v(units, units + n);
+    PgSlotModel m{};
+    m.n = n; m.origin = n ? v[0] : 0;
+    for (size_t i = 0; i < n; i++) {
+        const long long d = v[i] - m.origin; const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+        const unsigned long long h = ad >> PG_MODEL_LIMB_BITS, l = ad & ((1u << PG_MODEL_LIMB_BITS) - 1);
+        m.s1 += d; m.s2_hh += h * h; m.s2_hl += h * l; m.s2_ll += l * l;
+    }
+    std::sort(v.begin(), v.end());
+    if (n) { m.mid_lo = v[(n - 1) / 2]; m.mid_hi = v[n / 2]; }
+    med[0] = sd[0] = 0;
+    if (!n) return;
+    snprintf(med, cap, "%.14Lg", pg_model_median(m));
+    if (n < 2) snprintf(sd, cap, "nan"); else snprintf(sd, cap, "%.14Lg", pg_model_sstdev_units(m) / 1e8L);
+}

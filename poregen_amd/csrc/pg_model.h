@@ -1,0 +1,70 @@
+// pg_model.h -- fixed-point view of the kept samples for the per-k-mer model reduction (shared host + device code).
+//
+// The reference has no code for this step: its pipeline (scripts/poregen.sh:54-85, calculate_mean_stddev_all) reads
+// the dump files back as TEXT and pipes them through `tr ';,' '\n' | tail -n +2 | datamash median 1` and
+// `... | datamash sstdev 1`. What datamash sees is therefore not the double gmove held but its "%.8f" print-out
+// (src/gmove.cpp:941-944): a decimal with eight fractional digits, i.e. an integer number of 1e-8 units. The device
+// reduction works on exactly those integers, so the median is exact and the moments are exact integers.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define PGM_HD __host__ __device__ __forceinline__
+#else
+#define PGM_HD inline
+#endif
+
+#define PG_MODEL_MAX_ABS 4.0e7            /* |sample| the fixed-point view accepts (|units| < 2^52) */
+#define PG_MODEL_LIMB_BITS 20             /* deviations from the slot's first value are split in two 20-bit limbs */
+#define PG_MODEL_MAX_DEV (1ll << 40)      /* |value - first value| in 1e-8 units the moment sums accept (~10995 pA) */
+#define PG_MODEL_MAX_VALUES (1ull << 23)  /* values per slot the moment sums accept (limb^2 sums stay below 2^63) */
+
+// printf("%.8f", x) as an integer number of 1e-8 units: the correctly rounded (ties to even, on the exact binary value,
+// like glibc) product x * 10^8. p + e is that product exactly (10^8 is a double; the FMA returns the rounding error).
+PGM_HD int64_t pg_fixed8(double x, bool &bad) {
+    if (!(fabs(x) < PG_MODEL_MAX_ABS)) { bad = true; return 0; } // also NaN
+    const double p = x * 1e8;        // |p| < 2^52: ulp(p) <= 1/2
+    const double e = fma(x, 1e8, -p);
+    const double r = rint(p);        // ties to even in the default rounding mode
+    const double f = p - r;          // exact, a multiple of ulp(p) in [-1/2, 1/2]; |e| <= ulp(p)/2
+    int64_t v = (int64_t)r;
+    // |f| < 1/2: f + e cannot reach 1/2. |f| = 1/2: p sits on a tie that rint broke to even; e says on which side the
+    // exact product lies (e == 0: a true tie, already even).
+    if (f == 0.5 && e > 0.0) v += 1;
+    else if (f == -0.5 && e < 0.0) v -= 1;
+    return v;
+}
+
+// One slot's reduction as the kernel leaves it (64 bytes).
+struct PgSlotModel {
+    uint64_t n;        // values that reach datamash (all samples of the slot but the first: `tail -n +2`)
+    int64_t origin;    // fixed8 of the first value that counts; the sums below are over d = value - origin
+    int64_t s1;        // sum d
+    uint64_t s2_hh, s2_hl, s2_ll; // |d| = h * 2^20 + l:  sum h*h, sum h*l, sum l*l   (sum d^2 = hh*2^40 + hl*2^21 + ll)
+    int64_t mid_lo, mid_hi;       // the two middle order statistics (equal when n is odd), 1e-8 units
+};
+struct PgSlotDwell {
+    uint64_t n;        // fields awk sees in the file: kept events + the empty field behind the last ';'
+    uint32_t mid_lo, mid_hi; // middle order statistics of (samples in the event - 1) and that one 0
+    uint32_t flags;    // PG_MODEL_BAD_*
+    uint32_t pad;
+};
+enum { PG_MODEL_BAD_VALUE = 1, PG_MODEL_BAD_SPREAD = 2, PG_MODEL_BAD_COUNT = 4 };
+
+// Host side. sample standard deviation (datamash sstdev: sqrt(sum (x-mean)^2 / (n-1))) from the exact moments, in 1e-8 units.
+// n*sum d^2 - (sum d)^2 is an exact 128-bit integer; one rounding to long double, one division, one square root.
+inline long double pg_model_sstdev_units(const PgSlotModel &m) {
+    if (m.n < 2) return NAN;
+    const unsigned __int128 s2 = ((unsigned __int128)m.s2_hh << 40) + ((unsigned __int128)m.s2_hl << 21) + m.s2_ll;
+    const __int128 s1 = m.s1;
+    const unsigned __int128 num = (unsigned __int128)m.n * s2 - (unsigned __int128)(s1 * s1);
+    const long double den = (long double)m.n * (long double)(m.n - 1);
+    return sqrtl((long double)num / den);
+}
+// datamash median of the decimal texts: each text becomes the long double nearest to units/10^8 (strtold), the two
+// middle ones are averaged in long double.
+inline long double pg_model_median(const PgSlotModel &m) {
+    const long double a = (long double)m.mid_lo / 1e8L, b = (long double)m.mid_hi / 1e8L;
+    return m.mid_lo == m.mid_hi ? a : (a + b) / 2.0L;
+}

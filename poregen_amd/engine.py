@@ -161,6 +161,38 @@ class Result:
         return ",".join("%.8f" % x for x in v) + ";"
 
 
+@dataclass
+class Model:
+    """pg_model_result as numpy arrays (one entry per slot) plus datamash-formatted texts."""
+    n_values: np.ndarray
+    median: np.ndarray
+    sstdev: np.ndarray
+    mid_lo: np.ndarray
+    mid_hi: np.ndarray
+    origin: np.ndarray
+    sum1: np.ndarray
+    sum2_lo: np.ndarray
+    sum2_hi: np.ndarray
+    dwell_n: np.ndarray
+    dwell_median: np.ndarray
+    median_text: List[str]
+    sstdev_text: List[str]
+    dwell_text: List[str]
+
+    def raw_model_lines(self, kmers: List[str], limit: str = "3.1") -> str:
+        """The file calculate_mean_stddev_all writes (scripts/poregen.sh:54-85): sorted by name, stddev capped."""
+        out = []
+        for i in sorted(range(len(kmers)), key=lambda j: kmers[j]):
+            sd = self.sstdev_text[i]
+            if sd not in ("", "nan") and float(sd) > float(limit):
+                sd = limit
+            out.append(f"{kmers[i]}\t{self.median_text[i]}\t{sd}\n")
+        return "".join(out)
+
+    def dwell_lines(self, kmers: List[str]) -> str:
+        return "".join(f"{kmers[i]}\t{self.dwell_text[i]}\n" for i in sorted(range(len(kmers)), key=lambda j: kmers[j]))
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -292,6 +324,32 @@ class GmoveEngine:
                       ev_len=arr(r.ev_len, ne, np.uint32), ev_read=arr(r.ev_read, ne, np.uint32),
                       samp_off=arr(r.samp_off, ne + 1, np.uint64), samples=arr(r.samples, nsmp, np.float64),
                       read_skipped=arr(r.read_skipped, nr, np.uint8), n_reads=int(nr))
+
+    def model(self, keep_first: bool = False) -> "Model":
+        """Per-k-mer median / sample stddev / dwell median of everything collected so far, reduced on the device from
+        the kept samples (pg_model): the values `scripts/poregen.sh:54-85,33-52` derive from the dump files with
+        tr | tail | datamash. `text(slot, which)` gives the number exactly as datamash prints it."""
+        m = _abi.PgModelResult()
+        self._check(self._lib.pg_model(self._h, _abi.PG_MODEL_KEEP_FIRST if keep_first else 0, C.byref(m)))
+        ns = m.n_slots
+
+        def arr(ptr, dt):
+            if ns == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.frombuffer((C.c_char * (ns * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt).copy()
+        buf = C.create_string_buffer(64)
+        texts = []
+        for which in (_abi.PG_MODEL_TEXT_MEDIAN, _abi.PG_MODEL_TEXT_SSTDEV, _abi.PG_MODEL_TEXT_DWELL):
+            col = []
+            for s in range(ns):
+                n = self._lib.pg_model_format(C.byref(m), s, which, buf, 64)
+                col.append(buf.raw[:n].decode())
+            texts.append(col)
+        return Model(n_values=arr(m.n_values, np.uint64), median=arr(m.median, np.float64), sstdev=arr(m.sstdev, np.float64),
+                     mid_lo=arr(m.mid_lo, np.int64), mid_hi=arr(m.mid_hi, np.int64), origin=arr(m.origin, np.int64),
+                     sum1=arr(m.sum1, np.int64), sum2_lo=arr(m.sum2_lo, np.uint64), sum2_hi=arr(m.sum2_hi, np.uint64),
+                     dwell_n=arr(m.dwell_n, np.uint64), dwell_median=arr(m.dwell_median, np.float64),
+                     median_text=texts[0], sstdev_text=texts[1], dwell_text=texts[2])
 
     def device_view(self):
         v = _abi.PgDeviceView()

@@ -1,0 +1,163 @@
+"""pg_model (the k-mer model reduced on the device) against the CPU chain gmove oracle -> dump files -> model oracle
+(oracle/model_oracle.c: tr | tail | datamash restated). Median and dwell texts must be identical; the sstdev text may
+differ by one unit of its 14th significant digit (datamash sums left to right in long double, the device sums exact
+integers)."""
+import os
+import subprocess
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+from helpers import oracle_for
+from poregen_amd import synth
+from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle", "model_oracle")
+BIN = os.path.join(ROOT, "bin", "poregen")
+
+
+def oracle_lines(dump_dir, mode, *args):
+    out = subprocess.run([ORACLE, mode, str(dump_dir)] + list(args), capture_output=True, check=True).stdout.decode()
+    return out.splitlines(keepends=True)
+
+
+def same_number_14(a: str, b: str, ulps=1) -> bool:
+    if a == b:
+        return True
+    if a in ("", "nan") or b in ("", "nan"):
+        return False
+    x, y = Decimal(a), Decimal(b)
+    unit = Decimal(1).scaleb(max(x.adjusted(), y.adjusted()) - 13)
+    return abs(x - y) <= unit * ulps
+
+
+def compare_raw_model(mine: str, want_lines, allow_sd_digit=True):
+    got = mine.splitlines(keepends=True)
+    assert len(got) == len(want_lines)
+    off = 0
+    for g, w in zip(got, want_lines):
+        gk, gm, gs = g.rstrip("\n").split("\t"); wk, wm, ws = w.rstrip("\n").split("\t")
+        assert gk == wk and gm == wm, (g, w)
+        if gs != ws:
+            assert allow_sd_digit and same_number_14(gs, ws), (g, w)
+            off += 1
+    assert off <= max(2, len(got) // 50), f"{off} of {len(got)} stddev texts differ in the last digit"
+
+
+def dump_from_oracle(tmp_path, o, kmers, name="dump"):
+    d = tmp_path / name
+    d.mkdir()
+    for s, k in enumerate(kmers):
+        (d / k).write_text(o.text(s))
+    return d
+
+
+@pytest.mark.parametrize("scaling,limit,kind", [(1, 100, "rna004"), (0, 37, "dna_r10"), (1, 1, "dna_r10")])
+def test_model_equals_text_pipeline(tmp_path, scaling, limit, kind):
+    rna = kind == "rna004"
+    kmers = generate_kmers(5, rna=rna)
+    p = dict(kmer_size=5, scaling=scaling, sample_limit=limit, rna=rna)
+    b = synth.make_batch(1500, kind=kind, seed=77, indel_rate=0.02)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    d = dump_from_oracle(tmp_path, o, kmers)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    m = eng.model()
+    compare_raw_model(m.raw_model_lines(kmers, "3.1"), oracle_lines(d, "stats", "3.1"))
+    compare_raw_model(m.raw_model_lines(kmers, "0.5"), oracle_lines(d, "stats", "0.5"))
+    assert m.dwell_lines(kmers) == "".join(oracle_lines(d, "dwell"))
+    # the same job in three batches: merged on the host, reduced from the re-uploaded arrays
+    eng.reset()
+    for lo, hi in ((0, 400), (400, 401), (401, 1500)):
+        eng.submit(b.slice_reads(lo, hi))
+    m3 = eng.model()
+    assert m3.median_text == m.median_text and m3.sstdev_text == m.sstdev_text and m3.dwell_text == m.dwell_text
+    assert np.array_equal(m3.sum1, m.sum1) and np.array_equal(m3.sum2_lo, m.sum2_lo) and np.array_equal(m3.n_values, m.n_values)
+    # numeric fields agree with the texts
+    has = m.n_values > 0
+    assert np.allclose(m.median[has], [float(t) for t, h in zip(m.median_text, has) if h], rtol=1e-13, atol=0)
+    # keep_first: one more value per non-empty file
+    mk = eng.model(keep_first=True)
+    res = eng.finish()
+    per_slot = np.array([int(res.samp_off[int(res.ev_off[s + 1])] - res.samp_off[int(res.ev_off[s])]) for s in range(len(kmers))], dtype=np.uint64)
+    assert np.array_equal(mk.n_values, per_slot) and np.array_equal(m.n_values, np.where(per_slot > 0, per_slot - 1, 0))
+    for s in np.flatnonzero(per_slot)[:50]:
+        v = np.sort(np.array([int(Decimal("%.8f" % x).scaleb(8)) for x in res.slot_values(int(s))], dtype=np.int64))
+        n = v.size
+        assert mk.mid_lo[s] == v[(n - 1) // 2] and mk.mid_hi[s] == v[n // 2]
+        dd = (v - mk.origin[s]).astype(object)
+        assert int(mk.sum1[s]) == sum(dd) and (int(mk.sum2_hi[s]) << 64) + int(mk.sum2_lo[s]) == sum(x * x for x in dd)
+    eng.close()
+
+
+def test_model_tiny_files_one_value_and_empty(tmp_path):
+    """every event two samples long, one event per k-mer: `tail -n +2` leaves ONE value (sstdev nan); untouched k-mers are empty"""
+    kmers = generate_kmers(5)
+    b = synth.make_batch(4, kind="dna_r10", seed=5, read_len=4000)
+    b.op_n[:] = 2
+    p = dict(kmer_size=5, scaling=0, sample_limit=1, min_dur=1)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    d = dump_from_oracle(tmp_path, o, kmers)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    m = eng.model()
+    want = oracle_lines(d, "stats", "3.1")
+    assert m.raw_model_lines(kmers, "3.1") == "".join(want)
+    assert any(l.endswith("\tnan\n") for l in want) and any(l.endswith("\t\t\n") for l in want)
+    assert m.dwell_lines(kmers) == "".join(oracle_lines(d, "dwell"))
+    mk = eng.model(keep_first=True)
+    assert set(np.unique(mk.n_values)) == {0, 2}
+    eng.close()
+
+
+def test_model_large_slots_and_big_limit(tmp_path):
+    """a 64-k-mer list at sample_limit 4000: ~100 k values per slot (the 1024-thread variant), even and odd counts"""
+    kmers = generate_kmers(3, rna=True)
+    p = dict(kmer_size=3, scaling=1, sample_limit=4000, rna=True, min_dur=5, max_dur=70)
+    b = synth.make_batch(4000, kind="rna004", seed=123)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    d = dump_from_oracle(tmp_path, o, kmers)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    m = eng.model()
+    assert int(m.n_values.max()) > 50000
+    compare_raw_model(m.raw_model_lines(kmers, "3.1"), oracle_lines(d, "stats", "3.1"))
+    assert m.dwell_lines(kmers) == "".join(oracle_lines(d, "dwell"))
+    eng.close()
+
+
+def test_model_rejects_what_it_cannot_represent():
+    """pa_max far above the fixed-point range: a kept sample of 5e7 pA must be an error, not a wrong number"""
+    from poregen_amd.engine import PgError
+    kmers = generate_kmers(5)
+    b = synth.make_batch(20, kind="dna_r10", seed=9)
+    b.range[:] = b.range * 1e6                 # pA values around 1e8
+    eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=5, scaling=0, sample_limit=5, pa_min=-1e300, pa_max=1e300))
+    eng.submit(b)
+    with pytest.raises(PgError) as ei:
+        eng.model()
+    assert "4e7" in str(ei.value)
+    eng.close()
+
+
+def test_cli_raw_model_and_dwell_model(tmp_path):
+    b = synth.make_batch(300, kind="rna004", seed=31)
+    pre = str(tmp_path / "in")
+    synth.write_files(b, pre)
+    out = tmp_path / "out"
+    raw, dwell = tmp_path / "raw_model", tmp_path / "dwell_times"
+    r = subprocess.run([BIN, "gmove", "-k", "5", "--rna", "--scaling", "1", "--file_limit", "1024", "--sample_limit", "50", "--min_dur", "19",
+                        "--max_dur", "51", pre + ".slow5", pre + ".paf", str(out), "--fastq", pre + ".fastq", "--raw_model", str(raw),
+                        "--dwell_model", str(dwell), "--stdv_limit", "0.9"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    compare_raw_model(raw.read_text(), oracle_lines(out / "dump", "stats", "0.9"))
+    assert dwell.read_text() == "".join(oracle_lines(out / "dump", "dwell"))
+    assert "\t0.9\n" in raw.read_text()
+    # -d and --raw_model exclude each other; a bad limit is refused before any work
+    r = subprocess.run([BIN, "gmove", "-k", "5", "-d", pre + ".slow5", pre + ".paf", str(tmp_path / "o2"), "--fastq", pre + ".fastq", "--raw_model", str(raw)], capture_output=True)
+    assert r.returncode != 0 and b"cannot be combined with -d" in r.stderr
+    r = subprocess.run([BIN, "gmove", "-k", "5", pre + ".slow5", pre + ".paf", str(tmp_path / "o3"), "--fastq", pre + ".fastq", "--raw_model", str(raw), "--stdv_limit", "abc"], capture_output=True)
+    assert r.returncode != 0 and not (tmp_path / "o3").exists()
