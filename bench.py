@@ -133,6 +133,16 @@ def main():
     ks = prof.kernel_stats()
     res = prof.finish()
     kept_events = int(res.counts.sum()); kept_samples = int(res.samples.size)
+    # the k-mer model reduction (pg_model) over this batch's kept samples: once per JOB, not part of the step
+    for _ in range(2):
+        prof.model()                       # first launch loads the code object
+    prof.kernel_stats_reset()
+    for _ in range(5):
+        mdl = prof.model()
+    km = prof.kernel_stats()["k_slot_model"]
+    model_ms = km[1] / km[0]
+    model_info = {"kernel": "k_slot_model", "avg_launch_ms": model_ms, "values": int(mdl.n_values.sum()),
+                  "algorithmic_bytes": 8 * kept_samples + 4 * kept_events, "GB/s": (8 * kept_samples + 4 * kept_events) / (model_ms * 1e-3) / 1e9}
     prof.close()
     stats_ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]
     # algorithmic bytes of the statistics kernels per launch: every int16 sample once, the three
@@ -189,6 +199,7 @@ def main():
         "roofline": roofline,
         "kernels_ms_per_step": kernels_ms,
         "lazy_statistics_mode": lazy_info,
+        "kmer_model_once_per_job": model_info,
         "gen_seconds": gen_s,
     }
 

@@ -14,6 +14,12 @@
 namespace {
 
 constexpr int M_BITS = 12, M_BINS = 1 << M_BITS;
+// loads in flight per thread: the 1024-thread variant must stay within 64 VGPRs (two workgroups per CU), its memory
+// parallelism comes from 32 waves per CU; the 256-thread variant serves short files, where the round trips are the cost
+template <int MT> struct ModelCfg {
+    static constexpr int U = MT >= 1024 ? 2 : 8;
+    static constexpr int CACHE = MT >= 1024 ? 0 : 16; // keys a thread keeps in registers when the whole file fits (MT * CACHE values)
+};
 
 template <int MT> struct ModelSmem {
     uint32_t hist[M_BINS];
@@ -26,7 +32,10 @@ __device__ __forceinline__ uint64_t op_sum(uint64_t a, uint64_t b) { return a + 
 __device__ __forceinline__ uint64_t op_min(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t op_max(uint64_t a, uint64_t b) { return a > b ? a : b; }
 
-// every thread gets the reduction of v over the block
+__device__ __forceinline__ uint32_t uniform32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) { return ((uint64_t)uniform32((uint32_t)(v >> 32)) << 32) | uniform32((uint32_t)v); }
+
+// every thread gets the reduction of v over the block (in scalar registers: the value is the same in every lane)
 template <int MT, class Op> __device__ uint64_t block_reduce(ModelSmem<MT> &sm, uint64_t v, Op op) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = op(v, (uint64_t)__shfl_xor((unsigned long long)v, o, 64));
@@ -36,17 +45,17 @@ template <int MT, class Op> __device__ uint64_t block_reduce(ModelSmem<MT> &sm, 
     uint64_t r = sm.red[0];
 #pragma unroll
     for (int w = 1; w < MT / 64; ++w) r = op(r, sm.red[w]);
-    return r;
+    return uniform64(r);
 }
 
-// bin b with below(b) <= rank < below(b) + hist[b]; the total of hist must exceed rank
-template <int MT> __device__ void block_find_bin(ModelSmem<MT> &sm, uint32_t rank, uint32_t &bin, uint32_t &below) {
+// bin b < nbins with below(b) <= rank < below(b) + hist[b]; the total of hist[0..nbins) must exceed rank
+template <int MT> __device__ void block_find_bin(ModelSmem<MT> &sm, uint32_t rank, uint32_t nbins, uint32_t &bin, uint32_t &below) {
     constexpr int PER = M_BINS / MT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     __syncthreads(); // histogram complete
     uint32_t h[PER], s = 0;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { h[i] = sm.hist[t * PER + i]; s += h[i]; }
+    for (int i = 0; i < PER; ++i) { h[i] = (uint32_t)(t * PER + i) < nbins ? sm.hist[t * PER + i] : 0u; s += h[i]; }
     uint32_t inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= o) inc += u; }
@@ -63,53 +72,94 @@ template <int MT> __device__ void block_find_bin(ModelSmem<MT> &sm, uint32_t ran
         }
     }
     __syncthreads();
-    bin = sm.found_bin; below = sm.found_below;
+    bin = uniform32(sm.found_bin); below = uniform32(sm.found_below);
+}
+
+// fn(key_at(i)) for i in [0, n), this thread's share: U loads are issued before the first use, so that a pass costs
+// n / (MT * U) memory round trips instead of n / MT (the LDS atomics in fn keep the compiler from hoisting loads itself)
+template <int MT, int U, class T, class At, class Fn> __device__ __forceinline__ void for_each_mine(uint64_t n, At at, Fn fn) {
+    for (uint64_t base = 0; base < n; base += (uint64_t)MT * U) {
+        T k[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint64_t i = base + (uint64_t)u * MT + threadIdx.x; ok[u] = i < n; k[u] = at(ok[u] ? i : n - 1); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (ok[u]) fn(k[u]);
+    }
 }
 
 __device__ __forceinline__ uint64_t shr64(uint64_t v, int s) { return s >= 64 ? 0ull : v >> s; }
 
-// the rank-th smallest (0-based) of key_at(0..n-1); all keys < 2^bits
-template <int MT, class KeyAt> __device__ uint64_t block_select(ModelSmem<MT> &sm, uint64_t n, uint64_t rank, int bits, KeyAt key_at) {
-    const int passes = bits <= 0 ? 0 : (bits + M_BITS - 1) / M_BITS;
+// A source of keys hands every thread its share: each(fn) calls fn(key).
+template <int MT, class At> struct GlobalKeys { // re-read (L2 / MALL) and re-converted on every pass
+    uint64_t n; At at;
+    template <class Fn> __device__ __forceinline__ void each(Fn fn) const { for_each_mine<MT, ModelCfg<MT>::U, uint64_t>(n, at, fn); }
+};
+template <int C> struct RegKeys { // converted once, kept in registers: element u of thread t is value u * MT + t
+    uint64_t k[C > 0 ? C : 1]; int cnt; uint64_t mn;
+    template <class Fn> __device__ __forceinline__ void each(Fn fn) const {
+#pragma unroll
+        for (int u = 0; u < C; ++u) if (u < cnt) fn(k[u] - mn);
+    }
+};
+
+// the rank-th smallest (0-based) of the source's keys; all keys < 2^bits. The bits are consumed from the top in windows of
+// at most M_BITS; the last (lowest) window is the short one, so that a narrow key range costs a small histogram.
+template <int MT, class Src> __device__ uint64_t block_select(ModelSmem<MT> &sm, const Src &src, uint64_t rank, int bits) {
     uint64_t prefix = 0; // the bits above the current window
-    for (int p = passes - 1; p >= 0; --p) {
-        const int shift = p * M_BITS;
+    int hi = bits;       // bits [hi, 64) are settled
+    while (hi > 0) {
+        const int wbits = hi >= M_BITS ? M_BITS : hi, shift = hi - wbits;
+        const uint32_t nbins = 1u << wbits;
         __syncthreads();
-        for (int i = threadIdx.x; i < M_BINS; i += MT) sm.hist[i] = 0;
+        for (uint32_t i = threadIdx.x; i < nbins; i += MT) sm.hist[i] = 0;
         __syncthreads();
-        for (uint64_t i = threadIdx.x; i < n; i += MT) {
-            const uint64_t k = key_at(i);
-            if (shr64(k, shift + M_BITS) == prefix) atomicAdd(&sm.hist[(uint32_t)(k >> shift) & (M_BINS - 1)], 1u);
-        }
+        src.each([&](uint64_t k) {
+            if (shr64(k, hi) == prefix) atomicAdd(&sm.hist[(uint32_t)(k >> shift) & (nbins - 1)], 1u);
+        });
         uint32_t bin, below;
-        block_find_bin<MT>(sm, (uint32_t)rank, bin, below);
+        block_find_bin<MT>(sm, (uint32_t)rank, nbins, bin, below);
         rank -= below;
-        prefix = (prefix << M_BITS) | bin;
+        prefix = (prefix << wbits) | bin;
+        hi = shift;
     }
     return prefix;
 }
 
-template <int MT> __global__ __launch_bounds__(MT) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
+// datamash's two middle order statistics of n keys (equal when n is odd)
+template <int MT, class Src> __device__ void block_middle(ModelSmem<MT> &sm, const Src &src, uint64_t n, int bits, uint64_t &k_lo, uint64_t &k_hi) {
+    const uint64_t r_lo = (n - 1) / 2, r_hi = n / 2;
+    k_lo = block_select<MT>(sm, src, r_lo, bits);
+    k_hi = k_lo;
+    if (r_hi != r_lo) { // even count: the next order statistic is k_lo again or the smallest key above it
+        uint64_t le = 0, gt = ~0ull;
+        src.each([&](uint64_t k) { if (k <= k_lo) le++; else gt = op_min(gt, k); });
+        le = block_reduce<MT>(sm, le, op_sum); gt = block_reduce<MT>(sm, gt, op_min);
+        if (le <= r_hi) k_hi = gt;
+    }
+}
+
+template <int MT> __global__ __launch_bounds__(MT, MT >= 1024 ? 8 : 4) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
                                                                       const double *samples, uint32_t drop_first, PgSlotModel *out,
                                                                       PgSlotDwell *dwell) {
     __shared__ ModelSmem<MT> sm;
+    constexpr int C = ModelCfg<MT>::CACHE;
     const uint32_t s = blockIdx.x;
-    const uint64_t e0 = ev_off[s], e1 = ev_off[s + 1];
-    const uint64_t a0 = samp_off[e0], a1 = samp_off[e1];
+    const uint64_t e0 = uniform64(ev_off[s]), e1 = uniform64(ev_off[s + 1]);
+    const uint64_t a0 = uniform64(samp_off[e0]), a1 = uniform64(samp_off[e1]);
     const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
     const uint64_t first = a0 + skip, n = a1 - first;
     uint32_t flags = 0;
     PgSlotModel m{};
     m.n = n;
     if (n > 0) {
-        bool bad = false;
+        bool bad = false, wide = false;
         const int64_t origin = pg_fixed8(samples[first], bad);
         // pass A: range and moments about the first value
         uint64_t mn = ~0ull, mx = 0, hh = 0, hl = 0, ll = 0;
         int64_t s1 = 0;
-        bool wide = false;
-        for (uint64_t i = threadIdx.x; i < n; i += MT) {
-            const int64_t v = pg_fixed8(samples[first + i], bad);
+        auto account = [&](double x) {
+            const int64_t v = pg_fixed8(x, bad);
             const uint64_t key = (uint64_t)v ^ (1ull << 63); // order-preserving
             mn = op_min(mn, key); mx = op_max(mx, key);
             const int64_t d = v - origin;
@@ -117,31 +167,40 @@ template <int MT> __global__ __launch_bounds__(MT) void k_slot_model(const uint6
             if (ad >= (uint64_t)PG_MODEL_MAX_DEV) wide = true;
             const uint64_t h = (ad >> PG_MODEL_LIMB_BITS) & ((1u << PG_MODEL_LIMB_BITS) - 1), l = ad & ((1u << PG_MODEL_LIMB_BITS) - 1);
             s1 += d; hh += h * h; hl += h * l; ll += l * l;
+            return key;
+        };
+        const bool cached = C > 0 && n <= (uint64_t)MT * C; // the whole file fits the registers of the workgroup
+        RegKeys<C> rk;
+        rk.cnt = 0;
+        if constexpr (C > 0) {
+            if (cached) {
+                double x[C];
+                rk.cnt = n > threadIdx.x ? (int)((n - threadIdx.x + MT - 1) / MT) : 0;
+#pragma unroll
+                for (int u = 0; u < C; ++u) { const uint64_t i = (uint64_t)u * MT + threadIdx.x; x[u] = samples[first + (i < n ? i : n - 1)]; }
+#pragma unroll
+                for (int u = 0; u < C; ++u) rk.k[u] = u < rk.cnt ? account(x[u]) : 0ull;
+            }
         }
+        if (!cached) for_each_mine<MT, ModelCfg<MT>::U, double>(n, [&](uint64_t i) { return samples[first + i]; }, [&](double x) { (void)account(x); });
         mn = block_reduce<MT>(sm, mn, op_min); mx = block_reduce<MT>(sm, mx, op_max);
         m.s1 = (int64_t)block_reduce<MT>(sm, (uint64_t)s1, op_sum);
         m.s2_hh = block_reduce<MT>(sm, hh, op_sum); m.s2_hl = block_reduce<MT>(sm, hl, op_sum); m.s2_ll = block_reduce<MT>(sm, ll, op_sum);
         const uint64_t fl = block_reduce<MT>(sm, (bad ? PG_MODEL_BAD_VALUE : 0u) | (wide ? PG_MODEL_BAD_SPREAD : 0u), [](uint64_t a, uint64_t b) { return a | b; });
         flags = (uint32_t)fl | (n > PG_MODEL_MAX_VALUES ? PG_MODEL_BAD_COUNT : 0u);
         m.origin = origin;
-        if (!(flags & PG_MODEL_BAD_VALUE)) {
+        if (!(flags & (PG_MODEL_BAD_VALUE | PG_MODEL_BAD_COUNT))) {
             const uint64_t spread = mx - mn;
             const int bits = spread ? 64 - __builtin_clzll(spread) : 0;
-            auto key_at = [&](uint64_t i) {
-                bool b2 = false;
-                return ((uint64_t)pg_fixed8(samples[first + i], b2) ^ (1ull << 63)) - mn;
-            };
-            const uint64_t r_lo = (n - 1) / 2, r_hi = n / 2;
-            const uint64_t k_lo = block_select<MT>(sm, n, r_lo, bits, key_at);
-            uint64_t k_hi = k_lo;
-            if (r_hi != r_lo) { // even count: the next order statistic is k_lo again or the smallest key above it
-                uint64_t le = 0, gt = ~0ull;
-                for (uint64_t i = threadIdx.x; i < n; i += MT) {
-                    const uint64_t k = key_at(i);
-                    if (k <= k_lo) le++; else gt = op_min(gt, k);
-                }
-                le = block_reduce<MT>(sm, le, op_sum); gt = block_reduce<MT>(sm, gt, op_min);
-                if (le <= r_hi) k_hi = gt;
+            uint64_t k_lo, k_hi;
+            if (cached) { rk.mn = mn; block_middle<MT>(sm, rk, n, bits, k_lo, k_hi); }
+            else {
+                auto key_at = [&](uint64_t i) {
+                    bool b2 = false;
+                    return ((uint64_t)pg_fixed8(samples[first + i], b2) ^ (1ull << 63)) - mn;
+                };
+                const GlobalKeys<MT, decltype(key_at)> gk{n, key_at};
+                block_middle<MT>(sm, gk, n, bits, k_lo, k_hi);
             }
             m.mid_lo = (int64_t)((k_lo + mn) ^ (1ull << 63));
             m.mid_hi = (int64_t)((k_hi + mn) ^ (1ull << 63));
@@ -153,22 +212,13 @@ template <int MT> __global__ __launch_bounds__(MT) void k_slot_model(const uint6
     if (nev > 0) {
         const uint64_t nd = nev + 1;
         auto dkey = [&](uint64_t i) { const uint32_t len = i < nev ? ev_len[e0 + i] : 0u; return (uint64_t)(len ? len - 1 : 0u); };
+        const GlobalKeys<MT, decltype(dkey)> dk{nd, dkey};
         uint64_t mx = 0;
-        for (uint64_t i = threadIdx.x; i < nd; i += MT) mx = op_max(mx, dkey(i));
+        dk.each([&](uint64_t k) { mx = op_max(mx, k); });
         mx = block_reduce<MT>(sm, mx, op_max);
         const int bits = mx ? 64 - __builtin_clzll(mx) : 0;
-        const uint64_t r_lo = (nd - 1) / 2, r_hi = nd / 2;
-        const uint64_t k_lo = block_select<MT>(sm, nd, r_lo, bits, dkey);
-        uint64_t k_hi = k_lo;
-        if (r_hi != r_lo) {
-            uint64_t le = 0, gt = ~0ull;
-            for (uint64_t i = threadIdx.x; i < nd; i += MT) {
-                const uint64_t k = dkey(i);
-                if (k <= k_lo) le++; else gt = op_min(gt, k);
-            }
-            le = block_reduce<MT>(sm, le, op_sum); gt = block_reduce<MT>(sm, gt, op_min);
-            if (le <= r_hi) k_hi = gt;
-        }
+        uint64_t k_lo, k_hi;
+        block_middle<MT>(sm, dk, nd, bits, k_lo, k_hi);
         dw.n = nd; dw.mid_lo = (uint32_t)k_lo; dw.mid_hi = (uint32_t)k_hi;
     }
     dw.flags = flags;

@@ -7,11 +7,14 @@ import numpy as np
 from helpers import assert_result_equals_oracle, oracle_for
 from poregen_amd import synth
 from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+import pathlib, shutil, tempfile
+from test_gpu_model import compare_raw_model, dump_from_oracle, oracle_lines
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 skipped = 0
+n_model = 0
 for case in range(n_cases):
     rna = bool(rng.integers(0, 2))
     k = int(rng.choice([3, 5, 5, 6, 9]))
@@ -56,6 +59,17 @@ for case in range(n_cases):
             eng.submit(b)
         res = eng.finish()
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=p["sample_limit"])
+        if len(slice_kmers) <= 1024:  # the k-mer model (pg_model) against tr | tail | datamash restated on the oracle's dump files
+            tmp = pathlib.Path(tempfile.mkdtemp(prefix="pgfuzz"))
+            try:
+                d = dump_from_oracle(tmp, o, slice_kmers)
+                m = eng.model()
+                limit = str(rng.choice(["3.1", "0.5", "1e9"]))
+                compare_raw_model(m.raw_model_lines(slice_kmers, limit), oracle_lines(d, "stats", limit))
+                assert m.dwell_lines(slice_kmers) == "".join(oracle_lines(d, "dwell"))
+                n_model += 1
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("CASE", case, "FAILED:", p, n_reads, read_len, repr(e)[:300], flush=True)
@@ -63,5 +77,5 @@ for case in range(n_cases):
         eng.close()
     if case % 20 == 19:
         print("case", case + 1, "ok so far" if not bad else f"{bad} failures", flush=True)
-print("fuzz done:", n_cases, "cases,", skipped, "outside the reference's defined behaviour (skipped),", bad, "failures")
+print("fuzz done:", n_cases, "cases,", skipped, "outside the reference's defined behaviour (skipped),", n_model, "with the model step,", bad, "failures")
 sys.exit(1 if bad else 0)
