@@ -788,8 +788,14 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
         d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
     }
     HIP_TRY(c, c->md_out.ensure(ns * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure(ns * sizeof(PgSlotDwell)));
+    int any_short = 0, any_long = 0; // which of the two kernels has work (the host holds the offsets since pg_finish)
+    const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;
+    for (uint32_t i = 0; i < ns; i++) {
+        const uint64_t all = R.samp_off[R.ev_off[i + 1]] - R.samp_off[R.ev_off[i]], nv = all > drop ? all - drop : 0;
+        if (nv <= PG_MODEL_SHORT_MAX) any_short = 1; else any_long = 1;
+    }
     prof_begin(c, "k_slot_model", c->st);
-    HIP_TRY(c, pg_launch_slot_model(c->st, ns, R.n_samples, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
+    HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_short, any_long, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
                                     c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
     prof_end(c, c->st);
     c->mo_raw.resize(ns); c->mo_dw.resize(ns);

@@ -22,6 +22,9 @@ template <int MT> struct ModelCfg {
 };
 
 template <int MT> struct ModelSmem {
+    static constexpr int CAND = MT * 4; // keys of one top-window bin that a long file parks in LDS (see block_middle_long)
+    uint64_t cand[CAND];
+    uint32_t n_cand;
     uint32_t hist[M_BINS];
     uint64_t red[MT / 64];
     uint32_t wsum[MT / 64];
@@ -103,52 +106,102 @@ template <int C> struct RegKeys { // converted once, kept in registers: element 
     }
 };
 
+// One window of the radix select: histogram of bits [hi - wbits, hi) of the keys whose bits above hi equal prefix;
+// returns the bin holding `rank` and the number of such keys in the bins below it. sm.hist stays valid until the next call.
+template <int MT, class Src> __device__ void block_window(ModelSmem<MT> &sm, const Src &src, int hi, int wbits, uint64_t prefix, uint32_t rank,
+                                                           uint32_t &bin, uint32_t &below) {
+    const int shift = hi - wbits;
+    const uint32_t nbins = 1u << wbits;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += MT) sm.hist[i] = 0;
+    __syncthreads();
+    src.each([&](uint64_t k) {
+        if (shr64(k, hi) == prefix) atomicAdd(&sm.hist[(uint32_t)(k >> shift) & (nbins - 1)], 1u);
+    });
+    block_find_bin<MT>(sm, rank, nbins, bin, below);
+}
+
 // the rank-th smallest (0-based) of the source's keys; all keys < 2^bits. The bits are consumed from the top in windows of
 // at most M_BITS; the last (lowest) window is the short one, so that a narrow key range costs a small histogram.
 template <int MT, class Src> __device__ uint64_t block_select(ModelSmem<MT> &sm, const Src &src, uint64_t rank, int bits) {
     uint64_t prefix = 0; // the bits above the current window
     int hi = bits;       // bits [hi, 64) are settled
     while (hi > 0) {
-        const int wbits = hi >= M_BITS ? M_BITS : hi, shift = hi - wbits;
-        const uint32_t nbins = 1u << wbits;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nbins; i += MT) sm.hist[i] = 0;
-        __syncthreads();
-        src.each([&](uint64_t k) {
-            if (shr64(k, hi) == prefix) atomicAdd(&sm.hist[(uint32_t)(k >> shift) & (nbins - 1)], 1u);
-        });
+        const int wbits = hi >= M_BITS ? M_BITS : hi;
         uint32_t bin, below;
-        block_find_bin<MT>(sm, (uint32_t)rank, nbins, bin, below);
+        block_window<MT>(sm, src, hi, wbits, prefix, (uint32_t)rank, bin, below);
         rank -= below;
         prefix = (prefix << wbits) | bin;
-        hi = shift;
+        hi -= wbits;
     }
     return prefix;
 }
 
-// datamash's two middle order statistics of n keys (equal when n is odd)
-template <int MT, class Src> __device__ void block_middle(ModelSmem<MT> &sm, const Src &src, uint64_t n, int bits, uint64_t &k_lo, uint64_t &k_hi) {
-    const uint64_t r_lo = (n - 1) / 2, r_hi = n / 2;
+// order statistics r_lo and r_hi (r_hi = r_lo or r_lo + 1) of the source's keys
+template <int MT, class Src> __device__ void block_pair(ModelSmem<MT> &sm, const Src &src, uint64_t r_lo, uint64_t r_hi, int bits, uint64_t &k_lo, uint64_t &k_hi) {
     k_lo = block_select<MT>(sm, src, r_lo, bits);
     k_hi = k_lo;
-    if (r_hi != r_lo) { // even count: the next order statistic is k_lo again or the smallest key above it
+    if (r_hi != r_lo) { // the next order statistic is k_lo again or the smallest key above it
         uint64_t le = 0, gt = ~0ull;
         src.each([&](uint64_t k) { if (k <= k_lo) le++; else gt = op_min(gt, k); });
         le = block_reduce<MT>(sm, le, op_sum); gt = block_reduce<MT>(sm, gt, op_min);
         if (le <= r_hi) k_hi = gt;
     }
 }
+// datamash's two middle order statistics of n keys (equal when n is odd)
+template <int MT, class Src> __device__ void block_middle(ModelSmem<MT> &sm, const Src &src, uint64_t n, int bits, uint64_t &k_lo, uint64_t &k_hi) {
+    block_pair<MT>(sm, src, (n - 1) / 2, n / 2, bits, k_lo, k_hi);
+}
 
-template <int MT> __global__ __launch_bounds__(MT, MT >= 1024 ? 8 : 4) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
+template <int MT> struct LdsKeys { // the parked candidates (low bits of the keys of one top-window bin), in no particular order
+    const uint64_t *k; uint32_t n;
+    template <class Fn> __device__ __forceinline__ void each(Fn fn) const { for (uint32_t i = threadIdx.x; i < n; i += MT) fn(k[i]); }
+};
+
+// The same for a file that is re-read from memory on every pass: after the top window the median's bin holds a tiny part
+// of the file (a 12-bit window over a bell curve: ~0.1 %), so the second pass over the file parks that bin's keys in LDS
+// (and notes the smallest key above the bin, the upper middle value if the bin ends exactly at the lower one); the remaining
+// windows and the even-count step run on LDS. Three passes over the file (moments, top window, park) instead of 2 + windows + 1.
+template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm, const Src &src, uint64_t n, int bits, uint64_t &k_lo, uint64_t &k_hi) {
+    const uint64_t r_lo = (n - 1) / 2, r_hi = n / 2;
+    if (bits <= M_BITS) { block_pair<MT>(sm, src, r_lo, r_hi, bits, k_lo, k_hi); return; }
+    const int low = bits - M_BITS; // bits below the top window
+    uint32_t bin, below;
+    block_window<MT>(sm, src, bits, M_BITS, 0, (uint32_t)r_lo, bin, below);
+    const uint32_t cnt = uniform32(sm.hist[bin]);
+    if (cnt > (uint32_t)ModelSmem<MT>::CAND) { block_pair<MT>(sm, src, r_lo, r_hi, bits, k_lo, k_hi); return; } // a spike of equal-ish values: generic path
+    if (threadIdx.x == 0) sm.n_cand = 0;
+    __syncthreads();
+    uint64_t above = ~0ull;
+    const uint64_t low_mask = (1ull << low) - 1;
+    src.each([&](uint64_t k) {
+        const uint64_t top = k >> low;
+        if (top == bin) sm.cand[atomicAdd(&sm.n_cand, 1u)] = k & low_mask;
+        else if (top > bin) above = op_min(above, k);
+    });
+    above = block_reduce<MT>(sm, above, op_min); // (its barriers also publish cand[])
+    const LdsKeys<MT> lk{sm.cand, cnt};
+    const uint64_t q_lo = r_lo - below, q_hi = r_hi - below; // ranks inside the bin; q_lo < cnt
+    uint64_t c_lo, c_hi;
+    block_pair<MT>(sm, lk, q_lo, q_hi < cnt ? q_hi : q_lo, low, c_lo, c_hi);
+    k_lo = ((uint64_t)bin << low) | c_lo;
+    k_hi = q_hi < cnt ? (((uint64_t)bin << low) | c_hi) : above;
+}
+
+// Two kernels share this body: SHORT (256 threads, the whole file converted once into 16 registers per thread) takes the
+// k-mers with at most PG_MODEL_SHORT_MAX values, LONG (1024 threads, the file re-read per pass) the others; a workgroup whose
+// k-mer belongs to the other kernel leaves after two loads. Separate kernels because each needs its own register budget.
+template <int MT, bool SHORT> __global__ __launch_bounds__(MT, SHORT ? 4 : 8) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
                                                                       const double *samples, uint32_t drop_first, PgSlotModel *out,
                                                                       PgSlotDwell *dwell) {
     __shared__ ModelSmem<MT> sm;
-    constexpr int C = ModelCfg<MT>::CACHE;
+    constexpr int C = SHORT ? ModelCfg<MT>::CACHE : 0;
     const uint32_t s = blockIdx.x;
     const uint64_t e0 = uniform64(ev_off[s]), e1 = uniform64(ev_off[s + 1]);
     const uint64_t a0 = uniform64(samp_off[e0]), a1 = uniform64(samp_off[e1]);
     const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
     const uint64_t first = a0 + skip, n = a1 - first;
+    if ((n <= (uint64_t)PG_MODEL_SHORT_MAX) != SHORT) return;
     uint32_t flags = 0;
     PgSlotModel m{};
     m.n = n;
@@ -169,20 +222,17 @@ template <int MT> __global__ __launch_bounds__(MT, MT >= 1024 ? 8 : 4) void k_sl
             s1 += d; hh += h * h; hl += h * l; ll += l * l;
             return key;
         };
-        const bool cached = C > 0 && n <= (uint64_t)MT * C; // the whole file fits the registers of the workgroup
         RegKeys<C> rk;
         rk.cnt = 0;
-        if constexpr (C > 0) {
-            if (cached) {
-                double x[C];
-                rk.cnt = n > threadIdx.x ? (int)((n - threadIdx.x + MT - 1) / MT) : 0;
+        if constexpr (SHORT) {
+            static_assert(!SHORT || MT * ModelCfg<MT>::CACHE == PG_MODEL_SHORT_MAX, "the short kernel holds the whole file in registers");
+            double x[C];
+            rk.cnt = n > threadIdx.x ? (int)((n - threadIdx.x + MT - 1) / MT) : 0;
 #pragma unroll
-                for (int u = 0; u < C; ++u) { const uint64_t i = (uint64_t)u * MT + threadIdx.x; x[u] = samples[first + (i < n ? i : n - 1)]; }
+            for (int u = 0; u < C; ++u) { const uint64_t i = (uint64_t)u * MT + threadIdx.x; x[u] = samples[first + (i < n ? i : n - 1)]; }
 #pragma unroll
-                for (int u = 0; u < C; ++u) rk.k[u] = u < rk.cnt ? account(x[u]) : 0ull;
-            }
-        }
-        if (!cached) for_each_mine<MT, ModelCfg<MT>::U, double>(n, [&](uint64_t i) { return samples[first + i]; }, [&](double x) { (void)account(x); });
+            for (int u = 0; u < C; ++u) rk.k[u] = u < rk.cnt ? account(x[u]) : 0ull;
+        } else for_each_mine<MT, ModelCfg<MT>::U, double>(n, [&](uint64_t i) { return samples[first + i]; }, [&](double x) { (void)account(x); });
         mn = block_reduce<MT>(sm, mn, op_min); mx = block_reduce<MT>(sm, mx, op_max);
         m.s1 = (int64_t)block_reduce<MT>(sm, (uint64_t)s1, op_sum);
         m.s2_hh = block_reduce<MT>(sm, hh, op_sum); m.s2_hl = block_reduce<MT>(sm, hl, op_sum); m.s2_ll = block_reduce<MT>(sm, ll, op_sum);
@@ -193,14 +243,14 @@ template <int MT> __global__ __launch_bounds__(MT, MT >= 1024 ? 8 : 4) void k_sl
             const uint64_t spread = mx - mn;
             const int bits = spread ? 64 - __builtin_clzll(spread) : 0;
             uint64_t k_lo, k_hi;
-            if (cached) { rk.mn = mn; block_middle<MT>(sm, rk, n, bits, k_lo, k_hi); }
+            if constexpr (SHORT) { rk.mn = mn; block_middle<MT>(sm, rk, n, bits, k_lo, k_hi); }
             else {
                 auto key_at = [&](uint64_t i) {
                     bool b2 = false;
                     return ((uint64_t)pg_fixed8(samples[first + i], b2) ^ (1ull << 63)) - mn;
                 };
                 const GlobalKeys<MT, decltype(key_at)> gk{n, key_at};
-                block_middle<MT>(sm, gk, n, bits, k_lo, k_hi);
+                block_middle_long<MT>(sm, gk, n, bits, k_lo, k_hi);
             }
             m.mid_lo = (int64_t)((k_lo + mn) ^ (1ull << 63));
             m.mid_hi = (int64_t)((k_hi + mn) ^ (1ull << 63));
@@ -227,13 +277,10 @@ template <int MT> __global__ __launch_bounds__(MT, MT >= 1024 ? 8 : 4) void k_sl
 
 } // namespace
 
-hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, uint64_t n_samples, const uint64_t *ev_off, const uint64_t *samp_off,
+hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, int any_short, int any_long, const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell) {
     if (n_slots == 0) return hipSuccess;
-    // small files: four times as many workgroups per CU and a quarter of the barrier cost
-    if (n_samples / n_slots < 8192)
-        hipLaunchKernelGGL(k_slot_model<256>, dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
-    else
-        hipLaunchKernelGGL(k_slot_model<1024>, dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    if (any_short) hipLaunchKernelGGL((k_slot_model<256, true>), dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    if (any_long) hipLaunchKernelGGL((k_slot_model<1024, false>), dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
     return hipGetLastError();
 }

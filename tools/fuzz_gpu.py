@@ -65,7 +65,7 @@ for case in range(n_cases):
                 d = dump_from_oracle(tmp, o, slice_kmers)
                 m = eng.model()
                 limit = str(rng.choice(["3.1", "0.5", "1e9"]))
-                compare_raw_model(m.raw_model_lines(slice_kmers, limit), oracle_lines(d, "stats", limit))
+                compare_raw_model(m.raw_model_lines(slice_kmers, limit), oracle_lines(d, "stats", limit), d, limit)
                 assert m.dwell_lines(slice_kmers) == "".join(oracle_lines(d, "dwell"))
                 n_model += 1
             finally:
