@@ -29,8 +29,8 @@
  * pg_finish                        the bytes the fprintf calls would have produced, as binary
  *                                                                         src/gmove.cpp:938-950
  * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
- * pg_model / pg_model_format       the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
- *                                  median / sstdev per k-mer, awk | datamash median of the dwell times
+ * pg_model / pg_model_device /     the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
+ * pg_model_format                  median / sstdev per k-mer, awk | datamash median of the dwell times
  *                                                                         scripts/poregen.sh:54-85, 33-52
  * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
  * pg_last_batch_device / pg_kernel_stats*
@@ -247,6 +247,12 @@ typedef struct {
 } pg_model_result;
 enum { PG_MODEL_TEXT_MEDIAN = 0, PG_MODEL_TEXT_SSTDEV = 1, PG_MODEL_TEXT_DWELL = 2 };
 pg_status pg_model(pg_ctx *ctx, uint32_t flags, pg_model_result *out);
+/* The same reduction over caller-owned DEVICE arrays in pg_result layout: ev_off uint64[n_slots+1], samp_off
+ * uint64[ev_off[n_slots]+1], ev_len uint32[], samples double[] -- e.g. the kept events of all ranks of a multi-GPU job
+ * brought together on the writing rank (poregen_amd/dist.py gather_kept). Uses the context's stream and result buffers;
+ * the arrays must be complete before the call (no ordering with other streams is implied). */
+pg_status pg_model_device(pg_ctx *ctx, uint32_t n_slots, const uint64_t *d_ev_off, const uint64_t *d_samp_off,
+                          const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out);
 /* The number as datamash prints it ("%.14Lg" of its long double; "nan" for sstdev of one value; empty string when the
  * slot has no value at all, like datamash on empty input). Returns the length written (excluding the NUL), 0 on error. */
 size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap);

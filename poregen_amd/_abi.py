@@ -29,7 +29,7 @@ PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_collect_gathered", "pg_sync", "pg_finish", "pg_all_slots_full",
-    "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_format",
+    "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
 ]
 
 
@@ -138,6 +138,7 @@ def load():
     lib.pg_kernel_stats.argtypes = [vp, C.POINTER(PgKernelStat), u32, C.POINTER(u32)]; lib.pg_kernel_stats.restype = i32
     lib.pg_kernel_stats_reset.argtypes = [vp]; lib.pg_kernel_stats_reset.restype = i32
     lib.pg_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_model.restype = i32
+    lib.pg_model_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, C.POINTER(PgModelResult)]; lib.pg_model_device.restype = i32
     lib.pg_model_format.argtypes = [C.POINTER(PgModelResult), u32, i32, C.c_char_p, C.c_size_t]; lib.pg_model_format.restype = C.c_size_t
     _lib = lib
     return lib

@@ -768,39 +768,19 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     return PG_OK;
 }
 
-pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
-    if (!c || !out) return PG_ERR_INVALID_ARG;
-    pg_result R;
-    pg_status s = pg_finish(c, &R);
-    if (s != PG_OK) return s;
-    const uint32_t ns = c->prm.n_slots;
-    const uint64_t *d_ev_off, *d_samp_off; const uint32_t *d_ev_len; const double *d_samples;
-    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
-        // one batch: its kept events are still on the device, in the same order
-        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off.as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
-    } else { // several batches were merged on the host (slot-major): hand the merged arrays back
-        HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
-        HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4)); HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
-        HIP_TRY(c, hipMemcpyAsync(c->md_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
-        HIP_TRY(c, hipMemcpyAsync(c->md_samp_off.p, R.samp_off, (R.n_events + 1) * 8ull, hipMemcpyHostToDevice, c->st));
-        if (R.n_events) HIP_TRY(c, hipMemcpyAsync(c->md_ev_len.p, R.ev_len, R.n_events * 4ull, hipMemcpyHostToDevice, c->st));
-        if (R.n_samples) HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
-        d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
-    }
-    HIP_TRY(c, c->md_out.ensure(ns * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure(ns * sizeof(PgSlotDwell)));
-    int any_short = 0, any_long = 0; // which of the two kernels has work (the host holds the offsets since pg_finish)
-    const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;
-    for (uint32_t i = 0; i < ns; i++) {
-        const uint64_t all = R.samp_off[R.ev_off[i + 1]] - R.samp_off[R.ev_off[i]], nv = all > drop ? all - drop : 0;
-        if (nv <= PG_MODEL_SHORT_MAX) any_short = 1; else any_long = 1;
-    }
+// launch + download + host finishing of the model reduction over device arrays in pg_result layout
+static pg_status model_run(pg_ctx *c, uint32_t ns, int any_short, int any_long, const uint64_t *d_ev_off, const uint64_t *d_samp_off,
+                           const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out) {
+    HIP_TRY(c, c->md_out.ensure((ns + 1) * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure((ns + 1) * sizeof(PgSlotDwell)));
     prof_begin(c, "k_slot_model", c->st);
     HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_short, any_long, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
                                     c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
     prof_end(c, c->st);
     c->mo_raw.resize(ns); c->mo_dw.resize(ns);
-    HIP_TRY(c, hipMemcpyAsync(c->mo_raw.data(), c->md_out.p, ns * sizeof(PgSlotModel), hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipMemcpyAsync(c->mo_dw.data(), c->md_dwell.p, ns * sizeof(PgSlotDwell), hipMemcpyDeviceToHost, c->st));
+    if (ns) {
+        HIP_TRY(c, hipMemcpyAsync(c->mo_raw.data(), c->md_out.p, ns * sizeof(PgSlotModel), hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipMemcpyAsync(c->mo_dw.data(), c->md_dwell.p, ns * sizeof(PgSlotDwell), hipMemcpyDeviceToHost, c->st));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->mo_n.resize(ns); c->mo_s2lo.resize(ns); c->mo_s2hi.resize(ns); c->mo_dn.resize(ns); c->mo_lo.resize(ns); c->mo_hi.resize(ns);
     c->mo_origin.resize(ns); c->mo_s1.resize(ns); c->mo_med.resize(ns); c->mo_sd.resize(ns); c->mo_dmed.resize(ns);
@@ -820,6 +800,42 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
     out->mid_lo = c->mo_lo.data(); out->mid_hi = c->mo_hi.data(); out->origin = c->mo_origin.data(); out->sum1 = c->mo_s1.data();
     out->sum2_lo = c->mo_s2lo.data(); out->sum2_hi = c->mo_s2hi.data(); out->dwell_n = c->mo_dn.data(); out->dwell_median = c->mo_dmed.data();
     return PG_OK;
+}
+
+pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    pg_result R;
+    pg_status s = pg_finish(c, &R);
+    if (s != PG_OK) return s;
+    const uint32_t ns = c->prm.n_slots;
+    const uint64_t *d_ev_off, *d_samp_off; const uint32_t *d_ev_len; const double *d_samples;
+    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
+        // one batch: its kept events are still on the device, in the same order
+        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off.as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
+    } else { // several batches were merged on the host (slot-major): hand the merged arrays back
+        HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
+        HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4)); HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
+        HIP_TRY(c, hipMemcpyAsync(c->md_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, hipMemcpyAsync(c->md_samp_off.p, R.samp_off, (R.n_events + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        if (R.n_events) HIP_TRY(c, hipMemcpyAsync(c->md_ev_len.p, R.ev_len, R.n_events * 4ull, hipMemcpyHostToDevice, c->st));
+        if (R.n_samples) HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
+        d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
+    }
+    int any_short = 0, any_long = 0; // which of the two kernels has work (the host holds the offsets since pg_finish)
+    const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;
+    for (uint32_t i = 0; i < ns; i++) {
+        const uint64_t all = R.samp_off[R.ev_off[i + 1]] - R.samp_off[R.ev_off[i]], nv = all > drop ? all - drop : 0;
+        if (nv <= PG_MODEL_SHORT_MAX) any_short = 1; else any_long = 1;
+    }
+    return model_run(c, ns, any_short, any_long, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
+}
+
+pg_status pg_model_device(pg_ctx *c, uint32_t n_slots, const uint64_t *d_ev_off, const uint64_t *d_samp_off, const uint32_t *d_ev_len,
+                          const double *d_samples, uint32_t flags, pg_model_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    if (n_slots && (!d_ev_off || !d_samp_off)) return fail(c, PG_ERR_INVALID_ARG, "pg_model_device: ev_off / samp_off missing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return model_run(c, n_slots, 1, 1, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out); // offsets are not on the host: both kernels look
 }
 
 size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap) {

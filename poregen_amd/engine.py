@@ -331,6 +331,26 @@ class GmoveEngine:
         tr | tail | datamash. `text(slot, which)` gives the number exactly as datamash prints it."""
         m = _abi.PgModelResult()
         self._check(self._lib.pg_model(self._h, _abi.PG_MODEL_KEEP_FIRST if keep_first else 0, C.byref(m)))
+        return self._model_from(m)
+
+    def model_device(self, counts, ev_len, samples, keep_first: bool = False) -> "Model":
+        """The same reduction over torch CUDA tensors in the layout `dist.gather_kept` returns on the writing rank: counts
+        int64[n_slots] kept events per k-mer, ev_len int32/uint32[n_events] (k-mer-major), samples float64[] back to back
+        (pg_model_device)."""
+        import torch
+        ev_off = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=counts.device)
+        ev_off[1:] = torch.cumsum(counts.to(torch.int64), 0)
+        samp_off = torch.zeros(ev_len.numel() + 1, dtype=torch.int64, device=counts.device)
+        samp_off[1:] = torch.cumsum(ev_len.to(torch.int64), 0)
+        ev_len = ev_len.contiguous(); samples = samples.contiguous()
+        assert ev_len.element_size() == 4 and samples.dtype == torch.float64 and int(samp_off[-1]) == samples.numel()
+        torch.cuda.current_stream(counts.device).synchronize()   # the library launches on its own stream
+        m = _abi.PgModelResult()
+        self._check(self._lib.pg_model_device(self._h, counts.numel(), ev_off.data_ptr(), samp_off.data_ptr(), ev_len.data_ptr() or None,
+                                              samples.data_ptr() or None, _abi.PG_MODEL_KEEP_FIRST if keep_first else 0, C.byref(m)))
+        return self._model_from(m)
+
+    def _model_from(self, m) -> "Model":
         ns = m.n_slots
 
         def arr(ptr, dt):

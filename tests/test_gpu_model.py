@@ -192,3 +192,51 @@ def test_cli_raw_model_and_dwell_model(tmp_path):
     assert r.returncode != 0 and b"cannot be combined with -d" in r.stderr
     r = subprocess.run([BIN, "gmove", "-k", "5", pre + ".slow5", pre + ".paf", str(tmp_path / "o3"), "--fastq", pre + ".fastq", "--raw_model", str(raw), "--stdv_limit", "abc"], capture_output=True)
     assert r.returncode != 0 and not (tmp_path / "o3").exists()
+
+
+def test_model_device_on_the_writer_of_a_sharded_job():
+    """Three ranks emulated on one GPU (count -> bases -> collect per shard); the writer's view of the job (per k-mer the ranks'
+    kept events in rank order, as dist.gather_kept delivers it) reduced with pg_model_device equals the model of the unsharded
+    job; empty tensors are accepted."""
+    import torch
+    from poregen_amd import dist as pgdist
+    kmers = generate_kmers(5, rna=True)
+    p = dict(kmer_size=5, scaling=1, sample_limit=60, rna=True)
+    b = synth.make_batch(900, kind="rna004", seed=404, indel_rate=0.01)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    whole = eng.model()
+    shards = [b.slice_reads(0, 300), b.slice_reads(300, 650), b.slice_reads(650, 900)]
+    engs = [GmoveEngine(GmoveParams(kmers=kmers, **p)) for _ in shards]
+    cnts = [e.count(s) for e, s in zip(engs, shards)]
+    base = np.zeros(len(kmers), np.uint64)
+    for e, c in zip(engs, cnts):
+        e.collect(base.copy()); base = base + c
+    results = [e.finish() for e in engs]
+    counts = sum(r.counts.astype(np.int64) for r in results)
+    lens = np.concatenate([r.ev_len[int(r.ev_off[s]):int(r.ev_off[s + 1])] for s in range(len(kmers)) for r in results] + [np.zeros(0, np.uint32)])
+    vals = np.concatenate([r.slot_values(s) for s in range(len(kmers)) for r in results] + [np.zeros(0)])
+    dev = torch.device("cuda:0")
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    got = engs[0].model_device(t(counts, np.int64), t(lens, np.int32), t(vals, np.float64))
+    assert got.median_text == whole.median_text and got.sstdev_text == whole.sstdev_text and got.dwell_text == whole.dwell_text
+    assert np.array_equal(got.sum1, whole.sum1) and np.array_equal(got.mid_lo, whole.mid_lo)
+    assert got.raw_model_lines(kmers) == whole.raw_model_lines(kmers)
+    empty = engs[0].model_device(t(np.zeros(len(kmers)), np.int64), t(np.zeros(0), np.int32), t(np.zeros(0), np.float64))
+    assert not empty.n_values.any() and all(x == "" for x in empty.median_text + empty.dwell_text)
+    for e in engs + [eng]:
+        e.close()
+
+
+def test_model_rejects_a_spread_beyond_the_moment_sums():
+    """values 20 000 pA apart inside one k-mer file: beyond the 2^40-unit deviation the exact moment sums accept"""
+    from poregen_amd.engine import PgError
+    kmers = generate_kmers(3)
+    b = synth.make_batch(30, kind="dna_r10", seed=9)
+    b.range[::2] = b.range[::2] * 250           # every other read: pA values around 25 000
+    eng = GmoveEngine(GmoveParams(kmers=kmers, kmer_size=3, scaling=0, sample_limit=500, pa_min=-1e300, pa_max=1e300))
+    eng.submit(b)
+    with pytest.raises(PgError) as ei:
+        eng.model()
+    assert "2^40" in str(ei.value)
+    eng.close()

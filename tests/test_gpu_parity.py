@@ -246,6 +246,11 @@ def test_sharded_step_over_rccl_single_rank(tmp_path):
         assert np.array_equal(g[0].cpu().numpy().astype(np.uint64), o.counts())
         assert np.array_equal(g[1].cpu().numpy(), np.concatenate([o.event_lens(s) for s in range(len(kmers))]).astype(np.int32))
         assert np.array_equal(g[2].cpu().numpy().view(np.uint64), np.concatenate([o.values(s) for s in range(len(kmers))]).view(np.uint64))
+        # the k-mer model of the whole job on the writing rank, from the gathered device tensors (pg_model_device)
+        mg = eng2.model_device(*g)
+        m1 = eng2.model()
+        assert mg.median_text == m1.median_text and mg.sstdev_text == m1.sstdev_text and mg.dwell_text == m1.dwell_text
+        assert np.array_equal(mg.n_values, m1.n_values) and int(m1.n_values.sum()) > 1000
         eng2.close()
     finally:
         dist.destroy_process_group()
