@@ -3,6 +3,7 @@
 // parsing into batches, writing the dump directory. The per-read computation runs on the GPU.
 #include "../../../include/pgmove.h"
 #include "pg_host.h"
+#include <future>
 #include <algorithm>
 
 #include <cstdio>
@@ -97,6 +98,7 @@ int die(const char *fmt, const std::string &a = "") { fprintf(stderr, fmt, a.c_s
 } // namespace
 
 int gmove_main(int argc, char **argv) {
+    const std::chrono::steady_clock::time_point t_main0 = std::chrono::steady_clock::now();
     Opt opt;
     int longindex = 0, c, signal_scale = 0;
     const char *input_kmer_file = nullptr, *input_fastq_file = nullptr;
@@ -197,24 +199,12 @@ int gmove_main(int argc, char **argv) {
     else if (signal_scale == 1) { scaling = 1; fprintf(stderr, "scaling: %s\n", "medmad scale"); }
     else { print_help(fp_help, opt); return EXIT_FAILURE; }
 
-    pgh::Slow5File s5;
-    const std::chrono::steady_clock::time_point t_setup0 = std::chrono::steady_clock::now();
-    if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return EXIT_FAILURE; } // gmove.cpp:493-503
-
     const std::string mt(move_table); // src/gmove.cpp:505-521
     const std::string ext = mt.size() >= 4 ? mt.substr(mt.size() - 4) : "";
     const bool is_paf = ext == ".paf", is_bam = ext == ".bam" || ext == ".sam";
-    pgh::FastxIndex fai;
-    pgh::SamBamReader sam;
-    if (is_bam && !sam.open(move_table, err)) { fprintf(stderr, "[gmove] %s\n", err.c_str()); return EXIT_FAILURE; } // F_CHK(bam_fp), gmove.cpp:1067-1068
-    if (is_paf) {
-        if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return EXIT_FAILURE; } // gmove.cpp:510-513
-        if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return EXIT_FAILURE; }
-    }
-    FILE *paf_fp = fopen(move_table, "r");
-    if (!paf_fp) { fprintf(stderr, "Error in opening file %s\n", move_table); return EXIT_FAILURE; }
 
-    // ---- device context -----------------------------------------------------------------------------
+    // ---- device context: created on its own thread while this one builds the file indices (the HIP runtime takes 0.1-0.2 s
+    // to come up, about as long as indexing a compressed BLOW5) -------------------------------------------------------------
     if (opt.kmer_size > 13) return die("kmer sizes above 13 are not supported by this implementation");
     std::vector<int32_t> table_t((size_t)1 << (2 * opt.kmer_size)), table_u(table_t.size());
     {
@@ -235,8 +225,39 @@ int gmove_main(int argc, char **argv) {
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     pg_ctx *ctx = nullptr;
+    std::string ctx_err; double t_ctx = 0;
+    const std::chrono::steady_clock::time_point t_setup0 = std::chrono::steady_clock::now();
+    std::future<pg_status> ctx_ready = std::async(std::launch::async, [&]() {
+        const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+        const pg_status st = pg_create(&prm, &ctx);
+        if (st != PG_OK) ctx_err = pg_last_error(nullptr); // the text lives in the creating thread
+        t_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        return st;
+    });
+    auto give_up = [&](int code) { if (ctx_ready.valid() && ctx_ready.get() == PG_OK) pg_destroy(ctx); return code; }; // early error exits
+
+    pgh::Slow5File s5;
+    if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return give_up(EXIT_FAILURE); } // gmove.cpp:493-503
+
+    pgh::FastxIndex fai;
+    pgh::SamBamReader sam;
+    if (is_bam && !sam.open(move_table, err)) { fprintf(stderr, "[gmove] %s\n", err.c_str()); return give_up(EXIT_FAILURE); } // F_CHK(bam_fp), gmove.cpp:1067-1068
+    if (is_paf) {
+        if (!input_fastq_file) { fprintf(stderr, ".paf input requires an additional .fastq file\n"); return give_up(EXIT_FAILURE); } // gmove.cpp:510-513
+        if (!fai.load(input_fastq_file, err)) { fprintf(stderr, "Error in loading fastq index for %s\n", input_fastq_file); return give_up(EXIT_FAILURE); }
+    }
+    FILE *paf_fp = fopen(move_table, "r");
+    if (!paf_fp) { fprintf(stderr, "Error in opening file %s\n", move_table); return give_up(EXIT_FAILURE); }
     const std::chrono::steady_clock::time_point t_setup1 = std::chrono::steady_clock::now();
-    if (pg_create(&prm, &ctx) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(nullptr)); return EXIT_FAILURE; }
+    double t_ctx_wait = 0; // the context is awaited at its first use (the first batch), behind the parsing of that batch
+    auto need_ctx = [&]() -> bool {
+        if (!ctx_ready.valid()) return ctx != nullptr;
+        const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
+        const pg_status st = ctx_ready.get();
+        t_ctx_wait = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        if (st != PG_OK) { fprintf(stderr, "[gmove] %s\n", ctx_err.c_str()); ctx = nullptr; return false; }
+        return true;
+    };
 
     // ---- the read loop (src/gmove.cpp:732-969), batched ---------------------------------------------------
     HostBatch hb;
@@ -258,6 +279,7 @@ int gmove_main(int argc, char **argv) {
         b.sig = hb.sig.data(); b.sig_off = hb.sig_off.data(); b.digitisation = hb.dig.data(); b.offset = hb.off.data(); b.range = hb.range.data();
         b.query_start = hb.qs.data(); b.target_start = hb.ts.data(); b.target_end = hb.te.data(); b.seq = hb.seq.data(); b.seq_off = hb.seq_off.data();
         b.op_n = hb.op_n.data(); b.op_t = hb.op_t.data(); b.op_off = hb.op_off.data();
+        if (!need_ctx()) return false;
         pg_status s = pg_submit(ctx, &b);
         if (s == PG_OK) s = pg_sync(ctx);
         if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); return false; }
@@ -434,9 +456,9 @@ int gmove_main(int argc, char **argv) {
     if (status == EXIT_SUCCESS) {
         pg_result res;
         const clk::time_point tq0 = clk::now();
-        const pg_status fin = pg_finish(ctx, &res);
+        const pg_status fin = need_ctx() ? pg_finish(ctx, &res) : PG_ERR_NO_DEVICE;
         t_finish = secs(tq0, clk::now());
-        if (fin != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+        if (fin != PG_OK) { if (ctx) fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
         else {
             pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
@@ -476,13 +498,16 @@ int gmove_main(int argc, char **argv) {
                 }
                 fprintf(stderr, "\n[gmove] time: k-mer model on the device %.3f s", secs(tm0, clk::now()));
             }
-            fprintf(stderr, "\n[gmove] time: file indices + k-mer list %.3f s, device context %.3f s\n", secs(t_setup0, t_setup1), secs(t_setup1, t_loop0));
+            fprintf(stderr, "\n[gmove] time: file indices %.3f s next to device context %.3f s (own thread), waited %.3f s for it at the first batch\n", secs(t_setup0, t_setup1), t_ctx, t_ctx_wait);
             fprintf(stderr, "[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
                     t_loop - t_device, t_device, t_finish, t_dump);
             fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
                     (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, device);
         }
     }
-    pg_destroy(ctx);
+    (void)need_ctx(); // a failed run may not have reached the first use
+    const clk::time_point t_end0 = clk::now();
+    if (ctx) pg_destroy(ctx);
+    fprintf(stderr, "[gmove] time: %.3f s from the start of gmove to the end of the output, %.3f s to release the device\n", secs(t_main0, t_end0), secs(t_end0, clk::now()));
     return status;
 }
