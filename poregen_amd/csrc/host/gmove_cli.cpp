@@ -80,8 +80,30 @@ void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
     fprintf(fp, "   --dwell_model FILE         also write KMER<TAB>median dwell (scripts/poregen.sh calculate_dwell_times_medians)\n");
 }
 
+// The signal of a batch is hundreds of MB: a std::vector would zero every byte on resize (one thread, and the page faults
+// with it) before the pool threads overwrite it. Plain storage; the first touch of each page happens in the copying threads.
+struct SampleBuf {
+    int16_t *p = nullptr; size_t n = 0, cap = 0;
+    SampleBuf() = default;
+    SampleBuf(const SampleBuf &) = delete; SampleBuf &operator=(const SampleBuf &) = delete;
+    ~SampleBuf() { free(p); }
+    int16_t *data() { return p; } const int16_t *data() const { return p; }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void reserve(size_t want) {
+        if (want <= cap) return;
+        size_t c = cap ? cap : 4096; while (c < want) c += c / 2 + 4096;
+        int16_t *q = (int16_t *)realloc(p, c * sizeof(int16_t));
+        if (!q) { fprintf(stderr, "[gmove] out of memory for %zu samples\n", c); exit(EXIT_FAILURE); }
+        p = q; cap = c;
+    }
+    void resize(size_t want) { reserve(want); n = want; } // new elements are NOT initialised
+    void append(const int16_t *a, const int16_t *b) { const size_t k = (size_t)(b - a); reserve(n + k); if (k) memcpy(p + n, a, k * sizeof(int16_t)); n += k; }
+};
+
 struct HostBatch {
-    std::vector<int16_t> sig; std::vector<uint64_t> sig_off{0}, seq_off{0}, op_off{0};
+    SampleBuf sig;
+    std::vector<uint64_t> sig_off{0}, seq_off{0}, op_off{0};
     std::vector<double> dig, off, range;
     std::vector<int32_t> qs, ts, te;
     std::vector<uint8_t> seq, op_t;
@@ -269,7 +291,7 @@ int gmove_main(int argc, char **argv) {
     bool stop = false;
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    double t_device = 0, t_finish = 0, t_dump = 0;
+    double t_device = 0, t_finish = 0, t_dump = 0, t_lines = 0, t_decode = 0, t_concat = 0;
     const clk::time_point t_loop0 = clk::now();
     auto flush = [&]() -> bool {
         if (hb.n() == 0) return true;
@@ -300,7 +322,7 @@ int gmove_main(int argc, char **argv) {
         if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
             fprintf(stderr, "move record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", read_id); status = EXIT_FAILURE; return false;
         }
-        hb.sig.insert(hb.sig.end(), rec.raw.begin() + trim, rec.raw.end()); // gmove.cpp:591-598: only the trimmed signal is used
+        hb.sig.append(rec.raw.data() + trim, rec.raw.data() + rec.raw.size()); // gmove.cpp:591-598: only the trimmed signal is used
         total_samples += rec.raw.size();
         seq.clear();
         uint32_t qstart = 0;
@@ -347,12 +369,15 @@ int gmove_main(int argc, char **argv) {
         bool eof = false;
         while (!stop && !eof && status == EXIT_SUCCESS) {
             size_t n_lines = 0;
+            const clk::time_point tp0 = clk::now();
             while (n_lines < batch_reads) {
                 if ((got = getline(&line, &cap, paf_fp)) == -1) { eof = true; break; }
                 if (n_lines == lines.size()) lines.emplace_back();
                 lines[n_lines++].assign(line, (size_t)got);
             }
             if (n_lines == 0) break;
+            const clk::time_point tp1 = clk::now();
+            t_lines += secs(tp0, tp1);
             on_threads([&](unsigned t) {
                 Run &r = runs[t];
                 r.b.clear(); r.bad = false; r.msg.clear();
@@ -368,7 +393,8 @@ int gmove_main(int argc, char **argv) {
                     const int64_t a = paf.target_start, b2 = paf.target_end;
                     const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
                     fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), r.seq); // absent name: empty sequence -> the read is skipped on the device
-                    r.b.sig.insert(r.b.sig.end(), r.rec.raw.begin(), r.rec.raw.end());
+                    if (i == r.lo) r.b.sig.reserve((r.hi - r.lo) * (r.rec.raw.size() + r.rec.raw.size() / 8)); // reads of a run are of similar length
+                    r.b.sig.append(r.rec.raw.data(), r.rec.raw.data() + r.rec.raw.size());
                     r.b.sig_off.push_back(r.b.sig.size());
                     r.b.seq.insert(r.b.seq.end(), r.seq.begin(), r.seq.end()); r.b.seq_off.push_back(r.b.seq.size());
                     r.b.op_off.push_back(r.b.op_n.size());
@@ -377,6 +403,7 @@ int gmove_main(int argc, char **argv) {
                     r.n_ok++;
                 }
             });
+            t_decode += secs(tp1, clk::now());
             // runs in file order up to the first failing line; one device batch unless that would exceed 2^29 samples
             unsigned last_run = nt; // first run that stopped early
             for (unsigned t = 0; t < nt; t++) if (runs[t].bad) { last_run = t; break; }
@@ -388,6 +415,7 @@ int gmove_main(int argc, char **argv) {
                 const unsigned t1 = tot > ((uint64_t)1 << 29) ? t0 + 1 : n_runs; // too big for one batch: run by run
                 uint64_t ns = 0, nq = 0, no = 0, nb = 0;
                 for (unsigned t = t0; t < t1; t++) { ns += runs[t].b.sig_off.back(); nq += runs[t].b.seq_off.back(); no += runs[t].b.op_off.back(); nb += runs[t].b.n(); }
+                const clk::time_point tc0 = clk::now();
                 hb.sig.resize(ns); hb.seq.resize(nq); hb.op_n.resize(no); hb.op_t.resize(no);
                 hb.sig_off.resize(nb + 1); hb.seq_off.resize(nb + 1); hb.op_off.resize(nb + 1);
                 hb.dig.resize(nb); hb.off.resize(nb); hb.range.resize(nb); hb.qs.resize(nb); hb.ts.resize(nb); hb.te.resize(nb);
@@ -407,6 +435,7 @@ int gmove_main(int argc, char **argv) {
                     }
                 });
                 hb.sig_off[nb] = ns; hb.seq_off[nb] = nq; hb.op_off[nb] = no;
+                t_concat += secs(tc0, clk::now());
                 total_samples += ns;
                 for (uint64_t k = 0; k < nb; k++) if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
                 if (nb && !flush()) { status = EXIT_FAILURE; break; }
@@ -499,6 +528,7 @@ int gmove_main(int argc, char **argv) {
                 fprintf(stderr, "\n[gmove] time: k-mer model on the device %.3f s", secs(tm0, clk::now()));
             }
             fprintf(stderr, "\n[gmove] time: file indices %.3f s next to device context %.3f s (own thread), waited %.3f s for it at the first batch\n", secs(t_setup0, t_setup1), t_ctx, t_ctx_wait);
+            if (is_paf) fprintf(stderr, "[gmove] time: PAF lines %.3f s, parse + decode on the pool %.3f s, one batch from the runs %.3f s\n", t_lines, t_decode, t_concat);
             fprintf(stderr, "[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
                     t_loop - t_device, t_device, t_finish, t_dump);
             fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,

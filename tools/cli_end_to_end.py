@@ -16,4 +16,4 @@ for lim in (100, 5000):
         r = subprocess.run([root + "/bin/poregen", "gmove", "-k", "5", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40", "--file_limit", "1024",
                             "--sample_limit", str(lim), d + "/r.blow5", d + "/r.paf", "--fastq", d + "/r.fastq", out, "--batch_reads", "50000"], capture_output=True, text=True)
         dt = time.time() - t0
-        print(f"sample_limit {lim} run {rep}: exit {r.returncode}, wall {dt:.2f} s -> {b.n_samples / dt / 1e6:.1f} M samples/s end to end;", "; ".join(l for l in r.stderr.splitlines() if l.startswith("[gmove]"))[:400])
+        print(f"sample_limit {lim} run {rep}: exit {r.returncode}, wall {dt:.2f} s -> {b.n_samples / dt / 1e6:.1f} M samples/s end to end;", "; ".join(l for l in r.stderr.splitlines() if l.startswith("[gmove]"))[:900])
