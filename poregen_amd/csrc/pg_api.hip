@@ -7,6 +7,7 @@
 #include "pg_model.h"
 
 #include <algorithm>
+#include <thread>
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -37,11 +38,21 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// vector<double> whose resize() leaves new elements uninitialised: the kept samples (hundreds of MB at large limits) are
+// overwritten by the download / merge right away, zero-filling them first costs as much as the copy
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using SampleVec = std::vector<double, NoInitAlloc<double>>;
+
 struct HostBatchResult { // one collected batch, downloaded
     uint64_t n_reads = 0, n_events = 0, n_samples = 0;
     std::vector<uint64_t> keep, ev_off, samp_off;
     std::vector<uint32_t> ev_len, ev_read;
-    std::vector<double> samples;
+    SampleVec samples;
     std::vector<uint8_t> skipped;
 };
 
@@ -90,7 +101,7 @@ struct pg_ctx {
     // merged view
     std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
     std::vector<uint32_t> r_ev_len, r_ev_read;
-    std::vector<double> r_samples;
+    SampleVec r_samples;
     std::vector<uint8_t> r_skipped;
     // pg_model
     std::vector<PgSlotModel> mo_raw;
@@ -308,7 +319,27 @@ static pg_status download_last(pg_ctx *c) {
         HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
     } else h.samp_off[0] = 0;
-    if (h.n_samples) HIP_TRY(c, hipMemcpy(h.samples.data(), c->samples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
+    if (h.n_samples) {
+        // pageable destination: the runtime stages the copy through pinned bounce buffers with one host thread per call;
+        // several calls on slices run side by side (first touch of the fresh pages included)
+        const uint64_t bytes = h.n_samples * 8ull;
+        const unsigned parts = bytes >= (64ull << 20) ? 8u : 1u;
+        if (parts == 1) HIP_TRY(c, hipMemcpy(h.samples.data(), c->samples.p, bytes, hipMemcpyDeviceToHost));
+        else {
+            std::vector<hipError_t> rc(parts, hipSuccess);
+            std::vector<std::thread> pool;
+            const uint64_t step = ((h.n_samples + parts - 1) / parts + 511) & ~511ull; // samples per slice, 4 KB multiples
+            for (unsigned t = 0; t < parts; t++)
+                pool.emplace_back([&, t]() {
+                    const uint64_t a = std::min<uint64_t>(h.n_samples, t * step), b = std::min<uint64_t>(h.n_samples, a + step);
+                    if (b <= a) return;
+                    rc[t] = hipSetDevice(c->device);
+                    if (rc[t] == hipSuccess) rc[t] = hipMemcpy(h.samples.data() + a, c->samples.as<double>() + a, (b - a) * 8ull, hipMemcpyDeviceToHost);
+                });
+            for (auto &th : pool) th.join();
+            for (hipError_t e : rc) HIP_TRY(c, e);
+        }
+    }
     std::vector<int32_t> st(h.n_reads);
     if (h.n_reads) HIP_TRY(c, hipMemcpy(st.data(), c->status.p, h.n_reads * 4ull, hipMemcpyDeviceToHost));
     h.skipped.resize(h.n_reads);
