@@ -84,8 +84,9 @@ def main():
     n_ops = int(host.op_off[-1])
 
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
-    counts_buf = torch.empty(len(kmers), dtype=torch.int64, device=dev)
     gather_buf = torch.empty(world * len(kmers), dtype=torch.int64, device=dev)  # receive buffer of the per-step all_gather
+    # pg_count writes this rank's counts straight into its row of the receive buffer: the all_gather runs in place
+    counts_buf = gather_buf[rank * len(kmers):(rank + 1) * len(kmers)] if backend == "nccl" else torch.empty(len(kmers), dtype=torch.int64, device=dev)
     stream_ordered = dist_step and backend == "nccl"
     if stream_ordered:  # count -> RCCL all_gather -> collect ordered on one stream, no host sync inside a step
         side = torch.cuda.Stream(device=dev)
@@ -96,7 +97,7 @@ def main():
         eng.reset()
         if dist_step:
             total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered, gather_buf=gather_buf)
-            pgdist.merged_freq(total, args.sample_limit)
+            pgdist.merged_freq(total, args.sample_limit, engine=eng)
         else:
             eng.submit(shard)
 

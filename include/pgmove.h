@@ -196,6 +196,12 @@ pg_status pg_collect(pg_ctx *ctx, const uint64_t *base, int32_t base_location);
  * Replaces nothing in the reference (which is single-process); the order semantics are those of pg_collect. */
 pg_status pg_collect_gathered(pg_ctx *ctx, const uint64_t *all_counts, uint32_t world, uint32_t rank);
 
+/* After pg_collect_gathered: device pointers (uint64[n_slots], stable for the life of the context, contents rewritten by
+ * every pg_collect_gathered on the context's stream) to the accepted events of ALL ranks per slot and to the job's freq.txt
+ * values min(total, sample_limit) (src/gmove.cpp:945-953, 523-534) -- produced by the kernel that sums the lower ranks' rows,
+ * so a multi-GPU step needs no reduction of its own. Either output pointer may be NULL. */
+pg_status pg_job_totals_device(pg_ctx *ctx, const uint64_t **d_total, const uint64_t **d_freq);
+
 pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work of the context */
 /* Run the context's main chain on a caller-owned HIP stream (hipStream_t passed as void*), e.g. PyTorch's current
  * stream, so that collectives issued by the caller between pg_count and pg_collect are ordered without host

@@ -83,6 +83,7 @@ struct pg_ctx {
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf m_read, meta, huge_scratch, oor;
+    DevBuf job_total, job_freq; bool have_job_totals = false; // pg_collect_gathered / pg_job_totals_device
     DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
@@ -222,7 +223,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor,
-                      &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
+                      &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -275,6 +276,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
     CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull)); CTRY(c->tile_last.ensure(ns * 4ull));
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
+    CTRY(c->job_total.ensure(ns * 8ull)); CTRY(c->job_freq.ensure(ns * 8ull)); // allocated once: callers may cache the pointers
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
     CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
@@ -293,7 +295,7 @@ pg_status pg_reset(pg_ctx *c) {
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
     c->zero_running = true;
-    c->batches.clear(); c->single_moved = false;
+    c->batches.clear(); c->single_moved = false; c->have_job_totals = false;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->full_before_batch = false; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
@@ -583,17 +585,17 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     return PG_OK;
 }
 
-static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t rank);
+static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t world, uint32_t rank);
 
-pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0); }
+pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0, 0); }
 
 pg_status pg_collect_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!all_counts || world == 0 || rank >= world) return fail(c, PG_ERR_INVALID_ARG, "pg_collect_gathered: all_counts / world / rank");
-    return collect_impl(c, nullptr, PG_LOC_DEVICE, all_counts, rank);
+    return collect_impl(c, nullptr, PG_LOC_DEVICE, all_counts, world, rank);
 }
 
-static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t rank) {
+static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -602,7 +604,9 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     const bool direct = ns <= PG_DIRECT_MAX_SLOTS;
     const uint64_t *d_base = c->running.as<uint64_t>();
     if (all_counts) {
-        pg_launch_rank_base(c->st, all_counts, rank, ns, c->base_stage.as<uint64_t>());
+        pg_launch_rank_base(c->st, all_counts, world, rank, ns, c->prm.sample_limit, c->base_stage.as<uint64_t>(), c->job_total.as<uint64_t>(),
+                            c->job_freq.as<uint64_t>());
+        c->have_job_totals = true;
         d_base = c->base_stage.as<uint64_t>();
     } else if (base) {
         HIP_TRY(c, hipMemcpyAsync(c->base_stage.p, base, ns * 8ull,
@@ -705,6 +709,14 @@ pg_status pg_submit(pg_ctx *c, const pg_batch *b) {
     pg_status s = pg_count(c, b, nullptr, PG_LOC_HOST);
     if (s != PG_OK) return s;
     return pg_collect(c, nullptr, PG_LOC_HOST);
+}
+
+pg_status pg_job_totals_device(pg_ctx *c, const uint64_t **d_total, const uint64_t **d_freq) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_job_totals) return fail(c, PG_ERR_STATE, "pg_job_totals_device without a preceding pg_collect_gathered");
+    if (d_total) *d_total = c->job_total.as<uint64_t>();
+    if (d_freq) *d_freq = c->job_freq.as<uint64_t>();
+    return PG_OK;
 }
 
 pg_status pg_sync(pg_ctx *c) {

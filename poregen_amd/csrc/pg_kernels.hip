@@ -1439,17 +1439,24 @@ void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_
                        stat_flags);
 }
 
-__global__ __launch_bounds__(256) void k_rank_base(const uint64_t *__restrict__ all_counts, uint32_t rank, uint32_t n_slots,
-                                                   uint64_t *__restrict__ base) {
+__global__ __launch_bounds__(256) void k_rank_base(const uint64_t *__restrict__ all_counts, uint32_t world, uint32_t rank, uint32_t n_slots,
+                                                   uint32_t limit, uint64_t *__restrict__ base, uint64_t *__restrict__ total,
+                                                   uint64_t *__restrict__ freq) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_slots) return;
-    uint64_t b = 0;
-    for (uint32_t g = 0; g < rank; ++g) b += all_counts[(uint64_t)g * n_slots + s];
+    uint64_t b = 0, t = 0;
+    for (uint32_t g = 0; g < world; ++g) {
+        if (g == rank) b = t; // accepted events of the ranks below this one
+        t += all_counts[(uint64_t)g * n_slots + s];
+    }
     base[s] = b;
+    total[s] = t;                       // the job's accepted events for the k-mer ...
+    freq[s] = t < limit ? t : limit;    // ... and its freq.txt value (src/gmove.cpp:945-953: a file closes at sample_limit)
 }
 
-void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t rank, uint32_t n_slots, uint64_t *base) {
-    hipLaunchKernelGGL(k_rank_base, dim3((n_slots + 255) / 256), dim3(256), 0, st, all_counts, rank, n_slots, base);
+void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t world, uint32_t rank, uint32_t n_slots, uint32_t limit,
+                         uint64_t *base, uint64_t *total, uint64_t *freq) {
+    hipLaunchKernelGGL(k_rank_base, dim3((n_slots + 255) / 256), dim3(256), 0, st, all_counts, world, rank, n_slots, limit, base, total, freq);
 }
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {

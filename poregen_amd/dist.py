@@ -34,23 +34,31 @@ def exchange_bases(counts, group=None):
     return base, allc.sum(dim=0)
 
 
-def merged_freq(total_counts, sample_limit: int):
-    """freq.txt of the whole job from the job-wide accepted counts."""
+def merged_freq(total_counts, sample_limit: int, engine=None):
+    """freq.txt of the whole job from the job-wide accepted counts. With the engine of an RCCL step (sharded_step on device
+    shards) the column has already been produced on the device by pg_collect_gathered."""
     import torch
+    if engine is not None and getattr(engine, "_job_totals", None) is not None and total_counts is engine._job_totals[0]:
+        return engine._job_totals[1]
     return torch.clamp(total_counts, max=sample_limit)
 
 
 def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=False, gather_buf=None):
     """count -> exchange -> collect for one shard. Device-resident shards exchange on the GPU (RCCL); host
-    shards exchange CPU tensors (gloo). Returns the job-wide accepted counts.
+    shards exchange CPU tensors (gloo). Returns the job-wide accepted counts (on the RCCL path a tensor that aliases the
+    engine's buffer: valid until the engine's next step or close()).
     stream_ordered: the engine runs on torch's current stream (GmoveEngine.use_torch_stream), so the
     collective is ordered by the stream and no host synchronisation is needed.
     gather_buf: optional preallocated int64 tensor [world * n_slots] on the shard's device (receive buffer of the
     all_gather). With RCCL the buffer goes straight into pg_collect_gathered, which sums the lower ranks' rows on the
-    device: a step is count, ONE collective, collect, and one torch reduction for the job-wide counts."""
+    device together with the job-wide counts and the freq.txt column (engine.job_totals()): a step is count, ONE collective, collect."""
     import torch
     import torch.distributed as dist
     if shard.on_device:
+        if counts_buf is None and gather_buf is not None and dist.get_backend(group) != "gloo":
+            # this rank's row of the receive buffer: RCCL runs the all_gather in place (no local copy)
+            r = dist.get_rank(group)
+            counts_buf = gather_buf[r * engine.n_slots:(r + 1) * engine.n_slots]
         if counts_buf is None:
             counts_buf = torch.empty(engine.n_slots, dtype=torch.int64, device=shard.sig.device)
         engine.count(shard, out=counts_buf)
@@ -70,7 +78,7 @@ def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=Fals
             if not stream_ordered:
                 torch.cuda.current_stream().synchronize()
             engine.collect_gathered(gather_buf, world, rank)
-            total = gather_buf.view(world, -1).sum(dim=0)
+            total = engine.job_totals()[0]  # summed by the kernel that computes this rank's base; [1] is the job's freq.txt column
     else:
         c = engine.count(shard)
         t = torch.from_numpy(c.view(np.int64).copy())

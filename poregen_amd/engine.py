@@ -291,6 +291,21 @@ class GmoveEngine:
             raise ValueError("all_counts must be a contiguous world x n_slots tensor")
         self._check(self._lib.pg_collect_gathered(self._h, all_counts.data_ptr(), world, rank))
 
+    def job_totals(self, device=None):
+        """After collect_gathered: (accepted events of all ranks per slot, freq.txt values of the job) as int64 CUDA tensors that
+        alias the library's buffers (pg_job_totals_device); rewritten by every collect_gathered on the engine's stream."""
+        import torch
+        if getattr(self, "_job_totals", None) is None:
+            a, b = C.c_void_p(), C.c_void_p()
+            self._check(self._lib.pg_job_totals_device(self._h, C.byref(a), C.byref(b)))
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+
+            class _Alias:
+                def __init__(self, ptr, n):
+                    self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+            self._job_totals = tuple(torch.as_tensor(_Alias(x.value, self.n_slots), device=dev) for x in (a, b))
+        return self._job_totals
+
     def sync(self):
         self._check(self._lib.pg_sync(self._h))
 

@@ -206,6 +206,8 @@ def test_collect_gathered_three_ranks_on_one_gpu():
     for g, e in enumerate(engs):
         e.collect_gathered(allc, len(shards), g)
         results.append(e.finish())
+        tot, freq = (t.cpu().numpy() for t in e.job_totals())   # every rank holds the job's totals and freq.txt column
+        assert np.array_equal(tot, allc.view(3, -1).sum(0).cpu().numpy()) and np.array_equal(freq.astype(np.uint64), o.counts())
         e.close()
     for s in range(len(kmers)):
         vals = np.concatenate([r.slot_values(s) for r in results])
@@ -234,7 +236,11 @@ def test_sharded_step_over_rccl_single_rank(tmp_path):
             eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
             eng.use_torch_stream(side)
             total = pgdist.sharded_step(eng, b.to_device(dev), stream_ordered=True)
+            freq = pgdist.merged_freq(total, 15, engine=eng)   # produced on the device by pg_collect_gathered
             res = eng.finish()
+            assert freq is eng.job_totals()[1] and np.array_equal(freq.cpu().numpy().astype(np.uint64), o.counts())
+            assert np.array_equal(freq.cpu().numpy(), np.minimum(total.cpu().numpy(), 15))
+            total = total.clone()   # the step's totals alias the engine's buffers: keep a copy beyond close()
             eng.close()
         assert np.array_equal(np.minimum(total.cpu().numpy().astype(np.uint64), 15), o.counts())
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=15)
