@@ -25,7 +25,7 @@ poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h $(CSRC)
 	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread
 
 HOST = $(CSRC)/host
-bin/poregen: $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp $(HOST)/pg_host.h include/pgmove.h poregen_amd/libpgmove.so
+bin/poregen: $(CSRC)/pg_model.h $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp $(HOST)/pg_host.h include/pgmove.h poregen_amd/libpgmove.so
 	@mkdir -p bin
 	$(CXX) -O2 -g -std=c++17 -Wall -o $@ $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp \
 	    -Lporegen_amd -lpgmove -L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,'$$ORIGIN/../poregen_amd' -Wl,-rpath,/opt/rocm/lib

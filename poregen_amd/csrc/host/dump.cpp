@@ -1,5 +1,7 @@
 // dump.cpp -- k-mer list and the dump directory writer (exact "%.8f" text, -d delimiters, freq.txt).
 #include "pg_host.h"
+#include "../pg_model.h"
+#include <cmath>
 
 #include <atomic>
 #include <charconv>
@@ -52,10 +54,28 @@ int create_dir(const char *dir_name) { // src/gmove.cpp:126-140
 }
 
 size_t format_f8(double v, char *buf) {
-    // printf("%.8f") prints the exactly-rounded (round-half-even on the binary value) decimal expansion with
-    // 8 fractional digits; std::to_chars(fixed, 8) is specified to produce the same digits as printf.
-    auto r = std::to_chars(buf, buf + 380, v, std::chars_format::fixed, 8);
-    return (size_t)(r.ptr - buf);
+    // printf("%.8f") prints the exactly-rounded (round-half-even on the binary value) decimal expansion with 8 fractional
+    // digits. pg_fixed8 (../pg_model.h) is that rounding as an integer number of 1e-8 units for |v| < 4e7: digits by integer
+    // division, ~4x faster than the general routine, which stays for everything else (std::to_chars(fixed, 8) is specified
+    // to produce printf's digits).
+    bool general = false;
+    const int64_t units = pg_fixed8(v, general);
+    if (general) {
+        auto r = std::to_chars(buf, buf + 380, v, std::chars_format::fixed, 8);
+        return (size_t)(r.ptr - buf);
+    }
+    char *p = buf;
+    if (std::signbit(v)) *p++ = '-'; // also "-0.00000000" for a negative value that rounds to zero, like printf
+    const uint64_t mag = (uint64_t)(units < 0 ? -units : units);
+    uint64_t ip = mag / 100000000u;
+    uint32_t fp = (uint32_t)(mag % 100000000u);
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (n) *p++ = tmp[--n];
+    *p++ = '.';
+    for (int i = 7; i >= 0; --i) { p[i] = (char)('0' + fp % 10); fp /= 10; }
+    return (size_t)(p + 8 - buf);
 }
 
 bool touch_dump_files(const std::string &out_dir, const std::vector<std::string> &slot_kmers, std::string &err) {
@@ -71,6 +91,7 @@ bool touch_dump_files(const std::string &out_dir, const std::vector<std::string>
 static void slot_text(const DumpInput &in, uint32_t s, bool delimit, uint32_t sample_limit, std::string &out) {
     char buf[400];
     const uint64_t a = in.ev_off[s], b = in.ev_off[s + 1];
+    out.reserve((size_t)(in.samp_off[b] - in.samp_off[a]) * 13 + (delimit ? (size_t)in.n_reads : 0) + 64); // ~12 bytes per sample
     auto put_event = [&](uint64_t e) {
         const uint64_t so = in.samp_off[e], n = in.ev_len[e];
         for (uint64_t i = 0; i < n; i++) { // "%.8f," ... "%.8f;" (src/gmove.cpp:941-944)

@@ -33,6 +33,8 @@ def test_format_f8_equals_printf(h):
                   123456.123456785, 0.000000005, 0.000000015, 99999999.99999999, 1e15]),
         (rng.integers(-10 ** 12, 10 ** 12, 5000) + 0.5) / 1e8,   # decimal ties at the 9th digit (not exactly representable)
         rng.integers(-2 ** 20, 2 ** 20, 3000) / 2.0 ** 12,       # exactly representable, some with exact binary ties
+        np.arange(-3001, 3001, 2) / 512.0,                       # every odd multiple of 2^-9: exact ties at the 8th digit
+        np.array([3.9999999e7, -3.9999999e7, 4.0e7, -4.0e7, 4.1e7, 1e-300, -1e-300, 5e-324, -2.5e-9, -4.9e-9, -5.1e-9]),  # both sides of the fast path's range
     ])
     buf = C.create_string_buffer(400)
     for v in vals:
