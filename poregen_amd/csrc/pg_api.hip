@@ -99,6 +99,8 @@ struct pg_ctx {
 
     std::vector<HostBatchResult> batches;
     bool single_moved = false; // batches[0]'s arrays currently live in r_* (pg_finish of a one-batch job)
+    bool merged_valid = false; // r_* hold the merged view of all downloaded batches (a repeated pg_finish / pg_model returns it as it is)
+    uint64_t m_events = 0, m_samples = 0, m_reads = 0;
     // merged view
     std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
     std::vector<uint32_t> r_ev_len, r_ev_read;
@@ -295,7 +297,7 @@ pg_status pg_reset(pg_ctx *c) {
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
     c->zero_running = true;
-    c->batches.clear(); c->single_moved = false; c->have_job_totals = false;
+    c->batches.clear(); c->single_moved = false; c->have_job_totals = false; c->merged_valid = false;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->full_before_batch = false; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
@@ -309,6 +311,7 @@ static pg_status download_last(pg_ctx *c) {
     if (!c->have_batch_result || c->downloaded) return PG_OK;
     { pg_status s0 = settle_batch(c); if (s0 != PG_OK) return s0; }
     c->batches.emplace_back();
+    c->merged_valid = false;
     HostBatchResult &h = c->batches.back();
     const uint32_t ns = c->prm.n_slots;
     h.n_reads = c->B.n_reads; h.n_events = c->cur_n_kept; h.n_samples = c->cur_n_samples;
@@ -760,6 +763,13 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     pg_status s = download_last(c);
     if (s != PG_OK) return s;
     const uint32_t ns = c->prm.n_slots;
+    if (c->merged_valid) { // nothing was collected since the last call: the merged view is current
+        out->n_slots = ns; out->reserved = 0; out->n_events = c->m_events; out->n_samples = c->m_samples; out->n_reads = c->m_reads;
+        out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
+        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+        out->read_skipped = c->r_skipped.data();
+        return PG_OK;
+    }
     if (c->single_moved && !c->batches.empty()) { // give the first batch its arrays back (see the one-batch path below)
         HostBatchResult &h = c->batches[0];
         c->r_ev_off.swap(h.ev_off); c->r_samp_off.swap(h.samp_off); c->r_ev_len.swap(h.ev_len); c->r_ev_read.swap(h.ev_read);
@@ -780,6 +790,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
         out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
         out->read_skipped = c->r_skipped.data();
+        c->merged_valid = true; c->m_events = n_events; c->m_samples = n_samples; c->m_reads = n_reads;
         return PG_OK;
     }
     c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.assign(n_events + 1, 0);
@@ -808,6 +819,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
     out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
     out->read_skipped = c->r_skipped.data();
+    c->merged_valid = true; c->m_events = n_events; c->m_samples = n_samples; c->m_reads = n_reads;
     return PG_OK;
 }
 
