@@ -824,11 +824,11 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
 }
 
 // launch + download + host finishing of the model reduction over device arrays in pg_result layout
-static pg_status model_run(pg_ctx *c, uint32_t ns, int any_short, int any_long, const uint64_t *d_ev_off, const uint64_t *d_samp_off,
+static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[3], const uint64_t *d_ev_off, const uint64_t *d_samp_off,
                            const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out) {
     HIP_TRY(c, c->md_out.ensure((ns + 1) * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure((ns + 1) * sizeof(PgSlotDwell)));
     prof_begin(c, "k_slot_model", c->st);
-    HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_short, any_long, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
+    HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_kind, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
                                     c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
     prof_end(c, c->st);
     c->mo_raw.resize(ns); c->mo_dw.resize(ns);
@@ -876,13 +876,13 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
         if (R.n_samples) HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
         d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
     }
-    int any_short = 0, any_long = 0; // which of the two kernels has work (the host holds the offsets since pg_finish)
+    int any_kind[3] = {0, 0, 0}; // which of the three kernels have work (the host holds the offsets since pg_finish)
     const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;
     for (uint32_t i = 0; i < ns; i++) {
         const uint64_t all = R.samp_off[R.ev_off[i + 1]] - R.samp_off[R.ev_off[i]], nv = all > drop ? all - drop : 0;
-        if (nv <= PG_MODEL_SHORT_MAX) any_short = 1; else any_long = 1;
+        any_kind[pg_model_kind(nv)] = 1;
     }
-    return model_run(c, ns, any_short, any_long, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
+    return model_run(c, ns, any_kind, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
 }
 
 pg_status pg_model_device(pg_ctx *c, uint32_t n_slots, const uint64_t *d_ev_off, const uint64_t *d_samp_off, const uint32_t *d_ev_len,
@@ -890,7 +890,8 @@ pg_status pg_model_device(pg_ctx *c, uint32_t n_slots, const uint64_t *d_ev_off,
     if (!c || !out) return PG_ERR_INVALID_ARG;
     if (n_slots && (!d_ev_off || !d_samp_off)) return fail(c, PG_ERR_INVALID_ARG, "pg_model_device: ev_off / samp_off missing");
     HIP_TRY(c, hipSetDevice(c->device));
-    return model_run(c, n_slots, 1, 1, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out); // offsets are not on the host: both kernels look
+    const int all_kinds[3] = {1, 1, 1}; // the offsets are not on the host: every kernel looks
+    return model_run(c, n_slots, all_kinds, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
 }
 
 size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap) {

@@ -121,7 +121,7 @@ static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
 }
 // base[s] = sum over g < rank of all_counts[g * n_slots + s]
 struct PgSlotModel; struct PgSlotDwell; // pg_model.h
-hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, int any_short, int any_long, const uint64_t *ev_off, const uint64_t *samp_off,
+hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell);
 void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t world, uint32_t rank, uint32_t n_slots, uint32_t limit,
                          uint64_t *base, uint64_t *total, uint64_t *freq);

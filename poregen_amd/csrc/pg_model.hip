@@ -13,10 +13,11 @@
 
 namespace {
 
-constexpr int M_BITS = 12, M_BINS = 1 << M_BITS;
 // loads in flight per thread: the 1024-thread variant must stay within 64 VGPRs (two workgroups per CU), its memory
 // parallelism comes from 32 waves per CU; the 256-thread variant serves short files, where the round trips are the cost
 template <int MT> struct ModelCfg {
+    static constexpr int BITS = MT >= 256 ? 12 : 8;    // window of the radix select; a single wave scans 256 bins, not 4096
+    static constexpr int BINS = 1 << BITS;
     static constexpr int U = MT >= 1024 ? 2 : 8;
     static constexpr int CACHE = MT >= 1024 ? 0 : 16; // keys a thread keeps in registers when the whole file fits (MT * CACHE values)
 };
@@ -25,7 +26,7 @@ template <int MT> struct ModelSmem {
     static constexpr int CAND = MT * 4; // keys of one top-window bin that a long file parks in LDS (see block_middle_long)
     uint64_t cand[CAND];
     uint32_t n_cand;
-    uint32_t hist[M_BINS];
+    uint32_t hist[ModelCfg<MT>::BINS];
     uint64_t red[MT / 64];
     uint32_t wsum[MT / 64];
     uint32_t found_bin, found_below;
@@ -53,7 +54,7 @@ template <int MT, class Op> __device__ uint64_t block_reduce(ModelSmem<MT> &sm, 
 
 // bin b < nbins with below(b) <= rank < below(b) + hist[b]; the total of hist[0..nbins) must exceed rank
 template <int MT> __device__ void block_find_bin(ModelSmem<MT> &sm, uint32_t rank, uint32_t nbins, uint32_t &bin, uint32_t &below) {
-    constexpr int PER = M_BINS / MT;
+    constexpr int PER = ModelCfg<MT>::BINS / MT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     __syncthreads(); // histogram complete
     uint32_t h[PER], s = 0;
@@ -122,11 +123,12 @@ template <int MT, class Src> __device__ void block_window(ModelSmem<MT> &sm, con
 }
 
 // the rank-th smallest (0-based) of the source's keys; all keys < 2^bits. The bits are consumed from the top in windows of
-// at most M_BITS; the last (lowest) window is the short one, so that a narrow key range costs a small histogram.
+// at most ModelCfg<MT>::BITS; the last (lowest) window is the short one, so that a narrow key range costs a small histogram.
 template <int MT, class Src> __device__ uint64_t block_select(ModelSmem<MT> &sm, const Src &src, uint64_t rank, int bits) {
     uint64_t prefix = 0; // the bits above the current window
     int hi = bits;       // bits [hi, 64) are settled
     while (hi > 0) {
+        constexpr int M_BITS = ModelCfg<MT>::BITS;
         const int wbits = hi >= M_BITS ? M_BITS : hi;
         uint32_t bin, below;
         block_window<MT>(sm, src, hi, wbits, prefix, (uint32_t)rank, bin, below);
@@ -164,6 +166,7 @@ template <int MT> struct LdsKeys { // the parked candidates (low bits of the key
 // windows and the even-count step run on LDS. Three passes over the file (moments, top window, park) instead of 2 + windows + 1.
 template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm, const Src &src, uint64_t n, int bits, uint64_t &k_lo, uint64_t &k_hi) {
     const uint64_t r_lo = (n - 1) / 2, r_hi = n / 2;
+    constexpr int M_BITS = ModelCfg<MT>::BITS;
     if (bits <= M_BITS) { block_pair<MT>(sm, src, r_lo, r_hi, bits, k_lo, k_hi); return; }
     const int low = bits - M_BITS; // bits below the top window
     uint32_t bin, below;
@@ -188,12 +191,14 @@ template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm
     k_hi = q_hi < cnt ? (((uint64_t)bin << low) | c_hi) : above;
 }
 
-// Two kernels share this body: SHORT (256 threads, the whole file converted once into 16 registers per thread) takes the
-// k-mers with at most PG_MODEL_SHORT_MAX values, LONG (1024 threads, the file re-read per pass) the others; a workgroup whose
-// k-mer belongs to the other kernel leaves after two loads. Separate kernels because each needs its own register budget.
-template <int MT, bool SHORT> __global__ __launch_bounds__(MT, SHORT ? 4 : 8) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
+// Three kernels share this body, by file size: TINY (one wave, <= 1024 values: k = 9 jobs have 262 144 such files, and a wave
+// needs no workgroup barrier) and SHORT (256 threads, <= 4096 values) convert the whole file once into 16 registers per
+// thread; LONG (1024 threads) re-reads the file per pass. A workgroup whose k-mer belongs to another kernel leaves after two
+// loads. Separate kernels because each needs its own register budget; the host launches only the ones with work.
+template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : 4) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
                                                                       const double *samples, uint32_t drop_first, PgSlotModel *out,
                                                                       PgSlotDwell *dwell) {
+    constexpr bool SHORT = KIND != PG_MODEL_LONG; // register-resident
     __shared__ ModelSmem<MT> sm;
     constexpr int C = SHORT ? ModelCfg<MT>::CACHE : 0;
     const uint32_t s = blockIdx.x;
@@ -201,7 +206,7 @@ template <int MT, bool SHORT> __global__ __launch_bounds__(MT, SHORT ? 4 : 8) vo
     const uint64_t a0 = uniform64(samp_off[e0]), a1 = uniform64(samp_off[e1]);
     const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
     const uint64_t first = a0 + skip, n = a1 - first;
-    if ((n <= (uint64_t)PG_MODEL_SHORT_MAX) != SHORT) return;
+    if (pg_model_kind(n) != KIND) return;
     uint32_t flags = 0;
     PgSlotModel m{};
     m.n = n;
@@ -225,7 +230,7 @@ template <int MT, bool SHORT> __global__ __launch_bounds__(MT, SHORT ? 4 : 8) vo
         RegKeys<C> rk;
         rk.cnt = 0;
         if constexpr (SHORT) {
-            static_assert(!SHORT || MT * ModelCfg<MT>::CACHE == PG_MODEL_SHORT_MAX, "the short kernel holds the whole file in registers");
+            static_assert(MT * ModelCfg<MT>::CACHE == (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_MAX : PG_MODEL_SHORT_MAX), "the kernel holds the whole file in registers");
             double x[C];
             rk.cnt = n > threadIdx.x ? (int)((n - threadIdx.x + MT - 1) / MT) : 0;
 #pragma unroll
@@ -277,10 +282,11 @@ template <int MT, bool SHORT> __global__ __launch_bounds__(MT, SHORT ? 4 : 8) vo
 
 } // namespace
 
-hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, int any_short, int any_long, const uint64_t *ev_off, const uint64_t *samp_off,
+hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell) {
     if (n_slots == 0) return hipSuccess;
-    if (any_short) hipLaunchKernelGGL((k_slot_model<256, true>), dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
-    if (any_long) hipLaunchKernelGGL((k_slot_model<1024, false>), dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    if (any_kind[PG_MODEL_TINY]) hipLaunchKernelGGL((k_slot_model<64, PG_MODEL_TINY>), dim3(n_slots), dim3(64), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    if (any_kind[PG_MODEL_SHORT]) hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    if (any_kind[PG_MODEL_LONG]) hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
     return hipGetLastError();
 }
