@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
+    ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
     args = ap.parse_args()
 
@@ -83,7 +84,9 @@ def main():
     n_samples = host.n_samples
     n_ops = int(host.op_off[-1])
 
-    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    # multi-GPU step: the statistics are queued between the issue of the all_gather and the wait for it (dist.sharded_step)
+    defer = dist_step and not args.no_defer and not args.lazy and not args.overlap
+    eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=defer, **p))
     gather_buf = torch.empty(world * len(kmers), dtype=torch.int64, device=dev)  # receive buffer of the per-step all_gather
     # pg_count writes this rank's counts straight into its row of the receive buffer: the all_gather runs in place
     counts_buf = gather_buf[rank * len(kmers):(rank + 1) * len(kmers)] if backend == "nccl" else torch.empty(len(kmers), dtype=torch.int64, device=dev)
@@ -195,6 +198,7 @@ def main():
             "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
             "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
             "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if dist_step else None,
+            "statistics_placement": ("behind the issue of the all_gather (pg_stats)" if defer else "inside pg_count") if dist_step else None,
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples,
         },
         "roofline": roofline,

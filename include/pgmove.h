@@ -74,6 +74,11 @@ enum {
                                            zero-filling the sample: the SAM/BAM front-end (src/gmove.cpp:1149-1160). Event
                                            acceptance then depends on the signal, so the statistics pass runs first. */
     PG_FLAG_DEBUG_NARROW = 1u << 3, /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
+    PG_FLAG_DEFER_STATS = 1u << 7, /* multi-GPU step: pg_count does not queue the per-read statistics (median/MAD of every read, which
+                                     * do not depend on the exchange); pg_stats queues them -- between the ISSUE of the caller's
+                                     * collective and the wait for it, so that the all_gather's latency hides behind the streaming
+                                     * kernel -- or, if pg_stats is not called, pg_collect does. Ignored with PG_FLAG_LAZY_STATS,
+                                     * PG_FLAG_SKIP_OUT_OF_RANGE and PG_FLAG_OVERLAP (their statistics are placed already). */
     PG_FLAG_STOP_WHEN_FULL = 1u << 6 /* the slots are the WHOLE k-mer list: the reference stops reading PAF lines once every k-mer is
                                      * complete (src/gmove.cpp:733-735), so a read behind the one that completes the last k-mer
                                      * is never looked at and cannot fail the job. With this flag a per-read input error is
@@ -190,6 +195,9 @@ pg_status pg_count(pg_ctx *ctx, const pg_batch *batch, uint64_t *counts_out, int
  * reference order (earlier batches, lower ranks of a multi-GPU job); NULL = the context's own running
  * count. The batch pointers given to pg_count must still be valid. */
 pg_status pg_collect(pg_ctx *ctx, const uint64_t *base, int32_t base_location);
+/* Between pg_count and pg_collect of a context created with PG_FLAG_DEFER_STATS: queue the statistics of the counted batch
+ * (src/gmove.cpp:754-771 for every read) on the context's stream now. A no-op when nothing was deferred. */
+pg_status pg_stats(pg_ctx *ctx);
 /* Phase 2 of a multi-GPU job, straight from the all-gather: all_counts = uint64[world][n_slots] in DEVICE memory, row g =
  * pg_count's output of rank g (the receive buffer of the all_gather). base = sum of the rows below `rank`, computed on
  * the device on the context's stream: the step needs no host arithmetic and no extra kernels of the caller.

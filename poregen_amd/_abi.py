@@ -22,13 +22,14 @@ PG_FLAG_DEBUG_NARROW = 8
 PG_FLAG_SHORT_READS_OK = 16
 PG_FLAG_SKIP_OUT_OF_RANGE = 32
 PG_FLAG_STOP_WHEN_FULL = 64
+PG_FLAG_DEFER_STATS = 128
 PG_MODEL_KEEP_FIRST = 1
 PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
-    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_all_slots_full",
+    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
 ]
 
@@ -129,6 +130,7 @@ def load():
     lib.pg_submit.argtypes = [vp, C.POINTER(PgBatch)]; lib.pg_submit.restype = i32
     lib.pg_count.argtypes = [vp, C.POINTER(PgBatch), u64p, i32]; lib.pg_count.restype = i32
     lib.pg_collect.argtypes = [vp, u64p, i32]; lib.pg_collect.restype = i32
+    lib.pg_stats.argtypes = [vp]; lib.pg_stats.restype = i32
     lib.pg_collect_gathered.argtypes = [vp, u64p, C.c_uint32, C.c_uint32]; lib.pg_collect_gathered.restype = i32
     lib.pg_job_totals_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]; lib.pg_job_totals_device.restype = i32
     lib.pg_sync.argtypes = [vp]; lib.pg_sync.restype = i32

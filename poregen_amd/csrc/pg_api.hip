@@ -87,6 +87,7 @@ struct pg_ctx {
     DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
+    bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
 
     PgDevBatch B{};       // current batch (device view)
@@ -568,7 +569,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // Statistics only need the signal: in eager mode they run on the second stream, overlapping the
     // latency-bound walk/rank chain above; pg_collect joins the two streams before the gather.
     c->stats_in_flight = false;
-    if (eager_stats && !skip_oor) {
+    c->stats_deferred = eager_stats && !skip_oor && !overlap && (c->prm.flags & PG_FLAG_DEFER_STATS) != 0;
+    if (eager_stats && !skip_oor && !c->stats_deferred) {
         hipStream_t ss = overlap ? c->st2 : c->st;
         pg_status s2 = launch_stats(c, ss, nullptr);
         if (s2 != PG_OK) return s2;
@@ -590,6 +592,15 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
 
 static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_location, const uint64_t *all_counts, uint32_t world, uint32_t rank);
 
+pg_status pg_stats(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_stats without a preceding pg_count");
+    if (!c->stats_deferred) return PG_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->stats_deferred = false;
+    return launch_stats(c, c->st, nullptr);
+}
+
 pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0, 0); }
 
 pg_status pg_collect_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
@@ -602,6 +613,11 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stats_deferred) { // PG_FLAG_DEFER_STATS and the caller did not place them with pg_stats
+        c->stats_deferred = false;
+        pg_status s2 = launch_stats(c, c->st, nullptr);
+        if (s2 != PG_OK) return s2;
+    }
     const uint32_t ns = c->prm.n_slots;
     const uint64_t N = c->B.n_ops;
     const bool direct = ns <= PG_DIRECT_MAX_SLOTS;

@@ -4,6 +4,7 @@ Because the reference keeps the FIRST sample_limit accepted events of every k-me
 (src/gmove.cpp:732, 925-927), rank g only needs to know how many accepted events ranks < g hold per k-mer:
     1. every rank:   counts_g = pg_count(shard_g)                       (uint64[n_slots], on the GPU)
     2. all ranks:    all_gather(counts)  -> base_g = sum_{h<g} counts_h  (RCCL over xGMI; 8 KB at k=5, 2 MB at k=9)
+       meanwhile:    pg_stats()          median/MAD of every read of the shard (independent of the exchange)
     3. every rank:   pg_collect(base_g)  keeps the events whose global rank is < sample_limit
 The per-k-mer stream of the whole job is the concatenation of the ranks' streams in rank order; freq.txt is
 min(sum_g counts_g, sample_limit). Works with backend "nccl" (= RCCL, CUDA tensors) and "gloo" (CPU tensors).
@@ -69,12 +70,18 @@ def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=Fals
             base, total = exchange_bases(counts_buf.cpu(), group)
             base = base.to(counts_buf.device)
             torch.cuda.current_stream().synchronize()
+            engine.stats()
             engine.collect(base.contiguous())
         else:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
             if gather_buf is None:
                 gather_buf = torch.empty(world * counts_buf.numel(), dtype=counts_buf.dtype, device=counts_buf.device)
-            dist.all_gather_into_tensor(gather_buf, counts_buf.view(-1), group=group)
+            # The statistics of every read (the streaming kernel, a third of the step) do not depend on the exchange: an
+            # engine made with defer_stats queues them here, behind the ISSUE of the collective (which runs on RCCL's own
+            # stream) and in front of the wait for it, so the all_gather's xGMI latency hides behind them.
+            work = dist.all_gather_into_tensor(gather_buf, counts_buf.view(-1), group=group, async_op=True)
+            engine.stats()
+            work.wait()  # the current stream waits for the collective; the host does not
             if not stream_ordered:
                 torch.cuda.current_stream().synchronize()
             engine.collect_gathered(gather_buf, world, rank)
@@ -83,6 +90,7 @@ def sharded_step(engine, shard, group=None, counts_buf=None, stream_ordered=Fals
         c = engine.count(shard)
         t = torch.from_numpy(c.view(np.int64).copy())
         base, total = exchange_bases(t, group)
+        engine.stats()
         engine.collect(base.numpy().view(np.uint64).copy())
     return total
 

@@ -28,9 +28,15 @@ class OracleEngine:
 
     def count(self, shard):
         self.o.run_batch(shard)
+        self.calls = ["count"]
         return self.o.counts().astype(np.uint64)
 
+    def stats(self):  # GmoveEngine.stats (pg_stats): placed by sharded_step behind the exchange's issue, in front of collect
+        self.calls.append("stats")
+
     def collect(self, base):
+        assert self.calls == ["count", "stats"], self.calls
+        self.calls.append("collect")
         lim = self.p["sample_limit"]
         self.kept, self.kept_lens = [], []
         for s in range(self.n_slots):

@@ -184,6 +184,40 @@ def test_overlap_mode_same_bits():
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=60)
 
 
+def test_deferred_statistics_same_bits():
+    """PG_FLAG_DEFER_STATS: pg_count leaves the statistics of every read to pg_stats (called between count and collect) or,
+    when that call is missing, to pg_collect; pg_submit and several batches included. Same bits as the oracle each way."""
+    import torch
+    b = synth.make_batch(600, kind="rna004", seed=37, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    bounds = [0, 200, 201, 600]
+    for mode in ("stats", "collect", "submit", "twice"):
+        for on_device in (False, True):
+            eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=True, **p))
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                part = b.slice_reads(lo, hi)
+                part = part.to_device(torch.device("cuda:0")) if on_device else part
+                if mode == "submit":
+                    eng.submit(part)
+                    continue
+                eng.count(part)
+                if mode != "collect":
+                    eng.stats()
+                if mode == "twice":
+                    eng.stats()   # nothing left to place: a no-op
+                eng.collect()
+            res = eng.finish()
+            eng.close()
+            assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=40)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=True, **p))
+    with pytest.raises(Exception):
+        eng.stats()               # no counted batch
+    eng.close()
+
+
 def test_collect_gathered_three_ranks_on_one_gpu():
     """pg_collect_gathered: the all_gather's receive buffer (world x n_slots) goes in as it is and the library sums the
     rows below its rank on the device. Three 'ranks' (engines) on one GPU reproduce the single run / the oracle."""
@@ -217,7 +251,8 @@ def test_collect_gathered_three_ranks_on_one_gpu():
 
 
 def test_sharded_step_over_rccl_single_rank(tmp_path):
-    """dist.sharded_step on the RCCL ("nccl") backend, stream-ordered as bench.py runs it at N > 1: count ->
+    """Both placements of the statistics: queued by pg_stats between the issue of the all_gather and the wait for it (as
+    bench.py runs N > 1), and inside pg_count. dist.sharded_step on the RCCL ("nccl") backend, stream-ordered as bench.py runs it at N > 1: count ->
     all_gather_into_tensor -> pg_collect_gathered on one torch stream. A one-rank group is all a one-GPU box allows; it
     still runs the collective, the receive-buffer hand-over and the stream ordering."""
     import torch
@@ -232,18 +267,19 @@ def test_sharded_step_over_rccl_single_rank(tmp_path):
     dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1, device_id=dev)
     try:
         side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(side):
-            eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
-            eng.use_torch_stream(side)
-            total = pgdist.sharded_step(eng, b.to_device(dev), stream_ordered=True)
-            freq = pgdist.merged_freq(total, 15, engine=eng)   # produced on the device by pg_collect_gathered
-            res = eng.finish()
-            assert freq is eng.job_totals()[1] and np.array_equal(freq.cpu().numpy().astype(np.uint64), o.counts())
-            assert np.array_equal(freq.cpu().numpy(), np.minimum(total.cpu().numpy(), 15))
-            total = total.clone()   # the step's totals alias the engine's buffers: keep a copy beyond close()
-            eng.close()
-        assert np.array_equal(np.minimum(total.cpu().numpy().astype(np.uint64), 15), o.counts())
-        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=15)
+        for defer in (True, False):
+            with torch.cuda.stream(side):
+                eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=defer, **p))
+                eng.use_torch_stream(side)
+                total = pgdist.sharded_step(eng, b.to_device(dev), stream_ordered=True)
+                freq = pgdist.merged_freq(total, 15, engine=eng)   # produced on the device by pg_collect_gathered
+                res = eng.finish()
+                assert freq is eng.job_totals()[1] and np.array_equal(freq.cpu().numpy().astype(np.uint64), o.counts())
+                assert np.array_equal(freq.cpu().numpy(), np.minimum(total.cpu().numpy(), 15))
+                total = total.clone()   # the step's totals alias the engine's buffers: keep a copy beyond close()
+                eng.close()
+            assert np.array_equal(np.minimum(total.cpu().numpy().astype(np.uint64), 15), o.counts())
+            assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=15)
         # the single-writer end of the job over the same group: device tensors that alias the library's buffers
         eng2 = GmoveEngine(GmoveParams(kmers=kmers, **p))
         eng2.submit(b.to_device(dev))
