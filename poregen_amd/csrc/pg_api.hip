@@ -550,10 +550,11 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
 
     PgSortBufs S{};
     fill_sort(c, S, n_tiles);
+    uint64_t *acc_copy = (counts_out && counts_location == PG_LOC_DEVICE) ? counts_out : nullptr; // written by the counting kernels
     if (direct) {
         prof_begin(c, "rank_count", c->st);
         pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
-                                    c->tile_last.as<int32_t>());
+                                    c->tile_last.as<int32_t>(), acc_copy);
         prof_end(c, c->st);
     } else {
         prof_begin(c, "sort_events", c->st);
@@ -562,7 +563,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         prof_end(c, c->st);
         prof_begin(c, "slot_bounds", c->st);
         pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
-                              c->prm.n_slots, c->acc_cnt.as<uint64_t>());
+                              c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy);
         prof_end(c, c->st);
     }
 
@@ -578,13 +579,9 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         c->stats_in_flight = overlap;
     }
 
-    if (counts_out) {
-        if (counts_location == PG_LOC_DEVICE)
-            HIP_TRY(c, hipMemcpyAsync(counts_out, c->acc_cnt.p, c->prm.n_slots * 8ull, hipMemcpyDeviceToDevice, c->st));
-        else {
-            HIP_TRY(c, hipMemcpyAsync(counts_out, c->acc_cnt.p, c->prm.n_slots * 8ull, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
-        }
+    if (counts_out && counts_location != PG_LOC_DEVICE) { // a device output has been written by the counting kernels themselves
+        HIP_TRY(c, hipMemcpyAsync(counts_out, c->acc_cnt.p, c->prm.n_slots * 8ull, hipMemcpyDeviceToHost, c->st));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
     }
     c->have_count = true;
     return PG_OK;
@@ -622,11 +619,11 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     const uint64_t N = c->B.n_ops;
     const bool direct = ns <= PG_DIRECT_MAX_SLOTS;
     const uint64_t *d_base = c->running.as<uint64_t>();
+    PgGathered G{}; // multi-GPU job: k_slot_plan sums the lower ranks' rows itself (and leaves the job's totals / freq.txt column)
     if (all_counts) {
-        pg_launch_rank_base(c->st, all_counts, world, rank, ns, c->prm.sample_limit, c->base_stage.as<uint64_t>(), c->job_total.as<uint64_t>(),
-                            c->job_freq.as<uint64_t>());
+        G.all_counts = all_counts; G.world = world; G.rank = rank; G.total = c->job_total.as<uint64_t>(); G.freq = c->job_freq.as<uint64_t>();
         c->have_job_totals = true;
-        d_base = c->base_stage.as<uint64_t>();
+        d_base = nullptr;
     } else if (base) {
         HIP_TRY(c, hipMemcpyAsync(c->base_stage.p, base, ns * 8ull,
                                   base_location == PG_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
@@ -646,7 +643,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
                         pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
-                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr);
+                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr, G);
     prof_end(c, c->st);
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;

@@ -101,6 +101,12 @@ enum { PG_STAT_RUN = 0, PG_STAT_SKIP = 1, PG_STAT_BAD = 2 };
 #define PG_STAT_REC_BYTES 64
 #define PG_HUGE_SCRATCH_WORDS ((size_t)PG_HUGE_BLOCKS * (65536 + 64))
 
+// pg_collect_gathered: the all_gather's receive buffer uint64[world][n_slots]; all_counts == nullptr: a plain base array is used
+struct PgGathered {
+    const uint64_t *all_counts;
+    uint32_t world, rank;
+    uint64_t *total, *freq; // [n_slots] the job's accepted events per slot and min(total, sample_limit) (pg_job_totals_device)
+};
 // ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
 struct PgKeptOut {
     uint32_t *ev_len;     // [n_kept] window length incl. margin, clamped to the signal
@@ -123,13 +129,12 @@ static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
 struct PgSlotModel; struct PgSlotDwell; // pg_model.h
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell);
-void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t world, uint32_t rank, uint32_t n_slots, uint32_t limit,
-                         uint64_t *base, uint64_t *total, uint64_t *freq);
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last);
+                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last,
+                                 uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */);
 void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
@@ -137,7 +142,7 @@ void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_
 // S.keys[out]/S.vals[out], number of sorted pairs in S.count[0]. Returns `out`.
 int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S);
 void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
-                           uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt);
+                           uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy);
 void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
                          const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off,
                          const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
@@ -149,7 +154,8 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
                          uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals,
                          const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch,
-                         const int32_t *tile_last /* direct mode, base == running: from pg_launch_rank_direct_count; else null */);
+                         const int32_t *tile_last /* direct mode, base == running: from pg_launch_rank_direct_count; else null */,
+                         const PgGathered &G /* all_counts != null: base = the rows below G.rank, summed in the same pass */);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
 // entries ZERO before the first use (every launch leaves them zero again)
 void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);

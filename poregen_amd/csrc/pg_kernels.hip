@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_rank_count_direct(const uint32_t *__res
 // non-empty tile (k_tile_max finds the same by searching the finished prefix rows when the base arrives later).
 __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
                                                   uint64_t *__restrict__ acc_cnt, uint32_t n_slots, const uint64_t *__restrict__ running,
-                                                  uint32_t limit, int32_t *__restrict__ tile_last) {
+                                                  uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy) {
     const uint32_t d = blockIdx.x;
     const int lane = lane_id();
     uint32_t run = 0;
@@ -437,7 +437,10 @@ __global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, u
     }
     if (lane == 0) {
         totals[d] = run;
-        if (acc_cnt && d < n_slots) acc_cnt[d] = run; // direct mode: digit == slot, so this is the batch's accepted-event count
+        if (acc_cnt && d < n_slots) { // direct mode: digit == slot, so this is the batch's accepted-event count
+            acc_cnt[d] = run;
+            if (acc_copy) acc_copy[d] = run; // pg_count's device output (a rank's row of the all_gather buffer): no copy kernel
+        }
     }
 }
 
@@ -622,16 +625,35 @@ __global__ __launch_bounds__(256) void k_slot_bounds(const uint32_t *__restrict_
 }
 
 __global__ __launch_bounds__(256) void k_slot_counts(const uint32_t *__restrict__ slot_start, const uint32_t *__restrict__ slot_end,
-                                                     uint32_t n_slots, uint64_t *__restrict__ acc_cnt) {
+                                                     uint32_t n_slots, uint64_t *__restrict__ acc_cnt, uint64_t *__restrict__ acc_copy) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s < n_slots) acc_cnt[s] = (uint64_t)(slot_end[s] - slot_start[s]);
+    if (s < n_slots) {
+        acc_cnt[s] = (uint64_t)(slot_end[s] - slot_start[s]);
+        if (acc_copy) acc_copy[s] = acc_cnt[s];
+    }
+}
+
+// Multi-GPU job: the receive buffer of the all_gather (row g = accepted events of rank g per slot). The base of this rank
+// (events of the ranks below it), the job's accepted events per k-mer and its freq.txt value (src/gmove.cpp:945-953: a file
+// closes at sample_limit) come out of the same pass that applies the sample_limit cut: no kernel of their own.
+__device__ __forceinline__ uint64_t slot_base(const PgGathered &G, const uint64_t *base, uint32_t s, uint32_t n_slots, uint32_t limit) {
+    if (!G.all_counts) return base[s];
+    uint64_t b = 0, t = 0;
+    for (uint32_t g = 0; g < G.world; ++g) {
+        if (g == G.rank) b = t;
+        t += G.all_counts[(uint64_t)g * n_slots + s];
+    }
+    G.total[s] = t;
+    G.freq[s] = t < limit ? t : limit;
+    return b;
 }
 
 // single workgroup: the sample_limit cut (gmove.cpp:925-927, 945-950) and the output offsets
 __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running,
                                                     uint32_t limit, uint32_t n_slots, uint64_t *__restrict__ keep,
                                                     uint64_t *__restrict__ ev_off, uint64_t *__restrict__ totals,
-                                                    const uint32_t *__restrict__ hist, uint32_t n_tiles, const int32_t *__restrict__ tile_last) {
+                                                    const uint32_t *__restrict__ hist, uint32_t n_tiles, const int32_t *__restrict__ tile_last,
+                                                    PgGathered G) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t wfull[16];
     (void)hist; (void)n_tiles;
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
         const uint32_t s = c + tid;
         uint64_t kp = 0, isfull = 0;
         if (s < n_slots) {
-            const uint64_t cnt = acc_cnt[s], b = base[s];
+            const uint64_t cnt = acc_cnt[s], b = slot_base(G, base, s, n_slots, limit);
             const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
             kp = cnt < room ? cnt : room;
             isfull = (b + cnt >= limit) ? 1 : 0;
@@ -679,12 +701,12 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
 // atomic per workgroup (the single-workgroup loop above needs 256 trips there: 0.6 ms).
 __global__ __launch_bounds__(256) void k_slot_keep(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                                                    uint32_t n_slots, uint64_t *__restrict__ keep, uint32_t *__restrict__ keep32,
-                                                   uint64_t *__restrict__ totals) {
+                                                   uint64_t *__restrict__ totals, PgGathered G) {
     __shared__ uint32_t wfull[4];
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     bool isfull = false;
     if (s < n_slots) {
-        const uint64_t cnt = acc_cnt[s], b = base[s];
+        const uint64_t cnt = acc_cnt[s], b = slot_base(G, base, s, n_slots, limit);
         const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
         const uint64_t kp = cnt < room ? cnt : room;
         isfull = b + cnt >= limit;
@@ -1439,26 +1461,6 @@ void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_
                        stat_flags);
 }
 
-__global__ __launch_bounds__(256) void k_rank_base(const uint64_t *__restrict__ all_counts, uint32_t world, uint32_t rank, uint32_t n_slots,
-                                                   uint32_t limit, uint64_t *__restrict__ base, uint64_t *__restrict__ total,
-                                                   uint64_t *__restrict__ freq) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_slots) return;
-    uint64_t b = 0, t = 0;
-    for (uint32_t g = 0; g < world; ++g) {
-        if (g == rank) b = t; // accepted events of the ranks below this one
-        t += all_counts[(uint64_t)g * n_slots + s];
-    }
-    base[s] = b;
-    total[s] = t;                       // the job's accepted events for the k-mer ...
-    freq[s] = t < limit ? t : limit;    // ... and its freq.txt value (src/gmove.cpp:945-953: a file closes at sample_limit)
-}
-
-void pg_launch_rank_base(hipStream_t st, const uint64_t *all_counts, uint32_t world, uint32_t rank, uint32_t n_slots, uint32_t limit,
-                         uint64_t *base, uint64_t *total, uint64_t *freq) {
-    hipLaunchKernelGGL(k_rank_base, dim3((n_slots + 255) / 256), dim3(256), 0, st, all_counts, world, rank, n_slots, limit, base, total, freq);
-}
-
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_walk, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
@@ -1472,14 +1474,15 @@ void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W
 static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
 void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last) {
+                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (n_tiles) {
         hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last);
+        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
     } else {
         (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
+        if (acc_copy) (void)hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st);
         if (tile_last) (void)hipMemsetAsync(tile_last, 0xff, sizeof(int32_t) * n_slots, st); // -1: nothing to place
     }
 }
@@ -1508,7 +1511,7 @@ int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, u
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
         hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, (const uint64_t *)nullptr, 0u,
-                           (int32_t *)nullptr);
+                           (int32_t *)nullptr, (uint64_t *)nullptr);
         hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
@@ -1521,25 +1524,25 @@ int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, u
 }
 
 void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper, uint32_t *slot_start,
-                           uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt) {
+                           uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy) {
     (void)hipMemsetAsync(slot_start, 0, sizeof(uint32_t) * n_slots, st);
     (void)hipMemsetAsync(slot_end, 0, sizeof(uint32_t) * n_slots, st);
     if (n_upper) hipLaunchKernelGGL(k_slot_bounds, dim3((uint32_t)((n_upper + 255) / 256)), dim3(256), 0, st, skey, m_ptr, slot_start, slot_end);
     hipLaunchKernelGGL(k_slot_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, (const uint32_t *)slot_start,
-                       (const uint32_t *)slot_end, n_slots, acc_cnt);
+                       (const uint32_t *)slot_end, n_slots, acc_cnt, acc_copy);
 }
 
 void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                          uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles,
-                         uint32_t *keep32, uint64_t *scan_scratch, const int32_t *tile_last) {
+                         uint32_t *keep32, uint64_t *scan_scratch, const int32_t *tile_last, const PgGathered &G) {
     if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
         (void)hipMemsetAsync(totals, 0, 32, st);
-        hipLaunchKernelGGL(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals);
+        hipLaunchKernelGGL(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
         pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch);
         hipLaunchKernelGGL(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
         return;
     }
-    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last);
+    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last, G);
     if (hist && n_tiles && !tile_last) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
 }
 

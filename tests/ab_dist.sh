@@ -1,10 +1,12 @@
 #!/bin/bash
 # A/B of the multi-GPU step on a one-rank RCCL group: statistics behind the issue of the all_gather (default) or inside pg_count.
-# usage (GPU box, repo root): bash tests/ab_dist.sh <tag>  -> gpurun_out/<tag>/
+# usage (GPU box, repo root): bash tests/ab_dist.sh <tag> [nopytest]  -> gpurun_out/<tag>/
 set -o pipefail
 tag=${1:-ab}; out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $out/pytest_parity.txt 2>&1 || { tail -30 $out/pytest_parity.txt; exit 1; }
-tail -2 $out/pytest_parity.txt
+if [ "$2" != "nopytest" ]; then
+  timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $out/pytest_parity.txt 2>&1 || { tail -30 $out/pytest_parity.txt; exit 1; }
+  tail -2 $out/pytest_parity.txt
+fi
 for rep in 1 2; do
   timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra > $out/plain_$rep.json 2> $out/plain_$rep.err || { tail -5 $out/plain_$rep.err; exit 1; }
   timeout -k 10 200 python3 bench.py --force-dist --no-cpu-baseline --no-lazy-extra > $out/defer_$rep.json 2> $out/defer_$rep.err || { tail -5 $out/defer_$rep.err; exit 1; }
