@@ -74,6 +74,8 @@ enum {
                                            zero-filling the sample: the SAM/BAM front-end (src/gmove.cpp:1149-1160). Event
                                            acceptance then depends on the signal, so the statistics pass runs first. */
     PG_FLAG_DEBUG_NARROW = 1u << 3, /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
+    PG_FLAG_DEBUG_SPLIT_WALK = 1u << 8, /* tests / measurement: the ss walk and the event filter as two launches (k_walk, k_events)
+                                        * instead of one wave per read doing both */
     PG_FLAG_DEFER_STATS = 1u << 7, /* multi-GPU step: pg_count does not queue the per-read statistics (median/MAD of every read, which
                                      * do not depend on the exchange); pg_stats queues them -- between the ISSUE of the caller's
                                      * collective and the wait for it, so that the all_gather's latency hides behind the streaming

@@ -541,12 +541,15 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr); if (s2 != PG_OK) return s2; }
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
+    const bool fused = !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK);
     prof_begin(c, "k_walk", c->st);
-    pg_launch_walk(c->st, c->B, W, O);
+    pg_launch_walk(c->st, c->B, W, O, fused);
     prof_end(c, c->st);
-    prof_begin(c, "k_events", c->st);
-    pg_launch_events(c->st, c->B, W, O);
-    prof_end(c, c->st);
+    if (!fused) {
+        prof_begin(c, "k_events", c->st);
+        pg_launch_events(c->st, c->B, W, O);
+        prof_end(c, c->st);
+    }
 
     PgSortBufs S{};
     fill_sort(c, S, n_tiles);

@@ -115,7 +115,32 @@ __device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int
     atomicMin(&O.err[0], (int)r);
 }
 
-__global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+#define PG_EV_PER_THREAD 4 // four consecutive op indices per thread: 16-byte loads instead of four 4-byte ones
+// LDS copy of a short read's per-match values (reads of at most PG_WALK_LDS_OPS ss ops): what the event loop needs besides
+// the window starts -- base code, window length, I/D ops in front -- never goes to global memory for such a read
+#define PG_WALK_LDS_OPS 512
+struct WalkLds {
+    uint32_t code[PG_WALK_LDS_OPS / 16 + 2]; // 2-bit base codes, match p at bits 2(p & 15) of word p >> 4 (OR-ed in: zeroed first)
+    uint32_t bad[PG_WALK_LDS_OPS / 32 + 2];  // one bit per match: its base is not one of A C G T/U
+    uint32_t len[PG_WALK_LDS_OPS + 16];      // read at i + sig_move_offset (< n whenever it is used)
+    uint32_t tix[PG_WALK_LDS_OPS];
+};
+template <bool LDS> __device__ __forceinline__ void walk_events(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+                                                            uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane);
+
+// a read without events (skipped, failed, fewer than k matches): every op index of it still carries a slot entry
+__device__ __forceinline__ void walk_no_events(const PgWalkOut &O, uint64_t o0, uint32_t nops, int lane) {
+    for (uint32_t i = lane; i < nops; i += WAVE) O.ev_slot[o0 + i] = PG_INVALID_SLOT;
+}
+
+// FUSED: the event loop of the read (gmove.cpp:891-927) runs in the same wave right behind its walk: no second launch, no
+// per-event look-up of the owning read and its summary. A read of at most PG_WALK_LDS_OPS ops hands base codes, window
+// lengths and I/D counts over in LDS (they are never written to global memory); a longer read goes through the global
+// arrays the wave has just written. !FUSED: the walk only, k_events does the event loop over the whole batch (kept for
+// measurement: PG_FLAG_DEBUG_SPLIT_WALK).
+template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+    __shared__ WalkLds sm_store;
+    WalkLds *sm = &sm_store;
     const int lane = lane_id();
     const uint32_t r = blockIdx.x; // one wave per workgroup: a finished read frees its slot at once
     const uint64_t o0 = B.op_off[r];
@@ -129,6 +154,13 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
     // k_events / k_rank_emit find the read of an op index through m_read
     for (uint32_t i = lane; i < nops; i += WAVE) O.m_read[o0 + i] = r;
     const bool rna = ts > te;                                          // gmove.cpp:793
+    const bool in_lds = FUSED && nops <= PG_WALK_LDS_OPS;              // wave-uniform
+    if (in_lds) {
+        if (lane < PG_WALK_LDS_OPS / 16 + 2) sm->code[lane] = 0;
+        if (lane < PG_WALK_LDS_OPS / 32 + 2) sm->bad[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     auto put_meta = [&](uint32_t n_, uint32_t m_) {
         PgReadMeta mt; mt.o0 = o0; mt.n = n_; mt.m = m_; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
         mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.rna = rna ? 1u : 0u;
@@ -144,6 +176,7 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
     if (status == PGR_OK && O.oor && O.oor[r]) status = PGR_SKIPPED;   // SAM/BAM front-end: out-of-range sample (gmove.cpp:1158-1160)
     if (status != PGR_OK) {
         if (lane == 0) { if (status < 0) report_error(O, r, status); else O.status[r] = status; }
+        if (FUSED) walk_no_events(O, o0, nops, lane);
         return;
     }
 
@@ -206,9 +239,15 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
             if (okm[u]) {
                 O.m_start[o0 + jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
                 O.m_len[o0 + jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
-                O.m_base[o0 + jj[u]] = bc[u];
-                O.m_tix[o0 + jj[u]] = tix[u];    // I/D ops in front of this match (the indel positions themselves, i_k -
-                                                 // num_deletion at every I/D op, are only needed as these counts)
+                if (in_lds) {
+                    atomicOr(&sm->code[jj[u] >> 4], ((uint32_t)bc[u] & 3u) << (2u * (jj[u] & 15u)));
+                    if (bc[u] > 3) atomicOr(&sm->bad[jj[u] >> 5], 1u << (jj[u] & 31u));
+                    sm->len[jj[u]] = nn[u]; sm->tix[jj[u]] = tix[u];
+                } else {
+                    O.m_base[o0 + jj[u]] = bc[u];
+                    O.m_tix[o0 + jj[u]] = tix[u]; // I/D ops in front of this match (the indel positions themselves, i_k -
+                                                  // num_deletion at every I/D op, are only needed as these counts)
+                }
             }
         }
     }
@@ -216,19 +255,30 @@ __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWal
     if (bm) { // lowest failing lane decides the code
         const int code = __shfl(err, __ffsll((long long)bm) - 1, WAVE);
         if (lane == 0) report_error(O, r, code);
+        if (FUSED) walk_no_events(O, o0, nops, lane);
         return;
     }
     if (match_carry < k) { // unsigned wrap at gmove.cpp:891 in the PAF path; simply no events for the move-table front-end
         if (lane == 0 && !W.short_ok) report_error(O, r, PGR_ERR_SHORT);
+        if (FUSED) walk_no_events(O, o0, nops, lane);
         return;
     }
     if (lane == 0) put_meta(match_carry, indel_carry);
+    if (FUSED) {
+        if (in_lds) { // LDS operations of one wave execute in order: only the compiler has to be held back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            walk_events<true>(W, O, sm, o0, nops, match_carry, indel_carry, rna, rna ? te : ts, rna ? ts : te, lane);
+        } else {
+            __syncthreads(); // the wave's own global stores of phase 1 are complete and visible to all its lanes
+            walk_events<false>(W, O, sm, o0, nops, match_carry, indel_carry, rna, rna ? te : ts, rna ? ts : te, lane);
+        }
+    }
 }
 
 // =====================================================================================================
 // k_events: the event loop (gmove.cpp:891-927), one thread per (read, event index) = per op index
 // =====================================================================================================
-#define PG_EV_PER_THREAD 4 // four consecutive op indices per thread: 16-byte loads instead of four 4-byte ones
 
 // The kernel issues ~12 vector-memory instructions per event when written one event per thread and is bound by
 // that instruction rate, not by bytes; with four consecutive events per thread the per-op arrays are read with one
@@ -314,6 +364,111 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
         }
     }
     *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]); // entries past n_ops are padding
+}
+
+// Phase 2 of the fused k_walk: the event loop of ONE read by the wave that walked it. Same arithmetic as k_events, with the
+// read's summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event, four
+// consecutive events per lane. The read's op indices start at an arbitrary o0: the 4-byte arrays are read and written with
+// 16-byte vectors at 4-byte alignment (as k_events reads m_tix), the base codes as five aligned words shifted by o0 & 3.
+template <bool LDS> __device__ __forceinline__ void walk_events(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+                                                            uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane) {
+    constexpr int E = PG_EV_PER_THREAD;
+    static_assert(E == 4, "one 16-byte vector per array");
+    const uint32_t k = W.k;
+    const int32_t M = W.pick_margin;
+    const uint32_t kM = k + (uint32_t)M;
+    const int32_t *__restrict__ table = rna ? W.table_u : W.table_t;
+    const uint32_t sh = 8u * (uint32_t)(o0 & 3ull);
+    const uint64_t last = o0 + nops - 1;
+    for (uint32_t t0 = 0; t0 < nops; t0 += E * WAVE) {
+        const uint32_t i0 = t0 + E * lane;
+        if (i0 >= nops) continue;
+        const uint64_t g0 = o0 + i0;
+        // round trip 1: 16 base codes from match i0 on, the window lengths, the I/D counts at both bounds
+        uint64_t blo, bhi; uint32_t len[E], tx_lo[E], tx_hi[E];
+        uint32_t c2 = 0, badbits = 0; // LDS: the 2-bit codes of matches i0 .. i0+15 (match i0+p at bits 2p) and their "not ACGT/U" bits
+        if constexpr (LDS) {
+            const uint32_t wi = i0 >> 4, bi = i0 >> 5;
+            c2 = (uint32_t)(((uint64_t)sm->code[wi] | ((uint64_t)sm->code[wi + 1] << 32)) >> (2u * (i0 & 15u)));
+            badbits = (uint32_t)(((uint64_t)sm->bad[bi] | ((uint64_t)sm->bad[bi + 1] << 32)) >> (i0 & 31u));
+            blo = bhi = 0;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int32_t a = (int32_t)(i0 + j) - M;                 // used only when a >= 0
+                const uint32_t h = i0 + j + kM - 1;                      // used only when h < n
+                len[j] = sm->len[i0 + j + W.sig_move_offset];
+                tx_lo[j] = sm->tix[a > 0 ? a : 0];
+                tx_hi[j] = sm->tix[h < PG_WALK_LDS_OPS ? h : PG_WALK_LDS_OPS - 1];
+            }
+        } else {
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(O.m_base + (g0 & ~3ull));
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(bw);
+            const uint32_t b5 = bw[4];
+            const uint64_t q0 = (uint64_t)b4.x | ((uint64_t)b4.y << 32), q1 = (uint64_t)b4.y | ((uint64_t)b4.z << 32);
+            const uint64_t q2 = (uint64_t)b4.z | ((uint64_t)b4.w << 32), q3 = (uint64_t)b4.w | ((uint64_t)b5 << 32);
+            blo = (uint64_t)(uint32_t)(q0 >> sh) | ((uint64_t)(uint32_t)(q1 >> sh) << 32);
+            bhi = (uint64_t)(uint32_t)(q2 >> sh) | ((uint64_t)(uint32_t)(q3 >> sh) << 32);
+            if (W.sig_move_offset == 0) {
+                const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0);
+                len[0] = lv.x; len[1] = lv.y; len[2] = lv.z; len[3] = lv.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; }
+            }
+            const uint4 txl = *reinterpret_cast<const uint4 *>(O.m_tix + ((int64_t)g0 - (int64_t)M)); // padded front
+            const uint4 txh = *reinterpret_cast<const uint4 *>(O.m_tix + (g0 + kM - 1));               // padded back
+            tx_lo[0] = txl.x; tx_lo[1] = txl.y; tx_lo[2] = txl.z; tx_lo[3] = txl.w;
+            tx_hi[0] = txh.x; tx_hi[1] = txh.y; tx_hi[2] = txh.z; tx_hi[3] = txh.w;
+        }
+        // round trip 2: the slot of the k-mer of matched bases [i, i+k) (mirrored on RNA-oriented records: gmove.cpp:883, 899)
+        int32_t slot[E]; bool cand[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            uint32_t fwd = 0, rev = 0; bool bad = false;
+            if constexpr (LDS) {
+                // the mirrored code (base t at bits 2t) is a bit field of c2; the forward one (first base most significant) is
+                // its 2-bit groups in reverse order: reverse all bits, swap the bits inside each pair, drop the unused low end
+                rev = (c2 >> (2 * j)) & ((1u << (2 * k)) - 1u);          // k <= 13
+                const uint32_t x = __builtin_bitreverse32(rev);
+                fwd = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
+                bad = ((badbits >> j) & ((1u << k) - 1u)) != 0;
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < 13; ++t) if (t < k) {
+                    const uint32_t pos = j + t;
+                    const uint32_t b = (uint32_t)((pos < 8 ? blo >> (8 * pos) : bhi >> (8 * (pos - 8))) & 0xff);
+                    bad |= b > 3;
+                    fwd = (fwd << 2) | (b & 3u);
+                    rev |= (b & 3u) << (2 * t);
+                }
+            }
+            const uint32_t i = i0 + j, e = i + W.sig_move_offset;
+            cand[j] = i < nops && i <= n - k && e < n; // n >= k here; e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
+            slot[j] = (cand[j] && !bad) ? table[rna ? rev : fwd] : -1;
+        }
+        uint32_t out[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            out[j] = PG_INVALID_SLOT;
+            if (cand[j]) {
+                // pick_this_kmer (gmove.cpp:204-211) from the I/D counts: see k_events
+                const uint32_t i = i0 + j;
+                const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
+                const int32_t X = left + (int32_t)k + M, Y = left - M;
+                auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
+                const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
+                const uint32_t lo = rna ? m - cA : cB;
+                const bool prev_ok = lo == 0 ? (-st_k <= Y) : (cA == cB);
+                const bool pick = prev_ok && (lo < m || X <= end_k + M);
+                if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j]; // gmove.cpp:916-924
+            }
+        }
+        if (i0 + E <= nops) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
+        else { // the read's last, partial group: the entries behind it belong to the next read's wave
+#pragma unroll
+            for (int j = 0; j < E; ++j) if (i0 + j < nops) O.ev_slot[g0 + j] = out[j];
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1461,9 +1616,10 @@ void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_
                        stat_flags);
 }
 
-void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
+void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused) {
     if (B.n_reads == 0) return;
-    hipLaunchKernelGGL(k_walk, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+    if (fused) hipLaunchKernelGGL(k_walk<true>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+    else hipLaunchKernelGGL(k_walk<false>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
 }
 
 void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {

@@ -184,6 +184,24 @@ def test_overlap_mode_same_bits():
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=60)
 
 
+def test_split_walk_same_bits():
+    """PG_FLAG_DEBUG_SPLIT_WALK: the ss walk and the event filter as two launches (k_walk<false> + k_events) instead of the
+    fused kernel every other test runs. Indels, pick margin, move offset, DNA and RNA orientation, skipped reads."""
+    for kind, rna, extra in (("rna004", True, dict(min_dur=20, max_dur=40)), ("dna_r10", False, dict(sig_move_offset=1))):
+        b = synth.make_batch(500, kind=kind, seed=41, indel_rate=0.03)
+        p = dict(kmer_size=5, rna=rna, scaling=1, sample_limit=30, kmer_pick_margin=2, **extra)
+        kmers = generate_kmers(5, rna=rna)
+        o = oracle_for(kmers, **p)
+        o.run_batch(b)
+        for split in (True, False):
+            eng = GmoveEngine(GmoveParams(kmers=kmers, split_walk=split, **p))
+            for lo, hi in ((0, 123), (123, 500)):
+                eng.submit(b.slice_reads(lo, hi))
+            res = eng.finish()
+            eng.close()
+            assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=30)
+
+
 def test_deferred_statistics_same_bits():
     """PG_FLAG_DEFER_STATS: pg_count leaves the statistics of every read to pg_stats (called between count and collect) or,
     when that call is missing, to pg_collect; pg_submit and several batches included. Same bits as the oracle each way."""
