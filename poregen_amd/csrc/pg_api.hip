@@ -541,7 +541,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr); if (s2 != PG_OK) return s2; }
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
-    const bool fused = !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK);
+    // the fused kernel's LDS window holds 256 events plus the reach of pick_this_kmer on both sides (pg_kernels.hip: k_walk)
+    const bool fused = !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) && c->prm.kmer_pick_margin <= 100;
     prof_begin(c, "k_walk", c->st);
     pg_launch_walk(c->st, c->B, W, O, fused);
     prof_end(c, c->st);

@@ -100,14 +100,13 @@ template <class Pred> __device__ __forceinline__ void wave_first_true_pair(int n
 __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
     // DNA-oriented record: sequence as fetched, spelled with T. RNA-oriented record: the reference
     // replaces T by U before matching (gmove.cpp:815-817), so T and U are the same letter there.
-    switch (ch) {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T': return 3;
-        case 'U': return rna_read ? 3 : 4;
-        default: return 4;
-    }
+    // Branch-free: letter index ch - 'A' into a bit set of the valid letters and a packed table of their 2-bit codes
+    // (A = 0, C = 1, G = 2, T = 3, U = 3 on RNA-oriented records only); everything else is 4.
+    const uint32_t idx = (uint32_t)ch - (uint32_t)'A';
+    const uint32_t valid = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 19) | (rna_read ? (1u << 20) : 0u);
+    const uint64_t codes = (1ull << (2 * 2)) | (2ull << (2 * 6)) | (3ull << (2 * 19)) | (3ull << (2 * 20));
+    const bool ok = idx < 32u && ((valid >> (idx & 31u)) & 1u);
+    return ok ? (uint8_t)((codes >> (2u * (idx & 31u))) & 3u) : (uint8_t)4;
 }
 
 __device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int code) {
@@ -125,8 +124,8 @@ struct WalkLds {
     uint32_t len[PG_WALK_LDS_OPS + 16];      // read at i + sig_move_offset (< n whenever it is used)
     uint32_t tix[PG_WALK_LDS_OPS];
 };
-template <bool LDS> __device__ __forceinline__ void walk_events(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
-                                                            uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane);
+__device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops, uint32_t n,
+                                                 uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0);
 
 // a read without events (skipped, failed, fewer than k matches): every op index of it still carries a slot entry
 __device__ __forceinline__ void walk_no_events(const PgWalkOut &O, uint64_t o0, uint32_t nops, int lane) {
@@ -138,7 +137,7 @@ __device__ __forceinline__ void walk_no_events(const PgWalkOut &O, uint64_t o0, 
 // lengths and I/D counts over in LDS (they are never written to global memory); a longer read goes through the global
 // arrays the wave has just written. !FUSED: the walk only, k_events does the event loop over the whole batch (kept for
 // measurement: PG_FLAG_DEBUG_SPLIT_WALK).
-template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
     __shared__ WalkLds sm_store;
     WalkLds *sm = &sm_store;
     const int lane = lane_id();
@@ -151,8 +150,12 @@ template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_wav
     const int32_t ts = B.tstart[r], te = B.tend[r], qs = B.qstart[r];
     const uint32_t k = W.k;
 
+    // the read's own stretch of every per-op array: a uniform base pointer + a 32-bit lane offset per access
+    const uint32_t *__restrict__ r_op_n = B.op_n + o0; const uint8_t *__restrict__ r_op_t = B.op_t + o0; const uint8_t *__restrict__ r_seq = B.seq + s0;
+    uint32_t *__restrict__ r_start = O.m_start + o0, *__restrict__ r_len = O.m_len + o0, *__restrict__ r_tix = O.m_tix + o0, *__restrict__ r_read = O.m_read + o0;
+    uint8_t *__restrict__ r_base = O.m_base + o0;
     // k_events / k_rank_emit find the read of an op index through m_read
-    for (uint32_t i = lane; i < nops; i += WAVE) O.m_read[o0 + i] = r;
+    for (uint32_t i = lane; i < nops; i += WAVE) r_read[i] = r;
     const bool rna = ts > te;                                          // gmove.cpp:793
     const bool in_lds = FUSED && nops <= PG_WALK_LDS_OPS;              // wave-uniform
     if (in_lds) {
@@ -193,8 +196,8 @@ template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_wav
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t i = c + u * WAVE + lane;
-            nn[u] = i < nops ? B.op_n[o0 + i] : 0u;
-            tt[u] = i < nops ? (uint32_t)B.op_t[o0 + i] : 3u;
+            nn[u] = i < nops ? r_op_n[i] : 0u;
+            tt[u] = i < nops ? (uint32_t)r_op_t[i] : 3u;
         }
         uint32_t jj[U], tix[U], st32[U]; uint64_t ik[U]; bool ism[U], isid[U], okm[U];
 #pragma unroll
@@ -231,21 +234,21 @@ template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_wav
         uint8_t bc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t src = rna ? (uint64_t)slen - 1 - ik[u] : ik[u]; // gmove.cpp:849-853
-            bc[u] = okm[u] ? base_code(B.seq[s0 + src], rna) : (uint8_t)4;
+            const uint32_t src = rna ? slen - 1u - (uint32_t)ik[u] : (uint32_t)ik[u]; // gmove.cpp:849-853 (okm: ik < slen)
+            bc[u] = okm[u] ? base_code(r_seq[src], rna) : (uint8_t)4;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (okm[u]) {
-                O.m_start[o0 + jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
-                O.m_len[o0 + jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
+                r_start[jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
+                r_len[jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
                 if (in_lds) {
                     atomicOr(&sm->code[jj[u] >> 4], ((uint32_t)bc[u] & 3u) << (2u * (jj[u] & 15u)));
                     if (bc[u] > 3) atomicOr(&sm->bad[jj[u] >> 5], 1u << (jj[u] & 31u));
                     sm->len[jj[u]] = nn[u]; sm->tix[jj[u]] = tix[u];
                 } else {
-                    O.m_base[o0 + jj[u]] = bc[u];
-                    O.m_tix[o0 + jj[u]] = tix[u]; // I/D ops in front of this match (the indel positions themselves, i_k -
+                    r_base[jj[u]] = bc[u];
+                    r_tix[jj[u]] = tix[u];        // I/D ops in front of this match (the indel positions themselves, i_k -
                                                   // num_deletion at every I/D op, are only needed as these counts)
                 }
             }
@@ -265,13 +268,36 @@ template <bool FUSED> __global__ __launch_bounds__(64) __attribute__((amdgpu_wav
     }
     if (lane == 0) put_meta(match_carry, indel_carry);
     if (FUSED) {
-        if (in_lds) { // LDS operations of one wave execute in order: only the compiler has to be held back
+        const int32_t st_k = rna ? te : ts, end_k = rna ? ts : te;
+        if (in_lds) { // the whole read is in the window (base 0). LDS operations of one wave execute in order: only the compiler has to be held back
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            walk_events<true>(W, O, sm, o0, nops, match_carry, indel_carry, rna, rna ? te : ts, rna ? ts : te, lane);
+            for (uint32_t T0 = 0; T0 < nops; T0 += PG_EV_PER_THREAD * WAVE)
+                walk_events_tile(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
         } else {
-            __syncthreads(); // the wave's own global stores of phase 1 are complete and visible to all its lanes
-            walk_events<false>(W, O, sm, o0, nops, match_carry, indel_carry, rna, rna ? te : ts, rna ? ts : te, lane);
+            // A longer read: tile after tile of 256 events, the window re-filled from the global arrays the wave has just
+            // written. Window = matches [base, base + PG_WALK_LDS_OPS), base = T0 - min(T0, pick margin) -- the left bound of
+            // pick_this_kmer reaches that far back; 256 + k + 2 * margin + 16 <= PG_WALK_LDS_OPS (the host checks the margin).
+            __syncthreads(); // phase 1's global stores are complete and visible to all lanes of the wave
+            const uint32_t Mu = (uint32_t)W.pick_margin;
+            for (uint32_t T0 = 0; T0 < nops; T0 += PG_EV_PER_THREAD * WAVE) {
+                const uint32_t base = T0 - (T0 < Mu ? T0 : Mu);
+                if (lane < PG_WALK_LDS_OPS / 16 + 2) sm->code[lane] = 0;
+                if (lane < PG_WALK_LDS_OPS / 32 + 2) sm->bad[lane] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t q = lane; q < PG_WALK_LDS_OPS && base + q < match_carry; q += WAVE) {
+                    const uint32_t bcq = r_base[base + q];
+                    atomicOr(&sm->code[q >> 4], (bcq & 3u) << (2u * (q & 15u)));
+                    if (bcq > 3) atomicOr(&sm->bad[q >> 5], 1u << (q & 31u));
+                    sm->len[q] = r_len[base + q]; sm->tix[q] = r_tix[base + q];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                walk_events_tile(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, base, T0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }
@@ -366,108 +392,68 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
     *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]); // entries past n_ops are padding
 }
 
-// Phase 2 of the fused k_walk: the event loop of ONE read by the wave that walked it. Same arithmetic as k_events, with the
-// read's summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event, four
-// consecutive events per lane. The read's op indices start at an arbitrary o0: the 4-byte arrays are read and written with
-// 16-byte vectors at 4-byte alignment (as k_events reads m_tix), the base codes as five aligned words shifted by o0 & 3.
-template <bool LDS> __device__ __forceinline__ void walk_events(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
-                                                            uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane) {
+// Phase 2 of the fused k_walk: 256 events of ONE read -- matches T0 + 4*lane .. +3 -- by the wave that walked it, from the LDS
+// window that holds the values of matches base .. base + PG_WALK_LDS_OPS - 1. Same arithmetic as k_events, with the read's
+// summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event.
+__device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops, uint32_t n,
+                                                 uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0) {
     constexpr int E = PG_EV_PER_THREAD;
-    static_assert(E == 4, "one 16-byte vector per array");
+    static_assert(E == 4, "one 16-byte store per lane");
     const uint32_t k = W.k;
     const int32_t M = W.pick_margin;
     const uint32_t kM = k + (uint32_t)M;
     const int32_t *__restrict__ table = rna ? W.table_u : W.table_t;
-    const uint32_t sh = 8u * (uint32_t)(o0 & 3ull);
-    const uint64_t last = o0 + nops - 1;
-    for (uint32_t t0 = 0; t0 < nops; t0 += E * WAVE) {
-        const uint32_t i0 = t0 + E * lane;
-        if (i0 >= nops) continue;
-        const uint64_t g0 = o0 + i0;
-        // round trip 1: 16 base codes from match i0 on, the window lengths, the I/D counts at both bounds
-        uint64_t blo, bhi; uint32_t len[E], tx_lo[E], tx_hi[E];
-        uint32_t c2 = 0, badbits = 0; // LDS: the 2-bit codes of matches i0 .. i0+15 (match i0+p at bits 2p) and their "not ACGT/U" bits
-        if constexpr (LDS) {
-            const uint32_t wi = i0 >> 4, bi = i0 >> 5;
-            c2 = (uint32_t)(((uint64_t)sm->code[wi] | ((uint64_t)sm->code[wi + 1] << 32)) >> (2u * (i0 & 15u)));
-            badbits = (uint32_t)(((uint64_t)sm->bad[bi] | ((uint64_t)sm->bad[bi + 1] << 32)) >> (i0 & 31u));
-            blo = bhi = 0;
+    const uint32_t i0 = T0 + E * lane;
+    if (i0 >= nops) return;
+    const uint32_t l0 = i0 - base; // window index of match i0
+    // the 2-bit codes of matches i0 .. i0+15 (match i0+p at bits 2p) and their "not ACGT/U" bits
+    const uint32_t c2 = (uint32_t)(((uint64_t)sm->code[l0 >> 4] | ((uint64_t)sm->code[(l0 >> 4) + 1] << 32)) >> (2u * (l0 & 15u)));
+    const uint32_t badbits = (uint32_t)(((uint64_t)sm->bad[l0 >> 5] | ((uint64_t)sm->bad[(l0 >> 5) + 1] << 32)) >> (l0 & 31u));
+    uint32_t len[E], tx_lo[E], tx_hi[E];
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const int32_t a = (int32_t)(i0 + j) - M;                 // used only when a >= 0
-                const uint32_t h = i0 + j + kM - 1;                      // used only when h < n
-                len[j] = sm->len[i0 + j + W.sig_move_offset];
-                tx_lo[j] = sm->tix[a > 0 ? a : 0];
-                tx_hi[j] = sm->tix[h < PG_WALK_LDS_OPS ? h : PG_WALK_LDS_OPS - 1];
-            }
-        } else {
-            const uint32_t *bw = reinterpret_cast<const uint32_t *>(O.m_base + (g0 & ~3ull));
-            const uint4 b4 = *reinterpret_cast<const uint4 *>(bw);
-            const uint32_t b5 = bw[4];
-            const uint64_t q0 = (uint64_t)b4.x | ((uint64_t)b4.y << 32), q1 = (uint64_t)b4.y | ((uint64_t)b4.z << 32);
-            const uint64_t q2 = (uint64_t)b4.z | ((uint64_t)b4.w << 32), q3 = (uint64_t)b4.w | ((uint64_t)b5 << 32);
-            blo = (uint64_t)(uint32_t)(q0 >> sh) | ((uint64_t)(uint32_t)(q1 >> sh) << 32);
-            bhi = (uint64_t)(uint32_t)(q2 >> sh) | ((uint64_t)(uint32_t)(q3 >> sh) << 32);
-            if (W.sig_move_offset == 0) {
-                const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0);
-                len[0] = lv.x; len[1] = lv.y; len[2] = lv.z; len[3] = lv.w;
-            } else {
+    for (int j = 0; j < E; ++j) {
+        const int32_t a = (int32_t)(i0 + j) - M;                     // match whose I/D count bounds the event on the left: used when >= 0
+        const uint32_t h = i0 + j + kM - 1 - base;                   // ... on the right: used when the match exists (< n)
+        len[j] = sm->len[l0 + j + W.sig_move_offset];
+        tx_lo[j] = sm->tix[(a > 0 ? (uint32_t)a : 0u) - base];       // base <= max(i0 - M, 0): see the staging in k_walk
+        tx_hi[j] = sm->tix[h < PG_WALK_LDS_OPS ? h : PG_WALK_LDS_OPS - 1];
+    }
+    // the slot of the k-mer of matched bases [i, i+k) (mirrored on RNA-oriented records: gmove.cpp:883, 899)
+    int32_t slot[E]; bool cand[E];
 #pragma unroll
-                for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; }
-            }
-            const uint4 txl = *reinterpret_cast<const uint4 *>(O.m_tix + ((int64_t)g0 - (int64_t)M)); // padded front
-            const uint4 txh = *reinterpret_cast<const uint4 *>(O.m_tix + (g0 + kM - 1));               // padded back
-            tx_lo[0] = txl.x; tx_lo[1] = txl.y; tx_lo[2] = txl.z; tx_lo[3] = txl.w;
-            tx_hi[0] = txh.x; tx_hi[1] = txh.y; tx_hi[2] = txh.z; tx_hi[3] = txh.w;
+    for (int j = 0; j < E; ++j) {
+        // the mirrored code (base t at bits 2t) is a bit field of c2; the forward one (first base most significant) is its
+        // 2-bit groups in reverse order: reverse all bits, swap the bits inside each pair, drop the unused low end
+        const uint32_t rev = (c2 >> (2 * j)) & ((1u << (2 * k)) - 1u); // k <= 13
+        const uint32_t x = __builtin_bitreverse32(rev);
+        const uint32_t fwd = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
+        const bool bad = ((badbits >> j) & ((1u << k) - 1u)) != 0;
+        const uint32_t i = i0 + j, e = i + W.sig_move_offset;
+        cand[j] = i < nops && i <= n - k && e < n; // n >= k here; e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
+        slot[j] = (cand[j] && !bad) ? table[rna ? rev : fwd] : -1;
+    }
+    uint32_t out[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        out[j] = PG_INVALID_SLOT;
+        if (cand[j]) {
+            // pick_this_kmer (gmove.cpp:204-211) from the I/D counts: see k_events
+            const uint32_t i = i0 + j;
+            const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
+            const int32_t X = left + (int32_t)k + M, Y = left - M;
+            auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
+            const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
+            const uint32_t lo = rna ? m - cA : cB;
+            const bool prev_ok = lo == 0 ? (-st_k <= Y) : (cA == cB);
+            const bool pick = prev_ok && (lo < m || X <= end_k + M);
+            if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j]; // gmove.cpp:916-924
         }
-        // round trip 2: the slot of the k-mer of matched bases [i, i+k) (mirrored on RNA-oriented records: gmove.cpp:883, 899)
-        int32_t slot[E]; bool cand[E];
+    }
+    uint32_t *__restrict__ dst = O.ev_slot + o0; // uniform base, 32-bit lane offset; 16-byte stores at 4-byte alignment
+    if (i0 + E <= nops) *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(out[0], out[1], out[2], out[3]);
+    else { // the read's last, partial group: the entries behind it belong to the next read's wave
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            uint32_t fwd = 0, rev = 0; bool bad = false;
-            if constexpr (LDS) {
-                // the mirrored code (base t at bits 2t) is a bit field of c2; the forward one (first base most significant) is
-                // its 2-bit groups in reverse order: reverse all bits, swap the bits inside each pair, drop the unused low end
-                rev = (c2 >> (2 * j)) & ((1u << (2 * k)) - 1u);          // k <= 13
-                const uint32_t x = __builtin_bitreverse32(rev);
-                fwd = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
-                bad = ((badbits >> j) & ((1u << k) - 1u)) != 0;
-            } else {
-#pragma unroll
-                for (uint32_t t = 0; t < 13; ++t) if (t < k) {
-                    const uint32_t pos = j + t;
-                    const uint32_t b = (uint32_t)((pos < 8 ? blo >> (8 * pos) : bhi >> (8 * (pos - 8))) & 0xff);
-                    bad |= b > 3;
-                    fwd = (fwd << 2) | (b & 3u);
-                    rev |= (b & 3u) << (2 * t);
-                }
-            }
-            const uint32_t i = i0 + j, e = i + W.sig_move_offset;
-            cand[j] = i < nops && i <= n - k && e < n; // n >= k here; e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
-            slot[j] = (cand[j] && !bad) ? table[rna ? rev : fwd] : -1;
-        }
-        uint32_t out[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            out[j] = PG_INVALID_SLOT;
-            if (cand[j]) {
-                // pick_this_kmer (gmove.cpp:204-211) from the I/D counts: see k_events
-                const uint32_t i = i0 + j;
-                const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
-                const int32_t X = left + (int32_t)k + M, Y = left - M;
-                auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
-                const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
-                const uint32_t lo = rna ? m - cA : cB;
-                const bool prev_ok = lo == 0 ? (-st_k <= Y) : (cA == cB);
-                const bool pick = prev_ok && (lo < m || X <= end_k + M);
-                if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j]; // gmove.cpp:916-924
-            }
-        }
-        if (i0 + E <= nops) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
-        else { // the read's last, partial group: the entries behind it belong to the next read's wave
-#pragma unroll
-            for (int j = 0; j < E; ++j) if (i0 + j < nops) O.ev_slot[g0 + j] = out[j];
-        }
+        for (int j = 0; j < E; ++j) if (i0 + j < nops) dst[i0 + j] = out[j];
     }
 }
 

@@ -202,6 +202,25 @@ def test_split_walk_same_bits():
             assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=30)
 
 
+@pytest.mark.parametrize("margin", [0, 7, 100, 101, 150])
+def test_fused_walk_long_reads_and_wide_pick_margins(margin):
+    """The fused walk/event kernel keeps a 512-match window of a read in LDS: reads of more than 512 ss ops go through it in
+    tiles of 256 events (window re-filled per tile, reaching `margin` matches back), margins above 100 take the two-launch
+    form. Long DNA reads (about 1600 ops) with indels, both forms, against the oracle."""
+    b = synth.make_batch(40, read_len=20000, kind="dna_r10", seed=43 + margin, indel_rate=0.03)
+    assert int(np.diff(b.op_off).max()) > 1024
+    p = dict(kmer_size=6, scaling=1, sample_limit=50, kmer_pick_margin=margin, sig_move_offset=2)
+    kmers = generate_kmers(6)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    for split in (False, True):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, split_walk=split, **p))
+        eng.submit(b.slice_reads(0, 17)); eng.submit(b.slice_reads(17, 40))
+        res = eng.finish()
+        eng.close()
+        assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=50)
+
+
 def test_deferred_statistics_same_bits():
     """PG_FLAG_DEFER_STATS: pg_count leaves the statistics of every read to pg_stats (called between count and collect) or,
     when that call is missing, to pg_collect; pg_submit and several batches included. Same bits as the oracle each way."""
