@@ -122,10 +122,10 @@ struct WalkLds {
     uint32_t code[PG_WALK_LDS_OPS / 16 + 2]; // 2-bit base codes, match p at bits 2(p & 15) of word p >> 4 (OR-ed in: zeroed first)
     uint32_t bad[PG_WALK_LDS_OPS / 32 + 2];  // one bit per match: its base is not one of A C G T/U
     uint32_t len[PG_WALK_LDS_OPS + 16];      // read at i + sig_move_offset (< n whenever it is used)
-    uint32_t tix[PG_WALK_LDS_OPS];
+    uint32_t tix[PG_WALK_LDS_OPS + 4];       // + 4: lanes behind the read's last op still form their (unused) addresses
 };
-__device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops, uint32_t n,
-                                                 uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0);
+template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+                                                                  uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0);
 
 // a read without events (skipped, failed, fewer than k matches): every op index of it still carries a slot entry
 __device__ __forceinline__ void walk_no_events(const PgWalkOut &O, uint64_t o0, uint32_t nops, int lane) {
@@ -272,8 +272,15 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
         if (in_lds) { // the whole read is in the window (base 0). LDS operations of one wave execute in order: only the compiler has to be held back
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t T0 = 0; T0 < nops; T0 += PG_EV_PER_THREAD * WAVE)
-                walk_events_tile(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+            // events per lane: the fewest trips first, then the most lanes at work
+            const uint32_t trips4 = (nops + 4 * WAVE - 1) / (4 * WAVE);
+            if ((nops + 2 * WAVE - 1) / (2 * WAVE) == trips4) {
+                for (uint32_t T0 = 0; T0 < nops; T0 += 2 * WAVE) walk_events_tile<2>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+            } else if ((nops + 3 * WAVE - 1) / (3 * WAVE) == trips4) {
+                for (uint32_t T0 = 0; T0 < nops; T0 += 3 * WAVE) walk_events_tile<3>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+            } else {
+                for (uint32_t T0 = 0; T0 < nops; T0 += 4 * WAVE) walk_events_tile<4>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+            }
         } else {
             // A longer read: tile after tile of 256 events, the window re-filled from the global arrays the wave has just
             // written. Window = matches [base, base + PG_WALK_LDS_OPS), base = T0 - min(T0, pick margin) -- the left bound of
@@ -294,7 +301,7 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                walk_events_tile(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, base, T0);
+                walk_events_tile<PG_EV_PER_THREAD>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, base, T0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -392,13 +399,14 @@ __global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, Pg
     *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]); // entries past n_ops are padding
 }
 
-// Phase 2 of the fused k_walk: 256 events of ONE read -- matches T0 + 4*lane .. +3 -- by the wave that walked it, from the LDS
-// window that holds the values of matches base .. base + PG_WALK_LDS_OPS - 1. Same arithmetic as k_events, with the read's
-// summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event.
-__device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops, uint32_t n,
-                                                 uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0) {
-    constexpr int E = PG_EV_PER_THREAD;
-    static_assert(E == 4, "one 16-byte store per lane");
+// Phase 2 of the fused k_walk: 64 * E events of ONE read -- matches T0 + E*lane .. + E-1 -- by the wave that walked it, from the
+// LDS window that holds the values of matches base .. base + PG_WALK_LDS_OPS - 1. Same arithmetic as k_events, with the read's
+// summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event. E = events per
+// lane (2, 3 or 4): the kernel is bound by vector-instruction issue, so a short read spreads its events over as many lanes as
+// it can fill in one trip (130 ops: 44 lanes x 3 instead of 33 lanes x 4).
+template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+                                                                  uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0) {
+    static_assert(E >= 2 && E <= 4, "the 16 codes fetched per lane cover E - 1 + k <= 16 matches");
     const uint32_t k = W.k;
     const int32_t M = W.pick_margin;
     const uint32_t kM = k + (uint32_t)M;
@@ -449,9 +457,14 @@ __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const Pg
             if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j]; // gmove.cpp:916-924
         }
     }
-    uint32_t *__restrict__ dst = O.ev_slot + o0; // uniform base, 32-bit lane offset; 16-byte stores at 4-byte alignment
-    if (i0 + E <= nops) *reinterpret_cast<uint4 *>(dst + i0) = make_uint4(out[0], out[1], out[2], out[3]);
-    else { // the read's last, partial group: the entries behind it belong to the next read's wave
+    uint32_t *__restrict__ dst = O.ev_slot + o0; // uniform base, 32-bit lane offset; one 8/12/16-byte store at 4-byte alignment
+    if (i0 + E <= nops) {
+        struct alignas(4) Vec { uint32_t v[E]; }; // exactly E dwords: one global_store_dwordx2/x3/x4
+        Vec v;
+#pragma unroll
+        for (int j = 0; j < E; ++j) v.v[j] = out[j];
+        *reinterpret_cast<Vec *>(dst + i0) = v;
+    } else { // the read's last, partial group: the entries behind it belong to the next read's wave
 #pragma unroll
         for (int j = 0; j < E; ++j) if (i0 + j < nops) dst[i0 + j] = out[j];
     }
