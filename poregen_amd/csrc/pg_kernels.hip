@@ -530,16 +530,17 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
 // direct mode (slot == digit): counts per (tile, slot) only -- k_rank_emit recounts per wave for the few tiles it
 // really places events from. Four tiles per workgroup: their counts of one slot leave as ONE 16-byte store into
 // hist[slot][tile0..tile0+3] (n_tiles is a multiple of 4), a quarter of the scattered write transactions.
-__global__ __launch_bounds__(256) void k_rank_count_direct(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
-                                                           uint32_t *__restrict__ hist) {
+__global__ __launch_bounds__(1024) void k_rank_count_direct(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
+                                                            uint32_t *__restrict__ hist) {
+    // 1024 threads: the four tiles of the workgroup are counted side by side, one per group of four waves (as 256 threads
+    // walking through the four tiles one after the other the launch held 1.5 waves per SIMD and waited on its own loads)
     __shared__ uint32_t cnt[4][PG_RANK_MAX_DIGITS];
-    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u;
+    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, tt = tid >> 8, t = tid & 255u;
     const uint32_t ndig = 1u << nbits, mask = ndig - 1u;
-    for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 256) (&cnt[0][0])[i] = 0;
+    for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 1024) (&cnt[0][0])[i] = 0;
     __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const uint64_t base = (uint64_t)(tile0 + tt) * PG_SORT_TILE + tid; // counts are order-free: plain coalesced rows
+    {
+        const uint64_t base = (uint64_t)(tile0 + tt) * PG_SORT_TILE + t; // counts are order-free: plain coalesced rows
         uint32_t kv[PG_SORT_TILE / 256];
 #pragma unroll
         for (int i = 0; i < PG_SORT_TILE / 256; ++i) { const uint64_t idx = base + (uint64_t)i * 256; kv[i] = idx < n ? keys[idx] : PG_INVALID_SLOT; }
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_rank_count_direct(const uint32_t *__res
         for (int i = 0; i < PG_SORT_TILE / 256; ++i) if (kv[i] != PG_INVALID_SLOT) atomicAdd(&cnt[tt][kv[i] & mask], 1u);
     }
     __syncthreads();
-    for (uint32_t d = tid; d < ndig; d += 256)
+    for (uint32_t d = tid; d < ndig; d += 1024)
         *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
 }
 
@@ -1633,7 +1634,7 @@ void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (n_tiles) {
-        hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(256), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
+        hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(1024), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
         hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
     } else {
         (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
