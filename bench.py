@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
     ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
+    ap.add_argument("--overlap-tail", action="store_true", help="statistics on a second stream next to the cut/emit/scan launches (PG_FLAG_OVERLAP_TAIL)")
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
     args = ap.parse_args()
@@ -73,7 +74,7 @@ def main():
         dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="pg_rdv_"), rank=0, world_size=1, device_id=dev)
 
     rna = args.kind == "rna004"
-    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=args.overlap, split_walk=args.split_walk)
+    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=args.overlap, split_walk=args.split_walk, overlap_tail=args.overlap_tail)
     if rna:
         p.update(min_dur=20, max_dur=40)
     kmers = generate_kmers(args.k, rna=rna)

@@ -74,6 +74,10 @@ enum {
                                            zero-filling the sample: the SAM/BAM front-end (src/gmove.cpp:1149-1160). Event
                                            acceptance then depends on the signal, so the statistics pass runs first. */
     PG_FLAG_DEBUG_NARROW = 1u << 3, /* tests: shrink the exact MAD candidate window to one code so that the fallback search runs */
+    PG_FLAG_OVERLAP_TAIL = 1u << 9, /* the statistics of a batch on a second stream, forked BEHIND the walk and the counting kernels:
+                                     * the small launches of pg_collect (sample_limit cut, emit, offset scan) run next to the
+                                     * streaming kernel; the streams join in front of the gather. Ignored with PG_FLAG_LAZY_STATS,
+                                     * PG_FLAG_SKIP_OUT_OF_RANGE, PG_FLAG_OVERLAP and PG_FLAG_DEFER_STATS. */
     PG_FLAG_DEBUG_SPLIT_WALK = 1u << 8, /* tests / measurement: the ss walk and the event filter as two launches (k_walk, k_events)
                                         * instead of one wave per read doing both */
     PG_FLAG_DEFER_STATS = 1u << 7, /* multi-GPU step: pg_count does not queue the per-read statistics (median/MAD of every read, which

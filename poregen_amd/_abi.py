@@ -24,6 +24,7 @@ PG_FLAG_SKIP_OUT_OF_RANGE = 32
 PG_FLAG_STOP_WHEN_FULL = 64
 PG_FLAG_DEFER_STATS = 128
 PG_FLAG_DEBUG_SPLIT_WALK = 256
+PG_FLAG_OVERLAP_TAIL = 512
 PG_MODEL_KEEP_FIRST = 1
 PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 

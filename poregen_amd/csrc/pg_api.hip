@@ -415,8 +415,9 @@ static pg_status check_read_errors(pg_ctx *c) {
 
 // statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
 // handles the reads whose in-range code interval fits it (no host decision, no sync)
-static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed) {
-    const bool flags_are_reset = st == c->st && c->stat_flags_reset; // by this batch's k_batch_init, on the same stream
+static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, bool forked_behind_init = false) {
+    // by this batch's k_batch_init, on the same stream (or on the stream this one was forked from, behind that kernel)
+    const bool flags_are_reset = (st == c->st || forked_behind_init) && c->stat_flags_reset;
     c->stat_flags_reset = false;
     const uint32_t n = c->B.n_reads;
     const int sl = c->slot;
@@ -575,12 +576,20 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // latency-bound walk/rank chain above; pg_collect joins the two streams before the gather.
     c->stats_in_flight = false;
     c->stats_deferred = eager_stats && !skip_oor && !overlap && (c->prm.flags & PG_FLAG_DEFER_STATS) != 0;
+    // PG_FLAG_OVERLAP_TAIL: the statistics fork off HERE, behind the counting kernels, onto the second stream; the sample_limit
+    // cut, the emit kernel and the offset scan of pg_collect -- small launches that keep a fraction of the chip busy -- run
+    // next to the streaming kernel, and pg_collect joins the two streams in front of the gather (the only consumer of med/MAD).
+    const bool tail = eager_stats && !skip_oor && !overlap && !c->stats_deferred && (c->prm.flags & PG_FLAG_OVERLAP_TAIL) != 0;
     if (eager_stats && !skip_oor && !c->stats_deferred) {
-        hipStream_t ss = overlap ? c->st2 : c->st;
-        pg_status s2 = launch_stats(c, ss, nullptr);
+        hipStream_t ss = (overlap || tail) ? c->st2 : c->st;
+        if (tail) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+            HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
+        }
+        pg_status s2 = launch_stats(c, ss, nullptr, tail);
         if (s2 != PG_OK) return s2;
-        if (overlap) HIP_TRY(c, hipEventRecord(c->ev_join[c->slot], c->st2));
-        c->stats_in_flight = overlap;
+        if (overlap || tail) HIP_TRY(c, hipEventRecord(c->ev_join[c->slot], c->st2));
+        c->stats_in_flight = overlap || tail;
     }
 
     if (counts_out && counts_location != PG_LOC_DEVICE) { // a device output has been written by the counting kernels themselves

@@ -57,6 +57,7 @@ class GmoveParams:
     profile: bool = False
     overlap: bool = False
     debug_narrow: bool = False
+    overlap_tail: bool = False           # statistics on a second stream next to pg_collect's small launches (PG_FLAG_OVERLAP_TAIL)
     split_walk: bool = False             # measurement/tests: ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK)
     defer_stats: bool = False            # multi-GPU step: the statistics are queued by stats() (behind the issue of the collective) or by collect()
     stop_when_full: bool = False         # kmers is the WHOLE list: errors behind the read that completes the last k-mer do not count
@@ -227,7 +228,8 @@ class GmoveEngine:
         p.flags = ((_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
                    | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
                    | (_abi.PG_FLAG_STOP_WHEN_FULL if params.stop_when_full else 0) | (_abi.PG_FLAG_DEFER_STATS if params.defer_stats else 0)
-                   | (_abi.PG_FLAG_DEBUG_SPLIT_WALK if params.split_walk else 0))
+                   | (_abi.PG_FLAG_DEBUG_SPLIT_WALK if params.split_walk else 0)
+                   | (_abi.PG_FLAG_OVERLAP_TAIL if params.overlap_tail else 0))
         p.device = params.device
         p.table_t = self._table_t.ctypes.data; p.table_u = self._table_u.ctypes.data
         h = C.c_void_p()

@@ -164,8 +164,10 @@ def test_stream_ordered_count_collect_on_torch_stream():
         assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
 
 
-def test_overlap_mode_same_bits():
-    """PG_FLAG_OVERLAP: the statistics kernels of a batch on a second stream (double-buffered med/MAD), joined before
+@pytest.mark.parametrize("mode", ["overlap", "overlap_tail"])
+def test_overlap_mode_same_bits(mode):
+    """PG_FLAG_OVERLAP_TAIL: the same second stream, forked behind the counting kernels (next to pg_collect's small launches).
+    PG_FLAG_OVERLAP: the statistics kernels of a batch on a second stream (double-buffered med/MAD), joined before
     the gather. Several batches back to back, host- and device-resident: the same bits as the oracle."""
     import torch
     b = synth.make_batch(700, kind="rna004", seed=31, indel_rate=0.02)
@@ -175,7 +177,7 @@ def test_overlap_mode_same_bits():
     o.run_batch(b)
     bounds = [0, 90, 91, 300, 520, 700]
     for on_device in (False, True):
-        eng = GmoveEngine(GmoveParams(kmers=kmers, overlap=True, **p))
+        eng = GmoveEngine(GmoveParams(kmers=kmers, **{mode: True}, **p))
         for lo, hi in zip(bounds[:-1], bounds[1:]):
             part = b.slice_reads(lo, hi)
             eng.submit(part.to_device(torch.device("cuda:0")) if on_device else part)
