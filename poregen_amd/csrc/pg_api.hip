@@ -87,6 +87,7 @@ struct pg_ctx {
     DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
+    bool plan_in_init = false;   // this batch's statistics records were written by its k_batch_init
     bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
 
@@ -413,26 +414,36 @@ static pg_status check_read_errors(pg_ctx *c) {
                 (unsigned long long)(c->reads_before + idx), read_status_text(code));
 }
 
-// statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
-// handles the reads whose in-range code interval fits it (no host decision, no sync)
-static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, bool forked_behind_init = false) {
-    // by this batch's k_batch_init, on the same stream (or on the stream this one was forked from, behind that kernel)
-    const bool flags_are_reset = (st == c->st || forked_behind_init) && c->stat_flags_reset;
-    c->stat_flags_reset = false;
+// buffers of the statistics of the current batch (slot c->slot); idempotent
+static pg_status ensure_stats_buffers(pg_ctx *c) {
     const uint32_t n = c->B.n_reads;
     const int sl = c->slot;
-    const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0;
-    uint8_t *oor = nullptr;
-    if (skip_oor) { HIP_TRY(c, c->oor.ensure(n + 1ull)); oor = c->oor.as<uint8_t>(); }
-    const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
+    if (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) HIP_TRY(c, c->oor.ensure(n + 1ull));
     HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
     HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * (size_t)PG_STAT_REC_BYTES)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
     HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull)); HIP_TRY(c, c->huge_scratch.ensure(PG_HUGE_SCRATCH_WORDS * 4));
-    int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] length of the wide list
-    prof_begin(c, "k_read_plan", st);
-    pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, c->wide_list[sl].as<uint32_t>(), flags,
-                        c->stat_status[sl].as<int32_t>(), flags_are_reset);
-    prof_end(c, st);
+    return PG_OK;
+}
+
+// statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
+// handles the reads whose in-range code interval fits it (no host decision, no sync)
+// plan_done: the records (and the flag reset) were written by this batch's k_batch_init
+static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, bool forked_behind_init = false, bool plan_done = false) {
+    // by this batch's k_batch_init, on the same stream (or on the stream this one was forked from, behind that kernel)
+    const bool flags_are_reset = (st == c->st || forked_behind_init) && c->stat_flags_reset;
+    c->stat_flags_reset = false;
+    const int sl = c->slot;
+    const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0;
+    pg_status se = ensure_stats_buffers(c);
+    if (se != PG_OK) return se;
+    uint8_t *oor = skip_oor ? c->oor.as<uint8_t>() : nullptr;
+    const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
+    int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] / [2] lengths of the wide / huge list
+    if (!plan_done) {
+        prof_begin(c, "k_read_plan", st);
+        pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset);
+        prof_end(c, st);
+    }
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
@@ -534,12 +545,18 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         // ... and the buffers of this slot to be free: the gather of the batch that used them two batches ago
         if (c->slot_used[c->slot]) HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_gathered[c->slot], 0));
     }
+    // eager statistics on the main stream (or forked from it later): k_batch_init also writes the statistics record of every
+    // read -- k_read_plan's work, one kernel boundary less. The second-stream mode plans on its own stream; lazy statistics
+    // plan behind the emit kernel (they need its flags).
+    c->plan_in_init = eager_stats && !overlap && n > 0;
+    if (c->plan_in_init) { pg_status se = ensure_stats_buffers(c); if (se != PG_OK) return se; }
     pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
-                         c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>());
+                         c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>(), c->B, c->prm.pa_min, c->prm.pa_max,
+                         c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr);
     c->stat_flags_reset = !overlap;
     c->zero_running = false;
 
-    if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr); if (s2 != PG_OK) return s2; }
+    if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init); if (s2 != PG_OK) return s2; }
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     // the fused kernel's LDS window holds 256 events plus the reach of pick_this_kmer on both sides (pg_kernels.hip: k_walk)
@@ -586,7 +603,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
             HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
             HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
         }
-        pg_status s2 = launch_stats(c, ss, nullptr, tail);
+        pg_status s2 = launch_stats(c, ss, nullptr, tail, c->plan_in_init);
         if (s2 != PG_OK) return s2;
         if (overlap || tail) HIP_TRY(c, hipEventRecord(c->ev_join[c->slot], c->st2));
         c->stats_in_flight = overlap || tail;
@@ -608,7 +625,7 @@ pg_status pg_stats(pg_ctx *c) {
     if (!c->stats_deferred) return PG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     c->stats_deferred = false;
-    return launch_stats(c, c->st, nullptr);
+    return launch_stats(c, c->st, nullptr, false, c->plan_in_init);
 }
 
 pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0, 0); }
@@ -625,7 +642,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stats_deferred) { // PG_FLAG_DEFER_STATS and the caller did not place them with pg_stats
         c->stats_deferred = false;
-        pg_status s2 = launch_stats(c, c->st, nullptr);
+        pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init);
         if (s2 != PG_OK) return s2;
     }
     const uint32_t ns = c->prm.n_slots;

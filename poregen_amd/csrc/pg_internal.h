@@ -118,7 +118,9 @@ struct PgKeptOut {
 // context's running per-slot counts
 // stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch
 void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
-                          int zero_running, int32_t *stat_flags);
+                          int zero_running, int32_t *stat_flags,
+                          // plan_buf (may be null): also write the statistics record of every read (what k_read_plan does, needed == null)
+                          const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *stat_status);
 // tiles of PG_SORT_TILE events; in direct mode (n_slots <= PG_DIRECT_MAX_SLOTS) the count is padded to a multiple of 4:
 // k_rank_count_direct handles 4 tiles per workgroup and writes their counts of a slot as one 16-byte store
 static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
@@ -164,13 +166,13 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status, bool flags_are_reset);
+                         int32_t *flags, int32_t *stat_status, bool flags_are_reset);
 // bins: 1024 (one workgroup per read) or anything larger = the rare reads (wide list: PG_STATS_BINS LDS bins; huge list:
 // 65536 bins in global memory), one launch for both lists
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only);
+                          double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list /* filled by the 1024-bin launch */,
+                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

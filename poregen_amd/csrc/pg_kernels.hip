@@ -1068,11 +1068,11 @@ __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict
 
 __global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; flags[2] = 0; }
 
-__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
-                                                   PgStatRec *__restrict__ rec, uint32_t *__restrict__ wide_list,
-                                                   int32_t *__restrict__ wide_count, int32_t *__restrict__ stat_status) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= B.n_reads) return;
+// the record of one read. Reads whose in-range interval does not fit the 1024-bin LDS histogram put THEMSELVES on the lists of
+// the (rare) wide launch when k_read_stats meets them (stats_list_wide): nothing here depends on another thread, so the
+// records can also be written by k_batch_init's launch (eager statistics: one kernel boundary less per batch)
+__device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
+                                              PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status) {
     const double offset = B.off[r], scale = B.range[r] / B.dig[r];
     const PgReadPlan p = pg_make_plan(B.dig[r], offset, B.range[r], pa_min, pa_max);
     PgStatRec o;
@@ -1083,10 +1083,19 @@ __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *
     o.offset = offset; o.scale = scale; o.pad[0] = o.pad[1] = 0;
     rec[r] = o;
     stat_status[r] = 0;
-    // reads whose in-range interval does not fit the 1024-bin LDS histogram go to the (rare) wide launches: the list is
-    // filled from the front (<= PG_STATS_BINS codes, LDS) and from the back (more: global-memory histogram)
-    if (o.mode == PG_STAT_RUN && p.span > PG_STATS_BINS) wide_list[B.n_reads - 1 - (uint32_t)atomicAdd(wide_count + 1, 1)] = r;
-    else if (o.mode == PG_STAT_RUN && p.span > 1024) wide_list[atomicAdd(wide_count, 1)] = r;
+}
+
+__global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
+                                                   PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < B.n_reads) read_plan_one(B, r, needed, pa_min, pa_max, rec, stat_status);
+}
+
+// a read of the main statistics launch whose interval needs a wider histogram: the list is filled from the front
+// (<= PG_STATS_BINS codes, LDS) and from the back (more: global-memory histogram); wide_count[0] / [1] count the two ends
+__device__ __forceinline__ void stats_list_wide(uint32_t r, int32_t span, uint32_t n_reads, uint32_t *__restrict__ wide_list, int32_t *__restrict__ wide_count) {
+    if (span > PG_STATS_BINS) wide_list[n_reads - 1 - (uint32_t)atomicAdd(wide_count + 1, 1)] = r;
+    else wide_list[atomicAdd(wide_count, 1)] = r;
 }
 
 // prefix accessor over the padded LDS histogram: lane l owns BPL consecutive bins, stored with one pad
@@ -1447,13 +1456,14 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 // dispatcher does the load balancing and the overlap comes from eight resident waves per SIMD.
 __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
-                                                   int win, uint8_t *__restrict__ oor, int range_only) {
+                                                   int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
+                                                   int32_t *__restrict__ wide_count) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<1024>::LDS_WORDS];
     const uint32_t r = blockIdx.x;
     const int lane = lane_id();
     const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
     if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, status, err); return; }
-    if (m.span > 1024) return; // on the list of a wider launch
+    if (m.span > 1024) { if (lane == 0) stats_list_wide(r, m.span, B.n_reads, wide_list, wide_count); return; } // for the wider launch
     stats_zero<1024>(hist, lane);
     const int16_t *__restrict__ sig = B.sig;
     const int c_lo = m.c_lo;
@@ -1597,8 +1607,10 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, uint8_t *__restrict__ read_needed,
                                                     uint64_t *__restrict__ running, uint32_t n_slots, int zero_running,
-                                                    int32_t *__restrict__ stat_flags) {
+                                                    int32_t *__restrict__ stat_flags, PgDevBatch B, double pa_min, double pa_max,
+                                                    PgStatRec *__restrict__ plan_rec, int32_t *__restrict__ stat_status) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status); // eager statistics: see read_plan_one
     if (i == 0) { err[0] = INT_MAX; err[1] = 0; }
     if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; } // as k_stat_flags_init
     if (i <= n_reads) read_needed[i] = 0;
@@ -1610,10 +1622,11 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
 // =====================================================================================================
 
 void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
-                          int zero_running, int32_t *stat_flags) {
+                          int zero_running, int32_t *stat_flags, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf,
+                          int32_t *stat_status) {
     const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
     hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running,
-                       stat_flags);
+                       stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
 }
 
 void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused) {
@@ -1725,24 +1738,24 @@ void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, 
 }
 
 void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         uint32_t *wide_list, int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
+                         int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
     if (!flags_are_reset) hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
     if (B.n_reads == 0) return;
     hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
-                       reinterpret_cast<PgStatRec *>(plan_buf), wide_list, flags + 1, stat_status);
+                       reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
 }
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win, const uint32_t *wide_list,
-                          const int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only) {
+                          double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list,
+                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only) {
     if (B.n_reads == 0) return;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     if (bins <= 1024) {
-        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only);
+        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
     } else { // the wide and huge lists are usually empty: a small grid strides over them
         const uint32_t wide_blocks = B.n_reads < 2048 ? B.n_reads : 2048;
         hipLaunchKernelGGL(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
-                           wide_list, wide_count, huge_scratch, oor, range_only);
+                           (const uint32_t *)wide_list, (const int32_t *)wide_count, huge_scratch, oor, range_only);
     }
 }
 
