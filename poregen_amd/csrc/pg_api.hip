@@ -87,6 +87,7 @@ struct pg_ctx {
     DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
+    uint32_t wide_blocks = 0;    // wide-list length of the last settled batch (sizes the next rare launch)
     bool plan_in_init = false;   // this batch's statistics records were written by its k_batch_init
     bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
     const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
@@ -385,9 +386,12 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 }
 
 static pg_status check_read_errors(pg_ctx *c) {
-    int32_t errv[2] = {INT_MAX, 0}, errs[2] = {INT_MAX, 0};
+    int32_t errv[2] = {INT_MAX, 0}, errs[3] = {INT_MAX, 0, 0};
     HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 12, hipMemcpyDeviceToHost));
+    // the rare statistics launch of the NEXT batch is sized by what this one needed (its blocks stride over the list: the
+    // size only decides how fast a wide list is worked off; jobs without wide reads pay for 128 workgroups, not 2112)
+    c->wide_blocks = errs[1] > 0 ? (uint32_t)errs[1] : 0u;
     if (c->prm.scaling != 1 && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) errs[0] = INT_MAX;
     if (errv[0] == INT_MAX && errs[0] == INT_MAX) return PG_OK;
     const bool walk = errv[0] <= errs[0];
@@ -451,7 +455,7 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     prof_end(c, st);
     prof_begin(c, "k_read_stats_rare", st);
     pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only);
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only, c->wide_blocks);
     prof_end(c, st);
     return PG_OK;
 }

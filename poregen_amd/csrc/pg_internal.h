@@ -172,7 +172,8 @@ void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *rea
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list /* filled by the 1024-bin launch */,
-                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only);
+                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only,
+                          uint32_t wide_blocks_hint = 0 /* rare launch: workgroups for the wide list (64 .. 2048) */);
 void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

@@ -1747,13 +1747,15 @@ void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *rea
 
 void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list,
-                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only) {
+                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only, uint32_t wide_blocks_hint) {
     if (B.n_reads == 0) return;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     if (bins <= 1024) {
         hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
     } else { // the wide and huge lists are usually empty: a small grid strides over them
-        const uint32_t wide_blocks = B.n_reads < 2048 ? B.n_reads : 2048;
+        // the blocks stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
+        const uint32_t want = wide_blocks_hint < 64 ? 64u : (wide_blocks_hint > 2048 ? 2048u : wide_blocks_hint);
+        const uint32_t wide_blocks = B.n_reads < want ? B.n_reads : want;
         hipLaunchKernelGGL(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
                            (const uint32_t *)wide_list, (const int32_t *)wide_count, huge_scratch, oor, range_only);
     }
