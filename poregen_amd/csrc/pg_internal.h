@@ -95,7 +95,8 @@ struct PgStatRec {
     int32_t c_lo, span, z0;
     int32_t mode;        // PG_STAT_*
     double offset, scale;
-    uint64_t pad[2];
+    double inv;          // 1.0 / scale: only ever places the candidate windows of the selection (pg_select.h), computed once per read here
+    uint64_t pad;
 };
 enum { PG_STAT_RUN = 0, PG_STAT_SKIP = 1, PG_STAT_BAD = 2 };
 #define PG_STAT_REC_BYTES 64

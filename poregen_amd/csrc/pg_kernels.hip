@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, c
     o.c_lo = p.c_lo; o.span = p.span; o.z0 = p.z0;
     const bool skip = (needed && !needed[r]) || o.end == o.beg;
     o.mode = skip ? PG_STAT_SKIP : (p.status != 0 ? PG_STAT_BAD : PG_STAT_RUN);
-    o.offset = offset; o.scale = scale; o.pad[0] = o.pad[1] = 0;
+    o.offset = offset; o.scale = scale; o.inv = 1.0 / scale; o.pad = 0;
     rec[r] = o;
     stat_status[r] = 0;
 }
@@ -1287,7 +1287,7 @@ __device__ __forceinline__ void stats_select(const uint32_t *hist, int lane, con
 // between adjacent codes, a model that is off) it returns false and the caller runs stats_select.
 template <int BINS>
 __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane, const PgReadPlan &pl, uint64_t L, double offset,
-                                                  double scale, double &med_out, double &mad_out, uint32_t lane_end) {
+                                                  double scale, double &med_out, double &mad_out, uint32_t lane_end, double inv) {
     using Pre = typename StatsCfg<BINS>::Pre;
     PgSel<Pre> sel;
     sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = L;
@@ -1312,7 +1312,7 @@ __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane
         sel.nU = sel.span - sel.sp; sel.nD = sel.sp;
         sel.base = sel.P(sel.sp - 1);
         sel.dZ = fabs(0.0 - sel.med);
-        sel.inv = 1.0 / scale;
+        sel.inv = inv; // 1.0 / scale from the read's record (an FP64 division per wave otherwise)
         sel.need = sel.k + 1;
         sel.begin_approx();
         int aU, aD;
@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
     if (range_only) return;
     PgReadPlan pl; pl.c_lo = m.c_lo; pl.span = m.span; pl.z0 = m.z0; pl.status = 0;
     double m0, m1;
-    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end)) // win == 0: tests of the general path
+    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv)) // win == 0: tests of the general path
         stats_select<BINS>(hist, lane, pl, L, m.offset, m.scale, win, m0, m1);
     if (lane == 0) { med[r] = m0; mad[r] = m1; }
 }
