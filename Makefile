@@ -30,6 +30,12 @@ bin/poregen: $(CSRC)/pg_model.h $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/r
 	$(CXX) -O2 -g -std=c++17 -Wall -o $@ $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp \
 	    -Lporegen_amd -lpgmove -L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,'$$ORIGIN/../poregen_amd' -Wl,-rpath,/opt/rocm/lib
 
+# measurement build: counts the reads whose selection leaves the fast path (tools/count_fallbacks.py)
+fallback_probe:
+	@mkdir -p build/fb
+	for f in pg_kernels pg_api pg_model; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
+	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_api.o build/fb/pg_model.o -Wl,--allow-shlib-undefined
+
 oracle_build:
 	$(MAKE) -C oracle
 
@@ -37,4 +43,4 @@ clean:
 	rm -f poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all clean oracle_build
+.PHONY: all clean oracle_build fallback_probe

@@ -1126,6 +1126,15 @@ template <int BINS> struct StatsGeom {
     static constexpr int LDS_WORDS = TRASH + 32 + 4;  // + 32 dummy bins (padded) for out-of-range samples
 };
 
+#ifdef PG_COUNT_FALLBACKS
+__device__ unsigned long long g_pg_fallbacks; // measurement build only: reads whose selection took the general path
+extern "C" unsigned long long pg_debug_fallbacks(int reset) {
+    unsigned long long v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_pg_fallbacks), sizeof(v));
+    if (reset) { unsigned long long z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pg_fallbacks), &z, sizeof(z)); }
+    return v;
+}
+#endif
 // ---- pieces shared by the three statistics kernels -----------------------------------------------------------------
 // BINS == 1024 / PG_STATS_BINS: padded LDS histogram; BINS == PG_HUGE_BINS: global-memory histogram (one per block)
 template <int BINS> struct StatsCfg {
@@ -1392,8 +1401,12 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
     if (range_only) return;
     PgReadPlan pl; pl.c_lo = m.c_lo; pl.span = m.span; pl.z0 = m.z0; pl.status = 0;
     double m0, m1;
-    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv)) // win == 0: tests of the general path
+    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv)) { // win == 0: tests of the general path
+#ifdef PG_COUNT_FALLBACKS
+        if (lane == 0) atomicAdd(&g_pg_fallbacks, 1ull);
+#endif
         stats_select<BINS>(hist, lane, pl, L, m.offset, m.scale, win, m0, m1);
+    }
     if (lane == 0) { med[r] = m0; mad[r] = m1; }
 }
 
