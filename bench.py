@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
     ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
+    ap.add_argument("--lib", default=None, help="measurement builds: path of another libpgmove build to load instead of poregen_amd/libpgmove.so")
     ap.add_argument("--overlap-tail", action="store_true", help="statistics on a second stream next to the cut/emit/scan launches (PG_FLAG_OVERLAP_TAIL)")
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
@@ -47,6 +48,9 @@ def main():
 
     import numpy as np
     import torch
+    if args.lib:
+        from poregen_amd import _abi
+        _abi.LIB_PATH = os.path.abspath(args.lib)
     from poregen_amd import dist as pgdist
     from poregen_amd import synth
     from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
