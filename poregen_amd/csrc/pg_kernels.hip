@@ -687,6 +687,16 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
     if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
+    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
+    // phase 0: everything the ordered loop needs from global memory, all rows in flight at once. The slots of the tile's events
+    // are requested in front of the "any room left?" test: a tile up to the last useful one nearly always passes it, and the
+    // test's own loads and barrier then cost no round trip of their own
+    uint32_t kv[PG_EMIT_ROWS], kp[PG_EMIT_ROWS], eo[PG_EMIT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
+        const uint64_t idx = base + (uint64_t)row * WAVE + lane;
+        kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
+    }
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
     for (uint32_t d = tid; d < ndig; d += PG_EMIT_WAVES * WAVE) {
         if (d < n_slots && (uint64_t)hist[(uint64_t)d * n_tiles + tile] < keep[d]) any = 1;
@@ -694,14 +704,6 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     }
     if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
-    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
-    // phase 0: everything the ordered loop needs from global memory, all rows in flight at once
-    uint32_t kv[PG_EMIT_ROWS], kp[PG_EMIT_ROWS], eo[PG_EMIT_ROWS];
-#pragma unroll
-    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
-        const uint64_t idx = base + (uint64_t)row * WAVE + lane;
-        kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
-    }
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const bool valid = kv[row] != PG_INVALID_SLOT;
