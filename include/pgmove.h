@@ -120,9 +120,12 @@ typedef struct {
     const int32_t *table_u;
 } pg_params;
 
-/* One batch of reads in PAF line order, structure-of-arrays. All arrays are caller-owned and only
- * read during the call. `location` says whether every pointer is a host or a device pointer
- * (device pointers must belong to pg_params.device). sig must be 16-byte aligned.
+/* One batch of reads in PAF line order, structure-of-arrays. All arrays are caller-owned. LIFETIME: pg_count / pg_submit
+ * return with work still queued -- a device batch is read by kernels queued behind the call, a host batch is staged with
+ * asynchronous copies out of the caller's memory -- so the arrays must stay valid and unmodified until pg_sync (or pg_finish /
+ * pg_all_slots_full / the next pg_count / pg_submit on the context, which synchronise) has returned. `location` says whether
+ * every pointer is a host or a device pointer (device pointers must belong to pg_params.device). sig must be 16-byte aligned.
+ * A device batch must be complete on the context's stream (pg_set_stream) before the call, or be produced on that stream.
  *
  * Read r:  signal   sig[sig_off[r] .. sig_off[r+1])               slow5_rec_t.raw_signal
  *          digitisation/offset/range[r]                            slow5_rec_t fields
@@ -135,7 +138,10 @@ typedef struct {
     uint32_t struct_size;
     int32_t  location;
     uint32_t n_reads;
-    uint32_t reserved;
+    uint32_t n_ops;               /* device batches: op_off[n_reads] if the caller knows it (it sizes the work buffers without a
+                                   * round trip to the device); 0 = the library reads it back (one synchronisation of the
+                                   * context's stream per call). A wrong value is detected on the device and fails the batch
+                                   * with PG_ERR_INVALID_ARG; no kernel touches memory behind n_ops. Host batches: ignored. */
     const int16_t  *sig;
     const uint64_t *sig_off;      /* [n_reads+1] */
     const double   *digitisation; /* [n_reads] */

@@ -49,7 +49,7 @@ class PgParams(C.Structure):
 
 class PgBatch(C.Structure):
     _fields_ = [
-        ("struct_size", C.c_uint32), ("location", C.c_int32), ("n_reads", C.c_uint32), ("reserved", C.c_uint32),
+        ("struct_size", C.c_uint32), ("location", C.c_int32), ("n_reads", C.c_uint32), ("n_ops", C.c_uint32),
         ("sig", C.c_void_p), ("sig_off", C.c_void_p), ("digitisation", C.c_void_p), ("offset", C.c_void_p),
         ("range", C.c_void_p), ("query_start", C.c_void_p), ("target_start", C.c_void_p), ("target_end", C.c_void_p),
         ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("op_n", C.c_void_p), ("op_t", C.c_void_p), ("op_off", C.c_void_p),

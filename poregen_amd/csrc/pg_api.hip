@@ -90,7 +90,6 @@ struct pg_ctx {
     uint32_t wide_blocks = 0;    // wide-list length of the last settled batch (sizes the next rare launch)
     bool plan_in_init = false;   // this batch's statistics records were written by its k_batch_init
     bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
-    const void *dev_batch_key = nullptr; uint32_t dev_batch_reads = 0; uint64_t dev_batch_ops = 0;
 
     PgDevBatch B{};       // current batch (device view)
     bool have_count = false, have_batch_result = false, downloaded = true;
@@ -143,6 +142,7 @@ static const char *read_status_text(int code) {
         case PGR_ERR_RANGE: return "sample index exceeds INT32_MAX";
         case PGR_ERR_SCALE: return "range/digitisation is not a positive finite number";
         case PGR_ERR_WIDE: return "internal: statistics histogram too narrow for this read";
+        case PGR_ERR_LAYOUT: return "op_off of the device batch is not monotone or ends behind pg_batch.n_ops";
         default: return "unknown";
     }
 }
@@ -387,7 +387,8 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 
 static pg_status check_read_errors(pg_ctx *c) {
     int32_t errv[2] = {INT_MAX, 0}, errs[3] = {INT_MAX, 0, 0};
-    HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 8, hipMemcpyDeviceToHost));
+    if (errv[1]) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.n_ops (%llu) is not op_off[n_reads] of the device batch", (unsigned long long)c->B.n_ops);
     HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 12, hipMemcpyDeviceToHost));
     // the rare statistics launch of the NEXT batch is sized by what this one needed (its blocks stride over the list: the
     // size only decides how fast a wide list is worked off; jobs without wide reads pay for 128 workgroups, not 2112)
@@ -413,7 +414,7 @@ static pg_status check_read_errors(pg_ctx *c) {
     }
     int32_t code = 0;
     HIP_TRY(c, hipMemcpy(&code, (walk ? c->status.as<int32_t>() : c->stat_status[c->slot].as<int32_t>()) + idx, 4, hipMemcpyDeviceToHost));
-    pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : PG_ERR_INPUT);
+    pg_status s = code == PGR_ERR_RNA ? PG_ERR_RNA_FLAG : (code == PGR_ERR_WIDE ? PG_ERR_UNSUPPORTED : (code == PGR_ERR_LAYOUT ? PG_ERR_INVALID_ARG : PG_ERR_INPUT));
     return fail(c, s, "read %llu of the batch (global read %llu): %s", (unsigned long long)idx,
                 (unsigned long long)(c->reads_before + idx), read_status_text(code));
 }
@@ -445,17 +446,17 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] / [2] lengths of the wide / huge list
     if (!plan_done) {
         prof_begin(c, "k_read_plan", st);
-        pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset);
+        HIP_TRY(c, pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset));
         prof_end(c, st);
     }
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
-    pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only);
+    HIP_TRY(c, pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only));
     prof_end(c, st);
     prof_begin(c, "k_read_stats_rare", st);
-    pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only, c->wide_blocks);
+    HIP_TRY(c, pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only, c->wide_blocks));
     prof_end(c, st);
     return PG_OK;
 }
@@ -499,13 +500,16 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         B.qstart = b->query_start; B.tstart = b->target_start; B.tend = b->target_end; B.seq = b->seq; B.seq_off = b->seq_off;
         B.op_n = b->op_n; B.op_t = b->op_t; B.op_off = b->op_off;
         if (!B.sig_off || !B.seq_off || !B.op_off) return fail(c, PG_ERR_INVALID_ARG, "batch offsets missing");
-        if (c->dev_batch_key != (const void *)b->op_off || c->dev_batch_reads != n) { // op_off[n] of a new device batch
-            uint64_t no = 0;
-            HIP_TRY(c, hipMemcpy(&no, b->op_off + n, 8, hipMemcpyDeviceToHost));
-            c->dev_batch_key = b->op_off; c->dev_batch_reads = n; c->dev_batch_ops = no;
+        // op_off[n]: from the caller (pg_batch.n_ops; verified on the device by k_batch_init, and k_walk refuses reads whose ops end
+        // behind it), else read back on the context's stream -- never remembered from an earlier batch: an allocator hands the
+        // same address to the next batch of the same shape
+        uint64_t no = b->n_ops;
+        if (no == 0 && n > 0) {
+            HIP_TRY(c, hipMemcpyAsync(&no, b->op_off + n, 8, hipMemcpyDeviceToHost, c->st));
+            HIP_TRY(c, hipStreamSynchronize(c->st));
         }
         B.n_reads = n;
-        B.n_ops = c->dev_batch_ops;
+        B.n_ops = no;
     } else return fail(c, PG_ERR_INVALID_ARG, "pg_batch.location must be PG_LOC_HOST or PG_LOC_DEVICE");
     if (((uintptr_t)c->B.sig & 15) != 0) return fail(c, PG_ERR_INVALID_ARG, "sig must be 16-byte aligned");
     const uint64_t N = c->B.n_ops;
@@ -554,9 +558,9 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // plan behind the emit kernel (they need its flags).
     c->plan_in_init = eager_stats && !overlap && n > 0;
     if (c->plan_in_init) { pg_status se = ensure_stats_buffers(c); if (se != PG_OK) return se; }
-    pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
+    HIP_TRY(c, pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
                          c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>(), c->B, c->prm.pa_min, c->prm.pa_max,
-                         c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr);
+                         c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr));
     c->stat_flags_reset = !overlap;
     c->zero_running = false;
 
@@ -566,11 +570,11 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // the fused kernel's LDS window holds 256 events plus the reach of pick_this_kmer on both sides (pg_kernels.hip: k_walk)
     const bool fused = !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) && c->prm.kmer_pick_margin <= 100;
     prof_begin(c, "k_walk", c->st);
-    pg_launch_walk(c->st, c->B, W, O, fused);
+    HIP_TRY(c, pg_launch_walk(c->st, c->B, W, O, fused));
     prof_end(c, c->st);
     if (!fused) {
         prof_begin(c, "k_events", c->st);
-        pg_launch_events(c->st, c->B, W, O);
+        HIP_TRY(c, pg_launch_events(c->st, c->B, W, O));
         prof_end(c, c->st);
     }
 
@@ -579,17 +583,17 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     uint64_t *acc_copy = (counts_out && counts_location == PG_LOC_DEVICE) ? counts_out : nullptr; // written by the counting kernels
     if (direct) {
         prof_begin(c, "rank_count", c->st);
-        pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
-                                    c->tile_last.as<int32_t>(), acc_copy);
+        HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
+                                    c->tile_last.as<int32_t>(), acc_copy));
         prof_end(c, c->st);
     } else {
         prof_begin(c, "sort_events", c->st);
-        if (N) c->sorted_idx = pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S);
+        if (N) HIP_TRY(c, pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S, &c->sorted_idx));
         else { c->sorted_idx = 0; HIP_TRY(c, hipMemsetAsync(c->scount.p, 0, 8, c->st)); }
         prof_end(c, c->st);
         prof_begin(c, "slot_bounds", c->st);
-        pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
-                              c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy);
+        HIP_TRY(c, pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
+                              c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy));
         prof_end(c, c->st);
     }
 
@@ -674,10 +678,10 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     }
     if (!direct) HIP_TRY(c, c->keep32.ensure(ns * 4ull));
     prof_begin(c, "k_slot_plan", c->st);
-    pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
+    HIP_TRY(c, pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
                         pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
-                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr, G);
+                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr, G));
     prof_end(c, c->st);
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
@@ -695,12 +699,12 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         PgSortBufs S{};
         fill_sort(c, S, 0);
         prof_begin(c, "k_rank_emit", c->st);
-        pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K);
+        HIP_TRY(c, pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K));
         prof_end(c, c->st);
     } else {
         prof_begin(c, "k_kept_meta", c->st);
-        pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
-                            c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K);
+        HIP_TRY(c, pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
+                            c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K));
         prof_end(c, c->st);
     }
 
@@ -709,7 +713,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>()); if (s2 != PG_OK) return s2; }
 
     prof_begin(c, "scan_ev_len", c->st);
-    pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>());
+    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>()));
     prof_end(c, c->st);
 
     uint64_t gather_cap = ke_cap;
@@ -728,9 +732,9 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     }
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", c->st);
-    pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
+    HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
                      c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
-                     c->samples.as<double>());
+                     c->samples.as<double>()));
     prof_end(c, c->st);
     HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], c->st));
     c->slot_used[c->slot] = true;

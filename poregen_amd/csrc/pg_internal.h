@@ -37,7 +37,8 @@ enum {
     PGR_ERR_WINDOW = -6,      // an accepted event's window is empty / starts beyond the signal / margin > start
     PGR_ERR_RANGE = -7,       // sample index does not fit the reference's int arrays
     PGR_ERR_SCALE = -8,       // range/digitisation not positive finite (pg_select.h)
-    PGR_ERR_WIDE = -9         // pa window spans more than PG_STATS_BINS codes (not implemented yet)
+    PGR_ERR_WIDE = -9,        // pa window spans more than PG_STATS_BINS codes (not implemented yet)
+    PGR_ERR_LAYOUT = -10      // the read's ops end behind pg_batch.n_ops, or op_off is not monotone (device batches)
 };
 
 // per-read summary written by k_walk, read by k_events / k_rank_emit with two 16-byte loads
@@ -108,7 +109,7 @@ struct PgGathered {
     uint32_t world, rank;
     uint64_t *total, *freq; // [n_slots] the job's accepted events per slot and min(total, sample_limit) (pg_job_totals_device)
 };
-// ---- launchers (all asynchronous on `st`) -----------------------------------------------------------
+// ---- launchers (all asynchronous on `st`; the result is hipGetLastError() behind the launch / the queued copy's status) -----------------------------------------------------------
 struct PgKeptOut {
     uint32_t *ev_len;     // [n_kept] window length incl. margin, clamped to the signal
     uint32_t *ev_read;    // [n_kept] read index inside the batch
@@ -118,7 +119,7 @@ struct PgKeptOut {
 // resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
 // context's running per-slot counts
 // stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch
-void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags,
                           // plan_buf (may be null): also write the statistics record of every read (what k_read_plan does, needed == null)
                           const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *stat_status);
@@ -133,21 +134,21 @@ struct PgSlotModel; struct PgSlotDwell; // pg_model.h
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell);
 // fused: the walk and the event loop of every read in one launch (no pg_launch_events behind it)
-void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused);
-void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused);
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
-void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last,
                                  uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */);
-void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
 // generic ranking: stable LSD radix sort of (ev_slot, index) pairs by slot, dropping PG_INVALID_SLOT; result in
-// S.keys[out]/S.vals[out], number of sorted pairs in S.count[0]. Returns `out`.
-int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S);
-void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
+// S.keys[*sorted_idx]/S.vals[*sorted_idx], number of sorted pairs in S.count[0].
+hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S, int *sorted_idx);
+hipError_t pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
                            uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy);
-void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
+hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
                          const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off,
                          const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
 // keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
@@ -155,26 +156,26 @@ void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *s
 // hist/n_tiles (direct mode, else nullptr): also computes totals[3] = last tile that can still place an event
 // keep32 (uint32[n_slots]) + scan_scratch (as pg_launch_scan_u32_u64, >= ceil(n_slots/4096)+80 entries): work space of
 // the many-slot path (n_slots > 4096, sort mode); may be null for small slot counts
-void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
+hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running,
                          uint32_t limit, uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals,
                          const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch,
                          const int32_t *tile_last /* direct mode, base == running: from pg_launch_rank_direct_count; else null */,
                          const PgGathered &G /* all_counts != null: base = the rows below G.rank, summed in the same pass */);
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
 // entries ZERO before the first use (every launch leaves them zero again)
-void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
 // plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
+hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset);
 // bins: 1024 (one workgroup per read) or anything larger = the rare reads (wide list: PG_STATS_BINS LDS bins; huge list:
 // 65536 bins in global memory), one launch for both lists
 // win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
+hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list /* filled by the 1024-bin launch */,
                           int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only,
                           uint32_t wide_blocks_hint = 0 /* rare launch: workgroups for the wide list (64 .. 2048) */);
-void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
+hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

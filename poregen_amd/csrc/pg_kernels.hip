@@ -142,8 +142,17 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
     WalkLds *sm = &sm_store;
     const int lane = lane_id();
     const uint32_t r = blockIdx.x; // one wave per workgroup: a finished read frees its slot at once
-    const uint64_t o0 = B.op_off[r];
-    const uint32_t nops = (uint32_t)(B.op_off[r + 1] - o0);
+    const uint64_t o0 = B.op_off[r], o1 = B.op_off[r + 1];
+    const bool last_read = r + 1 == B.n_reads;
+    if (o1 > B.n_ops || o1 < o0 || (last_read && o1 != B.n_ops)) {
+        // pg_batch.n_ops (it sized the work buffers) disagrees with the offsets on the device: nothing is written behind n_ops,
+        // every op index below it still gets a slot entry, and the batch fails (k_batch_init raises the flag as well)
+        const uint64_t a = o0 < B.n_ops ? o0 : B.n_ops, e1 = o1 < a ? a : o1, b = (last_read || e1 > B.n_ops) ? B.n_ops : e1;
+        for (uint64_t i = a + lane_id(); i < b; i += WAVE) { O.ev_slot[i] = PG_INVALID_SLOT; O.m_read[i] = r; }
+        if (lane_id() == 0) { O.meta[r] = PgReadMeta{a, 0u, 0u, 0, 0, 0u, 0u}; report_error(O, r, PGR_ERR_LAYOUT); }
+        return;
+    }
+    const uint32_t nops = (uint32_t)(o1 - o0);
     const uint64_t s0 = B.seq_off[r];
     const uint32_t slen = (uint32_t)(B.seq_off[r + 1] - s0);
     const uint64_t L = B.sig_off[r + 1] - B.sig_off[r];
@@ -824,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
             const uint64_t cnt = acc_cnt[s], b = slot_base(G, base, s, n_slots, limit);
             const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
             kp = cnt < room ? cnt : room;
-            isfull = (b + cnt >= limit) ? 1 : 0;
+            isfull = (limit > 0 && b + cnt >= limit) ? 1 : 0; // at limit 0 no k-mer ever completes: the test at gmove.cpp:925-927 skips every event before 945-950 can count it
             if (running) running[s] = b + cnt;
             keep[s] = kp;
         }
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(256) void k_slot_keep(const uint64_t *__restrict__ 
         const uint64_t cnt = acc_cnt[s], b = slot_base(G, base, s, n_slots, limit);
         const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
         const uint64_t kp = cnt < room ? cnt : room;
-        isfull = b + cnt >= limit;
+        isfull = limit > 0 && b + cnt >= limit; // see k_slot_plan
         if (running) running[s] = b + cnt;
         keep[s] = kp; keep32[s] = (uint32_t)kp; // <= sample_limit
     }
@@ -1635,62 +1644,70 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
                                                     PgStatRec *__restrict__ plan_rec, int32_t *__restrict__ stat_status) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status); // eager statistics: see read_plan_one
-    if (i == 0) { err[0] = INT_MAX; err[1] = 0; }
+    if (i == 0) { err[0] = INT_MAX; err[1] = (n_reads ? B.op_off[n_reads] : B.n_ops) != B.n_ops; } // err[1]: pg_batch.n_ops is wrong
     if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; } // as k_stat_flags_init
     if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
 }
 
 // =====================================================================================================
-// launchers
+// launchers: every launch and every queued memset / copy is checked -- a rejected launch (bad configuration, missing code object,
+// a sticky earlier error) must fail the batch instead of leaving the previous batch's results in the buffers
 // =====================================================================================================
+#define PG_LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+#define PG_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
-void pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf,
                           int32_t *stat_status) {
     const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
-    hipLaunchKernelGGL(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running,
+    PG_LAUNCH(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running,
                        stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
+    return hipSuccess;
 }
 
-void pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused) {
-    if (B.n_reads == 0) return;
-    if (fused) hipLaunchKernelGGL(k_walk<true>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
-    else hipLaunchKernelGGL(k_walk<false>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused) {
+    if (B.n_reads == 0) return hipSuccess;
+    if (fused) PG_LAUNCH(k_walk<true>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+    else PG_LAUNCH(k_walk<false>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+    return hipSuccess;
 }
 
-void pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
-    if (B.n_ops == 0) return;
-    hipLaunchKernelGGL(k_events, dim3((uint32_t)((B.n_ops + 256 * PG_EV_PER_THREAD - 1) / (256 * PG_EV_PER_THREAD))), dim3(256), 0, st, B, W, O);
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
+    if (B.n_ops == 0) return hipSuccess;
+    PG_LAUNCH(k_events, dim3((uint32_t)((B.n_ops + 256 * PG_EV_PER_THREAD - 1) / (256 * PG_EV_PER_THREAD))), dim3(256), 0, st, B, W, O);
+    return hipSuccess;
 }
 
 static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
-void pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (n_tiles) {
-        hipLaunchKernelGGL(k_rank_count_direct, dim3(n_tiles / 4), dim3(1024), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
+        PG_LAUNCH(k_rank_count_direct, dim3(n_tiles / 4), dim3(1024), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
+        PG_LAUNCH(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
     } else {
-        (void)hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st);
-        if (acc_copy) (void)hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st);
-        if (tile_last) (void)hipMemsetAsync(tile_last, 0xff, sizeof(int32_t) * n_slots, st); // -1: nothing to place
+        PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
+        if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));
+        if (tile_last) PG_HIP(hipMemsetAsync(tile_last, 0xff, sizeof(int32_t) * n_slots, st)); // -1: nothing to place
     }
+    return hipSuccess;
 }
 
-void pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
+hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W,
                                 const PgWalkOut &O, const PgKeptOut &K) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
-    if (!n_tiles) return;
-    hipLaunchKernelGGL(k_rank_emit, dim3(n_tiles), dim3(PG_EMIT_WAVES * WAVE), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
+    if (!n_tiles) return hipSuccess;
+    PG_LAUNCH(k_rank_emit, dim3(n_tiles), dim3(PG_EMIT_WAVES * WAVE), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
                        keep, ev_off, totals, B, W, O, K);
+    return hipSuccess;
 }
 
-int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S) {
+hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S, int *sorted_idx) {
     const uint32_t n_tiles = tiles_for(n);
     if (key_bits == 0) key_bits = 1;
     const uint32_t passes = (key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
@@ -1702,95 +1719,103 @@ int pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, u
         const uint32_t shift = p * per;
         const int nbits = (int)((key_bits - shift) < per ? (key_bits - shift) : per);
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
-        hipLaunchKernelGGL(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
-        hipLaunchKernelGGL(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, (const uint64_t *)nullptr, 0u,
+        PG_LAUNCH(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
+        PG_LAUNCH(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, (const uint64_t *)nullptr, 0u,
                            (int32_t *)nullptr, (uint64_t *)nullptr);
-        hipLaunchKernelGGL(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
+        PG_LAUNCH(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
+        PG_LAUNCH(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
         // count[0] = number of keys for the next pass (pass 0 drops the invalid ones; later passes keep all)
-        (void)hipMemcpyAsync(S.count, S.count + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+        PG_HIP(hipMemcpyAsync(S.count, S.count + 1, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         kin = S.keys[out]; vin = S.vals[out];
         out ^= 1;
     }
-    return out ^ 1;
+    *sorted_idx = out ^ 1;
+    return hipSuccess;
 }
 
-void pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper, uint32_t *slot_start,
+hipError_t pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper, uint32_t *slot_start,
                            uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy) {
-    (void)hipMemsetAsync(slot_start, 0, sizeof(uint32_t) * n_slots, st);
-    (void)hipMemsetAsync(slot_end, 0, sizeof(uint32_t) * n_slots, st);
-    if (n_upper) hipLaunchKernelGGL(k_slot_bounds, dim3((uint32_t)((n_upper + 255) / 256)), dim3(256), 0, st, skey, m_ptr, slot_start, slot_end);
-    hipLaunchKernelGGL(k_slot_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, (const uint32_t *)slot_start,
+    PG_HIP(hipMemsetAsync(slot_start, 0, sizeof(uint32_t) * n_slots, st));
+    PG_HIP(hipMemsetAsync(slot_end, 0, sizeof(uint32_t) * n_slots, st));
+    if (n_upper) PG_LAUNCH(k_slot_bounds, dim3((uint32_t)((n_upper + 255) / 256)), dim3(256), 0, st, skey, m_ptr, slot_start, slot_end);
+    PG_LAUNCH(k_slot_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, (const uint32_t *)slot_start,
                        (const uint32_t *)slot_end, n_slots, acc_cnt, acc_copy);
+    return hipSuccess;
 }
 
-void pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
+hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                          uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles,
                          uint32_t *keep32, uint64_t *scan_scratch, const int32_t *tile_last, const PgGathered &G) {
     if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
-        (void)hipMemsetAsync(totals, 0, 32, st);
-        hipLaunchKernelGGL(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
-        pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch);
-        hipLaunchKernelGGL(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
-        return;
+        PG_HIP(hipMemsetAsync(totals, 0, 32, st));
+        PG_LAUNCH(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
+        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch));
+        PG_LAUNCH(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
+        return hipSuccess;
     }
-    hipLaunchKernelGGL(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last, G);
-    if (hist && n_tiles && !tile_last) hipLaunchKernelGGL(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
+    PG_LAUNCH(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last, G);
+    if (hist && n_tiles && !tile_last) PG_LAUNCH(k_tile_max, dim3((n_slots + 63) / 64), dim3(64), 0, st, hist, n_tiles, (const uint64_t *)keep, n_slots, totals);
+    return hipSuccess;
 }
 
-void pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
+hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
                          const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off, const PgDevBatch &B,
                          const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K) {
-    if (!n_upper) return;
-    hipLaunchKernelGGL(k_kept_meta, dim3((uint32_t)((n_upper + 255) / 256)), dim3(256), 0, st, skey, sval, m_ptr, slot_start, keep,
+    if (!n_upper) return hipSuccess;
+    PG_LAUNCH(k_kept_meta, dim3((uint32_t)((n_upper + 255) / 256)), dim3(256), 0, st, skey, sval, m_ptr, slot_start, keep,
                        ev_off, B, W, O, K);
+    return hipSuccess;
 }
 
-void pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
     const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK), nbl = nb ? nb : 1;
     if (nbl <= 64) { // one look-back round: a single launch wins (11 vs 17 us at 25 blocks)
-        hipLaunchKernelGGL(k_scan_chained, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
-        return;
+        PG_LAUNCH(k_scan_chained, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
+        return hipSuccess;
     }
     // long inputs: the look-back chain (one round per 64 blocks) costs more than two extra launches (52 vs 33 us at 523
     // blocks); the partial sums live behind the chained scan's state, which has to stay zero
     uint64_t *partial = scratch + 72;
-    hipLaunchKernelGGL(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
-    hipLaunchKernelGGL(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out);
+    PG_LAUNCH(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
+    PG_LAUNCH(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
+    PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out);
+    return hipSuccess;
 }
 
-void pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
+hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
-    if (!flags_are_reset) hipLaunchKernelGGL(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
-    if (B.n_reads == 0) return;
-    hipLaunchKernelGGL(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
+    if (!flags_are_reset) PG_LAUNCH(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
+    if (B.n_reads == 0) return hipSuccess;
+    PG_LAUNCH(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
                        reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
+    return hipSuccess;
 }
 
-void pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
+hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
                           double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list,
                           int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only, uint32_t wide_blocks_hint) {
-    if (B.n_reads == 0) return;
+    if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     if (bins <= 1024) {
-        hipLaunchKernelGGL(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
+        PG_LAUNCH(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
     } else { // the wide and huge lists are usually empty: a small grid strides over them
         // the blocks stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
         const uint32_t want = wide_blocks_hint < 64 ? 64u : (wide_blocks_hint > 2048 ? 2048u : wide_blocks_hint);
         const uint32_t wide_blocks = B.n_reads < want ? B.n_reads : want;
-        hipLaunchKernelGGL(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
+        PG_LAUNCH(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
                            (const uint32_t *)wide_list, (const int32_t *)wide_count, huge_scratch, oor, range_only);
     }
+    return hipSuccess;
 }
 
-void pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
+hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples) {
-    if (n_kept_cap == 0) return;
+    if (n_kept_cap == 0) return hipSuccess;
     uint64_t blocks = (n_kept_cap + 15) / 16;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
-    hipLaunchKernelGGL(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_start, samp_off, scaling,
+    PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_start, samp_off, scaling,
                        pa_min, pa_max, med, mad, samples);
+    return hipSuccess;
 }

@@ -88,6 +88,7 @@ class Batch:
     op_t: object
     op_off: object
     on_device: bool = False
+    n_ops: int = 0   # device batches: op_off[n_reads] when known (pg_batch.n_ops); 0 = the library reads it back (one sync per call)
 
     def validate_host(self):
         for name, dt in _BATCH_FIELDS:
@@ -106,7 +107,7 @@ class Batch:
             if name == "sig":  # 16-byte slack so the tail vector of the last read stays inside the allocation
                 t = torch.cat([t, torch.zeros(8, dtype=t.dtype)])
             kw[name] = t.to(device)
-        return Batch(n_reads=self.n_reads, on_device=True, **kw)
+        return Batch(n_reads=self.n_reads, on_device=True, n_ops=int(self.op_off[-1]), **kw)
 
     def slice_reads(self, lo: int, hi: int) -> "Batch":
         """Host batch holding reads [lo, hi) (used to shard a PAF-ordered batch across ranks)."""
@@ -259,6 +260,7 @@ class GmoveEngine:
         cb.struct_size = C.sizeof(_abi.PgBatch)
         cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
         cb.n_reads = b.n_reads
+        cb.n_ops = b.n_ops if b.on_device else 0
         for name, _ in _BATCH_FIELDS:
             setattr(cb, name, _ptr(getattr(b, name)))
         return cb

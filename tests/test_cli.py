@@ -255,3 +255,22 @@ def test_malformed_line_behind_the_completing_read(tmp_path):
     sl = [x if x != "64" else "10" for x in whole]                  # --file_limit 10: a slice, the loop never ends early
     assert cli(sl + [tmp_path / "gpu2"]).returncode == 1
     assert oracle_cli(sl + [tmp_path / "cpu2"]).returncode != 0
+
+
+@pytest.mark.gpu
+def test_sample_limit_zero_reads_every_line(tmp_path):
+    """--sample_limit 0: no k-mer ever completes (gmove.cpp:925-927 skips in front of 945-950), so the reference reads every
+    line, writes ':' per read with -d, and still exits on an RNA-oriented record without --rna behind the first batch."""
+    b = synth.make_batch(6, kind="dna_r10", seed=93)
+    pre = str(tmp_path / "syn"); synth.write_files(b, pre)
+    args = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq", "-k", "3", "--scaling", "1", "--file_limit", "64", "--sample_limit", "0", "-d"]
+    r = cli(args + [tmp_path / "gpu", "--batch_reads", "1"]); assert r.returncode == 0, r.stderr
+    o = oracle_cli(args + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+    assert open(tmp_path / "gpu" / "dump" / "AAA").read() == ":" * 6
+    lines = open(pre + ".paf").read().split("\n")
+    cols = lines[3].split("\t"); cols[7], cols[8] = cols[8], cols[7]      # target_start > target_end: RNA orientation
+    lines[3] = "\t".join(cols)
+    open(pre + ".paf", "w").write("\n".join(lines))
+    r = cli(args + [tmp_path / "gpu2", "--batch_reads", "1"]); assert r.returncode == 1 and "allow_rna" in r.stderr
+    assert oracle_cli(args + [tmp_path / "cpu2"]).returncode != 0

@@ -177,3 +177,79 @@ def test_errors_behind_the_completing_read_do_not_count_for_the_whole_list():
         eng.submit(bad); eng.sync()
     assert "read 250" in ei.value.text
     eng.close()
+
+
+# ---- round 2: device batches are never recognised by their address; pg_batch.n_ops is verified on the device -------------
+
+def _dev_batches_same_shape():
+    """Two DIFFERENT device batches with the same n_reads and the same array sizes except the ss ops: torch's caching
+    allocator hands the second one the addresses of the first once that is freed."""
+    b1 = synth.make_batch(120, kind="rna004", seed=501)
+    b2 = synth.make_batch(120, kind="rna004", seed=502, indel_rate=0.05)  # more ss ops than b1 at the same n_reads
+    assert int(b1.op_off[-1]) != int(b2.op_off[-1])
+    return b1, b2
+
+
+@pytest.mark.parametrize("known_n_ops", [True, False], ids=["n_ops_given", "n_ops_read_back"])
+def test_device_batches_of_equal_n_reads_at_the_same_address(known_n_ops):
+    import torch
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=30)
+    kmers = generate_kmers(5, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    dev = torch.device("cuda:0")
+    addrs = []
+    for hb in (*_dev_batches_same_shape(), *_dev_batches_same_shape()[::-1]):   # small op count first, then large, then back
+        o = oracle_for(kmers, **p); o.run_batch(hb)
+        db = hb.to_device(dev)
+        if not known_n_ops:
+            db.n_ops = 0
+        addrs.append((db.op_off.data_ptr(), db.n_reads))
+        eng.reset(); eng.submit(db)
+        assert_result_equals_oracle(eng.finish(), o, sample_limit=30)
+        del db
+    assert len(set(addrs)) < len(addrs), "the allocator did not reuse an address: the test does not exercise the case"
+    eng.close()
+
+
+@pytest.mark.parametrize("delta", [-7, 5, 4096])
+def test_wrong_n_ops_of_a_device_batch_is_an_error_not_a_fault(delta):
+    import torch
+    from poregen_amd.engine import PgError
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=30)
+    kmers = generate_kmers(5, rna=True)
+    hb = synth.make_batch(150, kind="rna004", seed=503)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    db = hb.to_device(torch.device("cuda:0"))
+    db.n_ops += delta
+    with pytest.raises(PgError) as ei:
+        eng.submit(db); eng.finish()
+    assert ei.value.status == -2 and "n_ops" in ei.value.text          # PG_ERR_INVALID_ARG
+    db.n_ops -= delta                                                  # the context is usable afterwards
+    o = oracle_for(kmers, **p); o.run_batch(hb)
+    eng.reset(); eng.submit(db)
+    assert_result_equals_oracle(eng.finish(), o, sample_limit=30)
+    eng.close()
+
+
+def test_sample_limit_zero_never_completes_a_kmer():
+    """gmove.cpp:925-927 skips every event at limit 0 before 945-950 could count it: no k-mer ever completes, the loop never
+    ends early, every read is looked at (and can fail the job), every read gets its ':' with -d."""
+    from poregen_amd.engine import PgError
+    p = dict(kmer_size=3, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=0)
+    kmers = generate_kmers(3, rna=True)
+    hb = synth.make_batch(60, kind="rna004", seed=504)
+    o = oracle_for(kmers, delimit=True, **p)
+    assert all(rc == 0 for rc in o.run_batch(hb))                      # never ORC_STOPPED
+    eng = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    for lo in range(0, 60, 20):
+        eng.submit(hb.slice_reads(lo, lo + 20))
+        assert not eng.all_slots_full()
+    res = eng.finish()
+    assert int(res.counts.sum()) == 0
+    assert_result_equals_oracle(res, o, delimit=True, sample_limit=0)
+    # an RNA record without --rna still fails the job although "all k-mers hold sample_limit events"
+    eng2 = GmoveEngine(GmoveParams(kmers=generate_kmers(3), stop_when_full=True, **dict(p, rna=False)))
+    with pytest.raises(PgError) as ei:
+        eng2.submit(hb.slice_reads(0, 20)); eng2.finish()
+    assert ei.value.status == -4
+    eng.close(); eng2.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the multi-GPU step on a one-rank RCCL group: statistics behind the issue of the all_gather (default) or inside pg_count.
-# usage (GPU box, repo root): bash tests/ab_dist.sh <tag> [nopytest]  -> gpurun_out/<tag>/
+# usage (GPU box, repo root): bash tools/ab_dist.sh <tag> [nopytest]  -> gpurun_out/<tag>/
 set -o pipefail
 tag=${1:-ab}; out=gpurun_out/$tag; mkdir -p $out
 if [ "$2" != "nopytest" ]; then

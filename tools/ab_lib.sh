@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on one box: bash tests/ab_lib.sh <tag> <build dir names under build/ ...>
+# A/B of library builds on one box: bash tools/ab_lib.sh <tag> <build dir names under build/ ...>
 set -o pipefail
 out=gpurun_out/$1; shift; mkdir -p $out
 for rep in 1 2 3; do for v in "$@"; do

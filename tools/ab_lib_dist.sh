@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on one box, multi-GPU step on a one-rank RCCL group: bash tests/ab_lib_dist.sh <tag> <build dir names under build/ ...>
+# A/B of library builds on one box, multi-GPU step on a one-rank RCCL group: bash tools/ab_lib_dist.sh <tag> <build dir names under build/ ...>
 set -o pipefail
 out=gpurun_out/$1; shift; mkdir -p $out
 for rep in 1 2 3; do for v in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite + three plain bench runs. usage: bash tests/ab_quick.sh <tag>
+# full GPU suite + three plain bench runs. usage: bash tools/ab_quick.sh <tag>
 set -o pipefail
 tag=${1:-abq}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -30 $out/pytest_gpu.txt; exit 1; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of PG_FLAG_OVERLAP_TAIL on one box. usage: bash tests/ab_tail.sh <tag>
+# A/B of PG_FLAG_OVERLAP_TAIL on one box. usage: bash tools/ab_tail.sh <tag>
 set -o pipefail
 tag=${1:-abt}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $out/pytest_parity.txt 2>&1 || { tail -30 $out/pytest_parity.txt; exit 1; }

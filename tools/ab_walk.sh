@@ -1,5 +1,5 @@
 #!/bin/bash
-# fused walk+events kernel: parity suite, a fuzz run, and the A/B against the two-launch form. usage: bash tests/ab_walk.sh <tag> [fuzz cases]
+# fused walk+events kernel: parity suite, a fuzz run, and the A/B against the two-launch form. usage: bash tools/ab_walk.sh <tag> [fuzz cases]
 set -o pipefail
 tag=${1:-abw}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -30 $out/pytest_gpu.txt; exit 1; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick A/B of the fused walk kernel (parity file + two bench pairs). usage: bash tests/ab_walk_quick.sh <tag>
+# quick A/B of the fused walk kernel (parity file + two bench pairs). usage: bash tools/ab_walk_quick.sh <tag>
 set -o pipefail
 tag=${1:-abq}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $out/pytest_parity.txt 2>&1 || { tail -30 $out/pytest_parity.txt; exit 1; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's profile artefacts come from, in one GPU call: the GPU test suite, the bench line, the kernel
 # trace of the same command and the HBM-traffic counters of the dominant kernel (separate --pmc passes).
-# usage (from the repo root, on the GPU box): bash tests/round_artifacts.sh <tag>   -> gpurun_out/<tag>/
+# usage (from the repo root, on the GPU box): bash tools/round_artifacts.sh <tag>   -> gpurun_out/<tag>/
 set -o pipefail
 tag=${1:-r01}
 out=gpurun_out/$tag; mkdir -p $out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of the multi-GPU step on a one-rank RCCL group. usage: bash tests/trace_dist.sh <tag>
+# kernel trace of the multi-GPU step on a one-rank RCCL group. usage: bash tools/trace_dist.sh <tag>
 set -o pipefail
 out=gpurun_out/${1:-trace_dist}; mkdir -p $out
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
