@@ -18,8 +18,8 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_select.h $(CSRC)/pg_mo
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_api.o build/pg_model.o
-	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined
+poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_api.o build/pg_model.o build/pg_job.o
+	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lpthread
 
 poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread
@@ -33,8 +33,8 @@ bin/poregen: $(CSRC)/pg_model.h $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/r
 # measurement build: counts the reads whose selection leaves the fast path (tools/count_fallbacks.py)
 fallback_probe:
 	@mkdir -p build/fb
-	for f in pg_kernels pg_api pg_model; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
-	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_api.o build/fb/pg_model.o -Wl,--allow-shlib-undefined
+	for f in pg_kernels pg_api pg_model pg_job; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
+	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_api.o build/fb/pg_model.o build/fb/pg_job.o -Wl,--allow-shlib-undefined
 
 oracle_build:
 	$(MAKE) -C oracle

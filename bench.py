@@ -8,13 +8,21 @@ BASELINE.json configs[1]: synthetic RNA004, 50 000 reads x 4 000 samples, k=5, -
 min/max_dur 20/40, sample_limit 100, all 1024 k-mers. At N>1 every rank holds its own 50 000-read shard of
 one PAF-ordered job (weak scaling); value = samples of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0). Extra objects: "roofline" (k_read_stats, the kernel that streams the signal,
-timed with HIP events on the library's stream) and, at N=1, "cpu_baseline" (the CPU oracle, a port of the
-reference algorithm, timed on a bounded sample of the same workload on this host's cores).
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its own
+`python -m torch.distributed.run --nproc-per-node N` child (before anything touches a GPU) and relays its JSON line.
+
+Prints ONE JSON line (rank 0). Extra objects: "roofline" (k_read_stats, the kernel that streams the signal, timed with
+HIP events on the library's stream), "whole_step" (SURVEY 8d's algorithmic bytes of the COMPLETE step over the step
+time), and at N=1: "cpu_baseline" (the CPU oracle, a port of the reference algorithm, on a bounded sample of the same
+workload on this host's cores), "all_kept_mode" (the same reads at sample_limit 5000, where nearly every accepted
+event is kept), "hbm_not_mall" (k_read_stats over a 3.2 GB batch: 12x the 256 MiB Infinity Cache),
+"pcie_inclusive" (the step fed from host memory) and "end_to_end" (`bin/poregen gmove` as a child process on the same
+workload as BLOW5 + PAF + FASTQ files in the page cache, until the dump files are closed).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,6 +30,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def relaunch_under_torchrun(args):
+    """--gpus N > 1 without a torch.distributed environment: one rank per GPU as a CHILD process group (never an exec of
+    this process, and nothing here has touched a GPU yet); the ranks' single JSON line is relayed."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line)
+    raise SystemExit(r.returncode if r.returncode else (0 if line else 1))
 
 
 def main():
@@ -37,6 +67,7 @@ def main():
     ap.add_argument("--lazy", action="store_true", help="statistics only for reads that own a kept event")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip all_kept_mode / hbm_not_mall / pcie_inclusive / end_to_end (profiling and A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
     ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
@@ -45,6 +76,12 @@ def main():
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
     import numpy as np
     import torch
@@ -57,9 +94,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     backend = os.environ.get("PG_BENCH_BACKEND", "nccl")  # "gloo": rehearse N>1 on fewer GPUs (ranks share devices)
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
@@ -161,18 +195,26 @@ def main():
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950
     # note of MI355X_MICROARCH.md): measured offline on this exact workload and committed under profiles/
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
-            traffic = pmc["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
+                traffic = pmc["traffic_bytes_per_launch"]
+            break
+        except Exception:
+            pass
     roofline = {
         "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
         "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
     }
     kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
+    # the COMPLETE step against the roofline: SURVEY 8(d)'s B_alg = every input byte once, every output byte once
+    n_bases = int(host.seq_off[-1])
+    b_alg = 2 * n_samples + 24 * host.n_reads + 5 * n_ops + n_bases + 8 * kept_samples + 12 * kept_events + 8 * len(kmers)
+    whole_step = {"algorithmic_bytes": b_alg, "bytes_per_sample": b_alg / n_samples, "ms_per_step": ms_per_step,
+                  "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "kernels_sum_ms": sum(kernels_ms.values())}
 
     # the same job with statistics only for the reads that own a kept event (legal: acceptance is signal-independent in
     # the PAF path); reported next to `value`, never as `value`
@@ -208,12 +250,24 @@ def main():
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples,
         },
         "roofline": roofline,
+        "whole_step": whole_step,
+        "whole_step_frac": whole_step["frac"],
         "kernels_ms_per_step": kernels_ms,
         "lazy_statistics_mode": lazy_info,
         "kmer_model_once_per_job": model_info,
         "gen_seconds": gen_s,
     }
 
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.force_dist
+    if extras:
+        t0 = time.time()
+        out["all_kept_mode"] = all_kept_mode(shard, host, kmers, p, n_ops, n_bases)
+        out["hbm_not_mall"] = hbm_not_mall(shard, kmers, p, dev)
+        out["pcie_inclusive"] = pcie_inclusive(host, kmers, p)
+        del shard
+        torch.cuda.empty_cache()
+        out["end_to_end"] = end_to_end(host, args)
+        out["extras_seconds"] = time.time() - t0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, kmers, p, args.cpu_seconds)
     eng.close()
@@ -221,6 +275,126 @@ def main():
         print(json.dumps(out))
     if dist_step:
         dist.destroy_process_group()
+
+
+def all_kept_mode(shard, host, kmers, p, n_ops, n_bases, steps=10):
+    """The same 50 000 reads at sample_limit 5000 (BASELINE configs[2]'s limit): no k-mer fills up, so nearly every accepted
+    event is kept and gathered -- the regime in which all of the streamed signal can reach an output."""
+    import torch
+    from poregen_amd.engine import GmoveEngine, GmoveParams
+    q = dict(p, sample_limit=5000)
+    e = GmoveEngine(GmoveParams(kmers=kmers, **q))
+    for _ in range(3):
+        e.reset(); e.submit(shard)
+    e.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.reset(); e.submit(shard)
+    e.sync(); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    v = e.device_view()
+    ke, ksm = int(v.n_events), int(v.n_samples)
+    e.close()
+    pe = GmoveEngine(GmoveParams(kmers=kmers, profile=True, **q))
+    for _ in range(2):
+        pe.reset(); pe.submit(shard)
+    pe.sync(); pe.kernel_stats_reset()
+    for _ in range(5):
+        pe.reset(); pe.submit(shard)
+    pe.sync()
+    ks = {k: v2[1] / 5 for k, v2 in pe.kernel_stats().items()}
+    pe.close()
+    b_alg = 2 * host.n_samples + 24 * host.n_reads + 5 * n_ops + n_bases + 8 * ksm + 12 * ke + 8 * len(kmers)
+    return {"sample_limit": 5000, "ms_per_step": ms, "value": host.n_samples / (ms * 1e-3), "unit": "samples/s", "kept_events": ke, "kept_samples": ksm,
+            "algorithmic_bytes": b_alg, "whole_step_frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_ms_per_step": ks}
+
+
+def hbm_not_mall(shard, kmers, p, dev, copies=8):
+    """k_read_stats over ONE batch of copies x 50 000 reads (3.2 GB of signal, 12x the 256 MiB Infinity Cache): the same rate as on
+    the replayed 400 MB buffer means the headline rate is an HBM rate, not a MALL rate. The batch is the shard replicated on the
+    device (offsets shifted), so its content repeats but no address does."""
+    import torch
+    from poregen_amd.engine import Batch, GmoveEngine, GmoveParams
+
+    def rep_off(o):
+        body = o[:-1]
+        return torch.cat([body + i * o[-1] for i in range(copies)] + [(copies * o[-1]).reshape(1)])
+    big = Batch(n_reads=shard.n_reads * copies, on_device=True, n_ops=shard.n_ops * copies,
+                sig=torch.cat([shard.sig[:-8].repeat(copies), torch.zeros(8, dtype=shard.sig.dtype, device=dev)]), sig_off=rep_off(shard.sig_off),
+                digitisation=shard.digitisation.repeat(copies), offset=shard.offset.repeat(copies), range=shard.range.repeat(copies),
+                query_start=shard.query_start.repeat(copies), target_start=shard.target_start.repeat(copies), target_end=shard.target_end.repeat(copies),
+                seq=shard.seq.repeat(copies), seq_off=rep_off(shard.seq_off), op_n=shard.op_n.repeat(copies), op_t=shard.op_t.repeat(copies),
+                op_off=rep_off(shard.op_off))
+    torch.cuda.synchronize()
+    e = GmoveEngine(GmoveParams(kmers=kmers, profile=True, **p))
+    e.reset(); e.submit(big); e.sync(); e.kernel_stats_reset()
+    n = 4
+    for _ in range(n):
+        e.reset(); e.submit(big)
+    e.sync()
+    ks = e.kernel_stats()
+    e.close()
+    ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]
+    n_samples = int(big.sig.numel()) - 8
+    nbytes = 2 * n_samples + 56 * big.n_reads
+    step_ms = sum(v[1] for v in ks.values()) / n
+    del big
+    return {"reads": shard.n_reads * copies, "signal_bytes": 2 * n_samples, "k_read_stats_ms": ms, "GB/s": nbytes / (ms * 1e-3) / 1e9,
+            "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_sum_ms_per_step": step_ms}
+
+
+def pcie_inclusive(host, kmers, p, steps=4):
+    """The step fed from HOST memory: pg_submit with host pointers stages the batch over PCIe first (never `value`)."""
+    from poregen_amd.engine import GmoveEngine, GmoveParams
+    e = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    e.reset(); e.submit(host); e.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.reset(); e.submit(host)
+    e.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    e.close()
+    nbytes = sum(getattr(host, f).nbytes for f in ("sig", "sig_off", "digitisation", "offset", "range", "query_start", "target_start", "target_end", "seq", "seq_off", "op_n", "op_t", "op_off"))
+    return {"ms_per_step": ms, "value": host.n_samples / (ms * 1e-3), "unit": "samples/s", "staged_bytes": nbytes, "staging_GB/s": nbytes / (ms * 1e-3) / 1e9,
+            "source": "pageable host memory (numpy arrays), hipMemcpyAsync per array"}
+
+
+def end_to_end(host, args):
+    """SURVEY 8(d) metric (i): `bin/poregen gmove` as a child process on the workload written as BLOW5 + PAF + FASTQ, input files in the
+    page cache, wall clock from process start until the dump files are closed and the process has exited."""
+    import shutil
+    import tempfile
+    from poregen_amd import synth
+    d = tempfile.mkdtemp(prefix="pg_e2e_", dir="/tmp")
+    try:
+        synth.write_blow5(host, d + "/r.blow5"); synth.write_paf_fastq(host, d + "/r")
+        for f in ("r.blow5", "r.paf", "r.fastq"):
+            with open(os.path.join(d, f), "rb") as fh:      # page cache
+                while fh.read(1 << 24):
+                    pass
+        threads = min(16, os.cpu_count() or 1)
+        out = {"host_threads": threads, "files": "uncompressed BLOW5 + PAF(ss) + FASTQ in the page cache", "runs": {}}
+        for lim in (args.sample_limit, 5000):
+            best = None
+            for rep in range(3):
+                o = f"{d}/out_{lim}_{rep}"
+                cmd = [os.path.join(ROOT, "bin", "poregen"), "gmove", "-k", str(args.k), "--scaling", "1", "--file_limit", str(4 ** args.k), "--sample_limit", str(lim),
+                       d + "/r.blow5", d + "/r.paf", "--fastq", d + "/r.fastq", o] + (["--rna", "--min_dur", "20", "--max_dur", "40"] if args.kind == "rna004" else [])
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                wall = time.perf_counter() - t0
+                if r.returncode != 0:
+                    return {"error": r.stderr[-400:]}
+                stages = [ln[len("[gmove] "):] for ln in r.stderr.splitlines() if ln.startswith("[gmove] ")]
+                if best is None or wall < best["wall_s"]:
+                    best = {"wall_s": wall, "value": host.n_samples / wall, "unit": "samples/s", "stages": stages}
+                shutil.rmtree(o, ignore_errors=True)
+            out["runs"][f"sample_limit_{lim}"] = best
+        first = out["runs"][f"sample_limit_{args.sample_limit}"]
+        out.update(value=first["value"], wall_s=first["wall_s"], unit="samples/s", stages=first["stages"])
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(host, kmers, p, budget_s):

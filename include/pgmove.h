@@ -32,6 +32,9 @@
  * pg_model / pg_model_device /     the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
  * pg_model_format                  median / sstdev per k-mer, awk | datamash median of the dwell times
  *                                                                         scripts/poregen.sh:54-85, 33-52
+ * pg_job_create / _submit / _sync  a batch split over the node's GPUs from one process: the shape of the reference's only
+ * / _finish / _all_slots_full /    parallel driver, work_db (a batch split over worker threads)   src/thread.c:119-132,
+ * _model / _destroy                plugged in at the same seam as pg_submit                       src/gmove.cpp:515
  * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
  * pg_last_batch_device / pg_kernel_stats*
  */
@@ -282,6 +285,39 @@ pg_status pg_model_device(pg_ctx *ctx, uint32_t n_slots, const uint64_t *d_ev_of
 /* The number as datamash prints it ("%.14Lg" of its long double; "nan" for sstdev of one value; empty string when the
  * slot has no value at all, like datamash on empty input). Returns the length written (excluding the NUL), 0 on error. */
 size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap);
+
+/* ---- one job over several GPUs of one node, driven from ONE host process ---------------------------------------------
+ * The reference is a single process (src/main.c:64-103 -> gmove(), src/gmove.cpp:213) whose only parallel driver is
+ * work_db (src/thread.c:119-132: a batch split over worker threads, each working a contiguous range); pg_job is that
+ * shape with GPUs as the workers, at the same seam as pg_submit (src/gmove.cpp:515, 732-969): a batch's reads are cut into
+ * n contiguous PAF-ordered shards, device i works shard i on its own host thread, and the "count == sample_limit" test
+ * (src/gmove.cpp:925-927) is resolved by ONE exchange per batch -- an ncclAllGather (RCCL over xGMI) of every shard's
+ * uint64[n_slots] accepted-event counts, in place in each device's receive buffer, whose rows below a shard (plus the
+ * running total of the earlier batches, kept as row 0 of the same buffer) are its base (pg_collect_gathered). The per-read
+ * statistics are queued behind the issue of the collective and hide it. pg_job_finish returns the job's per-k-mer streams
+ * in reference order (slot, then batch, then shard): byte for byte what one context fed the same batches returns.
+ * Host batches only. A device may be listed more than once (several shards on one GPU); the exchange then goes through
+ * host memory (RCCL needs distinct devices), as it does when librccl cannot be loaded and PG_JOB_EXCHANGE_RCCL is not set. */
+typedef struct pg_job pg_job;
+enum {
+    PG_JOB_EXCHANGE_AUTO = 0, /* RCCL when the listed devices are distinct and librccl loads, else through the host */
+    PG_JOB_EXCHANGE_HOST = 1, /* always through host memory */
+    PG_JOB_EXCHANGE_RCCL = 2  /* always RCCL: pg_job_create fails when it is unavailable or a device is listed twice */
+};
+/* params->device is ignored (devices[] decides); params->flags as for pg_create (PG_FLAG_DEFER_STATS is added). */
+pg_status   pg_job_create(const pg_params *params, const int32_t *devices, uint32_t n_devices, uint32_t exchange, pg_job **out);
+void        pg_job_destroy(pg_job *job);
+const char *pg_job_last_error(const pg_job *job);       /* job may be NULL: error of the last failed pg_job_create */
+/* Queues the whole batch on all devices and returns; the batch arrays must stay valid until pg_job_sync / the next
+ * pg_job_submit / pg_job_finish has returned (see pg_batch). */
+pg_status   pg_job_submit(pg_job *job, const pg_batch *host_batch);
+pg_status   pg_job_sync(pg_job *job);                   /* wait for every device; surfaces per-read errors (lowest shard first) */
+int32_t     pg_job_all_slots_full(pg_job *job);         /* src/gmove.cpp:733-735 for the job */
+pg_status   pg_job_finish(pg_job *job, pg_result *out); /* merged view, owned by the job until the next submit / destroy */
+/* 1 when the last pg_job_create chose RCCL for this job's exchange, 0 = host memory */
+int32_t     pg_job_uses_rccl(const pg_job *job);
+/* The k-mer model of the whole job (see pg_model): the merged kept samples are reduced on the job's first device. */
+pg_status   pg_job_model(pg_job *job, uint32_t flags, pg_model_result *out);
 
 /* profiling (PG_FLAG_PROFILE): per-kernel launch counts and HIP-event times since the last reset */
 pg_status pg_kernel_stats(pg_ctx *ctx, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out);

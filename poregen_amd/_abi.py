@@ -33,7 +33,10 @@ EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
+    "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
+    "pg_job_uses_rccl", "pg_job_model",
 ]
+PG_JOB_EXCHANGE_AUTO, PG_JOB_EXCHANGE_HOST, PG_JOB_EXCHANGE_RCCL = 0, 1, 2
 
 
 class PgParams(C.Structure):
@@ -145,5 +148,14 @@ def load():
     lib.pg_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_model.restype = i32
     lib.pg_model_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, C.POINTER(PgModelResult)]; lib.pg_model_device.restype = i32
     lib.pg_model_format.argtypes = [C.POINTER(PgModelResult), u32, i32, C.c_char_p, C.c_size_t]; lib.pg_model_format.restype = C.c_size_t
+    lib.pg_job_create.argtypes = [C.POINTER(PgParams), C.POINTER(C.c_int32), u32, u32, C.POINTER(vp)]; lib.pg_job_create.restype = i32
+    lib.pg_job_destroy.argtypes = [vp]; lib.pg_job_destroy.restype = None
+    lib.pg_job_last_error.argtypes = [vp]; lib.pg_job_last_error.restype = C.c_char_p
+    lib.pg_job_submit.argtypes = [vp, C.POINTER(PgBatch)]; lib.pg_job_submit.restype = i32
+    lib.pg_job_sync.argtypes = [vp]; lib.pg_job_sync.restype = i32
+    lib.pg_job_all_slots_full.argtypes = [vp]; lib.pg_job_all_slots_full.restype = i32
+    lib.pg_job_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish.restype = i32
+    lib.pg_job_uses_rccl.argtypes = [vp]; lib.pg_job_uses_rccl.restype = i32
+    lib.pg_job_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_job_model.restype = i32
     _lib = lib
     return lib

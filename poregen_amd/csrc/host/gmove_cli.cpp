@@ -44,6 +44,7 @@ struct option long_options[] = {
     // extensions of this implementation (not in the reference)
     {"batch_reads", required_argument, 0, 0}, {"device", required_argument, 0, 0}, {"lazy_stats", no_argument, 0, 0},
     {"raw_model", required_argument, 0, 0}, {"stdv_limit", required_argument, 0, 0}, {"dwell_model", required_argument, 0, 0},
+    {"devices", required_argument, 0, 0}, {"exchange", required_argument, 0, 0},
     {0, 0, 0, 0}};
 
 void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
@@ -73,6 +74,10 @@ void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
     fprintf(fp, "\nMI355X implementation options:\n");
     fprintf(fp, "   --batch_reads INT          reads per GPU batch [20000]\n");
     fprintf(fp, "   --device INT               HIP device [0]\n");
+    fprintf(fp, "   --devices LIST             several GPUs of this node, e.g. 0,1,2,3,4,5,6,7: every batch is cut into contiguous shards,\n");
+    fprintf(fp, "                              one per listed device, with one RCCL all-gather of per-k-mer counts per batch (pg_job_*);\n");
+    fprintf(fp, "                              a device may be listed twice (the exchange then goes through host memory)\n");
+    fprintf(fp, "   --exchange auto|host|rccl  how --devices exchanges the counts [auto]\n");
     fprintf(fp, "   --lazy_stats               median/MAD only for reads that contribute a kept event\n");
     fprintf(fp, "   --raw_model FILE           also write KMER<TAB>median<TAB>stddev of the kept samples per k-mer, computed on the GPU\n");
     fprintf(fp, "                              (what scripts/poregen.sh calculate_mean_stddev_all derives from the dump files)\n");
@@ -117,6 +122,19 @@ struct HostBatch {
 
 int die(const char *fmt, const std::string &a = "") { fprintf(stderr, fmt, a.c_str()); fputc('\n', stderr); return EXIT_FAILURE; }
 
+// the device side of the run: one context (--device) or one job over several GPUs (--devices), same calls either way
+struct Backend {
+    pg_ctx *ctx = nullptr; pg_job *job = nullptr;
+    bool ok() const { return ctx || job; }
+    pg_status submit(const pg_batch *b) { return job ? pg_job_submit(job, b) : pg_submit(ctx, b); }
+    pg_status sync() { return job ? pg_job_sync(job) : pg_sync(ctx); }
+    bool all_full() { return job ? pg_job_all_slots_full(job) != 0 : pg_all_slots_full(ctx) != 0; }
+    pg_status finish(pg_result *r) { return job ? pg_job_finish(job, r) : pg_finish(ctx, r); }
+    pg_status model(pg_model_result *m) { return job ? pg_job_model(job, 0, m) : pg_model(ctx, 0, m); }
+    const char *error() const { return job ? pg_job_last_error(job) : pg_last_error(ctx); }
+    void destroy() { if (job) pg_job_destroy(job); if (ctx) pg_destroy(ctx); job = nullptr; ctx = nullptr; }
+};
+
 } // namespace
 
 int gmove_main(int argc, char **argv) {
@@ -126,6 +144,7 @@ int gmove_main(int argc, char **argv) {
     const char *input_kmer_file = nullptr, *input_fastq_file = nullptr;
     FILE *fp_help = stderr;
     uint32_t batch_reads = 20000; int device = 0; bool lazy = false;
+    std::vector<int32_t> devices; uint32_t exchange = PG_JOB_EXCHANGE_AUTO;
     const char *raw_model_path = nullptr, *dwell_model_path = nullptr, *stdv_limit = "3.1";
     optind = 1;
     while ((c = getopt_long(argc, argv, "k:m:s:d", long_options, &longindex)) >= 0) { // src/gmove.cpp:240-327
@@ -156,6 +175,18 @@ int gmove_main(int argc, char **argv) {
         else if (c == 0 && longindex == 25) raw_model_path = optarg;
         else if (c == 0 && longindex == 26) stdv_limit = optarg;
         else if (c == 0 && longindex == 27) dwell_model_path = optarg;
+        else if (c == 0 && longindex == 28) {
+            for (const char *q = optarg; *q;) {
+                char *e = nullptr; const long v = strtol(q, &e, 10);
+                if (e == q || v < 0 || (*e && *e != ',')) return die("--devices takes a comma-separated list of device ordinals. You entered %s", optarg);
+                devices.push_back((int32_t)v); q = *e ? e + 1 : e;
+            }
+            if (devices.empty()) return die("--devices takes a comma-separated list of device ordinals. You entered %s", optarg);
+        }
+        else if (c == 0 && longindex == 29) {
+            if (!strcmp(optarg, "auto")) exchange = PG_JOB_EXCHANGE_AUTO; else if (!strcmp(optarg, "host")) exchange = PG_JOB_EXCHANGE_HOST;
+            else if (!strcmp(optarg, "rccl")) exchange = PG_JOB_EXCHANGE_RCCL; else return die("--exchange must be auto, host or rccl. You entered %s", optarg);
+        }
     }
     if (argc - optind != 3 || fp_help == stdout) { // src/gmove.cpp:330-336
         print_help(fp_help, opt);
@@ -246,17 +277,18 @@ int gmove_main(int argc, char **argv) {
     prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (whole_list ? PG_FLAG_STOP_WHEN_FULL : 0) | (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
-    pg_ctx *ctx = nullptr;
+    Backend dev;
     std::string ctx_err; double t_ctx = 0;
     const std::chrono::steady_clock::time_point t_setup0 = std::chrono::steady_clock::now();
     std::future<pg_status> ctx_ready = std::async(std::launch::async, [&]() {
         const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
-        const pg_status st = pg_create(&prm, &ctx);
-        if (st != PG_OK) ctx_err = pg_last_error(nullptr); // the text lives in the creating thread
+        pg_status st;
+        if (devices.empty()) { st = pg_create(&prm, &dev.ctx); if (st != PG_OK) ctx_err = pg_last_error(nullptr); } // the text lives in the creating thread
+        else { st = pg_job_create(&prm, devices.data(), (uint32_t)devices.size(), exchange, &dev.job); if (st != PG_OK) ctx_err = pg_job_last_error(nullptr); }
         t_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
         return st;
     });
-    auto give_up = [&](int code) { if (ctx_ready.valid() && ctx_ready.get() == PG_OK) pg_destroy(ctx); return code; }; // early error exits
+    auto give_up = [&](int code) { if (ctx_ready.valid() && ctx_ready.get() == PG_OK) dev.destroy(); return code; }; // early error exits
 
     pgh::Slow5File s5;
     if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return give_up(EXIT_FAILURE); } // gmove.cpp:493-503
@@ -273,11 +305,11 @@ int gmove_main(int argc, char **argv) {
     const std::chrono::steady_clock::time_point t_setup1 = std::chrono::steady_clock::now();
     double t_ctx_wait = 0; // the context is awaited at its first use (the first batch), behind the parsing of that batch
     auto need_ctx = [&]() -> bool {
-        if (!ctx_ready.valid()) return ctx != nullptr;
+        if (!ctx_ready.valid()) return dev.ok();
         const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
         const pg_status st = ctx_ready.get();
         t_ctx_wait = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
-        if (st != PG_OK) { fprintf(stderr, "[gmove] %s\n", ctx_err.c_str()); ctx = nullptr; return false; }
+        if (st != PG_OK) { fprintf(stderr, "[gmove] %s\n", ctx_err.c_str()); return false; }
         return true;
     };
 
@@ -302,14 +334,14 @@ int gmove_main(int argc, char **argv) {
         b.query_start = hb.qs.data(); b.target_start = hb.ts.data(); b.target_end = hb.te.data(); b.seq = hb.seq.data(); b.seq_off = hb.seq_off.data();
         b.op_n = hb.op_n.data(); b.op_t = hb.op_t.data(); b.op_off = hb.op_off.data();
         if (!need_ctx()) return false;
-        pg_status s = pg_submit(ctx, &b);
-        if (s == PG_OK) s = pg_sync(ctx);
-        if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); return false; }
+        pg_status s = dev.submit(&b);
+        if (s == PG_OK) s = dev.sync();
+        if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", dev.error()); return false; }
         hb.clear();
         t_device += secs(tf0, clk::now());
         // every k-mer of the WHOLE list complete: the reference stops reading (gmove.cpp:733-735). With a slice it reads on
         // (and would still fail on a malformed later line), so we do too.
-        if (whole_list && pg_all_slots_full(ctx)) stop = true;
+        if (whole_list && dev.all_full()) stop = true;
         return true;
     };
     // Move-table style records (table file and SAM/BAM, gmove.cpp:557-700 / 1080-1261): resolve -m (first window starts
@@ -485,9 +517,9 @@ int gmove_main(int argc, char **argv) {
     if (status == EXIT_SUCCESS) {
         pg_result res;
         const clk::time_point tq0 = clk::now();
-        const pg_status fin = need_ctx() ? pg_finish(ctx, &res) : PG_ERR_NO_DEVICE;
+        const pg_status fin = need_ctx() ? dev.finish(&res) : PG_ERR_NO_DEVICE;
         t_finish = secs(tq0, clk::now());
-        if (fin != PG_OK) { if (ctx) fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+        if (fin != PG_OK) { if (dev.ok()) fprintf(stderr, "[gmove] %s\n", dev.error()); status = EXIT_FAILURE; }
         else {
             pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
@@ -497,7 +529,7 @@ int gmove_main(int argc, char **argv) {
             if (status == EXIT_SUCCESS && (raw_model_path || dwell_model_path)) { // scripts/poregen.sh:54-85, 33-52 without the text round trip
                 const clk::time_point tm0 = clk::now();
                 pg_model_result mr;
-                if (pg_model(ctx, 0, &mr) != PG_OK) { fprintf(stderr, "[gmove] %s\n", pg_last_error(ctx)); status = EXIT_FAILURE; }
+                if (dev.model(&mr) != PG_OK) { fprintf(stderr, "[gmove] %s\n", dev.error()); status = EXIT_FAILURE; }
                 else {
                     std::vector<uint32_t> order(res.n_slots); // the shell glob lists the dump files sorted by name
                     for (uint32_t i = 0; i < res.n_slots; i++) order[i] = i;
@@ -531,13 +563,15 @@ int gmove_main(int argc, char **argv) {
             if (is_paf) fprintf(stderr, "[gmove] time: PAF lines %.3f s, parse + decode on the pool %.3f s, one batch from the runs %.3f s\n", t_lines, t_decode, t_concat);
             fprintf(stderr, "[gmove] time: reading + parsing %.3f s, staging + device %.3f s, download + merge %.3f s, dump files %.3f s\n",
                     t_loop - t_device, t_device, t_finish, t_dump);
-            fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on device %d\n", (unsigned long long)res.n_reads,
-                    (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, device);
+            std::string where = "device " + std::to_string(device);
+            if (dev.job) { where = "devices"; for (size_t i = 0; i < devices.size(); i++) where += (i ? "," : " ") + std::to_string(devices[i]); where += pg_job_uses_rccl(dev.job) ? " (RCCL all-gather)" : " (exchange through host memory)"; }
+            fprintf(stderr, "[gmove] %llu reads, %llu samples, %llu events kept (%llu samples) on %s\n", (unsigned long long)res.n_reads,
+                    (unsigned long long)total_samples, (unsigned long long)res.n_events, (unsigned long long)res.n_samples, where.c_str());
         }
     }
     (void)need_ctx(); // a failed run may not have reached the first use
     const clk::time_point t_end0 = clk::now();
-    if (ctx) pg_destroy(ctx);
+    dev.destroy();
     fprintf(stderr, "[gmove] time: %.3f s from the start of gmove to the end of the output, %.3f s to release the device\n", secs(t_main0, t_end0), secs(t_end0, clk::now()));
     return status;
 }

@@ -791,6 +791,9 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
     return PG_OK;
 }
 
+// pg_job.hip: the stream the chain runs on (events of the job's communication stream are ordered against it)
+void *pgi_stream(pg_ctx *c) { return c ? (void *)c->st : nullptr; }
+
 int32_t pg_all_slots_full(pg_ctx *c) {
     if (!c) return 0;
     if (settle_batch(c) != PG_OK) return 0;

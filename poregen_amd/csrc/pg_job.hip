@@ -1,0 +1,422 @@
+// pg_job.hip -- one gmove job over several GPUs of one node from ONE host process (include/pgmove.h: pg_job_*).
+//
+// The reference is a single process whose only parallel driver is work_db (src/thread.c:119-132): a batch split over
+// worker threads, each taking a contiguous range. This is that shape with one MI355X per worker: a batch's reads are cut
+// into contiguous PAF-ordered shards, rank g works shard g through its own pg_ctx on its own host thread, and the one
+// dependency between shards -- how many accepted events of a k-mer precede a shard (src/gmove.cpp:925-927) -- is one
+// ncclAllGather of uint64[n_slots] per batch over xGMI, in place in every rank's receive buffer:
+//     row 0        accepted events of all EARLIER batches (the job's running total; the previous batch's job_total)
+//     row 1 + g    accepted events of shard g of this batch (written by rank g's counting kernels themselves)
+// pg_collect_gathered(buf, n + 1, g + 1) then sums the rows below its own on the device. The collective runs on a
+// communication stream of its own: the statistics of every read (the streaming kernel, independent of the exchange) are
+// queued on the compute stream behind its ISSUE and hide its latency. Host code only; every kernel lives in pg_kernels.hip.
+// RCCL is resolved with dlopen at the first job that needs it, so libpgmove.so carries no DT_NEEDED on it (a process must
+// hold one copy: PyTorch's under Python, /opt/rocm's otherwise).
+#include "../../include/pgmove.h"
+#include "pg_internal.h"
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" void *pgi_stream(pg_ctx *c); // pg_api.hip: the stream the context's chain currently runs on
+
+static thread_local std::string g_job_create_error;
+
+namespace {
+
+// ---- RCCL through dlopen ---------------------------------------------------------------------------------------------
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+    bool ok() const { return h != nullptr; }
+};
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy that is already in the process (PyTorch's) first, then the system one
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (int pass = 0; pass < 2 && !r.h; ++pass)
+            for (const char *n : names) {
+                r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.h) break;
+            }
+        if (!r.h) { const char *e = dlerror(); r.why = e ? e : "librccl not found"; return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.h, n); if (!p) { r.why = std::string("librccl lacks ") + n; } return p; };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll"); r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather"); r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd"); r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!r.why.empty()) r.h = nullptr;
+    });
+    return r;
+}
+
+// ---- one persistent host thread per rank --------------------------------------------------------------------------------
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> task;
+    bool has_task = false, done = true, quit = false;
+    void start() {
+        th = std::thread([this] {
+            for (;;) {
+                std::function<void()> t;
+                { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return has_task || quit; }); if (quit) return; t = std::move(task); has_task = false; }
+                t();
+                { std::lock_guard<std::mutex> lk(m); done = true; }
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<void()> t) { { std::lock_guard<std::mutex> lk(m); task = std::move(t); has_task = true; done = false; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); }
+    void stop() { { std::lock_guard<std::mutex> lk(m); quit = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
+
+struct Shard { // one rank's part of the batch in flight: rebased offset arrays (a host batch's offsets start at 0)
+    std::vector<uint64_t> sig_off, seq_off, op_off;
+    pg_batch b{};
+};
+
+} // namespace
+
+struct pg_job {
+    uint32_t n = 0, n_slots = 0, sample_limit = 0;
+    std::vector<int> devices;
+    std::vector<pg_ctx *> ctx;
+    std::vector<Worker> workers;
+    std::vector<Shard> shard;
+    bool use_rccl = false, have_batch = false;
+    std::vector<ncclComm_t> comms;
+    std::vector<uint64_t *> gbuf;          // per rank, on its device: uint64[n + 1][n_slots] (see the head of this file)
+    std::vector<hipStream_t> comm_st;
+    std::vector<hipEvent_t> ev_counted, ev_gathered;
+    std::vector<uint64_t> host_rows;       // host exchange: uint64[n][n_slots]
+    std::vector<std::vector<uint64_t>> cuts; // per batch: n + 1 read boundaries inside the batch
+    std::vector<uint64_t> batch_reads;     // per batch
+    std::string err;
+    // merged view (pg_job_finish)
+    std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
+    std::vector<uint32_t> r_ev_len, r_ev_read;
+    std::vector<double> r_samples;
+    std::vector<uint8_t> r_skipped;
+    bool merged = false; pg_result merged_view{};
+    // pg_job_model
+    void *md[4] = {nullptr, nullptr, nullptr, nullptr}; size_t md_cap[4] = {0, 0, 0, 0};
+};
+
+static pg_status jfail(pg_job *j, pg_status code, const char *fmt, ...) {
+    char buf[1200];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (j) j->err = buf; else g_job_create_error = buf;
+    return code;
+}
+
+// fn(g) on rank g's own thread, all ranks at once; the first failing rank (lowest shard = first in PAF order) decides
+static pg_status on_ranks(pg_job *j, const std::function<pg_status(uint32_t, std::string &)> &fn) {
+    std::vector<pg_status> rc(j->n, PG_OK);
+    std::vector<std::string> msg(j->n);
+    for (uint32_t g = 0; g < j->n; ++g) j->workers[g].post([&, g] { rc[g] = fn(g, msg[g]); });
+    for (uint32_t g = 0; g < j->n; ++g) j->workers[g].wait();
+    for (uint32_t g = 0; g < j->n; ++g)
+        if (rc[g] != PG_OK) return jfail(j, rc[g], "shard %u (device %d): %s", g, j->devices[g], msg[g].c_str());
+    return PG_OK;
+}
+
+#define JHIP(j, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return jfail((j), PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)
+#define JNCCL(j, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return jfail((j), PG_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); } while (0)
+
+extern "C" {
+
+const char *pg_job_last_error(const pg_job *j) { return j ? j->err.c_str() : g_job_create_error.c_str(); }
+int32_t pg_job_uses_rccl(const pg_job *j) { return j && j->use_rccl; }
+
+void pg_job_destroy(pg_job *j) {
+    if (!j) return;
+    for (uint32_t g = 0; g < j->ctx.size(); ++g) {
+        if (j->ctx[g]) (void)pg_sync(j->ctx[g]);
+    }
+    for (uint32_t g = 0; g < j->n; ++g) {
+        (void)hipSetDevice(j->devices[g]);
+        if (g < j->comm_st.size() && j->comm_st[g]) { (void)hipStreamSynchronize(j->comm_st[g]); }
+    }
+    for (auto c : j->comms) if (c) (void)rccl().CommDestroy(c);
+    for (uint32_t g = 0; g < j->n; ++g) {
+        (void)hipSetDevice(j->devices[g]);
+        if (g < j->comm_st.size() && j->comm_st[g]) (void)hipStreamDestroy(j->comm_st[g]);
+        if (g < j->ev_counted.size() && j->ev_counted[g]) (void)hipEventDestroy(j->ev_counted[g]);
+        if (g < j->ev_gathered.size() && j->ev_gathered[g]) (void)hipEventDestroy(j->ev_gathered[g]);
+        if (g < j->gbuf.size() && j->gbuf[g]) (void)hipFree(j->gbuf[g]);
+    }
+    if (j->n) { (void)hipSetDevice(j->devices[0]); for (void *p : j->md) if (p) (void)hipFree(p); }
+    for (auto c : j->ctx) if (c) pg_destroy(c);
+    for (auto &w : j->workers) w.stop();
+    delete j;
+}
+
+pg_status pg_job_create(const pg_params *p, const int32_t *devices, uint32_t n, uint32_t exchange, pg_job **out) {
+    if (!p || !devices || !out || n == 0 || n > 64) return jfail(nullptr, PG_ERR_INVALID_ARG, "pg_job_create: params / devices / n_devices (1..64)");
+    *out = nullptr;
+    if (exchange > PG_JOB_EXCHANGE_RCCL) return jfail(nullptr, PG_ERR_INVALID_ARG, "pg_job_create: unknown exchange mode %u", exchange);
+    bool distinct = true;
+    for (uint32_t a = 0; a < n; ++a) for (uint32_t b = a + 1; b < n; ++b) if (devices[a] == devices[b]) distinct = false;
+    bool want_rccl = exchange == PG_JOB_EXCHANGE_RCCL || (exchange == PG_JOB_EXCHANGE_AUTO && distinct);
+    if (want_rccl && !distinct) return jfail(nullptr, PG_ERR_INVALID_ARG, "pg_job_create: RCCL needs distinct devices (a device is listed twice)");
+    if (want_rccl && !rccl().ok()) {
+        if (exchange == PG_JOB_EXCHANGE_RCCL) return jfail(nullptr, PG_ERR_NO_DEVICE, "pg_job_create: RCCL is not available: %s", rccl().why.c_str());
+        want_rccl = false;
+    }
+    pg_job *j = new pg_job();
+    j->n = n; j->n_slots = p->n_slots; j->sample_limit = p->sample_limit; j->use_rccl = want_rccl;
+    j->devices.assign(devices, devices + n);
+    j->ctx.assign(n, nullptr); j->gbuf.assign(n, nullptr); j->comm_st.assign(n, nullptr);
+    j->ev_counted.assign(n, nullptr); j->ev_gathered.assign(n, nullptr);
+    j->workers = std::vector<Worker>(n); j->shard = std::vector<Shard>(n);
+    for (auto &w : j->workers) w.start();
+    auto bail = [&](pg_status s) { g_job_create_error = j->err; pg_job_destroy(j); return s; };
+    // the contexts come up side by side (the HIP runtime takes 0.1-0.2 s per device)
+    pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        pg_params q = *p;
+        q.device = j->devices[g];
+        q.flags |= PG_FLAG_DEFER_STATS;
+        const pg_status st = pg_create(&q, &j->ctx[g]);
+        if (st != PG_OK) { msg = pg_last_error(nullptr); return st; }
+        hipError_t e = hipSetDevice(q.device);
+        const size_t bytes = (size_t)(n + 1) * p->n_slots * sizeof(uint64_t);
+        if (e == hipSuccess) e = hipMalloc((void **)&j->gbuf[g], bytes);
+        if (e == hipSuccess) e = hipMemset(j->gbuf[g], 0, bytes);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&j->comm_st[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_counted[g], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_gathered[g], hipEventDisableTiming);
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        return PG_OK;
+    });
+    if (s != PG_OK) return bail(s);
+    if (j->use_rccl) {
+        j->comms.assign(n, nullptr);
+        const ncclResult_t r = rccl().CommInitAll(j->comms.data(), (int)n, j->devices.data());
+        if (r != ncclSuccess) {
+            jfail(j, PG_ERR_HIP, "ncclCommInitAll over %u devices failed: %s", n, rccl().GetErrorString(r));
+            j->comms.clear();
+            if (exchange == PG_JOB_EXCHANGE_RCCL) return bail(PG_ERR_HIP);
+            j->use_rccl = false; j->err.clear();
+        }
+    }
+    if (!j->use_rccl) j->host_rows.assign((size_t)n * p->n_slots, 0);
+    *out = j;
+    return PG_OK;
+}
+
+pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
+    if (!j || !b) return PG_ERR_INVALID_ARG;
+    if (b->struct_size != sizeof(pg_batch)) return jfail(j, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch");
+    if (b->location != PG_LOC_HOST) return jfail(j, PG_ERR_UNSUPPORTED, "pg_job_submit takes host batches (a device batch lives on one GPU: use pg_submit)");
+    const uint32_t n = j->n, nr = b->n_reads, ns = j->n_slots;
+    if (!b->sig_off || !b->seq_off || !b->op_off) return jfail(j, PG_ERR_INVALID_ARG, "batch offsets missing");
+    j->merged = false;
+    // contiguous shards of about equal numbers of samples (reads differ in length; any contiguous cut is correct)
+    std::vector<uint64_t> cut(n + 1, 0);
+    const uint64_t total = b->sig_off[nr] - b->sig_off[0];
+    for (uint32_t g = 1; g < n; ++g) {
+        const uint64_t want = b->sig_off[0] + total / n * g;
+        uint64_t r = (uint64_t)(std::lower_bound(b->sig_off, b->sig_off + nr + 1, want) - b->sig_off);
+        if (r > nr) r = nr;
+        cut[g] = r < cut[g - 1] ? cut[g - 1] : r;
+    }
+    cut[n] = nr;
+    // phase 1, every rank on its own thread: settle + download its previous batch (pg_count does), stage its shard, walk,
+    // filter, count -- the counts land in row 1 + g of the rank's own receive buffer
+    pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        Shard &sh = j->shard[g];
+        const uint64_t lo = cut[g], hi = cut[g + 1], m = hi - lo;
+        // the previous batch of this rank may still be staging out of the old offset arrays: wait for it first
+        pg_status st = pg_sync(j->ctx[g]);
+        if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
+        sh.sig_off.resize(m + 1); sh.seq_off.resize(m + 1); sh.op_off.resize(m + 1);
+        for (uint64_t i = 0; i <= m; ++i) {
+            sh.sig_off[i] = b->sig_off[lo + i] - b->sig_off[lo]; sh.seq_off[i] = b->seq_off[lo + i] - b->seq_off[lo];
+            sh.op_off[i] = b->op_off[lo + i] - b->op_off[lo];
+        }
+        pg_batch &q = sh.b;
+        memset(&q, 0, sizeof q);
+        q.struct_size = sizeof q; q.location = PG_LOC_HOST; q.n_reads = (uint32_t)m;
+        q.sig = b->sig ? b->sig + b->sig_off[lo] : nullptr; q.sig_off = sh.sig_off.data();
+        q.digitisation = b->digitisation ? b->digitisation + lo : nullptr; q.offset = b->offset ? b->offset + lo : nullptr; q.range = b->range ? b->range + lo : nullptr;
+        q.query_start = b->query_start ? b->query_start + lo : nullptr; q.target_start = b->target_start ? b->target_start + lo : nullptr;
+        q.target_end = b->target_end ? b->target_end + lo : nullptr;
+        q.seq = b->seq ? b->seq + b->seq_off[lo] : nullptr; q.seq_off = sh.seq_off.data();
+        q.op_n = b->op_n ? b->op_n + b->op_off[lo] : nullptr; q.op_t = b->op_t ? b->op_t + b->op_off[lo] : nullptr; q.op_off = sh.op_off.data();
+        // the library stages the signal with 16-byte vectors in mind: a shard that starts at an odd multiple of 8 samples of
+        // the caller's buffer is still fine for a HOST batch (it is copied to a fresh, aligned device buffer)
+        st = pg_count(j->ctx[g], &q, j->gbuf[g] + (size_t)(1 + g) * ns, PG_LOC_DEVICE);
+        if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
+        hipError_t e = hipSetDevice(j->devices[g]);
+        if (e == hipSuccess) e = hipEventRecord(j->ev_counted[g], (hipStream_t)pgi_stream(j->ctx[g]));
+        if (e == hipSuccess && !j->use_rccl) // host exchange: this rank's row comes down behind its counting kernels
+            e = hipMemcpyAsync(j->host_rows.data() + (size_t)g * ns, j->gbuf[g] + (size_t)(1 + g) * ns, ns * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               (hipStream_t)pgi_stream(j->ctx[g]));
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        return PG_OK;
+    });
+    if (s != PG_OK) return s;
+    // phase 2: the exchange
+    if (j->use_rccl) {
+        for (uint32_t g = 0; g < n; ++g) { JHIP(j, hipSetDevice(j->devices[g])); JHIP(j, hipStreamWaitEvent(j->comm_st[g], j->ev_counted[g], 0)); }
+        JNCCL(j, rccl().GroupStart());
+        for (uint32_t g = 0; g < n; ++g) {
+            uint64_t *rows = j->gbuf[g] + ns; // rows 1..n: sendbuff == recvbuff + rank * count, i.e. in place
+            const ncclResult_t r = rccl().AllGather(rows + (size_t)g * ns, rows, ns, ncclUint64, j->comms[g], j->comm_st[g]);
+            if (r != ncclSuccess) { (void)rccl().GroupEnd(); return jfail(j, PG_ERR_HIP, "ncclAllGather (rank %u) failed: %s", g, rccl().GetErrorString(r)); }
+        }
+        JNCCL(j, rccl().GroupEnd());
+        for (uint32_t g = 0; g < n; ++g) { JHIP(j, hipSetDevice(j->devices[g])); JHIP(j, hipEventRecord(j->ev_gathered[g], j->comm_st[g])); }
+    }
+    else // through host memory: every rank's row has been queued for download behind its counting kernels (phase 1)
+        for (uint32_t g = 0; g < n; ++g) { JHIP(j, hipSetDevice(j->devices[g])); JHIP(j, hipStreamSynchronize((hipStream_t)pgi_stream(j->ctx[g]))); }
+    // phase 3, every rank on its own thread: the statistics behind the ISSUE of the collective, then the wait for it (on the
+    // stream, not on the host), the cut + gather, and the new running total into row 0 for the next batch
+    s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        pg_ctx *c = j->ctx[g];
+        hipStream_t st = (hipStream_t)pgi_stream(c);
+        pg_status ps = pg_stats(c);
+        if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
+        hipError_t e = hipSetDevice(j->devices[g]);
+        if (j->use_rccl) { if (e == hipSuccess) e = hipStreamWaitEvent(st, j->ev_gathered[g], 0); }
+        else if (e == hipSuccess) // the table assembled on the host in phase 2
+            e = hipMemcpyAsync(j->gbuf[g] + ns, j->host_rows.data(), (size_t)n * ns * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        ps = pg_collect_gathered(c, j->gbuf[g], n + 1, g + 1);
+        if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
+        const uint64_t *d_total = nullptr;
+        ps = pg_job_totals_device(c, &d_total, nullptr);
+        if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
+        e = hipMemcpyAsync(j->gbuf[g], d_total, ns * sizeof(uint64_t), hipMemcpyDeviceToDevice, st); // row 0 for the next batch
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        return PG_OK;
+    });
+    if (s != PG_OK) return s;
+    j->cuts.push_back(std::move(cut));
+    j->batch_reads.push_back(nr);
+    j->have_batch = true;
+    return PG_OK;
+}
+
+pg_status pg_job_sync(pg_job *j) {
+    if (!j) return PG_ERR_INVALID_ARG;
+    return on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        const pg_status st = pg_sync(j->ctx[g]);
+        if (st != PG_OK) msg = pg_last_error(j->ctx[g]);
+        return st;
+    });
+}
+
+int32_t pg_job_all_slots_full(pg_job *j) {
+    if (!j || !j->have_batch) return 0;
+    // the last shard's cut saw every accepted event of the job so far (its base is the sum of all rows below it)
+    return pg_all_slots_full(j->ctx[j->n - 1]);
+}
+
+pg_status pg_job_finish(pg_job *j, pg_result *out) {
+    if (!j || !out) return PG_ERR_INVALID_ARG;
+    if (j->merged) { *out = j->merged_view; return PG_OK; }
+    const uint32_t n = j->n, ns = j->n_slots;
+    std::vector<pg_result> R(n);
+    pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        const pg_status st = pg_finish(j->ctx[g], &R[g]);
+        if (st != PG_OK) msg = pg_last_error(j->ctx[g]);
+        return st;
+    });
+    if (s != PG_OK) return s;
+    // reference order inside a k-mer: batch, then shard (= PAF line order). A rank's own view is slot-major with its reads
+    // numbered over its shards of all batches, so the events of (slot, batch, rank) are a run of that rank's slot stream.
+    const size_t nb = j->cuts.size();
+    std::vector<std::vector<uint64_t>> rb(n, std::vector<uint64_t>(nb + 1, 0)); // rank-local read index where batch i starts
+    std::vector<uint64_t> bstart(nb + 1, 0);
+    for (size_t i = 0; i < nb; ++i) {
+        bstart[i + 1] = bstart[i] + j->batch_reads[i];
+        for (uint32_t g = 0; g < n; ++g) rb[g][i + 1] = rb[g][i] + (j->cuts[i][g + 1] - j->cuts[i][g]);
+    }
+    uint64_t n_events = 0, n_samples = 0;
+    for (uint32_t g = 0; g < n; ++g) { n_events += R[g].n_events; n_samples += R[g].n_samples; }
+    j->r_counts.assign(ns, 0); j->r_ev_off.assign(ns + 1, 0); j->r_samp_off.assign(n_events + 1, 0);
+    j->r_ev_len.resize(n_events); j->r_ev_read.resize(n_events); j->r_samples.resize(n_samples);
+    j->r_skipped.assign(bstart[nb], 0);
+    uint64_t e = 0, sp = 0;
+    std::vector<uint64_t> pos(n);
+    for (uint32_t sl = 0; sl < ns; ++sl) {
+        j->r_ev_off[sl] = e;
+        for (uint32_t g = 0; g < n; ++g) pos[g] = R[g].ev_off[sl];
+        for (size_t i = 0; i < nb; ++i)
+            for (uint32_t g = 0; g < n; ++g) {
+                const pg_result &r = R[g];
+                const uint64_t end = r.ev_off[sl + 1];
+                uint64_t &q = pos[g];
+                const uint64_t q0 = q;
+                while (q < end && r.ev_read[q] < rb[g][i + 1]) ++q;
+                if (q == q0) continue;
+                const uint64_t s0 = r.samp_off[q0], s1 = r.samp_off[q];
+                memcpy(&j->r_samples[sp], r.samples + s0, (s1 - s0) * sizeof(double));
+                for (uint64_t t = q0; t < q; ++t, ++e) {
+                    j->r_ev_len[e] = r.ev_len[t];
+                    j->r_ev_read[e] = (uint32_t)(bstart[i] + j->cuts[i][g] + (r.ev_read[t] - rb[g][i]));
+                    j->r_samp_off[e] = sp + (r.samp_off[t] - s0);
+                }
+                sp += s1 - s0;
+            }
+        j->r_counts[sl] = e - j->r_ev_off[sl];
+    }
+    j->r_ev_off[ns] = e; j->r_samp_off[n_events] = sp;
+    for (size_t i = 0; i < nb; ++i)
+        for (uint32_t g = 0; g < n; ++g) {
+            const uint64_t m = j->cuts[i][g + 1] - j->cuts[i][g];
+            if (m) memcpy(&j->r_skipped[bstart[i] + j->cuts[i][g]], R[g].read_skipped + rb[g][i], m);
+        }
+    pg_result &v = j->merged_view;
+    v.n_slots = ns; v.reserved = 0; v.n_events = n_events; v.n_samples = n_samples; v.n_reads = bstart[nb];
+    v.counts = j->r_counts.data(); v.ev_off = j->r_ev_off.data(); v.ev_len = j->r_ev_len.data(); v.ev_read = j->r_ev_read.data();
+    v.samp_off = j->r_samp_off.data(); v.samples = j->r_samples.data(); v.read_skipped = j->r_skipped.data();
+    j->merged = true;
+    *out = v;
+    return PG_OK;
+}
+
+pg_status pg_job_model(pg_job *j, uint32_t flags, pg_model_result *out) {
+    if (!j || !out) return PG_ERR_INVALID_ARG;
+    pg_result R;
+    pg_status s = pg_job_finish(j, &R);
+    if (s != PG_OK) return s;
+    JHIP(j, hipSetDevice(j->devices[0]));
+    const void *src[4] = {R.ev_off, R.samp_off, R.ev_len, R.samples};
+    const size_t bytes[4] = {(R.n_slots + 1) * 8ull, (R.n_events + 1) * 8ull, R.n_events * 4ull, R.n_samples * 8ull};
+    for (int i = 0; i < 4; ++i) {
+        if (bytes[i] + 16 > j->md_cap[i]) {
+            if (j->md[i]) JHIP(j, hipFree(j->md[i]));
+            j->md[i] = nullptr; j->md_cap[i] = 0;
+            JHIP(j, hipMalloc(&j->md[i], bytes[i] + bytes[i] / 8 + 64));
+            j->md_cap[i] = bytes[i] + bytes[i] / 8 + 64;
+        }
+        if (bytes[i]) JHIP(j, hipMemcpy(j->md[i], src[i], bytes[i], hipMemcpyHostToDevice));
+    }
+    s = pg_model_device(j->ctx[0], R.n_slots, (const uint64_t *)j->md[0], (const uint64_t *)j->md[1], (const uint32_t *)j->md[2], (const double *)j->md[3], flags, out);
+    if (s != PG_OK) return jfail(j, s, "%s", pg_last_error(j->ctx[0]));
+    return PG_OK;
+}
+
+} // extern "C"

@@ -205,6 +205,57 @@ def _ptr(a):
     return a.data_ptr()  # torch tensor
 
 
+def _fill_params(owner, lib, params: "GmoveParams"):
+    """pg_params for `params`; the code -> slot tables are kept alive on `owner`."""
+    n_slots = len(params.kmers)
+    k = params.kmer_size
+    n_codes = 4 ** k
+    owner._table_t = np.empty(n_codes, dtype=np.int32)
+    owner._table_u = np.empty(n_codes, dtype=np.int32)
+    arr = (C.c_char_p * n_slots)(*[s.encode() for s in params.kmers])
+    st = lib.pg_build_slot_tables(k, arr, n_slots, owner._table_t.ctypes.data, owner._table_u.ctypes.data)
+    if st != 0:
+        raise PgError(st, lib.pg_last_error(None).decode())
+    p = _abi.PgParams()
+    lib.pg_default_params(C.byref(p))
+    p.kmer_size = k; p.sig_move_offset = params.sig_move_offset; p.signal_print_margin = params.margin
+    p.sample_limit = params.sample_limit; p.max_dur = params.max_dur; p.min_dur = params.min_dur
+    p.kmer_pick_margin = params.kmer_pick_margin; p.scaling = params.scaling; p.allow_rna = int(params.rna)
+    p.pa_min = params.pa_min; p.pa_max = params.pa_max; p.n_slots = n_slots
+    p.flags = ((_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
+               | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
+               | (_abi.PG_FLAG_STOP_WHEN_FULL if params.stop_when_full else 0) | (_abi.PG_FLAG_DEFER_STATS if params.defer_stats else 0)
+               | (_abi.PG_FLAG_DEBUG_SPLIT_WALK if params.split_walk else 0)
+               | (_abi.PG_FLAG_OVERLAP_TAIL if params.overlap_tail else 0))
+    p.device = params.device
+    p.table_t = owner._table_t.ctypes.data; p.table_u = owner._table_u.ctypes.data
+    return p
+
+
+def _result_from(r) -> "Result":
+    def arr(ptr, n, dt):
+        if n == 0 or not ptr:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt).copy()
+    ns, ne, nsmp, nr = r.n_slots, r.n_events, r.n_samples, r.n_reads
+    return Result(counts=arr(r.counts, ns, np.uint64), ev_off=arr(r.ev_off, ns + 1, np.uint64),
+                  ev_len=arr(r.ev_len, ne, np.uint32), ev_read=arr(r.ev_read, ne, np.uint32),
+                  samp_off=arr(r.samp_off, ne + 1, np.uint64), samples=arr(r.samples, nsmp, np.float64),
+                  read_skipped=arr(r.read_skipped, nr, np.uint8), n_reads=int(nr))
+
+
+def _c_batch(b: "Batch"):
+    cb = _abi.PgBatch()
+    cb.struct_size = C.sizeof(_abi.PgBatch)
+    cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
+    cb.n_reads = b.n_reads
+    cb.n_ops = b.n_ops if b.on_device else 0
+    for name, _ in _BATCH_FIELDS:
+        setattr(cb, name, _ptr(getattr(b, name)))
+    return cb
+
+
 class GmoveEngine:
     """One gmove run on one GPU: the state the reference keeps in gmove() + process_move_table_paf()."""
 
@@ -212,27 +263,7 @@ class GmoveEngine:
         self._lib = _abi.load()
         self.params = params
         self.n_slots = len(params.kmers)
-        k = params.kmer_size
-        n_codes = 4 ** k
-        self._table_t = np.empty(n_codes, dtype=np.int32)
-        self._table_u = np.empty(n_codes, dtype=np.int32)
-        arr = (C.c_char_p * self.n_slots)(*[s.encode() for s in params.kmers])
-        st = self._lib.pg_build_slot_tables(k, arr, self.n_slots, self._table_t.ctypes.data, self._table_u.ctypes.data)
-        if st != 0:
-            raise PgError(st, self._lib.pg_last_error(None).decode())
-        p = _abi.PgParams()
-        self._lib.pg_default_params(C.byref(p))
-        p.kmer_size = k; p.sig_move_offset = params.sig_move_offset; p.signal_print_margin = params.margin
-        p.sample_limit = params.sample_limit; p.max_dur = params.max_dur; p.min_dur = params.min_dur
-        p.kmer_pick_margin = params.kmer_pick_margin; p.scaling = params.scaling; p.allow_rna = int(params.rna)
-        p.pa_min = params.pa_min; p.pa_max = params.pa_max; p.n_slots = self.n_slots
-        p.flags = ((_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
-                   | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
-                   | (_abi.PG_FLAG_STOP_WHEN_FULL if params.stop_when_full else 0) | (_abi.PG_FLAG_DEFER_STATS if params.defer_stats else 0)
-                   | (_abi.PG_FLAG_DEBUG_SPLIT_WALK if params.split_walk else 0)
-                   | (_abi.PG_FLAG_OVERLAP_TAIL if params.overlap_tail else 0))
-        p.device = params.device
-        p.table_t = self._table_t.ctypes.data; p.table_u = self._table_u.ctypes.data
+        p = _fill_params(self, self._lib, params)
         h = C.c_void_p()
         st = self._lib.pg_create(C.byref(p), C.byref(h))
         if st != 0:
@@ -256,14 +287,7 @@ class GmoveEngine:
             raise PgError(st, self._lib.pg_last_error(self._h).decode())
 
     def _c_batch(self, b: Batch):
-        cb = _abi.PgBatch()
-        cb.struct_size = C.sizeof(_abi.PgBatch)
-        cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
-        cb.n_reads = b.n_reads
-        cb.n_ops = b.n_ops if b.on_device else 0
-        for name, _ in _BATCH_FIELDS:
-            setattr(cb, name, _ptr(getattr(b, name)))
-        return cb
+        return _c_batch(b)
 
     def submit(self, b: Batch):
         self._keep = b
@@ -339,17 +363,7 @@ class GmoveEngine:
     def finish(self) -> Result:
         r = _abi.PgResult()
         self._check(self._lib.pg_finish(self._h, C.byref(r)))
-
-        def arr(ptr, n, dt):
-            if n == 0 or not ptr:
-                return np.zeros(0, dtype=dt)
-            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dt).copy()
-        ns, ne, nsmp, nr = r.n_slots, r.n_events, r.n_samples, r.n_reads
-        return Result(counts=arr(r.counts, ns, np.uint64), ev_off=arr(r.ev_off, ns + 1, np.uint64),
-                      ev_len=arr(r.ev_len, ne, np.uint32), ev_read=arr(r.ev_read, ne, np.uint32),
-                      samp_off=arr(r.samp_off, ne + 1, np.uint64), samples=arr(r.samples, nsmp, np.float64),
-                      read_skipped=arr(r.read_skipped, nr, np.uint8), n_reads=int(nr))
+        return _result_from(r)
 
     def model(self, keep_first: bool = False) -> "Model":
         """Per-k-mer median / sample stddev / dwell median of everything collected so far, reduced on the device from
@@ -433,3 +447,61 @@ class GmoveEngine:
 
     def kernel_stats_reset(self):
         self._check(self._lib.pg_kernel_stats_reset(self._h))
+
+
+class GmoveJob:
+    """One gmove job over several GPUs from THIS process (pg_job_*): the batch is cut into contiguous shards, one per listed
+    device, with one exchange of per-k-mer counts per batch (RCCL all-gather when the devices are distinct, host memory
+    otherwise). Same results as a GmoveEngine fed the same batches."""
+
+    def __init__(self, params: GmoveParams, devices: Sequence[int], exchange: int = _abi.PG_JOB_EXCHANGE_AUTO):
+        self._lib = _abi.load()
+        self.params = params
+        self.n_slots = len(params.kmers)
+        p = _fill_params(self, self._lib, params)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        st = self._lib.pg_job_create(C.byref(p), devs, len(devices), exchange, C.byref(h))
+        if st != 0:
+            raise PgError(st, self._lib.pg_job_last_error(None).decode())
+        self._h = h
+        self._keep = None
+
+    def _check(self, st):
+        if st != 0:
+            raise PgError(st, self._lib.pg_job_last_error(self._h).decode())
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._lib.pg_job_uses_rccl(self._h))
+
+    def submit(self, b: Batch):
+        self._keep = b
+        self._check(self._lib.pg_job_submit(self._h, C.byref(_c_batch(b))))
+
+    def sync(self):
+        self._check(self._lib.pg_job_sync(self._h))
+
+    def all_slots_full(self) -> bool:
+        return bool(self._lib.pg_job_all_slots_full(self._h))
+
+    def finish(self) -> Result:
+        r = _abi.PgResult()
+        self._check(self._lib.pg_job_finish(self._h, C.byref(r)))
+        return _result_from(r)
+
+    def model(self, keep_first: bool = False) -> "Model":
+        m = _abi.PgModelResult()
+        self._check(self._lib.pg_job_model(self._h, _abi.PG_MODEL_KEEP_FIRST if keep_first else 0, C.byref(m)))
+        return GmoveEngine._model_from(self, m)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pg_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

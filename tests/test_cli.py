@@ -274,3 +274,31 @@ def test_sample_limit_zero_reads_every_line(tmp_path):
     open(pre + ".paf", "w").write("\n".join(lines))
     r = cli(args + [tmp_path / "gpu2", "--batch_reads", "1"]); assert r.returncode == 1 and "allow_rna" in r.stderr
     assert oracle_cli(args + [tmp_path / "cpu2"]).returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devopts", [["--devices", "0,0,0"], ["--devices", "0", "--exchange", "rccl"]], ids=["three_shards_host_exchange", "rccl_one_rank"])
+def test_devices_option_equals_oracle(tmp_path, devopts):
+    """`poregen gmove --devices`: the multi-GPU job from the C++ host (pg_job_*). On a one-GPU box: three shards on device 0
+    (exchange through host memory) and the RCCL all-gather on a one-rank communicator; indels + shuffled whitelist slice +
+    -d, several batches; directory byte-identical to the oracle CLI's."""
+    rng = np.random.default_rng(9)
+    full = ["".join(t) for t in __import__("itertools").product("ACGU", repeat=5)]
+    wl = [full[i] for i in rng.permutation(len(full))[:300]]
+    (tmp_path / "wl.txt").write_text("".join(k + "\n" for k in wl))
+    b = synth.make_batch(260, kind="rna004", seed=94, indel_rate=0.03)
+    pre = str(tmp_path / "syn"); synth.write_files(b, pre)
+    args = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq", "-k", "5", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40",
+            "--kmer_file", tmp_path / "wl.txt", "--index_start", "51", "--index_end", "250", "--kmer_pick_margin", "2", "--sample_limit", "7", "-d"]
+    r = cli(args + [tmp_path / "gpu", "--batch_reads", "100"] + devopts); assert r.returncode == 0, r.stderr
+    assert ("RCCL all-gather" in r.stderr) == ("rccl" in devopts)
+    o = oracle_cli(args + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+    # the whole list, filled early: the job stops reading like one context does
+    args2 = [pre + ".slow5", pre + ".paf", "--fastq", pre + ".fastq", "-k", "3", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40",
+             "--file_limit", "64", "--sample_limit", "20", "--raw_model", tmp_path / "m_job.txt"]
+    r = cli(args2 + [tmp_path / "gpu2", "--batch_reads", "60"] + devopts); assert r.returncode == 0, r.stderr
+    r1 = cli(args2[:-1] + [tmp_path / "m_one.txt", tmp_path / "gpu3", "--batch_reads", "60"]); assert r1.returncode == 0, r1.stderr
+    o = oracle_cli(args2[:-2] + [tmp_path / "cpu2"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu2", tmp_path / "cpu2")
+    assert open(tmp_path / "m_job.txt").read() == open(tmp_path / "m_one.txt").read()

@@ -164,3 +164,79 @@ def test_config4_whitelist_slice_indels_rank_shards():
     assert done.size > 20
     for s in done:
         assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64)), int(s)
+
+
+def test_config2_full_size_8_rank_shards():
+    """BASELINE configs[2] AS STATED: 400 000 RNA reads x 4 000 samples (1.6e9 samples), k=5, sample_limit 5000, sharded 8
+    contiguous ways. The eight 'ranks' are eight contexts on this one GPU; every one counts its shard straight into its row
+    of the all_gather receive buffer (pg_count with a device output) and collects with pg_collect_gathered(world=8), exactly
+    the calls a rank of the 8-GPU job makes around its RCCL all_gather. Checked: the invariants, the concatenation of the
+    ranks' per-k-mer streams in rank order == the single unsharded run bit for bit (src/gmove.cpp:925-950: the first
+    sample_limit events in PAF-line order), freq.txt == min(sum of counts, limit), and the oracle on a prefix of the job for
+    the leading events of every k-mer."""
+    import torch
+    from poregen_amd.dist import shard_bounds
+    limit, world = 5000, 8
+    b = synth.make_batch_fast(400000, kind="rna004", seed=20251003 + 2)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=limit)
+    kmers = generate_kmers(5, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, limit, b.n_reads)
+    assert int(res.counts.min()) == limit and int(res.counts.sum()) == 1024 * limit   # 400 000 reads fill every 5-mer to the cap
+    dev = torch.device("cuda:0")
+    gather_buf = torch.zeros(world * len(kmers), dtype=torch.int64, device=dev)     # what ncclAllGather fills on every rank
+    engs, keep_alive = [], []
+    for g in range(world):
+        lo, hi = shard_bounds(b.n_reads, world, g)
+        e = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=True, **p))
+        sh = b.slice_reads(lo, hi)
+        e.count(sh, out=gather_buf[g * len(kmers):(g + 1) * len(kmers)])
+        e.sync()
+        engs.append(e); keep_alive.append(sh)
+    parts = []
+    for g, e in enumerate(engs):
+        e.stats()
+        e.collect_gathered(gather_buf, world, g)
+        parts.append(e.finish())
+        tot, freq = (t.cpu().numpy() for t in e.job_totals())
+        assert np.array_equal(freq.astype(np.uint64), res.counts) and np.array_equal(np.minimum(tot, limit), freq)
+        e.close(); keep_alive[g] = None
+    assert sum(int(r.counts.sum()) for r in parts) == int(res.counts.sum())
+    lo_reads = [shard_bounds(b.n_reads, world, g)[0] for g in range(world)]
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in parts])
+        assert np.array_equal(vals.view(np.uint64), res.slot_values(s).view(np.uint64)), s
+        a, e_ = int(res.ev_off[s]), int(res.ev_off[s + 1])
+        reads = np.concatenate([r.ev_read[int(r.ev_off[s]):int(r.ev_off[s + 1])].astype(np.int64) + lo_reads[g] for g, r in enumerate(parts)])
+        assert np.array_equal(reads, res.ev_read[a:e_].astype(np.int64)), s
+    # the oracle on the first 4 000 reads: it fills no k-mer there, so its streams are the leading events of the job's
+    o = oracle_for(kmers, **p)
+    o.run_batch(b.slice_reads(0, 4000))
+    oc = o.counts()
+    assert int(oc.max()) < limit and int(oc.min()) > 0
+    for s in range(len(kmers)):
+        ov = o.values(s)
+        assert np.array_equal(res.slot_values(s)[:ov.size].view(np.uint64), ov.view(np.uint64)), s
+        assert np.array_equal(res.ev_len[int(res.ev_off[s]):int(res.ev_off[s]) + int(oc[s])], o.event_lens(s)), s
+
+
+def test_sample_limit_5000_at_oracle_size():
+    """configs[2]'s limit where the oracle can run the whole job: 9 000 RNA reads, k=3 (64 k-mers, ~8 000 accepted events
+    each), sample_limit 5000 -- every k-mer reaches the cap; bit-exact against the oracle, one batch and three."""
+    b = synth.make_batch_fast(9000, kind="rna004", seed=20251003 + 22)
+    p = dict(kmer_size=3, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=5000)
+    kmers = generate_kmers(3, rna=True)
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(b)
+    assert int(o.counts().min()) == 5000 and rcs[-1] == orc.ORC_STOPPED
+    eng = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    eng.submit(b)
+    assert_result_equals_oracle(eng.finish(), o, check_text_slots=2, sample_limit=5000)
+    eng.reset()
+    for lo, hi in ((0, 2500), (2500, 2501), (2501, 9000)):
+        eng.submit(b.slice_reads(lo, hi))
+    assert_result_equals_oracle(eng.finish(), o, check_text_slots=0, sample_limit=5000)
+    eng.close()

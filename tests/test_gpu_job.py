@@ -1,0 +1,92 @@
+"""pg_job_*: one job over several GPUs from one process (include/pgmove.h). A one-GPU box allows: several shards on ONE device
+(the exchange through host memory) and the RCCL all-gather on a one-rank communicator. Both against the CPU oracle."""
+import numpy as np
+import pytest
+
+from helpers import assert_result_equals_oracle, oracle_for
+from poregen_amd import _abi, synth
+from poregen_amd.engine import GmoveEngine, GmoveJob, GmoveParams, PgError, generate_kmers
+
+pytestmark = pytest.mark.gpu
+
+
+def _whitelist_case():
+    rng = np.random.default_rng(6)
+    full = generate_kmers(5, rna=True)
+    wl = [full[i] for i in rng.permutation(len(full))[:300]]
+    b = synth.make_batch(420, kind="rna004", seed=601, indel_rate=0.03)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, kmer_pick_margin=2, sample_limit=9)
+    return wl, b, p
+
+
+@pytest.mark.parametrize("devices,exchange", [([0, 0, 0], _abi.PG_JOB_EXCHANGE_AUTO), ([0], _abi.PG_JOB_EXCHANGE_RCCL), ([0, 0], _abi.PG_JOB_EXCHANGE_HOST)],
+                         ids=["three_shards_on_one_device", "rccl_one_rank", "two_shards_host"])
+def test_job_equals_oracle_whitelist_indels_delimiters(devices, exchange):
+    """configs[4] shape at oracle size (shuffled whitelist slice, indels, pick margin 2, -d) in three uneven batches."""
+    wl, b, p = _whitelist_case()
+    o = oracle_for(wl, index_start=51, index_end=250, delimit=True, **p)
+    o.run_batch(b)
+    job = GmoveJob(GmoveParams(kmers=wl[50:250], **p), devices, exchange)
+    assert job.uses_rccl == (exchange == _abi.PG_JOB_EXCHANGE_RCCL)
+    for lo, hi in ((0, 150), (150, 151), (151, 420)):
+        job.submit(b.slice_reads(lo, hi))
+    res = job.finish()
+    assert_result_equals_oracle(res, o, delimit=True, sample_limit=9)
+    res2 = job.finish()                       # a repeated call returns the same merged view
+    assert np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
+    job.close()
+
+
+def test_job_equals_single_context_and_stops_when_full():
+    """All 64 3-mers fill up inside the second batch: the job reports it like a context does, the streams are identical, and
+    a batch with fewer reads than shards (empty shards) is fine."""
+    b = synth.make_batch(300, kind="rna004", seed=602)
+    p = dict(kmer_size=3, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(3, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+    job = GmoveJob(GmoveParams(kmers=kmers, stop_when_full=True, **p), [0, 0, 0, 0])
+    full_e, full_j = [], []
+    for lo, hi in ((0, 2), (2, 120), (120, 300)):
+        part = b.slice_reads(lo, hi)
+        eng.submit(part); job.submit(part)
+        full_e.append(eng.all_slots_full()); full_j.append(job.all_slots_full())
+    assert full_e == full_j and full_j[-1]
+    re, rj = eng.finish(), job.finish()
+    for name in ("counts", "ev_off", "ev_len", "ev_read", "samp_off", "read_skipped"):
+        assert np.array_equal(getattr(re, name), getattr(rj, name)), name
+    assert np.array_equal(re.samples.view(np.uint64), rj.samples.view(np.uint64))
+    me, mj = eng.model(), job.model()
+    assert me.median_text == mj.median_text and me.sstdev_text == mj.sstdev_text and me.dwell_text == mj.dwell_text
+    eng.close(); job.close()
+
+
+def test_job_rccl_large_limit_many_batches():
+    """The RCCL path (one-rank communicator) with the running total carried in row 0 of the receive buffer over five batches."""
+    b = synth.make_batch_fast(2500, kind="rna004", seed=603)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=100)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    job = GmoveJob(GmoveParams(kmers=kmers, **p), [0], _abi.PG_JOB_EXCHANGE_RCCL)
+    for lo in range(0, 2500, 500):
+        job.submit(b.slice_reads(lo, lo + 500))
+    assert_result_equals_oracle(job.finish(), o, sample_limit=100)
+    job.close()
+
+
+def test_job_errors():
+    kmers = generate_kmers(3)
+    with pytest.raises(PgError) as ei:
+        GmoveJob(GmoveParams(kmers=kmers, kmer_size=3), [0, 0], _abi.PG_JOB_EXCHANGE_RCCL)
+    assert ei.value.status == _abi.PG_ERR_INVALID_ARG and "distinct" in ei.value.text
+    with pytest.raises(PgError) as ei:
+        GmoveJob(GmoveParams(kmers=kmers, kmer_size=3), [0, 99])
+    assert ei.value.status == _abi.PG_ERR_NO_DEVICE
+    # an RNA-oriented record without --rna in the LAST shard fails the job, with the shard named
+    b = synth.make_batch(30, kind="dna_r10", seed=604)
+    b.target_start[27], b.target_end[27] = b.target_end[27], b.target_start[27]
+    job = GmoveJob(GmoveParams(kmers=kmers, kmer_size=3, scaling=1), [0, 0, 0])
+    with pytest.raises(PgError) as ei:
+        job.submit(b); job.finish()
+    assert ei.value.status == _abi.PG_ERR_RNA_FLAG and "shard 2" in ei.value.text
+    job.close()

@@ -8,9 +8,9 @@ if [ "$2" != "nopytest" ]; then
   tail -2 $out/pytest_parity.txt
 fi
 for rep in 1 2; do
-  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra > $out/plain_$rep.json 2> $out/plain_$rep.err || { tail -5 $out/plain_$rep.err; exit 1; }
-  timeout -k 10 200 python3 bench.py --force-dist --no-cpu-baseline --no-lazy-extra > $out/defer_$rep.json 2> $out/defer_$rep.err || { tail -5 $out/defer_$rep.err; exit 1; }
-  timeout -k 10 200 python3 bench.py --force-dist --no-defer --no-cpu-baseline --no-lazy-extra > $out/nodefer_$rep.json 2> $out/nodefer_$rep.err || { tail -5 $out/nodefer_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra --no-extras > $out/plain_$rep.json 2> $out/plain_$rep.err || { tail -5 $out/plain_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --force-dist --no-cpu-baseline --no-lazy-extra --no-extras > $out/defer_$rep.json 2> $out/defer_$rep.err || { tail -5 $out/defer_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --force-dist --no-defer --no-cpu-baseline --no-lazy-extra --no-extras > $out/nodefer_$rep.json 2> $out/nodefer_$rep.err || { tail -5 $out/nodefer_$rep.err; exit 1; }
 done
 python3 - $out <<'PY'
 import json, sys, glob

@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/$1; shift; mkdir -p $out
 for rep in 1 2 3; do for v in "$@"; do
-  timeout -k 10 200 python3 bench.py --lib build/$v/libpgmove.so --no-cpu-baseline --no-lazy-extra > $out/${v}_$rep.json 2> $out/${v}_$rep.err || { tail -5 $out/${v}_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --lib build/$v/libpgmove.so --no-cpu-baseline --no-lazy-extra --no-extras > $out/${v}_$rep.json 2> $out/${v}_$rep.err || { tail -5 $out/${v}_$rep.err; exit 1; }
 done; done
 python3 - $out <<'PY'
 import json, sys, glob

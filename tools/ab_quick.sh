@@ -5,9 +5,9 @@ tag=${1:-abq}; out=gpurun_out/$tag; mkdir -p $out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -30 $out/pytest_gpu.txt; exit 1; }
 tail -1 $out/pytest_gpu.txt
 for rep in 1 2 3; do
-  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra > $out/plain_$rep.json 2> $out/plain_$rep.err || { tail -5 $out/plain_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra --no-extras > $out/plain_$rep.json 2> $out/plain_$rep.err || { tail -5 $out/plain_$rep.err; exit 1; }
 done
-timeout -k 10 200 python3 bench.py --force-dist --no-cpu-baseline --no-lazy-extra > $out/dist_1.json 2> $out/dist_1.err || { tail -5 $out/dist_1.err; exit 1; }
+timeout -k 10 200 python3 bench.py --force-dist --no-cpu-baseline --no-lazy-extra --no-extras > $out/dist_1.json 2> $out/dist_1.err || { tail -5 $out/dist_1.err; exit 1; }
 python3 - $out <<'PY'
 import json, sys, glob
 for f in sorted(glob.glob(sys.argv[1] + "/*_[123].json")):

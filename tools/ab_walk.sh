@@ -7,8 +7,8 @@ tail -2 $out/pytest_gpu.txt
 timeout -k 10 500 python3 tools/fuzz_gpu.py ${2:-150} 777 > $out/fuzz.txt 2>&1 || { tail -20 $out/fuzz.txt; exit 1; }
 tail -3 $out/fuzz.txt
 for rep in 1 2; do
-  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra > $out/fused_$rep.json 2> $out/fused_$rep.err || { tail -5 $out/fused_$rep.err; exit 1; }
-  timeout -k 10 200 python3 bench.py --split-walk --no-cpu-baseline --no-lazy-extra > $out/split_$rep.json 2> $out/split_$rep.err || { tail -5 $out/split_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-lazy-extra --no-extras > $out/fused_$rep.json 2> $out/fused_$rep.err || { tail -5 $out/fused_$rep.err; exit 1; }
+  timeout -k 10 200 python3 bench.py --split-walk --no-cpu-baseline --no-lazy-extra --no-extras > $out/split_$rep.json 2> $out/split_$rep.err || { tail -5 $out/split_$rep.err; exit 1; }
 done
 python3 - $out <<'PY'
 import json, sys, glob

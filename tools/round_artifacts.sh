@@ -9,9 +9,9 @@ R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -20 $out/pytest_gpu.txt; exit 1; }
 tail -2 $out/pytest_gpu.txt
 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra --no-extras > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 for pass in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$pass -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lazy-extra > /dev/null 2> $out/pmc_$pass.err || { tail -5 $out/pmc_$pass.err; exit 1; }
+  rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$pass -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lazy-extra --no-extras > /dev/null 2> $out/pmc_$pass.err || { tail -5 $out/pmc_$pass.err; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, collections, json, sqlite3, sys

@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/${1:-trace_dist}; mkdir -p $out
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --force-dist --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra > $out/bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --force-dist --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra --no-extras > $out/bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 python3 - "$out" <<'PY'
 import csv, glob, sqlite3, sys
 out = sys.argv[1]
