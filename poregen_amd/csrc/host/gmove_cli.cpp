@@ -571,7 +571,7 @@ int gmove_main(int argc, char **argv) {
     }
     (void)need_ctx(); // a failed run may not have reached the first use
     const clk::time_point t_end0 = clk::now();
-    dev.destroy();
+    if (status != EXIT_SUCCESS || getenv("POREGEN_CLEAN_EXIT")) dev.destroy(); // a successful run leaves its (idle) device to the exit of the process: main.cpp
     fprintf(stderr, "[gmove] time: %.3f s from the start of gmove to the end of the output, %.3f s to release the device\n", secs(t_main0, t_end0), secs(t_end0, clk::now()));
     return status;
 }

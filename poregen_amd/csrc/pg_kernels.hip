@@ -1654,7 +1654,8 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
 // launchers: every launch and every queued memset / copy is checked -- a rejected launch (bad configuration, missing code object,
 // a sticky earlier error) must fail the batch instead of leaving the previous batch's results in the buffers
 // =====================================================================================================
-#define PG_LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+// (hipGetLastError is per host thread and sticky: an unrelated earlier failure, e.g. a refused hipSetDevice, is cleared first)
+#define PG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 #define PG_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,

@@ -285,6 +285,7 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell) {
     if (n_slots == 0) return hipSuccess;
+    (void)hipGetLastError(); // sticky per-thread state of an unrelated earlier failure
     if (any_kind[PG_MODEL_TINY]) hipLaunchKernelGGL((k_slot_model<64, PG_MODEL_TINY>), dim3(n_slots), dim3(64), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
     if (any_kind[PG_MODEL_SHORT]) hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
     if (any_kind[PG_MODEL_LONG]) hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);

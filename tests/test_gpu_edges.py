@@ -197,17 +197,18 @@ def test_device_batches_of_equal_n_reads_at_the_same_address(known_n_ops):
     kmers = generate_kmers(5, rna=True)
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
     dev = torch.device("cuda:0")
-    addrs = []
+    # the offsets of every batch live in ONE device buffer: same address, same n_reads, different content -- what a caching
+    # allocator produces for consecutive shards of equal shape
+    op_off_buf = torch.empty(121, dtype=torch.int64, device=dev)
     for hb in (*_dev_batches_same_shape(), *_dev_batches_same_shape()[::-1]):   # small op count first, then large, then back
         o = oracle_for(kmers, **p); o.run_batch(hb)
         db = hb.to_device(dev)
+        op_off_buf.copy_(db.op_off); db.op_off = op_off_buf
+        torch.cuda.synchronize()
         if not known_n_ops:
             db.n_ops = 0
-        addrs.append((db.op_off.data_ptr(), db.n_reads))
         eng.reset(); eng.submit(db)
         assert_result_equals_oracle(eng.finish(), o, sample_limit=30)
-        del db
-    assert len(set(addrs)) < len(addrs), "the allocator did not reuse an address: the test does not exercise the case"
     eng.close()
 
 
