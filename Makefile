@@ -36,6 +36,12 @@ fallback_probe:
 	for f in pg_kernels pg_api pg_model pg_job; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
 	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_api.o build/fb/pg_model.o build/fb/pg_job.o -Wl,--allow-shlib-undefined
 
+# A/B builds: `make variant NAME=x EXTRA="-DPG_..."` -> build/x/libpgmove.so (bench.py --lib, tools/ab_lib.sh)
+variant:
+	@mkdir -p build/$(NAME)
+	for f in pg_kernels pg_api pg_model pg_job; do $(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o build/$(NAME)/$$f.o $(CSRC)/$$f.hip || exit 1; done
+	$(CXX) -shared -o build/$(NAME)/libpgmove.so build/$(NAME)/pg_kernels.o build/$(NAME)/pg_api.o build/$(NAME)/pg_model.o build/$(NAME)/pg_job.o -Wl,--allow-shlib-undefined -ldl -lpthread
+
 oracle_build:
 	$(MAKE) -C oracle
 
@@ -43,4 +49,4 @@ clean:
 	rm -f poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all clean oracle_build fallback_probe
+.PHONY: all clean oracle_build fallback_probe variant

@@ -319,7 +319,7 @@ def hbm_not_mall(shard, kmers, p, dev, copies=8):
     def rep_off(o):
         body = o[:-1]
         return torch.cat([body + i * o[-1] for i in range(copies)] + [(copies * o[-1]).reshape(1)])
-    big = Batch(n_reads=shard.n_reads * copies, on_device=True, n_ops=shard.n_ops * copies,
+    big = Batch(n_reads=shard.n_reads * copies, on_device=True, n_ops=shard.n_ops * copies, all_matches=shard.all_matches,
                 sig=torch.cat([shard.sig[:-8].repeat(copies), torch.zeros(8, dtype=shard.sig.dtype, device=dev)]), sig_off=rep_off(shard.sig_off),
                 digitisation=shard.digitisation.repeat(copies), offset=shard.offset.repeat(copies), range=shard.range.repeat(copies),
                 query_start=shard.query_start.repeat(copies), target_start=shard.target_start.repeat(copies), target_end=shard.target_end.repeat(copies),

@@ -81,8 +81,8 @@ enum {
                                      * the small launches of pg_collect (sample_limit cut, emit, offset scan) run next to the
                                      * streaming kernel; the streams join in front of the gather. Ignored with PG_FLAG_LAZY_STATS,
                                      * PG_FLAG_SKIP_OUT_OF_RANGE, PG_FLAG_OVERLAP and PG_FLAG_DEFER_STATS. */
-    PG_FLAG_DEBUG_SPLIT_WALK = 1u << 8, /* tests / measurement: the ss walk and the event filter as two launches (k_walk, k_events)
-                                        * instead of one wave per read doing both */
+    PG_FLAG_DEBUG_SPLIT_WALK = 1u << 8, /* tests / measurement: every read takes the generic wave-per-read walk (k_walk), also the reads of
+                                        * matches only that the op-parallel event kernel (k_events) would handle */
     PG_FLAG_DEFER_STATS = 1u << 7, /* multi-GPU step: pg_count does not queue the per-read statistics (median/MAD of every read, which
                                      * do not depend on the exchange); pg_stats queues them -- between the ISSUE of the caller's
                                      * collective and the wait for it, so that the all_gather's latency hides behind the streaming
@@ -158,7 +158,15 @@ typedef struct {
     const uint32_t *op_n;
     const uint8_t  *op_t;
     const uint64_t *op_off;       /* [n_reads+1] */
+    uint32_t flags;               /* PG_BATCH_* */
+    uint32_t reserved;
 } pg_batch;
+/* pg_batch.flags */
+enum {
+    PG_BATCH_ALL_MATCHES = 1u << 0 /* the caller vouches that every ss op of the batch is a match (what `reform` writes): the generic
+                                    * wave-per-read walk is not launched at all. Verified on the device: a batch that holds an I, a D or
+                                    * an unknown op after all fails with PG_ERR_INVALID_ARG (never a wrong result). */
+};
 
 /* Host-side view of everything collected so far, in reference order: for slot s, its kept events are
  * e in [ev_off[s], ev_off[s+1]); event e has ev_len[e] samples at samples[samp_off[e] ..], and came

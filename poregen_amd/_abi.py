@@ -56,7 +56,11 @@ class PgBatch(C.Structure):
         ("sig", C.c_void_p), ("sig_off", C.c_void_p), ("digitisation", C.c_void_p), ("offset", C.c_void_p),
         ("range", C.c_void_p), ("query_start", C.c_void_p), ("target_start", C.c_void_p), ("target_end", C.c_void_p),
         ("seq", C.c_void_p), ("seq_off", C.c_void_p), ("op_n", C.c_void_p), ("op_t", C.c_void_p), ("op_off", C.c_void_p),
+        ("flags", C.c_uint32), ("reserved", C.c_uint32),
     ]
+
+
+PG_BATCH_ALL_MATCHES = 1
 
 
 class PgResult(C.Structure):

@@ -321,6 +321,7 @@ int gmove_main(int argc, char **argv) {
     int status = EXIT_SUCCESS;
     uint64_t count_reads = 0, total_samples = 0;
     bool stop = false;
+    std::atomic<bool> batch_all_matches(true); // cleared by whoever puts an I or a D op into the batch under construction
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     double t_device = 0, t_finish = 0, t_dump = 0, t_lines = 0, t_decode = 0, t_concat = 0;
@@ -333,6 +334,8 @@ int gmove_main(int argc, char **argv) {
         b.sig = hb.sig.data(); b.sig_off = hb.sig_off.data(); b.digitisation = hb.dig.data(); b.offset = hb.off.data(); b.range = hb.range.data();
         b.query_start = hb.qs.data(); b.target_start = hb.ts.data(); b.target_end = hb.te.data(); b.seq = hb.seq.data(); b.seq_off = hb.seq_off.data();
         b.op_n = hb.op_n.data(); b.op_t = hb.op_t.data(); b.op_off = hb.op_off.data();
+        if (batch_all_matches) b.flags |= PG_BATCH_ALL_MATCHES; // no I / D op in the batch (every ss string `reform` writes): verified on the device
+        batch_all_matches = true;
         if (!need_ctx()) return false;
         pg_status s = dev.submit(&b);
         if (s == PG_OK) s = dev.sync();
@@ -460,6 +463,7 @@ int gmove_main(int argc, char **argv) {
                     if (b.sig_off.back()) memcpy(hb.sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t));
                     if (b.seq_off.back()) memcpy(hb.seq.data() + bq[t], b.seq.data(), b.seq_off.back());
                     if (b.op_off.back()) { memcpy(hb.op_n.data() + bo[t], b.op_n.data(), b.op_off.back() * sizeof(uint32_t)); memcpy(hb.op_t.data() + bo[t], b.op_t.data(), b.op_off.back()); } // a failed line may have left ops behind op_off.back()
+                    if (std::any_of(b.op_t.begin(), b.op_t.begin() + (ptrdiff_t)b.op_off.back(), [](uint8_t x) { return x != 0; })) batch_all_matches = false;
                     for (size_t k = 0; k < n; k++) {
                         const size_t g = bn[t] + k;
                         hb.sig_off[g] = bs[t] + b.sig_off[k]; hb.seq_off[g] = bq[t] + b.seq_off[k]; hb.op_off[g] = bo[t] + b.op_off[k];

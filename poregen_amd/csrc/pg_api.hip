@@ -82,7 +82,11 @@ struct pg_ctx {
     DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
-    DevBuf m_read, meta, huge_scratch, oor;
+    DevBuf meta, huge_scratch, oor;
+    DevBuf blk_read, gen_flag, gen_list, cum, btot; // PgWalkOut: owner index, generic-read list, block sums of op_n
+    uint32_t batch_id = 0;  // serial number of the batch being counted (tags gen_flag entries and the error word)
+    uint32_t gen_reads = 0; // generic reads of the last settled batch
+    bool batch_all_matches = false; // PG_BATCH_ALL_MATCHES of the current batch (and not PG_FLAG_DEBUG_SPLIT_WALK)
     DevBuf job_total, job_freq; bool have_job_totals = false; // pg_collect_gathered / pg_job_totals_device
     DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
     bool zero_running = false;
@@ -227,7 +231,8 @@ void pg_destroy(pg_ctx *c) {
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
-                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->m_read, &c->meta, &c->huge_scratch, &c->oor,
+                      &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
+                      &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -282,7 +287,8 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull)); CTRY(c->tile_last.ensure(ns * 4ull));
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->job_total.ensure(ns * 8ull)); CTRY(c->job_freq.ensure(ns * 8ull)); // allocated once: callers may cache the pointers
-    CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(16));
+    CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(32));
+    CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut)
     CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
 #undef CTRY
@@ -386,9 +392,13 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 }
 
 static pg_status check_read_errors(pg_ctx *c) {
-    int32_t errv[2] = {INT_MAX, 0}, errs[3] = {INT_MAX, 0, 0};
-    HIP_TRY(c, hipMemcpy(errv, c->errflag.p, 8, hipMemcpyDeviceToHost));
-    if (errv[1]) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.n_ops (%llu) is not op_off[n_reads] of the device batch", (unsigned long long)c->B.n_ops);
+    struct { unsigned long long word; int32_t layout, pad; uint32_t gen_count[2]; } ef;
+    int32_t errv[1] = {INT_MAX}, errs[3] = {INT_MAX, 0, 0};
+    HIP_TRY(c, hipMemcpy(&ef, c->errflag.p, sizeof ef, hipMemcpyDeviceToHost));
+    if (ef.layout) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.n_ops (%llu) is not op_off[n_reads] of the device batch", (unsigned long long)c->B.n_ops);
+    if ((uint32_t)(ef.word >> 32) == c->batch_id) errv[0] = (int32_t)(0xFFFFFFFFu - (uint32_t)ef.word); // PgWalkOut::err
+    c->gen_reads = ef.gen_count[c->batch_id & 1u];
+    if (c->batch_all_matches && c->gen_reads) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.flags says PG_BATCH_ALL_MATCHES but %u reads hold I / D / unknown ops (or fewer ops than k, or more than bases)", c->gen_reads);
     HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 12, hipMemcpyDeviceToHost));
     // the rare statistics launch of the NEXT batch is sized by what this one needed (its blocks stride over the list: the
     // size only decides how fast a wide list is worked off; jobs without wide reads pay for 128 workgroups, not 2112)
@@ -465,11 +475,15 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.k = c->prm.kmer_size; W.sig_move_offset = c->prm.sig_move_offset; W.print_margin = c->prm.signal_print_margin;
     W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
     W.short_ok = (c->prm.flags & PG_FLAG_SHORT_READS_OK) ? 1 : 0;
+    W.no_generic = c->batch_all_matches ? 1 : 0;
     W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
     O.m_tix = c->m_tix.as<uint32_t>() + PG_TIX_FRONT(c->prm.kmer_pick_margin); O.ev_slot = c->ev_slot.as<uint32_t>();
-    O.m_read = c->m_read.as<uint32_t>(); O.meta = c->meta.as<PgReadMeta>();
-    O.status = c->status.as<int32_t>(); O.err = c->errflag.as<int32_t>();
+    O.meta = c->meta.as<PgReadMeta>();
+    O.status = c->status.as<int32_t>();
+    O.err = c->errflag.as<unsigned long long>(); O.layout_err = c->errflag.as<int32_t>() + 2; O.gen_count = c->errflag.as<uint32_t>() + 4;
+    O.blk_read = c->blk_read.as<uint32_t>(); O.gen_flag = c->gen_flag.as<uint32_t>(); O.gen_list = c->gen_list.as<uint32_t>();
+    O.cum = c->cum.as<uint32_t>(); O.btot = c->btot.as<uint32_t>(); O.batch_id = c->batch_id;
     O.oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) ? c->oor.as<uint8_t>() : nullptr;
 }
 
@@ -491,6 +505,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     const uint32_t n = b->n_reads;
 
     c->batch_is_host = b->location == PG_LOC_HOST;
+    c->batch_all_matches = (b->flags & PG_BATCH_ALL_MATCHES) != 0 && !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK);
     if (b->location == PG_LOC_HOST) {
         s = stage_host_batch(c, b);
         if (s != PG_OK) return s;
@@ -512,6 +527,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         B.n_ops = no;
     } else return fail(c, PG_ERR_INVALID_ARG, "pg_batch.location must be PG_LOC_HOST or PG_LOC_DEVICE");
     if (((uintptr_t)c->B.sig & 15) != 0) return fail(c, PG_ERR_INVALID_ARG, "sig must be 16-byte aligned");
+    if (((uintptr_t)c->B.seq & 3) != 0 || ((uintptr_t)c->B.op_n & 15) != 0) return fail(c, PG_ERR_INVALID_ARG, "seq must be 4-byte aligned and op_n 16-byte aligned");
     const uint64_t N = c->B.n_ops;
     if (N >= 0x7fffffffull) return fail(c, PG_ERR_INVALID_ARG, "more than 2^31 ss ops in one batch; split the batch");
 
@@ -521,7 +537,15 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // +32 entries: k_events reads/writes these per-op arrays with 16-byte vectors that may overrun n_ops
     HIP_TRY(c, c->m_start.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_len.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_base.ensure(Nn + 32));
     HIP_TRY(c, c->m_tix.ensure((Nn + 64 + c->prm.kmer_size + 2 * PG_TIX_FRONT(c->prm.kmer_pick_margin)) * 4));
-    HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4)); HIP_TRY(c, c->m_read.ensure((Nn + 32) * 4));
+    HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4));
+    HIP_TRY(c, c->blk_read.ensure((Nn / 64 + 2) * 4)); HIP_TRY(c, c->cum.ensure((Nn / 4 + 64) * 4)); HIP_TRY(c, c->btot.ensure((Nn / 256 + 2) * 4));
+    HIP_TRY(c, c->gen_list.ensure((n + 1) * 4ull));
+    { // gen_flag entries are compared with the batch's serial number: fresh memory must not hold one by accident
+        const size_t before = c->gen_flag.cap;
+        HIP_TRY(c, c->gen_flag.ensure((n + 1) * 4ull));
+        if (c->gen_flag.cap != before) HIP_TRY(c, hipMemsetAsync(c->gen_flag.p, 0, c->gen_flag.cap, c->st));
+    }
+    if (++c->batch_id == 0) { c->batch_id = 1; HIP_TRY(c, hipMemsetAsync(c->gen_flag.p, 0, c->gen_flag.cap, c->st)); }
     HIP_TRY(c, c->meta.ensure((n + 1) * sizeof(PgReadMeta))); HIP_TRY(c, c->status.ensure((n + 1) * 4ull));
     HIP_TRY(c, c->read_needed.ensure(n + 2ull));
     const uint32_t n_tiles = pg_tiles(Nn, direct);
@@ -558,31 +582,35 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     // plan behind the emit kernel (they need its flags).
     c->plan_in_init = eager_stats && !overlap && n > 0;
     if (c->plan_in_init) { pg_status se = ensure_stats_buffers(c); if (se != PG_OK) return se; }
-    HIP_TRY(c, pg_launch_batch_init(c->st, n, c->errflag.as<int32_t>(), c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
+    PgWalkParams W{}; PgWalkOut O{};
+    fill_walk(c, W, O);
+    const bool force_generic = (c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) != 0;
+    HIP_TRY(c, pg_launch_batch_init(c->st, n, c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
                          c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>(), c->B, c->prm.pa_min, c->prm.pa_max,
-                         c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr));
+                         c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr,
+                         W, O, force_generic ? 1 : 0));
     c->stat_flags_reset = !overlap;
     c->zero_running = false;
 
-    if (skip_oor) { pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init); if (s2 != PG_OK) return s2; }
-    PgWalkParams W{}; PgWalkOut O{};
-    fill_walk(c, W, O);
-    // the fused kernel's LDS window holds 256 events plus the reach of pick_this_kmer on both sides (pg_kernels.hip: k_walk)
-    const bool fused = !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) && c->prm.kmer_pick_margin <= 100;
-    prof_begin(c, "k_walk", c->st);
-    HIP_TRY(c, pg_launch_walk(c->st, c->B, W, O, fused));
-    prof_end(c, c->st);
-    if (!fused) {
-        prof_begin(c, "k_events", c->st);
-        HIP_TRY(c, pg_launch_events(c->st, c->B, W, O));
+    if (skip_oor) {
+        pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init); if (s2 != PG_OK) return s2;
+        HIP_TRY(c, pg_launch_apply_oor(c->st, c->B, O));
+    }
+    // the generic walk over the list k_batch_init has just built; not launched when the caller vouches for a batch of matches only
+    if (!c->batch_all_matches) {
+        prof_begin(c, "k_walk", c->st);
+        HIP_TRY(c, pg_launch_walk(c->st, c->B, W, O));
         prof_end(c, c->st);
     }
 
     PgSortBufs S{};
     fill_sort(c, S, n_tiles);
+    prof_begin(c, "k_events", c->st);
+    HIP_TRY(c, pg_launch_events(c->st, c->B, W, O, c->prm.n_slots, direct ? S.hist : nullptr));
+    prof_end(c, c->st);
     uint64_t *acc_copy = (counts_out && counts_location == PG_LOC_DEVICE) ? counts_out : nullptr; // written by the counting kernels
     if (direct) {
-        prof_begin(c, "rank_count", c->st);
+        prof_begin(c, "rank_scan", c->st);
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
                                     c->tile_last.as<int32_t>(), acc_copy));
         prof_end(c, c->st);

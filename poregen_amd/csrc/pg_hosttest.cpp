@@ -27,6 +27,23 @@ extern "C" int pgt_medmad(const int16_t *raw, uint64_t n, double dig, double off
     return 0;
 }
 
+// the symmetric fast path of the selection alone: 1 = applicable (outputs set), 0 = the kernel would take the general path
+extern "C" int pgt_medmad_sym(const int16_t *raw, uint64_t n, double dig, double off, double range,
+                              double pa_min, double pa_max, double *med, double *mad, double *mad_raw) {
+    PgReadPlan p = pg_make_plan(dig, off, range, pa_min, pa_max);
+    if (p.status != 0) return p.status;
+    std::vector<uint32_t> pre((size_t)(p.span > 0 ? p.span : 1), 0u);
+    for (uint64_t i = 0; i < n; i++) {
+        int idx = (int)raw[i] - p.c_lo;
+        if (idx >= 0 && idx < p.span) pre[(size_t)idx]++;
+    }
+    for (int b = 1; b < p.span; b++) pre[(size_t)b] += pre[(size_t)b - 1];
+    PgMedMad mm;
+    if (!pg_medmad_sym(pre.data(), p, n, off, range / dig, mm)) return 0;
+    *med = mm.med; *mad = mm.mad; *mad_raw = mm.mad_raw;
+    return 1;
+}
+
 // ---- host parsers / writer of the CLI (poregen_amd/csrc/host) ------------------------------------------
 #include "host/pg_host.h"
 #include <cstring>

@@ -21,6 +21,7 @@ struct PgDevBatch {
 struct PgWalkParams {
     uint32_t k, sig_move_offset, print_margin, max_dur, min_dur;
     int32_t pick_margin, allow_rna, short_ok;
+    int32_t no_generic; // PG_BATCH_ALL_MATCHES: k_walk is not launched, a read that needs it has no events and fails the batch
     uint32_t n_codes; // 4^k
     const int32_t *table_t, *table_u;
 };
@@ -41,29 +42,57 @@ enum {
     PGR_ERR_LAYOUT = -10      // the read's ops end behind pg_batch.n_ops, or op_off is not monotone (device batches)
 };
 
-// per-read summary written by k_walk, read by k_events / k_rank_emit with two 16-byte loads
+// per-read record (64 bytes) written by k_batch_init for EVERY read; the generic walk refines n / m of the reads it walks, the
+// op-parallel event kernel adds pcum0 for the reads it handles
 struct __attribute__((aligned(16))) PgReadMeta {
     uint64_t o0;     // op_off[r]
-    uint32_t n;      // matched bases (fastq_len after refinement, gmove.cpp:872); 0 for skipped / failed reads
+    uint64_t s0;     // seq_off[r]
+    uint32_t nops;   // ss ops of the read
+    uint32_t slen;   // fetched bases
+    uint32_t n;      // matched bases (fastq_len after refinement, gmove.cpp:872): nops for a read of matches only, else set by the
+                     // generic walk; 0 = the read has no events (skipped, failed, fewer than k matches)
     uint32_t m;      // number of I/D ops
     int32_t st_k, end_k; // min / max of the PAF target columns (gmove.cpp:792-794)
-    uint32_t L;      // len_raw_signal
-    uint32_t rna;    // target_start > target_end
+    uint32_t L;      // len_raw_signal (clamped to 2^32 - 1; > INT32_MAX is an error)
+    int32_t qs;      // query_start
+    uint32_t flags;  // PG_RM_*
+    uint32_t pcum0;  // direct reads: sum of op_n over [first op of the 256-op block of o0, o0) (see PgWalkOut::cum)
+    uint32_t pad[2];
+};
+enum {
+    PG_RM_RNA = 1u,       // target_start > target_end
+    PG_RM_LIVE = 2u,      // passed the per-read checks: not skipped, no error so far
+    PG_RM_DIRECT_OK = 4u  // live, k <= nops <= fetched bases: takes the op-parallel event path unless one of its ops is an I or a D
 };
 
 struct PgWalkOut {
-    uint32_t *m_start; // [n_ops] window start of match j of read r at op_off[r]+j  (end_raw_idx in the reference)
-    uint32_t *m_len;   // [n_ops] window length
-    uint8_t *m_base;   // [n_ops] 2-bit base code of the matched base, 4 = not ACGT/U
-    uint32_t *m_tix;   // [-front .. n_ops + pad) I/D ops in front of match j of read r at op_off[r]+j = #{indel_pos entries <= j}
-                       // (the interior of indel_pos, gmove.cpp:843,845, is never materialised); readable from index
+    uint32_t *m_start; // [n_ops] GENERIC reads: window start of match j of read r at op_off[r]+j  (end_raw_idx in the reference)
+    uint32_t *m_len;   // [n_ops] GENERIC reads: window length
+    uint8_t *m_base;   // [n_ops] GENERIC reads longer than the LDS window: 2-bit base code of the matched base, 4 = not ACGT/U
+    uint32_t *m_tix;   // [-front .. n_ops + pad) GENERIC reads: I/D ops in front of match j of read r at op_off[r]+j = #{indel_pos
+                       // entries <= j} (the interior of indel_pos, gmove.cpp:843,845, is never materialised); readable from index
                        // -kmer_pick_margin: the pointer sits PG_TIX_FRONT entries into its buffer
     uint32_t *ev_slot; // [n_ops] slot of event i of read r at op_off[r]+i, 0xFFFFFFFF = not accepted
-    uint32_t *m_read;  // [n_ops] read that owns op index g
     PgReadMeta *meta;  // [n_reads]
     const uint8_t *oor; // [n_reads] or nullptr: 1 = the read holds an out-of-range sample and the caller wants such reads skipped
     int32_t *status;   // [n_reads]
-    int32_t *err;      // [2] err[0] = lowest read index with an error (init INT32_MAX), err[1] = its code
+    // lowest failing read of the batch, never reset: (batch_id << 32) | (0xFFFFFFFF - read), raised with a 64-bit atomicMax, so a later
+    // batch always wins and inside a batch the lowest read does; a value whose high half is not batch_id means "no error"
+    unsigned long long *err;
+    int32_t *layout_err; // [1] pg_batch.n_ops is not op_off[n_reads] (k_batch_init)
+    // who owns an op index: blk_read[g >> 6] = read of op (g & ~63), then a short probe along op_off (pg_kernels.hip: owner_of)
+    uint32_t *blk_read; // [n_ops / 64 + 1]
+    // reads that need the generic (wave per read) walk: an I / D / unknown op, fewer than k ops, more ops than bases, or all live
+    // reads with PG_FLAG_DEBUG_SPLIT_WALK. gen_flag[r] == batch_id marks them (no clearing between batches), gen_list holds them in
+    // arrival order, gen_count[batch_id & 1] is the list length (the other entry is zeroed for the next batch)
+    uint32_t *gen_flag;  // [n_reads]
+    uint32_t *gen_list;  // [n_reads]
+    uint32_t *gen_count; // [2]
+    uint32_t batch_id;
+    // op_n summed for the window starts of DIRECT reads (only ever evaluated for kept events, in the emit kernels):
+    // cum[g >> 2] = sum of op_n over [g & ~255, g & ~3), btot[g >> 8] = sum over the whole 256-op block (ops < 2^24: no overflow)
+    uint32_t *cum;   // [n_ops / 4 + 64]
+    uint32_t *btot;  // [n_ops / 256 + 1]
 };
 
 #define PG_INVALID_SLOT 0xFFFFFFFFu
@@ -97,7 +126,8 @@ struct PgStatRec {
     int32_t mode;        // PG_STAT_*
     double offset, scale;
     double inv;          // 1.0 / scale: only ever places the candidate windows of the selection (pg_select.h), computed once per read here
-    uint64_t pad;
+    uint32_t sym;        // pg_sym_guard: the symmetric selection path may be tried (pg_select.h)
+    uint32_t pad;
 };
 enum { PG_STAT_RUN = 0, PG_STAT_SKIP = 1, PG_STAT_BAD = 2 };
 #define PG_STAT_REC_BYTES 64
@@ -119,10 +149,12 @@ struct PgKeptOut {
 // resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
 // context's running per-slot counts
 // stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch
-hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags,
                           // plan_buf (may be null): also write the statistics record of every read (what k_read_plan does, needed == null)
-                          const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *stat_status);
+                          const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *stat_status,
+                          // the per-read records, the owner index and the classification of the reads (PgWalkOut)
+                          const PgWalkParams &W, const PgWalkOut &O, int force_generic);
 // tiles of PG_SORT_TILE events; in direct mode (n_slots <= PG_DIRECT_MAX_SLOTS) the count is padded to a multiple of 4:
 // k_rank_count_direct handles 4 tiles per workgroup and writes their counts of a slot as one 16-byte store
 static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
@@ -133,10 +165,15 @@ static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
 struct PgSlotModel; struct PgSlotDwell; // pg_model.h
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell);
-// fused: the walk and the event loop of every read in one launch (no pg_launch_events behind it)
-hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused);
-hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
-// direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): per-tile per-slot counts + tile prefix; acc_cnt = events per slot
+// the generic walk (one wave per listed read: walk + event loop) over O.gen_list
+hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+// the op-parallel event kernel over ALL op indices: computes the events of direct reads, passes the generic reads' through, and (hist
+// != null, direct ranking) counts the accepted events per tile and slot as pg_launch_rank_direct_count's first kernel would
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist);
+// SAM/BAM front-end: reads with an out-of-range sample become skipped reads (behind the statistics, in front of the walk)
+hipError_t pg_launch_apply_oor(hipStream_t st, const PgDevBatch &B, const PgWalkOut &O);
+// direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): tile prefix of the per-tile per-slot counts pg_launch_events left in S.hist;
+// acc_cnt = events per slot
 hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last,
                                  uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */);

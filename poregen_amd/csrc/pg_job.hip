@@ -256,7 +256,7 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         }
         pg_batch &q = sh.b;
         memset(&q, 0, sizeof q);
-        q.struct_size = sizeof q; q.location = PG_LOC_HOST; q.n_reads = (uint32_t)m;
+        q.struct_size = sizeof q; q.location = PG_LOC_HOST; q.n_reads = (uint32_t)m; q.flags = b->flags;
         q.sig = b->sig ? b->sig + b->sig_off[lo] : nullptr; q.sig_off = sh.sig_off.data();
         q.digitisation = b->digitisation ? b->digitisation + lo : nullptr; q.offset = b->offset ? b->offset + lo : nullptr; q.range = b->range ? b->range + lo : nullptr;
         q.query_start = b->query_start ? b->query_start + lo : nullptr; q.target_start = b->target_start ? b->target_start + lo : nullptr;

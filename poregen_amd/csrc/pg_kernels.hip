@@ -21,6 +21,30 @@
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+#ifdef PG_PHASE_PROBE
+// Measurement build only (make variant NAME=phase EXTRA=-DPG_PHASE_PROBE; tools/phase_probe.py): per-wave time stamps (s_memtime)
+// between the phases of the two large kernels. A wave keeps its phase times in registers (PG_MARK(k, i): wait for the wave's
+// outstanding memory operations, then the time since the previous mark goes to phase i) and stores them once, at its end, into
+// its own record g_pg_phase[kernel][wave][phase] -- no atomics, nothing shared between waves.
+#define PG_PROBE_WAVES 65536
+__device__ unsigned long long g_pg_phase[2][PG_PROBE_WAVES][8];
+extern "C" void pg_debug_phases(unsigned long long *out, int kernel, int reset) { // out: [PG_PROBE_WAVES][8]
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pg_phase), sizeof(unsigned long long) * PG_PROBE_WAVES * 8, sizeof(unsigned long long) * PG_PROBE_WAVES * 8 * kernel);
+    if (reset) { void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pg_phase)); (void)hipMemset(p, 0, sizeof(unsigned long long) * 2 * PG_PROBE_WAVES * 8); }
+}
+#define PG_PROBE_BEGIN(k) unsigned long long pg_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pg_t_ = __builtin_readcyclecounter(); const unsigned long long pg_t0_ = pg_t_
+#define PG_MARK(k, i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = __builtin_readcyclecounter(); pg_acc_[i] += n_ - pg_t_; pg_t_ = n_; } while (0)
+#define PG_PROBE_END(k, wave) do { if (lane_id() == 0 && (wave) < PG_PROBE_WAVES) { pg_acc_[7] = __builtin_readcyclecounter() - pg_t0_; for (int i_ = 0; i_ < 8; ++i_) g_pg_phase[k][wave][i_] = pg_acc_[i_]; } } while (0)
+#define PG_PROBE_PARAM , unsigned long long &pg_t_, unsigned long long (&pg_acc_)[8]
+#define PG_PROBE_ARG , pg_t_, pg_acc_
+#else
+#define PG_PROBE_BEGIN(k) do {} while (0)
+#define PG_MARK(k, i) do {} while (0)
+#define PG_PROBE_END(k, wave) do {} while (0)
+#define PG_PROBE_PARAM
+#define PG_PROBE_ARG
+#endif
+
 // Inclusive wave64 scan with DPP row shifts + row broadcasts (no LDS traffic, 6 VALU ops): rows of 16 lanes
 // are scanned with row_shr:1/2/4/8, then lane 15 of each row is broadcast into the next row (rows 1,3) and
 // lane 31 into rows 2,3.
@@ -94,7 +118,15 @@ template <class Pred> __device__ __forceinline__ void wave_first_true_pair(int n
 }
 
 // =====================================================================================================
-// k_walk: the ss walk (gmove.cpp:831-871), one wave (= one workgroup) per read.
+// Events of a batch (gmove.cpp:822-927), two ways:
+//   * k_events, op-parallel, for the reads whose ss string holds matches only ("direct" reads: every ss string `reform`
+//     writes, and BASELINE's synthetic workloads): match index = op index = base index, so the slot of event i depends on
+//     k bases, one window length and the read's scalars only -- no prefix sums, no per-read dependency chain. A thread takes
+//     4 consecutive op indices of the whole batch. The window STARTS (prefix sums of op_n) are needed for kept events only:
+//     every wave leaves the sums over its 256-op block (cum / btot) and the emit kernels evaluate them.
+//   * k_walk, one wave per read, for everything else (I / D ops, reads the reference treats as errors): the ss walk with
+//     DPP wave scans followed by the event loop of the same read. A persistent grid strides over the list of such reads.
+// k_batch_init writes the per-read records and classifies the reads (its op-parallel part looks for non-match ops).
 // =====================================================================================================
 
 __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
@@ -111,12 +143,66 @@ __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
 
 __device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int code) {
     O.status[r] = code;
-    atomicMin(&O.err[0], (int)r);
+    atomicMax(O.err, ((unsigned long long)O.batch_id << 32) | (unsigned long long)(0xFFFFFFFFu - r)); // PgWalkOut::err
 }
 
-#define PG_EV_PER_THREAD 4 // four consecutive op indices per thread: 16-byte loads instead of four 4-byte ones
-// LDS copy of a short read's per-match values (reads of at most PG_WALK_LDS_OPS ss ops): what the event loop needs besides
-// the window starts -- base code, window length, I/D ops in front -- never goes to global memory for such a read
+// the read that owns op index g (g < n_ops): the read of the 64-op block's first op, then along op_off (reads without ops
+// are stepped over; a read of >= 64 ops ends the probe at once)
+__device__ __forceinline__ uint32_t owner_of(const PgDevBatch &B, const PgWalkOut &O, uint64_t g) {
+    uint32_t r = O.blk_read[g >> 6];
+    if (r >= B.n_reads) r = B.n_reads - 1; // only with a broken op_off (the batch fails anyway): stay inside the arrays
+    while (r + 1 < B.n_reads && B.op_off[r + 1] <= g) ++r;
+    return r;
+}
+// ... by binary search (k_batch_init's op-parallel part runs next to the threads that write blk_read)
+__device__ __forceinline__ uint32_t owner_search(const PgDevBatch &B, uint64_t g) {
+    uint32_t lo = 0, hi = B.n_reads; // first r with op_off[r + 1] > g
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (B.op_off[mid + 1] > g) hi = mid; else lo = mid + 1; }
+    return lo < B.n_reads ? lo : B.n_reads - 1;
+}
+__device__ __forceinline__ void list_generic(const PgWalkOut &O, uint32_t r) {
+    if (atomicExch(&O.gen_flag[r], O.batch_id) != O.batch_id) O.gen_list[atomicAdd(&O.gen_count[O.batch_id & 1u], 1u)] = r;
+}
+
+#define PG_OP_N_LIMIT (1u << 24) // an op of 2^24 samples or more is refused (PGR_ERR_RANGE): 256 of them fit a 32-bit block sum
+
+// One read's record, checks and class (k_batch_init, one thread per read). The checks are those at the head of the reference's
+// loop body: gmove.cpp:752 (assert), 792-798 (orientation), 806-808 (short fetch).
+__device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t r, int force_generic) {
+    const uint64_t o0 = B.op_off[r], o1 = B.op_off[r + 1], s0 = B.seq_off[r], s1 = B.seq_off[r + 1];
+    const uint64_t L = B.sig_off[r + 1] - B.sig_off[r];
+    const int32_t ts = B.tstart[r], te = B.tend[r], qs = B.qstart[r];
+    const bool rna = ts > te; // gmove.cpp:793
+    const bool layout_ok = o1 >= o0 && o1 <= B.n_ops && s1 >= s0 && (r + 1 < B.n_reads || o1 == B.n_ops);
+    PgReadMeta mt;
+    mt.o0 = o0 < B.n_ops ? o0 : B.n_ops; mt.s0 = s0;
+    mt.nops = layout_ok ? (uint32_t)(o1 - o0) : 0u;
+    mt.slen = (uint32_t)(s1 - s0 > 0xffffffffull ? 0xffffffffull : s1 - s0);
+    mt.n = 0; mt.m = 0; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
+    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pcum0 = 0; mt.pad[0] = mt.pad[1] = 0;
+    int status = PGR_OK;
+    if (!layout_ok) status = PGR_ERR_LAYOUT;
+    // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
+    else if (qs < 0 || ts < 0 || te < 0 || (uint64_t)qs >= L || L > 0x7fffffffull) status = PGR_ERR_NEG;
+    else if (rna && !W.allow_rna) status = PGR_ERR_RNA;  // gmove.cpp:795-798
+    else if (mt.slen < W.k) status = PGR_SKIPPED;        // gmove.cpp:806-808
+    if (status < 0) report_error(O, r, status); else O.status[r] = status;
+    const bool live = status == PGR_OK;
+    const bool direct_ok = live && !force_generic && mt.nops >= W.k && mt.nops <= mt.slen;
+    mt.flags = (rna ? PG_RM_RNA : 0u) | (live ? PG_RM_LIVE : 0u) | (direct_ok ? PG_RM_DIRECT_OK : 0u);
+    if (direct_ok) mt.n = mt.nops;
+    O.meta[r] = mt;
+    if (live && !direct_ok) list_generic(O, r); // the generic walk produces its events or its error
+    // owner index: this read owns every 64-op block whose first op is one of its ops
+    if (layout_ok) for (uint64_t b = (o0 + 63) >> 6; (b << 6) < o1; ++b) O.blk_read[b] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_walk: the generic walk (gmove.cpp:831-871) and event loop (891-927) of one read by one wave
+// ---------------------------------------------------------------------------------------------------------------------
+#define PG_EV_PER_THREAD 4 // four consecutive op indices per thread / lane
+// LDS window of a read's per-match values: what the event loop needs besides the window starts -- base code, window length, I/D ops
+// in front. A read of at most PG_WALK_LDS_OPS ss ops never writes them to global memory; a longer one re-fills the window per tile.
 #define PG_WALK_LDS_OPS 512
 struct WalkLds {
     uint32_t code[PG_WALK_LDS_OPS / 16 + 2]; // 2-bit base codes, match p at bits 2(p & 15) of word p >> 4 (OR-ed in: zeroed first)
@@ -124,75 +210,41 @@ struct WalkLds {
     uint32_t len[PG_WALK_LDS_OPS + 16];      // read at i + sig_move_offset (< n whenever it is used)
     uint32_t tix[PG_WALK_LDS_OPS + 4];       // + 4: lanes behind the read's last op still form their (unused) addresses
 };
-template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+template <int E, bool TIXG> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
                                                                   uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0);
 
-// a read without events (skipped, failed, fewer than k matches): every op index of it still carries a slot entry
+// a read without events (failed, fewer than k matches): every op index of it still carries a slot entry
 __device__ __forceinline__ void walk_no_events(const PgWalkOut &O, uint64_t o0, uint32_t nops, int lane) {
     for (uint32_t i = lane; i < nops; i += WAVE) O.ev_slot[o0 + i] = PG_INVALID_SLOT;
 }
 
-// FUSED: the event loop of the read (gmove.cpp:891-927) runs in the same wave right behind its walk: no second launch, no
-// per-event look-up of the owning read and its summary. A read of at most PG_WALK_LDS_OPS ops hands base codes, window
-// lengths and I/D counts over in LDS (they are never written to global memory); a longer read goes through the global
-// arrays the wave has just written. !FUSED: the walk only, k_events does the event loop over the whole batch (kept for
-// measurement: PG_FLAG_DEBUG_SPLIT_WALK).
-template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
-    __shared__ WalkLds sm_store;
-    WalkLds *sm = &sm_store;
+// TIXG: the pick margin is too wide for the LDS window (> 100): the event loop reads the I/D counts from the global array
+template <bool TIXG> __device__ __forceinline__ void walk_one_read(WalkLds *sm, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t r) {
     const int lane = lane_id();
-    const uint32_t r = blockIdx.x; // one wave per workgroup: a finished read frees its slot at once
-    const uint64_t o0 = B.op_off[r], o1 = B.op_off[r + 1];
-    const bool last_read = r + 1 == B.n_reads;
-    if (o1 > B.n_ops || o1 < o0 || (last_read && o1 != B.n_ops)) {
-        // pg_batch.n_ops (it sized the work buffers) disagrees with the offsets on the device: nothing is written behind n_ops,
-        // every op index below it still gets a slot entry, and the batch fails (k_batch_init raises the flag as well)
-        const uint64_t a = o0 < B.n_ops ? o0 : B.n_ops, e1 = o1 < a ? a : o1, b = (last_read || e1 > B.n_ops) ? B.n_ops : e1;
-        for (uint64_t i = a + lane_id(); i < b; i += WAVE) { O.ev_slot[i] = PG_INVALID_SLOT; O.m_read[i] = r; }
-        if (lane_id() == 0) { O.meta[r] = PgReadMeta{a, 0u, 0u, 0, 0, 0u, 0u}; report_error(O, r, PGR_ERR_LAYOUT); }
-        return;
-    }
-    const uint32_t nops = (uint32_t)(o1 - o0);
-    const uint64_t s0 = B.seq_off[r];
-    const uint32_t slen = (uint32_t)(B.seq_off[r + 1] - s0);
-    const uint64_t L = B.sig_off[r + 1] - B.sig_off[r];
-    const int32_t ts = B.tstart[r], te = B.tend[r], qs = B.qstart[r];
-    const uint32_t k = W.k;
+    // k_batch_init's record: offsets, lengths, PAF columns. The kernel also writes records (n, m of the reads it walks), so the
+    // compiler loads this one per lane: every field goes back to a scalar register (the whole walk is written around uniform values)
+    const PgReadMeta *mp = O.meta + r;
+    auto sc32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto sc64 = [&](uint64_t v) { return (uint64_t)sc32((uint32_t)v) | ((uint64_t)sc32((uint32_t)(v >> 32)) << 32); };
+    const uint64_t o0 = sc64(mp->o0), s0 = sc64(mp->s0);
+    const uint32_t nops = sc32(mp->nops), slen = sc32(mp->slen), k = W.k, flags = sc32(mp->flags);
+    const bool rna = (flags & PG_RM_RNA) != 0;
+    const int32_t st_k = (int32_t)sc32((uint32_t)mp->st_k), end_k = (int32_t)sc32((uint32_t)mp->end_k), qs = (int32_t)sc32((uint32_t)mp->qs);
+    if (!(flags & PG_RM_LIVE)) { walk_no_events(O, o0, nops, lane); return; }
+    if (O.oor && O.oor[r]) { walk_no_events(O, o0, nops, lane); return; } // SAM/BAM front-end (k_apply_oor has marked the read)
 
     // the read's own stretch of every per-op array: a uniform base pointer + a 32-bit lane offset per access
     const uint32_t *__restrict__ r_op_n = B.op_n + o0; const uint8_t *__restrict__ r_op_t = B.op_t + o0; const uint8_t *__restrict__ r_seq = B.seq + s0;
-    uint32_t *__restrict__ r_start = O.m_start + o0, *__restrict__ r_len = O.m_len + o0, *__restrict__ r_tix = O.m_tix + o0, *__restrict__ r_read = O.m_read + o0;
+    uint32_t *__restrict__ r_start = O.m_start + o0, *__restrict__ r_len = O.m_len + o0, *__restrict__ r_tix = O.m_tix + o0;
     uint8_t *__restrict__ r_base = O.m_base + o0;
-    // k_events / k_rank_emit find the read of an op index through m_read
-    for (uint32_t i = lane; i < nops; i += WAVE) r_read[i] = r;
-    const bool rna = ts > te;                                          // gmove.cpp:793
-    const bool in_lds = FUSED && nops <= PG_WALK_LDS_OPS;              // wave-uniform
+    const bool in_lds = nops <= PG_WALK_LDS_OPS; // wave-uniform
     if (in_lds) {
         if (lane < PG_WALK_LDS_OPS / 16 + 2) sm->code[lane] = 0;
         if (lane < PG_WALK_LDS_OPS / 32 + 2) sm->bad[lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    auto put_meta = [&](uint32_t n_, uint32_t m_) {
-        PgReadMeta mt; mt.o0 = o0; mt.n = n_; mt.m = m_; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
-        mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.rna = rna ? 1u : 0u;
-        O.meta[r] = mt;
-    };
-    if (lane == 0) { put_meta(0, 0); O.status[r] = PGR_OK; }
-
-    int status = PGR_OK;
-    // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
-    if (qs < 0 || ts < 0 || te < 0 || (uint64_t)qs >= L || L > 0x7fffffffull) status = PGR_ERR_NEG;
-    if (status == PGR_OK && rna && !W.allow_rna) status = PGR_ERR_RNA; // gmove.cpp:795-798
-    if (status == PGR_OK && slen < k) status = PGR_SKIPPED;            // gmove.cpp:806-808
-    if (status == PGR_OK && O.oor && O.oor[r]) status = PGR_SKIPPED;   // SAM/BAM front-end: out-of-range sample (gmove.cpp:1158-1160)
-    if (status != PGR_OK) {
-        if (lane == 0) { if (status < 0) report_error(O, r, status); else O.status[r] = status; }
-        if (FUSED) walk_no_events(O, o0, nops, lane);
-        return;
-    }
-
-    uint64_t raw_carry = (uint64_t)qs;   // i_raw
+    uint64_t raw_carry = (uint64_t)(uint32_t)qs; // i_raw
     uint32_t match_carry = 0;            // i_k_raw  (matched bases so far)
     uint64_t del_carry = 0;              // num_deletion
     uint32_t indel_carry = 0;            // entries pushed to indel_pos so far (interior only)
@@ -208,27 +260,26 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
             nn[u] = i < nops ? r_op_n[i] : 0u;
             tt[u] = i < nops ? (uint32_t)r_op_t[i] : 3u;
         }
-        uint32_t jj[U], tix[U], st32[U]; uint64_t ik[U]; bool ism[U], isid[U], okm[U];
+        uint32_t jj[U], tix[U], st32[U]; uint64_t ik[U]; bool okm[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            jj[u] = 0; tix[u] = 0; st32[u] = 0; ik[u] = 0; ism[u] = isid[u] = okm[u] = false;
+            jj[u] = 0; tix[u] = 0; st32[u] = 0; ik[u] = 0; okm[u] = false;
             if (c + u * WAVE >= nops) continue; // wave-uniform: a chunk behind the read's last op costs nothing
             const uint32_t i = c + u * WAVE + lane;
             const bool act = i < nops;
             const uint32_t n = nn[u], t = tt[u];
             const bool is_m = act && t == 0, is_i = act && t == 1, is_d = act && t == 2;
             if (act && t > 2) err = PGR_ERR_OP;
-            if (n >= (1u << 25)) err = PGR_ERR_RANGE; // keeps the 32-bit chunk scans below exact (64 ops x 2^25 < 2^31)
+            if (n >= PG_OP_N_LIMIT) err = PGR_ERR_RANGE; // keeps the 32-bit chunk scans (and k_events' block sums) exact
             const uint64_t mm = __ballot(is_m), mi = __ballot(is_i || is_d);
             jj[u] = match_carry + (uint32_t)__popcll(mm & lanemask_lt());
             tix[u] = indel_carry + (uint32_t)__popcll(mi & lanemask_lt());
-            const uint32_t radv = (is_m || is_i) ? (n & 0x1ffffffu) : 0u;
-            const uint32_t dadv = is_d ? (n & 0x1ffffffu) : 0u;
+            const uint32_t radv = (is_m || is_i) ? (n & (PG_OP_N_LIMIT - 1u)) : 0u;
+            const uint32_t dadv = is_d ? (n & (PG_OP_N_LIMIT - 1u)) : 0u;
             const uint32_t rinc = wave_incl_scan_u32(radv);
             const uint32_t dinc = __ballot(is_d) ? wave_incl_scan_u32(dadv) : 0u; // most chunks hold no deletion
             const uint64_t start = raw_carry + rinc - radv;
             ik[u] = (uint64_t)jj[u] + del_carry + dinc - dadv; // i_k at this op
-            ism[u] = is_m; isid[u] = is_i || is_d; okm[u] = false;
             if (is_m) {
                 if (ik[u] >= slen) err = PGR_ERR_SEQ_OVERRUN;
                 else if (start + n > 0x7fffffffull) err = PGR_ERR_RANGE;
@@ -251,14 +302,15 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
             if (okm[u]) {
                 r_start[jj[u]] = st32[u]; // end_raw_idx[i_k_raw]
                 r_len[jj[u]] = nn[u];     // st_raw_idx - end_raw_idx
+                if (TIXG) r_tix[jj[u]] = tix[u];
                 if (in_lds) {
                     atomicOr(&sm->code[jj[u] >> 4], ((uint32_t)bc[u] & 3u) << (2u * (jj[u] & 15u)));
                     if (bc[u] > 3) atomicOr(&sm->bad[jj[u] >> 5], 1u << (jj[u] & 31u));
                     sm->len[jj[u]] = nn[u]; sm->tix[jj[u]] = tix[u];
                 } else {
                     r_base[jj[u]] = bc[u];
-                    r_tix[jj[u]] = tix[u];        // I/D ops in front of this match (the indel positions themselves, i_k -
-                                                  // num_deletion at every I/D op, are only needed as these counts)
+                    if (!TIXG) r_tix[jj[u]] = tix[u]; // I/D ops in front of this match (the indel positions themselves, i_k -
+                                                      // num_deletion at every I/D op, are only needed as these counts)
                 }
             }
         }
@@ -267,153 +319,83 @@ template <bool FUSED> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B,
     if (bm) { // lowest failing lane decides the code
         const int code = __shfl(err, __ffsll((long long)bm) - 1, WAVE);
         if (lane == 0) report_error(O, r, code);
-        if (FUSED) walk_no_events(O, o0, nops, lane);
+        walk_no_events(O, o0, nops, lane);
         return;
     }
     if (match_carry < k) { // unsigned wrap at gmove.cpp:891 in the PAF path; simply no events for the move-table front-end
         if (lane == 0 && !W.short_ok) report_error(O, r, PGR_ERR_SHORT);
-        if (FUSED) walk_no_events(O, o0, nops, lane);
+        walk_no_events(O, o0, nops, lane);
         return;
     }
-    if (lane == 0) put_meta(match_carry, indel_carry);
-    if (FUSED) {
-        const int32_t st_k = rna ? te : ts, end_k = rna ? ts : te;
-        if (in_lds) { // the whole read is in the window (base 0). LDS operations of one wave execute in order: only the compiler has to be held back
+    if (lane == 0) { O.meta[r].n = match_carry; O.meta[r].m = indel_carry; } // the emit kernels read them
+    if (TIXG) __syncthreads(); // the event loop reads the I/D counts back from global memory
+    if (in_lds) { // the whole read is in the window (base 0). LDS operations of one wave execute in order: only the compiler has to be held back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // events per lane: the fewest trips first, then the most lanes at work
+        const uint32_t trips4 = (nops + 4 * WAVE - 1) / (4 * WAVE);
+        if ((nops + 2 * WAVE - 1) / (2 * WAVE) == trips4) {
+            for (uint32_t T0 = 0; T0 < nops; T0 += 2 * WAVE) walk_events_tile<2, TIXG>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+        } else if ((nops + 3 * WAVE - 1) / (3 * WAVE) == trips4) {
+            for (uint32_t T0 = 0; T0 < nops; T0 += 3 * WAVE) walk_events_tile<3, TIXG>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+        } else {
+            for (uint32_t T0 = 0; T0 < nops; T0 += 4 * WAVE) walk_events_tile<4, TIXG>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+        }
+    } else {
+        // A longer read: tile after tile of 256 events, the window re-filled from the global arrays the wave has just
+        // written. Window = matches [base, base + PG_WALK_LDS_OPS), base = T0 - min(T0, pick margin) -- the left bound of
+        // pick_this_kmer reaches that far back; 256 + k + 2 * margin + 16 <= PG_WALK_LDS_OPS (wider margins: TIXG).
+        __syncthreads(); // phase 1's global stores are complete and visible to all lanes of the wave
+        const uint32_t Mu = TIXG ? 0u : (uint32_t)W.pick_margin;
+        for (uint32_t T0 = 0; T0 < nops; T0 += PG_EV_PER_THREAD * WAVE) {
+            const uint32_t base = T0 - (T0 < Mu ? T0 : Mu);
+            if (lane < PG_WALK_LDS_OPS / 16 + 2) sm->code[lane] = 0;
+            if (lane < PG_WALK_LDS_OPS / 32 + 2) sm->bad[lane] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // events per lane: the fewest trips first, then the most lanes at work
-            const uint32_t trips4 = (nops + 4 * WAVE - 1) / (4 * WAVE);
-            if ((nops + 2 * WAVE - 1) / (2 * WAVE) == trips4) {
-                for (uint32_t T0 = 0; T0 < nops; T0 += 2 * WAVE) walk_events_tile<2>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
-            } else if ((nops + 3 * WAVE - 1) / (3 * WAVE) == trips4) {
-                for (uint32_t T0 = 0; T0 < nops; T0 += 3 * WAVE) walk_events_tile<3>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
-            } else {
-                for (uint32_t T0 = 0; T0 < nops; T0 += 4 * WAVE) walk_events_tile<4>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, 0u, T0);
+            for (uint32_t q = lane; q < PG_WALK_LDS_OPS && base + q < match_carry; q += WAVE) {
+                const uint32_t bcq = r_base[base + q];
+                atomicOr(&sm->code[q >> 4], (bcq & 3u) << (2u * (q & 15u)));
+                if (bcq > 3) atomicOr(&sm->bad[q >> 5], 1u << (q & 31u));
+                sm->len[q] = r_len[base + q];
+                if (!TIXG) sm->tix[q] = r_tix[base + q];
             }
-        } else {
-            // A longer read: tile after tile of 256 events, the window re-filled from the global arrays the wave has just
-            // written. Window = matches [base, base + PG_WALK_LDS_OPS), base = T0 - min(T0, pick margin) -- the left bound of
-            // pick_this_kmer reaches that far back; 256 + k + 2 * margin + 16 <= PG_WALK_LDS_OPS (the host checks the margin).
-            __syncthreads(); // phase 1's global stores are complete and visible to all lanes of the wave
-            const uint32_t Mu = (uint32_t)W.pick_margin;
-            for (uint32_t T0 = 0; T0 < nops; T0 += PG_EV_PER_THREAD * WAVE) {
-                const uint32_t base = T0 - (T0 < Mu ? T0 : Mu);
-                if (lane < PG_WALK_LDS_OPS / 16 + 2) sm->code[lane] = 0;
-                if (lane < PG_WALK_LDS_OPS / 32 + 2) sm->bad[lane] = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t q = lane; q < PG_WALK_LDS_OPS && base + q < match_carry; q += WAVE) {
-                    const uint32_t bcq = r_base[base + q];
-                    atomicOr(&sm->code[q >> 4], (bcq & 3u) << (2u * (q & 15u)));
-                    if (bcq > 3) atomicOr(&sm->bad[q >> 5], 1u << (q & 31u));
-                    sm->len[q] = r_len[base + q]; sm->tix[q] = r_tix[base + q];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                walk_events_tile<PG_EV_PER_THREAD>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, base, T0);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            walk_events_tile<PG_EV_PER_THREAD, TIXG>(W, O, sm, o0, nops, match_carry, indel_carry, rna, st_k, end_k, lane, base, T0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-// =====================================================================================================
-// k_events: the event loop (gmove.cpp:891-927), one thread per (read, event index) = per op index
-// =====================================================================================================
-
-// The kernel issues ~12 vector-memory instructions per event when written one event per thread and is bound by
-// that instruction rate, not by bytes; with four consecutive events per thread the per-op arrays are read with one
-// 16-byte load each (buffers are padded by 16 bytes so the last vector may overrun n_ops).
-__global__ __launch_bounds__(256) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
-    constexpr int E = PG_EV_PER_THREAD;
-    const uint32_t k = W.k;
-    const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * E;
-    if (g0 >= B.n_ops) return;
-    const uint64_t last = B.n_ops - 1;
-    // round trip 1: owning reads, the 16 base codes starting at g0, window lengths of matches g0+off..
-    const uint4 rv = *reinterpret_cast<const uint4 *>(O.m_read + g0);
-    const uint32_t r[E] = {rv.x, rv.y, rv.z, rv.w};
-    const uint4 bv = *reinterpret_cast<const uint4 *>(O.m_base + g0); // bases g0 .. g0+15 (k <= 13 needs g0 .. g0+15)
-    const uint64_t blo = (uint64_t)bv.x | ((uint64_t)bv.y << 32), bhi = (uint64_t)bv.z | ((uint64_t)bv.w << 32);
-    uint32_t len[E];
-    if (W.sig_move_offset == 0) {
-        const uint4 lv = *reinterpret_cast<const uint4 *>(O.m_len + g0);
-        len[0] = lv.x; len[1] = lv.y; len[2] = lv.z; len[3] = lv.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < E; ++j) { const uint64_t ge = g0 + j + W.sig_move_offset; len[j] = O.m_len[ge > last ? last : ge]; }
-    }
-    // ... and, for pick_this_kmer, the number of I/D ops in front of match i-M and in front of match i+k+M-1 of the event's
-    // read (both orientations need exactly these two)
-    static_assert(E == 4, "one 16-byte load per bound");
-    const uint32_t kM = k + (uint32_t)W.pick_margin;
-    const uint4 txl = *reinterpret_cast<const uint4 *>(O.m_tix + ((int64_t)g0 - (int64_t)W.pick_margin)); // 4-byte aligned; padded front
-    const uint4 txh = *reinterpret_cast<const uint4 *>(O.m_tix + (g0 + kM - 1));                            // padded back
-    const uint32_t tx_lo[E] = {txl.x, txl.y, txl.z, txl.w}, tx_hi[E] = {txh.x, txh.y, txh.z, txh.w};
-    // round trip 2: the reads' summaries (one load when the four events belong to one read)
-    PgReadMeta mt[E];
-    mt[0] = O.meta[r[0]];
-#pragma unroll
-    for (int j = 1; j < E; ++j) { mt[j] = mt[0]; if (g0 + j <= last && r[j] != r[0]) mt[j] = O.meta[r[j]]; }
-    // round trip 3: the slot of the k-mer of matched bases [g, g+k): forward code (first base most significant) or its
-    // mirror, which is what the reference reads on RNA-oriented records (gmove.cpp:883, 899)
-    int32_t slot[E]; bool cand[E]; uint32_t idx[E];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        uint32_t fwd = 0, rev = 0; bool bad = false;
-#pragma unroll
-        for (uint32_t t = 0; t < 13; ++t) if (t < k) {
-            const uint32_t pos = j + t; // byte pos of the 16-byte window
-            const uint32_t b = (uint32_t)((pos < 8 ? blo >> (8 * pos) : bhi >> (8 * (pos - 8))) & 0xff);
-            bad |= b > 3;
-            fwd = (fwd << 2) | (b & 3u);
-            rev |= (b & 3u) << (2 * t);
-        }
-        const uint32_t n = mt[j].n; // 0 for skipped / failed reads
-        idx[j] = (uint32_t)(g0 + j - mt[j].o0);
-        const uint32_t e = idx[j] + W.sig_move_offset;
-        cand[j] = g0 + j <= last && n >= k && idx[j] <= n - k && e < n; // e >= n: end_raw_idx[e] == -1 (gmove.cpp:892-894)
-        const uint32_t code = mt[j].rna ? rev : fwd;
-        slot[j] = (cand[j] && !bad) ? (mt[j].rna ? W.table_u : W.table_t)[code] : -1;
-    }
-    uint32_t out[E];
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        out[j] = PG_INVALID_SLOT;
-        if (cand[j]) {
-            const bool rna = mt[j].rna != 0;
-            const uint32_t n = mt[j].n, m = mt[j].m, i = idx[j];
-            // pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M]
-            const int32_t M = W.pick_margin;
-            const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
-            const int32_t X = left + (int32_t)k + M, Y = left - M;
-            // indel_pos is never built: with cp(Z) = #{interior entries p < Z} = I/D ops in front of match Z-1 (0 for Z <= 0,
-            // all m for Z > n), the entries strictly between the event's bounds number cp(i+k+M) - cp(i-M+1) in BOTH
-            // orientations (the RNA list is the mirrored one), and the search result `lo` of the reference's loop is
-            // cp(i+k+M) on DNA-oriented records and m - cp(i-M+1) on RNA-oriented ones.
-            auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
-            const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
-            const uint32_t lo = rna ? m - cA : cB;       // first interior entry >= X
-            const bool prev_ok = lo == 0 ? (-mt[j].st_k <= Y) : (cA == cB); // the entry in front of it is <= Y
-            const bool pick = prev_ok && (lo < m || X <= mt[j].end_k + M);
-            if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) { // gmove.cpp:916-924
-                // accepted. Whether its window can be printed (gmove.cpp:928-944 is undefined for margin > start or an empty
-                // window) only matters if the event is KEPT: the reference never looks at the window of an event whose k-mer
-                // is already complete. k_rank_emit / k_kept_meta check it there.
-                out[j] = (uint32_t)slot[j];
-            }
-        }
-    }
-    *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]); // entries past n_ops are padding
+// one one-wave workgroup per LISTED read: the grid is the number of reads (the host does not know the list's length), workgroups
+// behind the list leave at once. (A persistent grid striding over the list compiles to 91 VGPRs instead of 48: the loop keeps the
+// event loop's values alive across reads. A caller that knows its batch holds matches only says so -- PG_BATCH_ALL_MATCHES -- and
+// the launch is skipped altogether.)
+template <bool TIXG> __global__ __launch_bounds__(64) void k_walk(PgDevBatch B, PgWalkParams W, PgWalkOut O) {
+    __shared__ WalkLds sm_store;
+    if (blockIdx.x >= O.gen_count[O.batch_id & 1u]) return;
+    walk_one_read<TIXG>(&sm_store, B, W, O, (uint32_t)__builtin_amdgcn_readfirstlane((int)O.gen_list[blockIdx.x]));
 }
 
-// Phase 2 of the fused k_walk: 64 * E events of ONE read -- matches T0 + E*lane .. + E-1 -- by the wave that walked it, from the
-// LDS window that holds the values of matches base .. base + PG_WALK_LDS_OPS - 1. Same arithmetic as k_events, with the read's
-// summary (n matches, m I/D ops, orientation, target range) in scalar registers instead of a look-up per event. E = events per
-// lane (2, 3 or 4): the kernel is bound by vector-instruction issue, so a short read spreads its events over as many lanes as
-// it can fill in one trip (130 ops: 44 lanes x 3 instead of 33 lanes x 4).
-template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
+// pick_this_kmer (gmove.cpp:204-211) over indel_pos = [-st_k, interior..., end_k + M] without the list: with cp(Z) = #{interior
+// entries p < Z} = I/D ops in front of match Z-1 (0 for Z <= 0, all m for Z > n), the entries strictly between the event's bounds
+// number cp(i+k+M) - cp(i-M+1) in BOTH orientations (the RNA list is the mirrored one), and the search result `lo` of the reference's
+// loop is cp(i+k+M) on DNA-oriented records and m - cp(i-M+1) on RNA-oriented ones. cA / cB: the two counts.
+__device__ __forceinline__ bool pick_kmer(uint32_t i, uint32_t k, int32_t M, uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, uint32_t cA, uint32_t cB) {
+    const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
+    const int32_t X = left + (int32_t)k + M, Y = left - M;
+    const uint32_t lo = rna ? m - cA : cB;                       // first interior entry >= X
+    const bool prev_ok = lo == 0 ? (-st_k <= Y) : (cA == cB);    // the entry in front of it is <= Y
+    return prev_ok && (lo < m || X <= end_k + M);
+}
+
+// The event loop of the generic walk: 64 * E events of ONE read -- matches T0 + E*lane .. + E-1 -- by the wave that walked it, from the
+// LDS window that holds the values of matches base .. base + PG_WALK_LDS_OPS - 1, with the read's summary (n matches, m I/D ops,
+// orientation, target range) in scalar registers. E = events per lane (2, 3 or 4): a short read spreads its events over as many lanes
+// as it can fill in one trip (130 ops: 44 lanes x 3 instead of 33 lanes x 4).
+template <int E, bool TIXG> __device__ __forceinline__ void walk_events_tile(const PgWalkParams &W, const PgWalkOut &O, const WalkLds *sm, uint64_t o0, uint32_t nops,
                                                                   uint32_t n, uint32_t m, bool rna, int32_t st_k, int32_t end_k, int lane, uint32_t base, uint32_t T0) {
     static_assert(E >= 2 && E <= 4, "the 16 codes fetched per lane cover E - 1 + k <= 16 matches");
     const uint32_t k = W.k;
@@ -426,14 +408,21 @@ template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkPa
     // the 2-bit codes of matches i0 .. i0+15 (match i0+p at bits 2p) and their "not ACGT/U" bits
     const uint32_t c2 = (uint32_t)(((uint64_t)sm->code[l0 >> 4] | ((uint64_t)sm->code[(l0 >> 4) + 1] << 32)) >> (2u * (l0 & 15u)));
     const uint32_t badbits = (uint32_t)(((uint64_t)sm->bad[l0 >> 5] | ((uint64_t)sm->bad[(l0 >> 5) + 1] << 32)) >> (l0 & 31u));
+    const uint32_t *__restrict__ g_tix = O.m_tix + o0; // TIXG: readable from index -front (pg_api.hip pads both ends)
     uint32_t len[E], tx_lo[E], tx_hi[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int32_t a = (int32_t)(i0 + j) - M;                     // match whose I/D count bounds the event on the left: used when >= 0
-        const uint32_t h = i0 + j + kM - 1 - base;                   // ... on the right: used when the match exists (< n)
         len[j] = sm->len[l0 + j + W.sig_move_offset];
-        tx_lo[j] = sm->tix[(a > 0 ? (uint32_t)a : 0u) - base];       // base <= max(i0 - M, 0): see the staging in k_walk
-        tx_hi[j] = sm->tix[h < PG_WALK_LDS_OPS ? h : PG_WALK_LDS_OPS - 1];
+        if (TIXG) {
+            const uint32_t h = i0 + j + kM - 1;                      // ... on the right: used when the match exists (< n)
+            tx_lo[j] = g_tix[a > 0 ? (uint32_t)a : 0u];
+            tx_hi[j] = g_tix[h < n ? h : n - 1];
+        } else {
+            const uint32_t h = i0 + j + kM - 1 - base;
+            tx_lo[j] = sm->tix[(a > 0 ? (uint32_t)a : 0u) - base];   // base <= max(i0 - M, 0): see the staging in walk_one_read
+            tx_hi[j] = sm->tix[h < PG_WALK_LDS_OPS ? h : PG_WALK_LDS_OPS - 1];
+        }
     }
     // the slot of the k-mer of matched bases [i, i+k) (mirrored on RNA-oriented records: gmove.cpp:883, 899)
     int32_t slot[E]; bool cand[E];
@@ -454,16 +443,12 @@ template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkPa
     for (int j = 0; j < E; ++j) {
         out[j] = PG_INVALID_SLOT;
         if (cand[j]) {
-            // pick_this_kmer (gmove.cpp:204-211) from the I/D counts: see k_events
             const uint32_t i = i0 + j;
-            const int32_t left = rna ? (int32_t)(n - i - k) : (int32_t)i;
-            const int32_t X = left + (int32_t)k + M, Y = left - M;
             auto cp = [&](int32_t Z, uint32_t tix_of_match_Zm1) -> uint32_t { return Z <= 0 ? 0u : ((uint32_t)Z > n ? m : tix_of_match_Zm1); };
             const uint32_t cA = cp((int32_t)i - M + 1, tx_lo[j]), cB = cp((int32_t)i + (int32_t)k + M, tx_hi[j]);
-            const uint32_t lo = rna ? m - cA : cB;
-            const bool prev_ok = lo == 0 ? (-st_k <= Y) : (cA == cB);
-            const bool pick = prev_ok && (lo < m || X <= end_k + M);
-            if (pick && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j]; // gmove.cpp:916-924
+            // accepted (gmove.cpp:916-924). Whether its window can be printed (gmove.cpp:928-944 is undefined for margin > start or an
+            // empty window) only matters if the event is KEPT: the emit kernels check it there.
+            if (pick_kmer(i, k, M, n, m, rna, st_k, end_k, cA, cB) && slot[j] >= 0 && len[j] <= W.max_dur && len[j] >= W.min_dur) out[j] = (uint32_t)slot[j];
         }
     }
     uint32_t *__restrict__ dst = O.ev_slot + o0; // uniform base, 32-bit lane offset; one 8/12/16-byte store at 4-byte alignment
@@ -473,10 +458,181 @@ template <int E> __device__ __forceinline__ void walk_events_tile(const PgWalkPa
 #pragma unroll
         for (int j = 0; j < E; ++j) v.v[j] = out[j];
         *reinterpret_cast<Vec *>(dst + i0) = v;
-    } else { // the read's last, partial group: the entries behind it belong to the next read's wave
+    } else { // the read's last, partial group: the entries behind it belong to the next read
 #pragma unroll
         for (int j = 0; j < E; ++j) if (i0 + j < nops) dst[i0 + j] = out[j];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_events: op-parallel. Thread t of workgroup w takes op indices g0 .. g0+3 of each of the workgroup's 4 tiles of 4096.
+// ---------------------------------------------------------------------------------------------------------------------
+// 16 sequence bytes -> 2-bit codes (byte q at bits 2q) + one "not A C G T/U" bit per byte, four bytes at a time:
+// code = ((x >> 1) & 3) ^ (((x >> 1) & 3) >> 1) maps A C G T U to 0 1 2 3 3; the letter a code stands for is rebuilt
+// (0x41 + 2 b0 + 6 b1 + 11 b0 b1) and compared with the byte, 'U' (= 'T' ^ 1) passing on RNA-oriented records only.
+__device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, uint32_t &code2, uint32_t &bad) {
+    code2 = 0; bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = w[q];
+        uint32_t y = (x >> 1) & 0x03030303u;
+        y ^= (y >> 1) & 0x01010101u;
+        const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u, b01 = b0 & b1;
+        const uint32_t expect = 0x41414141u + 2u * b0 + 6u * b1 + 11u * b01;
+        uint32_t d = x ^ expect;
+        if (rna) d &= ~b01; // 'U' against the 'T' of code 3
+        const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; // 0x80 in every non-zero byte
+        code2 |= ((y * 0x01041040u) >> 24) << (8 * q);
+        bad |= ((((nz >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * q);
+    }
+}
+
+struct EvCtx { // the read an event belongs to, and the 16 bases of the thread's group inside it
+    uint64_t o0, o1;
+    uint32_t r, n, kind; // kind: 0 dead (no events), 1 direct, 2 generic (events computed by k_walk)
+    bool rna; int32_t st_k, end_k;
+    uint32_t i_first;    // event index of the group's first op that belongs to this read
+    uint32_t code2, bad;
+};
+
+// COUNT: direct ranking -- also per-(tile, slot) counts of the accepted events into hist[slot][tile..tile+3]
+template <bool COUNT> __global__ __launch_bounds__(1024) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS : 1];
+    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k;
+    const int lane = lane_id();
+    const uint64_t N = B.n_ops;
+    if (COUNT) { for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 1024) (&cnt[0][0])[i] = 0; __syncthreads(); }
+    const uint64_t seq_total = B.seq_off[B.n_reads];
+    const uint32_t *__restrict__ seq32 = reinterpret_cast<const uint32_t *>(B.seq); // 4-byte aligned (checked by the host)
+    const uint64_t seq_last_dw = seq_total ? (seq_total - 1) >> 2 : 0;
+
+    // window of the group's part inside read `c.r`, whose first event index there is c.i_first: the 16 bases
+    auto load_window = [&](EvCtx &c, const PgReadMeta &mt) {
+        // DNA-oriented: bases i .. i+15 are sequence bytes s0+i ..; RNA-oriented: match p is byte s0+slen-1-p, so the window is the 16
+        // bytes that END at s0+slen-1-i (byte q of the window = match i+15-q). Bytes outside the read belong to non-candidates.
+        const int64_t a = c.rna ? (int64_t)(mt.s0 + mt.slen) - 16 - (int64_t)c.i_first : (int64_t)(mt.s0 + c.i_first);
+        const int64_t adw = a >> 2; // floor
+        const uint32_t sh = (uint32_t)(a & 3) * 8u;
+        uint32_t d[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > (int64_t)seq_last_dw ? (int64_t)seq_last_dw : x); d[q] = seq_total ? seq32[x] : 0u; }
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
+        codes_of_16(w, c.rna, c.code2, c.bad);
+    };
+    auto open_read = [&](EvCtx &c, uint32_t r, uint64_t g_first) {
+        const PgReadMeta mt = O.meta[r];
+        c.r = r; c.o0 = mt.o0; c.o1 = mt.o0 + mt.nops; c.n = mt.nops; c.rna = (mt.flags & PG_RM_RNA) != 0; c.st_k = mt.st_k; c.end_k = mt.end_k;
+        const bool generic = O.gen_flag[r] == O.batch_id;
+        const bool skip = O.oor && O.oor[r];
+        // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has no
+        // events here and fails the batch on the host (pg_api.hip: check_read_errors)
+        c.kind = (!(mt.flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((mt.flags & PG_RM_DIRECT_OK) ? 1u : 0u));
+        c.i_first = (uint32_t)(g_first - mt.o0);
+        c.code2 = 0; c.bad = 0xffffu;
+        if (c.kind == 1u) load_window(c, mt);
+    };
+
+#pragma unroll 1
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint64_t g0 = (uint64_t)(tile0 + q) * PG_SORT_TILE + (uint64_t)tid * 4u;
+        uint32_t out[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
+        uint32_t opn[4] = {0, 0, 0, 0}; // op_n of the group's own ops
+        if (g0 + 4 <= N) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_n + g0); opn[0] = v.x; opn[1] = v.y; opn[2] = v.z; opn[3] = v.w; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
+        }
+        // sums of op_n over the wave's 256-op block (all 64 lanes take part): cum at 4-op granularity, the block total, and for a
+        // read that starts in this group the sum in front of its first op (PgReadMeta::pcum0). Ops of ANY kind count: the emit
+        // kernels only take differences inside one read.
+        const uint32_t s4 = opn[0] + opn[1] + opn[2] + opn[3];
+        const uint32_t inc = wave_incl_scan_u32(s4);
+        const uint32_t pre[4] = {inc - s4, inc - s4 + opn[0], inc - s4 + opn[0] + opn[1], inc - opn[3]};
+        if (g0 < N) {
+            O.cum[g0 >> 2] = pre[0];
+            if (lane == WAVE - 1 || g0 + 4 >= N) O.btot[g0 >> 8] = inc;
+            EvCtx c;
+            open_read(c, owner_of(B, O, g0), g0);
+            if (c.o0 == g0) O.meta[c.r].pcum0 = pre[0];
+            uint32_t jb = 0; // index inside the group of the first op of the current read
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t g = g0 + j;
+                if (g >= N) break;
+                if (g >= c.o1) { // the next read (with ops) starts inside the group: a few threads per tile
+                    uint32_t r = c.r + 1;
+                    while (r + 1 < B.n_reads && B.op_off[r + 1] <= g) ++r;
+                    open_read(c, r, g);
+                    O.meta[r].pcum0 = pre[j];
+                    jb = (uint32_t)j;
+                }
+                if (opn[j] >= PG_OP_N_LIMIT && c.kind == 1u) report_error(O, c.r, PGR_ERR_RANGE);
+                if (c.kind == 2u) { out[j] = O.ev_slot[g]; continue; } // computed by k_walk
+                if (c.kind != 1u) continue;
+                const uint32_t i = (uint32_t)(g - c.o0), e = i + W.sig_move_offset, jj = (uint32_t)j - jb;
+                if (!(i <= c.n - k && e < c.n)) continue; // not an event of the read (gmove.cpp:891-894); n >= k for direct reads
+                // the k bases: DNA-oriented window byte jj+t = base i+t, RNA-oriented window byte 16-jj-k+t = base t of the k-mer
+                // string; either way a field of k 2-bit groups with the FIRST base lowest, reversed into the table's code
+                const uint32_t pos = c.rna ? 16u - jj - k : jj;
+                const uint32_t field = (c.code2 >> (2u * pos)) & ((1u << (2u * k)) - 1u), badf = (c.bad >> pos) & ((1u << k) - 1u);
+                const uint32_t x = __builtin_bitreverse32(field);
+                const uint32_t code = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
+                if (badf) continue;
+                const int32_t slot = (c.rna ? W.table_u : W.table_t)[code];
+                // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
+                const uint32_t dur = W.sig_move_offset == 0 ? opn[j] : B.op_n[g + W.sig_move_offset];
+                // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
+                if (slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, c.n, 0u, c.rna, c.st_k, c.end_k, 0u, 0u)) out[j] = (uint32_t)slot;
+            }
+            if (g0 + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
+            else { for (int j = 0; j < 4 && g0 + j < N; ++j) O.ev_slot[g0 + j] = out[j]; }
+        }
+        if (COUNT) {
+            const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (out[j] != PG_INVALID_SLOT) atomicAdd(&cnt[q][out[j] & mask], 1u);
+        }
+    }
+    if (COUNT) {
+        __syncthreads();
+        for (uint32_t d = tid; d < (1u << nbits); d += 1024)
+            *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
+    }
+}
+
+// SAM/BAM front-end (gmove.cpp:1149-1160): a read with an out-of-range sample is a skipped read (no events, no ':')
+__global__ __launch_bounds__(256) void k_apply_oor(uint32_t n_reads, PgWalkOut O) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads && O.oor[r] && O.status[r] == PGR_OK) O.status[r] = PGR_SKIPPED;
+}
+
+// what the emit kernels need of the read of a kept event
+struct KeptRead { uint64_t o0; uint32_t qs, pcum0, L; bool generic; };
+__device__ __forceinline__ KeptRead kept_read(const PgWalkOut &O, uint32_t rd) {
+    const PgReadMeta *mt = O.meta + rd;
+    KeptRead k; k.o0 = mt->o0; k.qs = (uint32_t)mt->qs; k.pcum0 = mt->pcum0; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
+    return k;
+}
+// window start and length of a kept event (gmove.cpp:854-855) at op index g of read rd: from the generic walk's arrays, or, for a
+// direct read, op_n itself and the block sums k_events left. Returns false when the sample index leaves the reference's int range.
+__device__ __forceinline__ bool kept_window(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const KeptRead &kr, uint64_t g, uint32_t &start, uint32_t &len) {
+    const uint64_t ge = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
+    if (kr.generic) { start = O.m_start[ge]; len = O.m_len[ge]; return true; }
+    len = B.op_n[ge];
+    uint32_t pge = O.cum[ge >> 2]; // P(ge) = sum of op_n over [ge & ~255, ge)
+    for (uint64_t y = ge & ~3ull; y < ge; ++y) pge += B.op_n[y];
+    uint64_t sum;
+    const uint64_t b0 = kr.o0 >> 8, b1 = ge >> 8;
+    if (b0 == b1) sum = (uint64_t)(pge - kr.pcum0);
+    else {
+        sum = (uint64_t)(O.btot[b0] - kr.pcum0) + pge;
+        for (uint64_t b = b0 + 1; b < b1; ++b) sum += O.btot[b];
+    }
+    const uint64_t st = (uint64_t)kr.qs + sum;
+    start = (uint32_t)st;
+    return st + len <= 0x7fffffffull;
 }
 
 // =====================================================================================================
@@ -535,32 +691,8 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
     }
 }
 
-// exclusive prefix over tiles, one wave per digit; totals[d] = number of keys with that digit
-// direct mode (slot == digit): counts per (tile, slot) only -- k_rank_emit recounts per wave for the few tiles it
-// really places events from. Four tiles per workgroup: their counts of one slot leave as ONE 16-byte store into
-// hist[slot][tile0..tile0+3] (n_tiles is a multiple of 4), a quarter of the scattered write transactions.
-__global__ __launch_bounds__(1024) void k_rank_count_direct(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_tiles,
-                                                            uint32_t *__restrict__ hist) {
-    // 1024 threads: the four tiles of the workgroup are counted side by side, one per group of four waves (as 256 threads
-    // walking through the four tiles one after the other the launch held 1.5 waves per SIMD and waited on its own loads)
-    __shared__ uint32_t cnt[4][PG_RANK_MAX_DIGITS];
-    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, tt = tid >> 8, t = tid & 255u;
-    const uint32_t ndig = 1u << nbits, mask = ndig - 1u;
-    for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 1024) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    {
-        const uint64_t base = (uint64_t)(tile0 + tt) * PG_SORT_TILE + t; // counts are order-free: plain coalesced rows
-        uint32_t kv[PG_SORT_TILE / 256];
-#pragma unroll
-        for (int i = 0; i < PG_SORT_TILE / 256; ++i) { const uint64_t idx = base + (uint64_t)i * 256; kv[i] = idx < n ? keys[idx] : PG_INVALID_SLOT; }
-#pragma unroll
-        for (int i = 0; i < PG_SORT_TILE / 256; ++i) if (kv[i] != PG_INVALID_SLOT) atomicAdd(&cnt[tt][kv[i] & mask], 1u);
-    }
-    __syncthreads();
-    for (uint32_t d = tid; d < ndig; d += 1024)
-        *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
-}
-
+// exclusive prefix over tiles, one wave per digit; totals[d] = number of keys with that digit. Direct mode (slot == digit): the
+// per-(tile, slot) counts come from k_events<true>; k_rank_emit recounts per wave for the few tiles it really places events from.
 // running / limit / tile_last (direct mode, may be null): with base = the context's own running counts -- what pg_submit
 // collects with -- the last tile that still places an event of this slot falls out of the same pass: keep = min(cnt,
 // room), room = limit - base; it is the largest tile whose exclusive prefix is < room when cnt >= room, else the last
@@ -666,10 +798,11 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t *__restrict
 // window of a kept event (gmove.cpp:928-937) and its bookkeeping
 __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K,
                                            uint64_t e, uint64_t g) {
-    const uint32_t rd = O.m_read[g];
-    const uint64_t gm = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
-    const uint32_t start = O.m_start[gm], len = O.m_len[gm];
-    const uint64_t L = O.meta[rd].L;
+    const uint32_t rd = owner_of(B, O, g);
+    const KeptRead kr = kept_read(O, rd);
+    uint32_t start, len;
+    if (!kept_window(B, W, O, kr, g, start, len)) { report_error(O, rd, PGR_ERR_RANGE); start = 0; len = 0; }
+    const uint64_t L = kr.L;
     const uint64_t we64 = (uint64_t)start + len + W.print_margin;
     uint32_t we = (uint32_t)(we64 > L ? L : we64), ws = start - W.print_margin;
     // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
@@ -745,28 +878,29 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         const uint32_t rank = b + (uint32_t)__popcll(peers & lanemask_lt());
         dst[row] = (valid && rank < kp[row]) ? eo[row] + rank : 0xFFFFFFFFu;
     }
-    // phase 2: the kept events' windows (gmove.cpp:928-937). Staged across rows so that every stage is one set of
-    // independent loads: owning read + window of match i+off, then the read's length, then the stores.
-    uint32_t rd[PG_EMIT_ROWS], ws[PG_EMIT_ROWS], wl[PG_EMIT_ROWS];
+    // phase 2: the kept events' windows (gmove.cpp:928-937). Staged across rows so that every stage is one set of independent
+    // loads: the owning read, then its record, then the window (start / length arrays of the generic walk, or op_n and k_events' block
+    // sums), then the stores.
+    uint32_t rd[PG_EMIT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) rd[row] = dst[row] != 0xFFFFFFFFu ? owner_of(B, O, base + (uint64_t)row * WAVE + lane) : 0u;
+    KeptRead kr[PG_EMIT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) if (dst[row] != 0xFFFFFFFFu) kr[row] = kept_read(O, rd[row]);
+    uint32_t ws[PG_EMIT_ROWS], wl[PG_EMIT_ROWS]; bool okr[PG_EMIT_ROWS];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
-        rd[row] = 0; ws[row] = 0; wl[row] = 0;
-        if (dst[row] != 0xFFFFFFFFu) {
-            const uint64_t g = base + (uint64_t)row * WAVE + lane;
-            rd[row] = O.m_read[g];
-            ws[row] = O.m_start[g + W.sig_move_offset]; // the event's window is that of match i + sig_move_offset
-            wl[row] = O.m_len[g + W.sig_move_offset];
-        }
+        ws[row] = 0; wl[row] = 0; okr[row] = true;
+        if (dst[row] != 0xFFFFFFFFu) okr[row] = kept_window(B, W, O, kr[row], base + (uint64_t)row * WAVE + lane, ws[row], wl[row]);
     }
-    uint32_t Lr[PG_EMIT_ROWS];
-#pragma unroll
-    for (int row = 0; row < PG_EMIT_ROWS; ++row) Lr[row] = dst[row] != 0xFFFFFFFFu ? O.meta[rd[row]].L : 0u;
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         if (dst[row] == 0xFFFFFFFFu) continue;
+        if (!okr[row]) { report_error(O, rd[row], PGR_ERR_RANGE); ws[row] = 0; wl[row] = 0; }
+        const uint32_t Lr = kr[row].L;
         uint32_t start = ws[row] - W.print_margin;
         const uint64_t we64 = (uint64_t)ws[row] + wl[row] + W.print_margin;
-        uint32_t we = (uint32_t)(we64 > Lr[row] ? Lr[row] : we64);
+        uint32_t we = (uint32_t)(we64 > Lr ? Lr : we64);
         // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
         if (W.print_margin > ws[row] || we <= start) { report_error(O, rd[row], PGR_ERR_WINDOW); start = we = 0; }
         K.ev_len[dst[row]] = we - start;
@@ -1091,7 +1225,9 @@ __device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, c
     o.c_lo = p.c_lo; o.span = p.span; o.z0 = p.z0;
     const bool skip = (needed && !needed[r]) || o.end == o.beg;
     o.mode = skip ? PG_STAT_SKIP : (p.status != 0 ? PG_STAT_BAD : PG_STAT_RUN);
-    o.offset = offset; o.scale = scale; o.inv = 1.0 / scale; o.pad = 0;
+    o.offset = offset; o.scale = scale; o.inv = 1.0 / scale;
+    o.sym = (p.status == 0 && p.span > 0 && pg_sym_guard(offset, scale, pg_pa(p.c_lo, offset, scale), pg_pa(p.c_lo + p.span - 1, offset, scale))) ? 1u : 0u;
+    o.pad = 0;
     rec[r] = o;
     stat_status[r] = 0;
 }
@@ -1398,13 +1534,58 @@ __device__ __forceinline__ bool stats_select_fast(const uint32_t *hist, int lane
     return true;
 }
 
+// The usual read in ~1/5 of the instructions again (pg_select.h, PgSym): the median is a sample, so the deviations come in
+// rings of codes m - t / m + t around its bin, and the k-th smallest one is settled by W(t) = samples inside ring t: two 64-lane
+// rounds of two prefix look-ups each find t*, one exact comparison of the ring's two values decides. False = not applicable
+// (median in the zero-filled class, the zero-filled class inside ring t*, degenerate calibration): the caller searches.
+template <int BINS>
+__device__ __forceinline__ bool stats_select_sym(const uint32_t *hist, int lane, const PgReadPlan &pl, uint64_t L, double offset, double scale,
+                                                 double &med_out, double &mad_out, uint32_t lane_end) {
+    using C = StatsCfg<BINS>;
+    using Pre = typename C::Pre;
+    if constexpr (C::GLOBAL) return false;
+    else {
+        PgSel<Pre> sel;
+        sel.pre = Pre{hist}; sel.span = pl.span; sel.c_lo = pl.c_lo; sel.z0 = pl.z0; sel.L = L; sel.offset = offset; sel.scale = scale;
+        sel.begin();
+        if (sel.zmed || sel.span <= 0) return false;
+        constexpr int BPL = C::BPL;
+        // the median's bin from the prefix at the end of every lane's bins (still in a register): the lane, then the bin inside it
+        const uint64_t lm = __ballot(lane_end > sel.jmed); // jmed < nV <= the last lane's value: never empty
+        const int l0 = __ffsll((long long)lm) - 1;
+        const int b = l0 * BPL + (lane < BPL ? lane : BPL - 1);
+        const uint64_t bmask = __ballot(lane < BPL && sel.pre[b < sel.span ? b : sel.span - 1] > sel.jmed);
+        const int bm = l0 * BPL + __ffsll((long long)bmask) - 1;
+        sel.set_median(bm);
+        double best = 0.0;
+        if (L > 1) {
+            sel.dZ = fabs(0.0 - sel.med); sel.need = sel.k + 1;
+            const PgSym<Pre> y{&sel, bm};
+            const int tm = y.t_max();
+            constexpr int STEP = BINS / WAVE; // 64 * STEP >= every possible t
+            int t1 = STEP * lane + STEP - 1; t1 = t1 > tm ? tm : t1;
+            const uint64_t b1 = __ballot(y.W(t1) >= sel.need);
+            if (!b1) return false; // the in-range samples do not reach the rank: the zero-filled class decides
+            const int base_t = STEP * (__ffsll((long long)b1) - 1);
+            int t2 = base_t + (lane & (STEP - 1)); t2 = t2 > tm ? tm : t2;
+            const uint64_t b2 = __ballot(lane < STEP && y.W(t2) >= sel.need); // its last candidate is round 1's: never empty
+            int ts = base_t + __ffsll((long long)b2) - 1; ts = ts > tm ? tm : ts;
+            if (!y.decide(ts, best)) return false;
+        }
+        const PgMedMad mm = sel.finish(best);
+        med_out = mm.med; mad_out = mm.mad;
+        return true;
+    }
+}
+
 // everything after the histogram is complete: prefix, the out-of-range flag, the selection, the two stores
 template <int BINS>
 __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t r, const PgStatRec &m, double *__restrict__ med,
-                                             double *__restrict__ mad, int win, uint8_t *__restrict__ oor, int range_only) {
+                                             double *__restrict__ mad, int win, uint8_t *__restrict__ oor, int range_only PG_PROBE_PARAM) {
     using Pre = typename StatsCfg<BINS>::Pre;
     const uint64_t L = m.end - m.beg;
     const uint32_t lane_end = stats_prefix<BINS>(hist, lane, (uint32_t)m.span);
+    PG_MARK(0, 3); // prefix scan
     if (oor) { // SAM/BAM front-end: a read with ANY out-of-range sample is skipped as a whole (gmove.cpp:1149-1160)
         const uint32_t in_range = m.span ? Pre{hist}[(int)m.span - 1] : 0u;
         if (lane == 0) oor[r] = in_range != (uint32_t)L;
@@ -1412,7 +1593,22 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
     if (range_only) return;
     PgReadPlan pl; pl.c_lo = m.c_lo; pl.span = m.span; pl.z0 = m.z0; pl.status = 0;
     double m0, m1;
-    if (win == 0 || !stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv)) { // win == 0: tests of the general path
+    // win == 0: tests of the general path. m.sym: pg_sym_guard of this read's calibration (k_read_plan)
+#ifdef PG_NO_SYM
+    const bool try_sym = false;
+#else
+    const bool try_sym = m.sym != 0;
+#endif
+#ifdef PG_PROBE_NO_SELECT // timing probe only: what the kernel costs without any selection (results are garbage)
+    if (lane == 0) { med[r] = (double)lane_end; mad[r] = 1.0; }
+    return;
+#endif
+#ifdef PG_PROBE_SYM_ONLY // measurement: symmetric path, then straight to the general search
+    if (win == 0 || !(try_sym && stats_select_sym<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end))) {
+#else
+    if (win == 0 || !((try_sym && stats_select_sym<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end)) ||
+                      stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv))) {
+#endif
 #ifdef PG_COUNT_FALLBACKS
         if (lane == 0) atomicAdd(&g_pg_fallbacks, 1ull);
 #endif
@@ -1470,7 +1666,10 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
     } else {
         for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<BINS>(hist, (int)sig[s2], c_lo, lane);
     }
-    stats_finish<BINS>(hist, lane, r, m, med, mad, win, oor, range_only);
+#ifdef PG_PHASE_PROBE
+    unsigned long long pg_t_ = 0, pg_acc_[8]; // the rare launches are not profiled
+#endif
+    stats_finish<BINS>(hist, lane, r, m, med, mad, win, oor, range_only PG_PROBE_ARG);
 }
 
 #ifndef PG_STATS_SETPRIO
@@ -1481,14 +1680,21 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 // streams at 5.9 TB/s whether the waves are launched per read or kept persistent with a rolling register prefetch of the
 // next read; the persistent form only added bookkeeping and registers (fewer resident waves), so the hardware
 // dispatcher does the load balancing and the overlap comes from eight resident waves per SIMD.
-__global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
+#ifndef PG_STATS_WPB
+#define PG_STATS_WPB 1 // reads (= independent waves, no barrier between them) per workgroup
+#endif
+__global__ __launch_bounds__(64 * PG_STATS_WPB) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
                                                    int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
                                                    int32_t *__restrict__ wide_count) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<1024>::LDS_WORDS];
-    const uint32_t r = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[PG_STATS_WPB][StatsGeom<1024>::LDS_WORDS];
+    uint32_t *hist = hist_all[threadIdx.x >> 6];
+    const uint32_t r = blockIdx.x * PG_STATS_WPB + (threadIdx.x >> 6);
+    if (r >= B.n_reads) return;
     const int lane = lane_id();
+    PG_PROBE_BEGIN(0);
     const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
+    PG_MARK(0, 0); // the record
     if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, status, err); return; }
     if (m.span > 1024) { if (lane == 0) stats_list_wide(r, m.span, B.n_reads, wide_list, wide_count); return; } // for the wider launch
     const int16_t *__restrict__ sig = B.sig;
@@ -1508,8 +1714,17 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec
 #pragma unroll
             for (int u = 0; u < 8; ++u) q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
             if (p == 0) stats_zero<1024>(hist, lane); // behind the first pass's loads: the histogram is cleared while they are in flight
+            PG_MARK(0, 1); // the samples have arrived
+#ifdef PG_PROBE_NO_BIN // timing probe only: the samples are consumed, nothing is binned (results are garbage)
+            { int acc_ = 0;
+#pragma unroll
+              for (int u = 0; u < 8; ++u) acc_ ^= q[u].x ^ q[u].y ^ q[u].z ^ q[u].w;
+              if (acc_ == 0x12345678) hist[lane] = 1; }
+#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) if ((uint32_t)(u * WAVE + lane) <= last) stats_bin8<1024>(hist, q[u], c2, cap2);
+#endif
+            PG_MARK(0, 2); // binned
         }
         if ((va << 3) != beg || (vb << 3) != end) {
             for (uint64_t s2 = beg + lane; s2 < (va << 3); s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
@@ -1520,7 +1735,9 @@ __global__ __launch_bounds__(64) void k_read_stats(PgDevBatch B, const PgStatRec
         for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
     }
     if (PG_STATS_SETPRIO) __builtin_amdgcn_s_setprio(PG_STATS_SETPRIO); // the selection is a serial chain: let it through in front of the streaming waves
-    stats_finish<1024>(hist, lane, r, m, med, mad, win, oor, range_only);
+    stats_finish<1024>(hist, lane, r, m, med, mad, win, oor, range_only PG_PROBE_ARG);
+    PG_MARK(0, 4); // selection + stores (slot 3: the prefix scan, marked inside stats_finish)
+    PG_PROBE_END(0, r);
 }
 
 // The rare reads: in-range interval wider than 1024 codes. ONE launch covers both lists (usually both are empty, and an
@@ -1638,16 +1855,36 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
     else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_start, samp_off, scaling, pa_min, pa_max, med, mad, samples);
 }
 
-__global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *__restrict__ err, uint8_t *__restrict__ read_needed,
+__global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *__restrict__ read_needed,
                                                     uint64_t *__restrict__ running, uint32_t n_slots, int zero_running,
                                                     int32_t *__restrict__ stat_flags, PgDevBatch B, double pa_min, double pa_max,
-                                                    PgStatRec *__restrict__ plan_rec, int32_t *__restrict__ stat_status) {
+                                                    PgStatRec *__restrict__ plan_rec, int32_t *__restrict__ stat_status,
+                                                    PgWalkParams W, PgWalkOut O, int force_generic, int op_t_aligned) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_reads) read_head_one(B, W, O, i, force_generic);
     if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status); // eager statistics: see read_plan_one
-    if (i == 0) { err[0] = INT_MAX; err[1] = (n_reads ? B.op_off[n_reads] : B.n_ops) != B.n_ops; } // err[1]: pg_batch.n_ops is wrong
+    if (i == 0) {
+        O.layout_err[0] = (n_reads ? B.op_off[n_reads] : B.n_ops) != B.n_ops; // pg_batch.n_ops is wrong
+        O.gen_count[(O.batch_id + 1u) & 1u] = 0; // the next batch's list
+    }
     if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; } // as k_stat_flags_init
     if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
+    // op-parallel part: 16 ops per thread; any op that is not a match (or not an op at all) sends its read to the generic walk
+    const uint64_t a = (uint64_t)i * 16u;
+    if (a < B.n_ops && n_reads) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (op_t_aligned && a + 16 <= B.n_ops) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_t + a); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else for (uint64_t x = a; x < a + 16 && x < B.n_ops; ++x) w[(x - a) >> 2] |= (uint32_t)B.op_t[x] << (8 * ((x - a) & 3));
+        if (w[0] | w[1] | w[2] | w[3]) {
+            uint32_t last = 0xffffffffu;
+            for (uint32_t x = 0; x < 16; ++x)
+                if ((w[x >> 2] >> (8 * (x & 3))) & 0xffu) {
+                    const uint32_t r = owner_search(B, a + x);
+                    if (r != last) { list_generic(O, r); last = r; }
+                }
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1658,25 +1895,40 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, int32_t *_
 #define PG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 #define PG_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, int32_t *err, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
+hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf,
-                          int32_t *stat_status) {
-    const uint32_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
-    PG_LAUNCH(k_batch_init, dim3((n + 255) / 256), dim3(256), 0, st, n_reads, err, read_needed, running, n_slots, zero_running,
-                       stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
+                          int32_t *stat_status, const PgWalkParams &W, const PgWalkOut &O, int force_generic) {
+    uint64_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
+    const uint64_t n_op_threads = (B.n_ops + 15) / 16;
+    if (n_op_threads > n) n = n_op_threads;
+    const int op_t_aligned = ((uintptr_t)B.op_t & 15) == 0;
+    PG_LAUNCH(k_batch_init, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n_reads, read_needed, running, n_slots, zero_running,
+              stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status, W, O, force_generic, op_t_aligned);
     return hipSuccess;
 }
 
-hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, bool fused) {
+hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
     if (B.n_reads == 0) return hipSuccess;
-    if (fused) PG_LAUNCH(k_walk<true>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
+    // the LDS window of the event loop holds 256 events plus the reach of pick_this_kmer on both sides: wider margins read the I/D
+    // counts from global memory
+    if (W.pick_margin > 100) PG_LAUNCH(k_walk<true>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
     else PG_LAUNCH(k_walk<false>, dim3(B.n_reads), dim3(64), 0, st, B, W, O);
     return hipSuccess;
 }
 
-hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
-    if (B.n_ops == 0) return hipSuccess;
-    PG_LAUNCH(k_events, dim3((uint32_t)((B.n_ops + 256 * PG_EV_PER_THREAD - 1) / (256 * PG_EV_PER_THREAD))), dim3(256), 0, st, B, W, O);
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist) {
+    if (B.n_reads == 0 || B.n_ops == 0) return hipSuccess;
+    const uint32_t n_tiles = pg_tiles(B.n_ops, hist != nullptr);
+    const uint32_t blocks = (n_tiles + 3) / 4;
+    int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
+    if (hist) PG_LAUNCH(k_events<true>, dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
+    else PG_LAUNCH(k_events<false>, dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, (uint32_t *)nullptr);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_apply_oor(hipStream_t st, const PgDevBatch &B, const PgWalkOut &O) {
+    if (B.n_reads == 0 || !O.oor) return hipSuccess;
+    PG_LAUNCH(k_apply_oor, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B.n_reads, O);
     return hipSuccess;
 }
 
@@ -1686,8 +1938,7 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
                                  uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
-    if (n_tiles) {
-        PG_LAUNCH(k_rank_count_direct, dim3(n_tiles / 4), dim3(1024), 0, st, ev_slot, (uint32_t)n, nbits, n_tiles, S.hist);
+    if (n_tiles) { // the counts are in S.hist (k_events<true>)
         PG_LAUNCH(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
@@ -1799,7 +2050,7 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, c
     if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     if (bins <= 1024) {
-        PG_LAUNCH(k_read_stats, dim3(B.n_reads), dim3(64), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
+        PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
     } else { // the wide and huge lists are usually empty: a small grid strides over them
         // the blocks stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
         const uint32_t want = wide_blocks_hint < 64 ? 64u : (wide_blocks_hint > 2048 ? 2048u : wide_blocks_hint);

@@ -207,6 +207,65 @@ struct PgSel {
     }
 };
 
+// ---- the symmetric path: the usual read in ~1/5 of the instructions of the general search ---------------------------
+// When the median is a sample (not the zero-filled class) it is the value of one code bin m: med == pA(c_lo + m) bit for
+// bit, and the deviation of code m +- t is t * scale up to a few ulps. With scale well above those ulps (pg_sym_guard) the
+// deviations of ring t (codes m - t and m + t) lie strictly between those of rings t - 1 and t + 1, so sorted(|x - med|)
+// is: ring 0, ring 1, ... with only the ORDER INSIDE a ring left to rounding. Hence with W(t) = samples in bins
+// [m - t, m + t] (two prefix look-ups), t* = least t with W(t) >= k + 1, the k-th smallest deviation is one of the (at
+// most) two exact values of ring t*: the smaller one a if W(t* - 1) + count(a) >= k + 1, else the larger one. The
+// zero-filled class (deviation dZ = |0 - med|) must lie strictly above ring t*, else the caller takes the general path.
+// Every double compared or returned is still produced by the reference's expressions (dev()).
+PG_HD bool pg_sym_guard(double offset, double scale, double pa_first, double pa_last) {
+    // ring separation scale*(1 - 2^-11) must dominate the rounding of (code + offset) [<= 2^-13 for |.| < 2^40], of the
+    // product and of the difference [a few ulps of the largest in-range |pA|]
+    const double pmax = fabs(pa_first) > fabs(pa_last) ? fabs(pa_first) : fabs(pa_last);
+    return fabs(offset) < 1099511627776.0 && scale * 1099511627776.0 > pmax + 1.0; // NaN fails both
+}
+template <class PrePtr> struct PgSym {
+    const PgSel<PrePtr> *s;
+    int m; // bin of the median
+    PG_HD uint32_t W(int t) const { return s->P(m + t) - s->P(m - t - 1); } // P clamps on both sides
+    PG_HD int t_max() const { const int a = m, b = s->span - 1 - m; return a > b ? a : b; }
+    // the decision once t* is known (W(ts) >= need > W(ts - 1)); false = the zero-filled class interferes
+    PG_HD bool decide(int ts, double &best) const {
+        const bool has_up = m + ts < s->span, has_dn = ts > 0 && m - ts >= 0;
+        const double du = has_up ? fabs(pg_pa(s->c_lo + m + ts, s->offset, s->scale) - s->med) : 0.0;
+        const double dd = has_dn ? fabs(pg_pa(s->c_lo + m - ts, s->offset, s->scale) - s->med) : 0.0;
+        const uint32_t hu = has_up ? s->P(m + ts) - s->P(m + ts - 1) : 0u, hd = has_dn ? s->P(m - ts) - s->P(m - ts - 1) : 0u;
+        const uint32_t below = ts > 0 ? W(ts - 1) : 0u;
+        double lo, hi; uint32_t hlo;
+        if (has_up && has_dn) { const bool up_first = du <= dd; lo = up_first ? du : dd; hi = up_first ? dd : du; hlo = up_first ? hu : hd; if (du == dd) hlo = hu + hd; }
+        else { lo = hi = has_up ? du : dd; hlo = hu + hd; }
+        if (s->nZ > 0 && !(s->dZ > hi)) return false;
+        best = below + hlo >= s->need ? lo : hi;
+        return true;
+    }
+};
+// scalar driver of the symmetric path (host tests): false = not applicable, take pg_medmad_from_prefix
+template <class PrePtr>
+PG_HD bool pg_medmad_sym(PrePtr pre, const PgReadPlan &pl, uint64_t L, double offset, double scale, PgMedMad &out) {
+    PgSel<PrePtr> s;
+    s.pre = pre; s.span = pl.span; s.c_lo = pl.c_lo; s.z0 = pl.z0; s.L = L; s.offset = offset; s.scale = scale;
+    s.begin();
+    if (s.zmed || s.span <= 0) return false;
+    if (!pg_sym_guard(offset, scale, pg_pa(pl.c_lo, offset, scale), pg_pa(pl.c_lo + pl.span - 1, offset, scale))) return false;
+    int bm; { int lo = 0, hi = s.span; while (lo < hi) { int mid = (lo + hi) >> 1; if (s.med_pred(mid)) hi = mid; else lo = mid + 1; } bm = lo; }
+    s.set_median(bm);
+    double best = 0.0;
+    if (L > 1) {
+        s.dZ = fabs(0.0 - s.med); s.need = s.k + 1;
+        PgSym<PrePtr> y{&s, bm};
+        const int tm = y.t_max();
+        if (y.W(tm) < s.need) return false; // the in-range samples alone do not reach the rank: the zero-filled class decides
+        int lo = 0, hi = tm; // least t with W(t) >= need
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (y.W(mid) >= s.need) hi = mid; else lo = mid + 1; }
+        if (!y.decide(lo, best)) return false;
+    }
+    out = s.finish(best);
+    return true;
+}
+
 // scalar driver (binary searches): host tests and the reference point for the 64-lane driver
 template <class PrePtr>
 PG_HD PgMedMad pg_medmad_from_prefix(PrePtr pre, const PgReadPlan &pl, uint64_t L, double offset, double scale) {

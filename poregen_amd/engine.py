@@ -89,6 +89,7 @@ class Batch:
     op_off: object
     on_device: bool = False
     n_ops: int = 0   # device batches: op_off[n_reads] when known (pg_batch.n_ops); 0 = the library reads it back (one sync per call)
+    all_matches: bool = False  # the batch holds match ops only and the caller vouches for it (PG_BATCH_ALL_MATCHES, verified on the device)
 
     def validate_host(self):
         for name, dt in _BATCH_FIELDS:
@@ -107,7 +108,7 @@ class Batch:
             if name == "sig":  # 16-byte slack so the tail vector of the last read stays inside the allocation
                 t = torch.cat([t, torch.zeros(8, dtype=t.dtype)])
             kw[name] = t.to(device)
-        return Batch(n_reads=self.n_reads, on_device=True, n_ops=int(self.op_off[-1]), **kw)
+        return Batch(n_reads=self.n_reads, on_device=True, n_ops=int(self.op_off[-1]), all_matches=not bool(np.any(self.op_t)), **kw)
 
     def slice_reads(self, lo: int, hi: int) -> "Batch":
         """Host batch holding reads [lo, hi) (used to shard a PAF-ordered batch across ranks)."""
@@ -251,6 +252,7 @@ def _c_batch(b: "Batch"):
     cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
     cb.n_reads = b.n_reads
     cb.n_ops = b.n_ops if b.on_device else 0
+    cb.flags = _abi.PG_BATCH_ALL_MATCHES if b.all_matches else 0
     for name, _ in _BATCH_FIELDS:
         setattr(cb, name, _ptr(getattr(b, name)))
     return cb

@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def shim():
     h = ctypes.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
     h.pgt_medmad.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_double] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3
+    h.pgt_medmad_sym.argtypes = h.pgt_medmad.argtypes
     h.pgt_plan.argtypes = [ctypes.c_double] * 5 + [ctypes.c_void_p]
     return h
 
@@ -54,6 +55,54 @@ def test_fuzz_bit_exact(shim, mode):
         assert np.float64(med).tobytes() == np.float64(rm).tobytes(), (mode, trial, n)
         assert np.float64(mad_raw * 1.4826).tobytes() == np.float64(rd).tobytes(), (mode, trial, n)
         assert mad == (rd if rd > 1.0 else 1.0)
+
+
+def shim_medmad_sym(h, raw, dig, off, rg, pmin, pmax):
+    med, mad, mr = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    rc = h.pgt_medmad_sym(raw.ctypes.data, raw.size, dig, off, rg, pmin, pmax, ctypes.byref(med), ctypes.byref(mad), ctypes.byref(mr))
+    return rc, med.value, mad.value, mr.value
+
+
+@pytest.mark.parametrize("mode", range(10))
+def test_symmetric_fast_path_is_exact_whenever_it_applies(shim, mode):
+    """The ring argument of pg_select.h (PgSym): wherever the fast path says "applicable" its doubles are the oracle's, bit
+    for bit; and it does apply to ordinary reads (otherwise the kernel would always pay for the general search)."""
+    rng = np.random.default_rng(900 + mode)
+    applied = ordinary = ordinary_applied = 0
+    trials = 400
+    for trial in range(trials):
+        n = int(rng.choice([2, 3, 4, 5, 7, 16, 100, 1000, 4000]))
+        dig = float(rng.choice([2048.0, 8192.0])); rg = float(rng.uniform(200, 1500))
+        off = float(rng.integers(-300, 300))
+        sd = rng.choice([1, 5, 50, 300])
+        raw = np.clip(np.rint(rng.normal(rng.uniform(300, 1500), sd, n)), -32768, 32767).astype(np.int16)
+        pmin, pmax = 40.0, 180.0
+        if mode == 1: raw[rng.random(n) < 0.05] = rng.integers(-32768, 32767)      # spikes: a zero-filled class far above the MAD
+        if mode == 2: raw[rng.random(n) < 0.45] = rng.integers(-32768, 32767)      # ... of nearly half of the samples
+        if mode == 3: off = float(rng.uniform(-300, 300))                           # fractional offsets: code + offset rounds
+        if mode == 4: pmin, pmax = -50.0, 60.0
+        if mode == 5: rg = float(10 ** rng.uniform(-9, 9))                          # tiny / huge scales: the guard decides
+        if mode == 6: raw = (raw[0] + rng.integers(-1, 2, n)).astype(np.int16)     # three adjacent codes: ties in every ring
+        if mode == 7: pmin, pmax = float(rng.uniform(60, 100)), float(rng.uniform(100, 140))   # narrow window: rings clipped on one side
+        if mode == 8: off = float(rng.uniform(-1e13, 1e13)); rg = 1e14                # |offset| beyond the guard
+        if mode == 9: raw = np.sort(raw)[:: int(rng.choice([1, -1]))].copy()
+        rc, med, mad, mad_raw = shim_medmad_sym(shim, raw, dig, off, rg, pmin, pmax)
+        pa = (raw.astype(np.float64) + off) * (rg / dig)
+        inr = (pa >= pmin) & (pa <= pmax)
+        # an ordinary read: nearly all samples in range, their spread small against the distance of the values from zero
+        is_ordinary = n >= 16 and inr.mean() >= 0.9 and np.ptp(pa[inr]) < 0.5 * np.abs(pa[inr]).min()
+        ordinary += is_ordinary
+        if rc != 1:
+            assert rc == 0
+            continue
+        applied += 1
+        ordinary_applied += is_ordinary
+        rm, rd = ref_medmad(raw, dig, off, rg, pmin, pmax)
+        assert np.float64(med).tobytes() == np.float64(rm).tobytes(), (mode, trial, n)
+        assert np.float64(mad_raw * 1.4826).tobytes() == np.float64(rd).tobytes(), (mode, trial, n, mad_raw * 1.4826, rd)
+        assert mad == (rd if rd > 1.0 else 1.0)
+    if mode in (0, 1, 3, 9):
+        assert ordinary > 20 and ordinary_applied == ordinary, (ordinary, ordinary_applied, applied)
 
 
 def test_fixture_read_known_answers(shim):

@@ -1,0 +1,37 @@
+"""Per-wave phase times of k_read_stats and k_walk on bench.py's workload, from the measurement build
+(make variant NAME=phase EXTRA=-DPG_PHASE_PROBE). usage (GPU box): python3 tools/phase_probe.py [reads] [sample_limit]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from poregen_amd import _abi
+_abi.LIB_PATH = os.path.join(ROOT, "build", "phase", "libpgmove.so")
+import torch
+from poregen_amd import synth
+from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+limit = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+host = synth.make_batch_fast(reads, read_len=4000, kind="rna004", seed=20251003 + 1)
+p = dict(kmer_size=5, rna=True, scaling=1, sample_limit=limit, min_dur=20, max_dur=40)
+eng = GmoveEngine(GmoveParams(kmers=generate_kmers(5, rna=True), **p))
+lib = eng._lib
+import numpy as np
+W = 65536
+buf = np.zeros((W, 8), np.uint64)
+lib.pg_debug_phases.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]; lib.pg_debug_phases.restype = None
+shard = host.to_device(torch.device("cuda:0"))
+for _ in range(3):
+    eng.reset(); eng.submit(shard)
+eng.sync()
+lib.pg_debug_phases(buf.ctypes.data, 0, 1)
+eng.reset(); eng.submit(shard); eng.sync()
+names = {0: ("k_read_stats", ["record load", "samples arrive", "binning", "prefix scan", "selection + stores"]),
+         1: ("k_walk<true>", ["header loads", "ops arrive", "scans + bases arrive", "walk stores", "event loop"])}
+for k, (name, ph) in names.items():
+    lib.pg_debug_phases(buf.ctypes.data, k, 0)
+    live = buf[:, 7] > 0
+    a = buf[live].astype(np.float64)
+    if not a.size: continue
+    print(f"{name}: {int(live.sum())} waves recorded; wave lifetime mean {a[:, 7].mean():.0f} ticks (median {np.median(a[:, 7]):.0f}, p90 {np.percentile(a[:, 7], 90):.0f}) of s_memtime")
+    for i, nm in enumerate(ph):
+        print(f"   {nm:24s} mean {a[:, i].mean():9.0f} ticks  {100.0 * a[:, i].sum() / a[:, 7].sum():5.1f} % of the lifetime   median {np.median(a[:, i]):7.0f}")
