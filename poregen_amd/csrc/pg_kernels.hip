@@ -487,16 +487,18 @@ __device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, ui
     }
 }
 
-struct EvCtx { // the read an event belongs to, and the 16 bases of the thread's group inside it
-    uint64_t o0, o1;
-    uint32_t r, n, kind; // kind: 0 dead (no events), 1 direct, 2 generic (events computed by k_walk)
+// the read an event belongs to, as k_events' event test needs it, and the 16 bases of the thread's group in it
+struct EvRead {
+    uint32_t r, n, kind;  // kind: 0 no events (dead / skipped read), 1 direct, 2 generic (events computed by k_walk)
+    uint32_t i0;          // event index (inside the read) of the group's op 0, modulo 2^32: event index of op j = i0 + j
+    uint32_t jb;          // index inside the group of the read's first op there (0 for the read that owns op 0)
     bool rna; int32_t st_k, end_k;
-    uint32_t i_first;    // event index of the group's first op that belongs to this read
-    uint32_t code2, bad;
+    uint32_t code2, bad;  // 2-bit codes / "not A C G T/U" bits of the 16 window bytes (window byte 0 = base of the op at jb)
 };
+struct EvOpen { uint64_t s0; uint32_t slen, i_first; }; // what the window load needs on top of EvRead
 
 // COUNT: direct ranking -- also per-(tile, slot) counts of the accepted events into hist[slot][tile..tile+3]
-template <bool COUNT> __global__ __launch_bounds__(1024) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
+template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS : 1];
     const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k;
     const int lane = lane_id();
@@ -504,34 +506,59 @@ template <bool COUNT> __global__ __launch_bounds__(1024) void k_events(PgDevBatc
     if (COUNT) { for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 1024) (&cnt[0][0])[i] = 0; __syncthreads(); }
     const uint64_t seq_total = B.seq_off[B.n_reads];
     const uint32_t *__restrict__ seq32 = reinterpret_cast<const uint32_t *>(B.seq); // 4-byte aligned (checked by the host)
-    const uint64_t seq_last_dw = seq_total ? (seq_total - 1) >> 2 : 0;
+    const int64_t seq_last_dw = seq_total ? (int64_t)((seq_total - 1) >> 2) : 0;
 
-    // window of the group's part inside read `c.r`, whose first event index there is c.i_first: the 16 bases
-    auto load_window = [&](EvCtx &c, const PgReadMeta &mt) {
-        // DNA-oriented: bases i .. i+15 are sequence bytes s0+i ..; RNA-oriented: match p is byte s0+slen-1-p, so the window is the 16
-        // bytes that END at s0+slen-1-i (byte q of the window = match i+15-q). Bytes outside the read belong to non-candidates.
-        const int64_t a = c.rna ? (int64_t)(mt.s0 + mt.slen) - 16 - (int64_t)c.i_first : (int64_t)(mt.s0 + c.i_first);
+    // stage 1 of opening a read: its record (k_batch_init) and class. g0 = the group's first op, g_first = the read's first op in it
+    auto read_record = [&](EvRead &c, EvOpen &w, uint32_t r, uint64_t g0, uint64_t g_first) {
+        const PgReadMeta *mp = O.meta + r;
+        const uint32_t flags = mp->flags;
+        const uint64_t o0 = mp->o0;
+        c.r = r; c.n = mp->nops; c.rna = (flags & PG_RM_RNA) != 0; c.st_k = mp->st_k; c.end_k = mp->end_k;
+        w.s0 = mp->s0; w.slen = mp->slen; w.i_first = (uint32_t)(g_first - o0);
+        const bool generic = O.gen_flag[r] == O.batch_id;
+        const bool skip = O.oor && O.oor[r];
+        // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has no
+        // events here and fails the batch on the host (pg_api.hip: check_read_errors)
+        c.kind = (!(flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((flags & PG_RM_DIRECT_OK) ? 1u : 0u));
+        c.i0 = (uint32_t)(g0 - o0); c.jb = (uint32_t)(g_first - g0);
+        c.code2 = 0; c.bad = 0xffffu;
+    };
+    // stage 2: the 16 window bytes as 5 aligned dwords. DNA-oriented: bases i .. i+15 are sequence bytes s0+i ..; RNA-oriented: match p
+    // is byte s0+slen-1-p, so the window is the 16 bytes that END at s0+slen-1-i (byte q of the window = match i+15-q). Bytes outside
+    // the read (or the buffer: clamped) belong to non-candidates.
+    auto window_load = [&](const EvRead &c, const EvOpen &w, uint32_t (&d)[5]) -> uint32_t {
+        const int64_t a = c.rna ? (int64_t)(w.s0 + w.slen) - 16 - (int64_t)w.i_first : (int64_t)(w.s0 + w.i_first);
         const int64_t adw = a >> 2; // floor
-        const uint32_t sh = (uint32_t)(a & 3) * 8u;
-        uint32_t d[5];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > (int64_t)seq_last_dw ? (int64_t)seq_last_dw : x); d[q] = seq_total ? seq32[x] : 0u; }
+        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
+        return (uint32_t)(a & 3) * 8u;
+    };
+    // stage 3: bytes -> codes
+    auto window_codes = [&](EvRead &c, const uint32_t (&d)[5], uint32_t sh) {
         uint32_t w[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
         codes_of_16(w, c.rna, c.code2, c.bad);
     };
-    auto open_read = [&](EvCtx &c, uint32_t r, uint64_t g_first) {
-        const PgReadMeta mt = O.meta[r];
-        c.r = r; c.o0 = mt.o0; c.o1 = mt.o0 + mt.nops; c.n = mt.nops; c.rna = (mt.flags & PG_RM_RNA) != 0; c.st_k = mt.st_k; c.end_k = mt.end_k;
-        const bool generic = O.gen_flag[r] == O.batch_id;
-        const bool skip = O.oor && O.oor[r];
-        // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has no
-        // events here and fails the batch on the host (pg_api.hip: check_read_errors)
-        c.kind = (!(mt.flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((mt.flags & PG_RM_DIRECT_OK) ? 1u : 0u));
-        c.i_first = (uint32_t)(g_first - mt.o0);
-        c.code2 = 0; c.bad = 0xffffu;
-        if (c.kind == 1u) load_window(c, mt);
+    // one event: op index g = g0 + j of read c
+    auto event_slot = [&](const EvRead &c, uint64_t g, uint32_t j, uint32_t own_len) -> uint32_t {
+        if (c.kind == 2u) return O.ev_slot[g]; // computed by k_walk
+        if (c.kind != 1u) return PG_INVALID_SLOT;
+        const uint32_t i = c.i0 + j, e = i + W.sig_move_offset, jj = j - c.jb;
+        if (!(i <= c.n - k && e < c.n)) return PG_INVALID_SLOT; // not an event of the read (gmove.cpp:891-894); n >= k for direct reads
+        // the k bases: DNA-oriented window byte jj+t = base i+t, RNA-oriented window byte 16-jj-k+t = base t of the k-mer string;
+        // either way a field of k 2-bit groups with the FIRST base lowest, reversed into the table's code (first base highest)
+        const uint32_t pos = c.rna ? 16u - jj - k : jj;
+        const uint32_t field = (c.code2 >> (2u * pos)) & ((1u << (2u * k)) - 1u), badf = (c.bad >> pos) & ((1u << k) - 1u);
+        const uint32_t x = __builtin_bitreverse32(field);
+        const uint32_t code = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
+        if (badf) return PG_INVALID_SLOT;
+        const int32_t slot = (c.rna ? W.table_u : W.table_t)[code];
+        // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
+        const uint32_t dur = W.sig_move_offset == 0 ? own_len : B.op_n[g + W.sig_move_offset];
+        // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
+        const bool ok = slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, c.n, 0u, c.rna, c.st_k, c.end_k, 0u, 0u);
+        return ok ? (uint32_t)slot : PG_INVALID_SLOT;
     };
 
 #pragma unroll 1
@@ -544,6 +571,22 @@ template <bool COUNT> __global__ __launch_bounds__(1024) void k_events(PgDevBatc
 #pragma unroll
             for (int j = 0; j < 4; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
         }
+        // the reads of the group: A owns g0; B (few threads per tile) is the next read with ops, if it starts inside the group. Both are
+        // opened side by side, stage by stage, so that a group on a read boundary costs no extra dependent round trip.
+        uint32_t rA = 0, rB = 0; uint64_t o1A = ~0ull; bool needB = false, needC = false;
+        if (g0 < N) {
+            rA = O.blk_read[g0 >> 6];
+            if (rA >= B.n_reads) rA = B.n_reads - 1; // only with a broken op_off (the batch fails anyway)
+            o1A = B.op_off[rA + 1];
+            while (o1A <= g0 && rA + 1 < B.n_reads) { ++rA; o1A = B.op_off[rA + 1]; }
+            needB = o1A < g0 + 4 && o1A < N;
+            if (needB) {
+                rB = rA + 1;
+                uint64_t o1B = rB < B.n_reads ? B.op_off[rB + 1] : N;
+                while (o1B <= o1A && rB + 1 < B.n_reads) { ++rB; o1B = B.op_off[rB + 1]; } // reads without ops
+                needC = o1B < g0 + 4 && o1B < N; // a third read inside the group (reads of 1-2 ops): the slow way below
+            }
+        }
         // sums of op_n over the wave's 256-op block (all 64 lanes take part): cum at 4-op granularity, the block total, and for a
         // read that starts in this group the sum in front of its first op (PgReadMeta::pcum0). Ops of ANY kind count: the emit
         // kernels only take differences inside one read.
@@ -553,38 +596,43 @@ template <bool COUNT> __global__ __launch_bounds__(1024) void k_events(PgDevBatc
         if (g0 < N) {
             O.cum[g0 >> 2] = pre[0];
             if (lane == WAVE - 1 || g0 + 4 >= N) O.btot[g0 >> 8] = inc;
-            EvCtx c;
-            open_read(c, owner_of(B, O, g0), g0);
-            if (c.o0 == g0) O.meta[c.r].pcum0 = pre[0];
-            uint32_t jb = 0; // index inside the group of the first op of the current read
+            EvRead A, Bq; EvOpen wA, wB;
+            read_record(A, wA, rA, g0, g0);
+            if (needB) read_record(Bq, wB, rB, g0, o1A);
+            else { Bq.r = 0; Bq.n = 0; Bq.kind = 0; Bq.i0 = 0; Bq.jb = 0; Bq.rna = false; Bq.st_k = Bq.end_k = 0; Bq.code2 = 0; Bq.bad = 0xffffu; }
+            uint32_t dA[5], dB[5], shA = 0, shB = 0;
+            const bool winA = A.kind == 1u, winB = needB && Bq.kind == 1u;
+            if (winA) shA = window_load(A, wA, dA);
+            if (winB) shB = window_load(Bq, wB, dB);
+            if (winA) window_codes(A, dA, shA);
+            if (winB) window_codes(Bq, dB, shB);
+            if (A.i0 == 0) O.meta[rA].pcum0 = pre[0];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint64_t g = g0 + j;
                 if (g >= N) break;
-                if (g >= c.o1) { // the next read (with ops) starts inside the group: a few threads per tile
-                    uint32_t r = c.r + 1;
-                    while (r + 1 < B.n_reads && B.op_off[r + 1] <= g) ++r;
-                    open_read(c, r, g);
-                    O.meta[r].pcum0 = pre[j];
-                    jb = (uint32_t)j;
+                const bool inB = needB && g >= o1A;
+                if (inB && g == o1A) O.meta[rB].pcum0 = pre[j];
+                if (opn[j] >= PG_OP_N_LIMIT && (inB ? Bq.kind : A.kind) == 1u) report_error(O, inB ? Bq.r : A.r, PGR_ERR_RANGE);
+                if (inB) out[j] = event_slot(Bq, g, (uint32_t)j, opn[j]); // (two inlined copies: a reference chosen at run time would
+                else out[j] = event_slot(A, g, (uint32_t)j, opn[j]);      //  put both records into scratch memory)
+            }
+            if (needC) { // three or more reads inside four ops (reads of one or two ops): every later op opens its read on its own
+                const uint64_t o1B = B.op_off[rB + 1];
+#pragma unroll
+                for (int j = 2; j < 4; ++j) { // a third read cannot start in front of op 2
+                    const uint64_t g = g0 + j;
+                    if (g < N && g >= o1B) {
+                        uint32_t rc = rB + 1;
+                        while (rc + 1 < B.n_reads && B.op_off[rc + 1] <= g) ++rc;
+                        EvRead c; EvOpen wc; uint32_t d[5];
+                        read_record(c, wc, rc, g0, B.op_off[rc]);
+                        if (B.op_off[rc] == g) O.meta[rc].pcum0 = pre[j];
+                        if (c.kind == 1u) { const uint32_t sh = window_load(c, wc, d); window_codes(c, d, sh); }
+                        if (opn[j] >= PG_OP_N_LIMIT && c.kind == 1u) report_error(O, c.r, PGR_ERR_RANGE);
+                        out[j] = event_slot(c, g, (uint32_t)j, opn[j]);
+                    }
                 }
-                if (opn[j] >= PG_OP_N_LIMIT && c.kind == 1u) report_error(O, c.r, PGR_ERR_RANGE);
-                if (c.kind == 2u) { out[j] = O.ev_slot[g]; continue; } // computed by k_walk
-                if (c.kind != 1u) continue;
-                const uint32_t i = (uint32_t)(g - c.o0), e = i + W.sig_move_offset, jj = (uint32_t)j - jb;
-                if (!(i <= c.n - k && e < c.n)) continue; // not an event of the read (gmove.cpp:891-894); n >= k for direct reads
-                // the k bases: DNA-oriented window byte jj+t = base i+t, RNA-oriented window byte 16-jj-k+t = base t of the k-mer
-                // string; either way a field of k 2-bit groups with the FIRST base lowest, reversed into the table's code
-                const uint32_t pos = c.rna ? 16u - jj - k : jj;
-                const uint32_t field = (c.code2 >> (2u * pos)) & ((1u << (2u * k)) - 1u), badf = (c.bad >> pos) & ((1u << k) - 1u);
-                const uint32_t x = __builtin_bitreverse32(field);
-                const uint32_t code = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
-                if (badf) continue;
-                const int32_t slot = (c.rna ? W.table_u : W.table_t)[code];
-                // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
-                const uint32_t dur = W.sig_move_offset == 0 ? opn[j] : B.op_n[g + W.sig_move_offset];
-                // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
-                if (slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, c.n, 0u, c.rna, c.st_k, c.end_k, 0u, 0u)) out[j] = (uint32_t)slot;
             }
             if (g0 + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
             else { for (int j = 0; j < 4 && g0 + j < N; ++j) O.ev_slot[g0 + j] = out[j]; }

@@ -254,3 +254,48 @@ def test_sample_limit_zero_never_completes_a_kmer():
         eng2.submit(hb.slice_reads(0, 20)); eng2.finish()
     assert ei.value.status == -4
     eng.close(); eng2.close()
+
+
+def _tiny_reads_batch(n_reads, seed, k, rna, max_ops=6, op_len=(18, 45), indel_every=0):
+    """Reads of 1 .. max_ops ss ops (matches; every indel_every-th read gets an insertion): several reads inside one group of
+    four op indices, more than a thousand reads inside one tile of 4096 -- the rare paths of the op-parallel event kernel."""
+    rng = np.random.default_rng(seed)
+    sig, sig_off, seq, seq_off, op_n, op_t, op_off = [], [0], [], [0], [], [], [0]
+    ts, te, qs = [], [], []
+    for r in range(n_reads):
+        nm = int(rng.integers(1, max_ops + 1))
+        ops = [(int(rng.integers(*op_len)), 0) for _ in range(nm)]
+        if indel_every and r % indel_every == 1 and nm >= 2:
+            ops.insert(1, (int(rng.integers(3, 9)), 1))
+        L = sum(n for n, _ in ops) + int(rng.integers(0, 5))
+        raw = np.clip(np.rint(rng.normal(900, 60, L)), 300, 1500).astype(np.int16)
+        bases = rng.integers(0, 4, nm)
+        s = synth.BASES[bases[::-1]] if rna else synth.BASES[bases]
+        sig.append(raw); sig_off.append(sig_off[-1] + L); seq.append(s); seq_off.append(seq_off[-1] + nm)
+        op_n += [n for n, _ in ops]; op_t += [t for _, t in ops]; op_off.append(op_off[-1] + len(ops))
+        ts.append(nm if rna else 0); te.append(0 if rna else nm); qs.append(0)
+    n = n_reads
+    return Batch(n_reads=n, sig=np.concatenate(sig), sig_off=np.asarray(sig_off, np.uint64), digitisation=np.full(n, 2048.0),
+                 offset=np.full(n, -240.0), range=np.full(n, 281.0), query_start=np.asarray(qs, np.int32), target_start=np.asarray(ts, np.int32),
+                 target_end=np.asarray(te, np.int32), seq=np.concatenate(seq).astype(np.uint8), seq_off=np.asarray(seq_off, np.uint64),
+                 op_n=np.asarray(op_n, np.uint32), op_t=np.asarray(op_t, np.uint8), op_off=np.asarray(op_off, np.uint64)).validate_host()
+
+
+@pytest.mark.parametrize("k,rna,max_ops,indel_every", [(1, False, 3, 0), (2, True, 4, 0), (3, False, 6, 0), (2, False, 5, 7), (1, True, 2, 0)])
+def test_tiny_reads_many_per_group_and_per_tile(k, rna, max_ops, indel_every):
+    """Reads far shorter than a 256-op block: three or four reads inside one thread's group of four ops, > 1024 reads inside one
+    tile of 4096 ops. Direct path, the forced generic path and the oracle agree bit for bit."""
+    import torch
+    b = _tiny_reads_batch(9000, 700 + k, k, rna, max_ops=max_ops, indel_every=indel_every)
+    limit = 1000000  # no k-mer ever completes: every read of the batch reaches the output
+    p = dict(kmer_size=k, rna=rna, scaling=1, sample_limit=limit, kmer_pick_margin=0, min_dur=5, max_dur=70)
+    kmers = generate_kmers(k, rna=rna)
+    o = oracle_for(kmers, **p)
+    rcs = o.run_batch(b)
+    assert min(rcs) >= 0 and max(rcs) <= 1, "the generator must stay inside the reference's defined behaviour"
+    for split in (False, True):
+        for dev in (False, True):
+            eng = GmoveEngine(GmoveParams(kmers=kmers, split_walk=split, **p))
+            eng.submit(b.to_device(torch.device("cuda:0")) if dev else b)
+            assert_result_equals_oracle(eng.finish(), o, check_text_slots=2, sample_limit=limit)
+            eng.close()
