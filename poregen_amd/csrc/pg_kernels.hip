@@ -201,6 +201,7 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
 // k_walk: the generic walk (gmove.cpp:831-871) and event loop (891-927) of one read by one wave
 // ---------------------------------------------------------------------------------------------------------------------
 #define PG_EV_PER_THREAD 4 // four consecutive op indices per thread / lane
+#define PG_EV_TBL 1024       // reads per tile k_events keeps in LDS
 // LDS window of a read's per-match values: what the event loop needs besides the window starts -- base code, window length, I/D ops
 // in front. A read of at most PG_WALK_LDS_OPS ss ops never writes them to global memory; a longer one re-fills the window per tile.
 #define PG_WALK_LDS_OPS 512
@@ -487,15 +488,35 @@ __device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, ui
     }
 }
 
-// the read an event belongs to, as k_events' event test needs it, and the 16 bases of the thread's group in it
-struct EvRead {
-    uint32_t r, n, kind;  // kind: 0 no events (dead / skipped read), 1 direct, 2 generic (events computed by k_walk)
-    uint32_t i0;          // event index (inside the read) of the group's op 0, modulo 2^32: event index of op j = i0 + j
-    uint32_t jb;          // index inside the group of the read's first op there (0 for the read that owns op 0)
-    bool rna; int32_t st_k, end_k;
-    uint32_t code2, bad;  // 2-bit codes / "not A C G T/U" bits of the 16 window bytes (window byte 0 = base of the op at jb)
-};
-struct EvOpen { uint64_t s0; uint32_t slen, i_first; }; // what the window load needs on top of EvRead
+// One op's event with every look-up done by the thread itself and the k bases fetched one by one: k_events' way for a tile that
+// more than PG_EV_TBL reads touch (reads of a few ops each). Small, not fast. pre_g = sum of op_n in front of g inside its 256-op block.
+__device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint64_t g, uint32_t own_len, uint32_t pre_g) {
+    const uint32_t r = owner_search(B, g), k = W.k;
+    const PgReadMeta *mp = O.meta + r;
+    const uint32_t flags = mp->flags, n = mp->nops;
+    const uint64_t o0 = mp->o0;
+    if (o0 == g) O.meta[r].pcum0 = pre_g;
+    const bool generic = O.gen_flag[r] == O.batch_id, skip = O.oor && O.oor[r];
+    if (!(flags & PG_RM_LIVE) || skip) return PG_INVALID_SLOT;
+    if (generic) return W.no_generic ? PG_INVALID_SLOT : O.ev_slot[g]; // computed by k_walk
+    if (!(flags & PG_RM_DIRECT_OK)) return PG_INVALID_SLOT;
+    if (own_len >= PG_OP_N_LIMIT) report_error(O, r, PGR_ERR_RANGE);
+    const bool rna = (flags & PG_RM_RNA) != 0;
+    const uint32_t i = (uint32_t)(g - o0), e = i + W.sig_move_offset;
+    if (!(i <= n - k && e < n)) return PG_INVALID_SLOT; // gmove.cpp:891-894
+    const uint64_t s0 = mp->s0; const uint32_t slen = mp->slen;
+    uint32_t code = 0;
+    for (uint32_t t = 0; t < k; ++t) { // gmove.cpp:849-853, 883, 899: base t of the k-mer string is match i+t, mirrored on RNA-oriented records
+        const uint32_t pidx = i + t;
+        const uint8_t bc = base_code(B.seq[rna ? s0 + slen - 1u - pidx : s0 + pidx], rna);
+        if (bc > 3) return PG_INVALID_SLOT;
+        code = rna ? code | ((uint32_t)bc << (2u * t)) : (code << 2) | bc;
+    }
+    const int32_t slot = (rna ? W.table_u : W.table_t)[code];
+    const uint32_t dur = W.sig_move_offset == 0 ? own_len : B.op_n[g + W.sig_move_offset];
+    const bool ok = slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, n, 0u, rna, mp->st_k, mp->end_k, 0u, 0u);
+    return ok ? (uint32_t)slot : PG_INVALID_SLOT;
+}
 
 // COUNT: direct ranking -- also per-(tile, slot) counts of the accepted events into hist[slot][tile..tile+3]
 template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
@@ -508,84 +529,78 @@ template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_w
     const uint32_t *__restrict__ seq32 = reinterpret_cast<const uint32_t *>(B.seq); // 4-byte aligned (checked by the host)
     const int64_t seq_last_dw = seq_total ? (int64_t)((seq_total - 1) >> 2) : 0;
 
-    // stage 1 of opening a read: its record (k_batch_init) and class. g0 = the group's first op, g_first = the read's first op in it
-    auto read_record = [&](EvRead &c, EvOpen &w, uint32_t r, uint64_t g0, uint64_t g_first) {
-        const PgReadMeta *mp = O.meta + r;
-        const uint32_t flags = mp->flags;
-        const uint64_t o0 = mp->o0;
-        c.r = r; c.n = mp->nops; c.rna = (flags & PG_RM_RNA) != 0; c.st_k = mp->st_k; c.end_k = mp->end_k;
-        w.s0 = mp->s0; w.slen = mp->slen; w.i_first = (uint32_t)(g_first - o0);
-        const bool generic = O.gen_flag[r] == O.batch_id;
-        const bool skip = O.oor && O.oor[r];
-        // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has no
-        // events here and fails the batch on the host (pg_api.hip: check_read_errors)
-        c.kind = (!(flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((flags & PG_RM_DIRECT_OK) ? 1u : 0u));
-        c.i0 = (uint32_t)(g0 - o0); c.jb = (uint32_t)(g_first - g0);
-        c.code2 = 0; c.bad = 0xffffu;
-    };
-    // stage 2: the 16 window bytes as 5 aligned dwords. DNA-oriented: bases i .. i+15 are sequence bytes s0+i ..; RNA-oriented: match p
-    // is byte s0+slen-1-p, so the window is the 16 bytes that END at s0+slen-1-i (byte q of the window = match i+15-q). Bytes outside
-    // the read (or the buffer: clamped) belong to non-candidates.
-    auto window_load = [&](const EvRead &c, const EvOpen &w, uint32_t (&d)[5]) -> uint32_t {
-        const int64_t a = c.rna ? (int64_t)(w.s0 + w.slen) - 16 - (int64_t)w.i_first : (int64_t)(w.s0 + w.i_first);
-        const int64_t adw = a >> 2; // floor
+    // ---- the tile's reads, once per tile, in LDS (the usual case: <= PG_EV_TBL reads touch the tile and its 16-op halo) ----------
+    // entry e = read rFirst + e: first op relative to the tile, ops, class | orientation, sequence offset and length, target range.
+    // A thread finds the read of an op by a binary search over t_o0 (the LAST entry whose first op is not behind it owns it: reads
+    // without ops share their o0 with the read behind them) and takes everything else of the read from its entry: no per-thread
+    // global look-ups. The bases come in once per op: every thread turns the 4 bases of its OWN ops into a code byte (match order),
+    // the 16 bases an event group needs are the bytes of four neighbouring threads.
+    constexpr int TBL = PG_EV_TBL;
+    __shared__ int32_t t_o0[TBL], t_stk[TBL], t_endk[TBL];
+    __shared__ uint32_t t_n[TBL], t_fl[TBL], t_s0lo[TBL], t_s0hi[TBL], t_slen[TBL];
+    __shared__ uint8_t codeb[1024 + 8], badb[1024 + 8];
+    __shared__ uint32_t sh_rf[5];
+    if (tid < 5) { const uint64_t T = (uint64_t)(tile0 + tid) * PG_SORT_TILE; sh_rf[tid] = T < N ? owner_of(B, O, T) : B.n_reads; }
+    __syncthreads();
+
+    // the four base codes (match order: op j of the group at bits 2j) and "not A C G T/U" bits of the group of 4 ops that starts at
+    // tile-relative op index x; idx[j] = table entry of op j's read
+    auto group_codes = [&](uint64_t T0, uint32_t x, uint32_t R, uint32_t (&idx)[4], uint32_t &code8, uint32_t &bad4) {
+        uint32_t lo = 0, hi = R;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (t_o0[mid] <= (int32_t)x) lo = mid; else hi = mid; }
+        idx[0] = lo;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
-        return (uint32_t)(a & 3) * 8u;
-    };
-    // stage 3: bytes -> codes
-    auto window_codes = [&](EvRead &c, const uint32_t (&d)[5], uint32_t sh) {
-        uint32_t w[4];
+        for (int j = 1; j < 4; ++j) { uint32_t e = idx[j - 1]; while (e + 1 < R && t_o0[e + 1] <= (int32_t)(x + j)) ++e; idx[j] = e; }
+        code8 = 0; bad4 = 0xfu;
+        const uint64_t g0 = T0 + x;
+        if (idx[3] == idx[0] && g0 + 4 <= N) { // one read owns the whole group: its 4 bases are 4 consecutive sequence bytes
+            const uint32_t e = idx[0], fl = t_fl[e];
+            if ((fl & 3u) == 1u) {
+                const bool rna = (fl >> 2) & 1u;
+                const uint64_t s0 = (uint64_t)t_s0lo[e] | ((uint64_t)t_s0hi[e] << 32);
+                const uint32_t i0 = (uint32_t)((int32_t)x - t_o0[e]);
+                const uint64_t a = rna ? s0 + t_slen[e] - 4u - i0 : s0 + i0; // RNA-oriented: match p is byte s0+slen-1-p
+                const int64_t adw = (int64_t)(a >> 2);
+                const uint32_t d0 = seq32[adw], d1 = seq32[adw + 1 > seq_last_dw ? seq_last_dw : adw + 1];
+                const uint32_t sh = (uint32_t)(a & 3) * 8u;
+                uint32_t v = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0;
+                if (rna) v = __builtin_bswap32(v);
+                uint32_t y = (v >> 1) & 0x03030303u;
+                y ^= (y >> 1) & 0x01010101u;
+                const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u, b01 = b0 & b1;
+                uint32_t d = v ^ (0x41414141u + 2u * b0 + 6u * b1 + 11u * b01); // see codes_of_16
+                if (rna) d &= ~b01;
+                const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
+                code8 = (y * 0x01041040u) >> 24;
+                bad4 = (((nz >> 7) * 0x00204081u) >> 21) & 0xfu;
+            }
+        } else { // a read boundary (or the batch's end) inside the group: op by op
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
-        codes_of_16(w, c.rna, c.code2, c.bad);
-    };
-    // one event: op index g = g0 + j of read c
-    auto event_slot = [&](const EvRead &c, uint64_t g, uint32_t j, uint32_t own_len) -> uint32_t {
-        if (c.kind == 2u) return O.ev_slot[g]; // computed by k_walk
-        if (c.kind != 1u) return PG_INVALID_SLOT;
-        const uint32_t i = c.i0 + j, e = i + W.sig_move_offset, jj = j - c.jb;
-        if (!(i <= c.n - k && e < c.n)) return PG_INVALID_SLOT; // not an event of the read (gmove.cpp:891-894); n >= k for direct reads
-        // the k bases: DNA-oriented window byte jj+t = base i+t, RNA-oriented window byte 16-jj-k+t = base t of the k-mer string;
-        // either way a field of k 2-bit groups with the FIRST base lowest, reversed into the table's code (first base highest)
-        const uint32_t pos = c.rna ? 16u - jj - k : jj;
-        const uint32_t field = (c.code2 >> (2u * pos)) & ((1u << (2u * k)) - 1u), badf = (c.bad >> pos) & ((1u << k) - 1u);
-        const uint32_t x = __builtin_bitreverse32(field);
-        const uint32_t code = (((x & 0xAAAAAAAAu) >> 1) | ((x & 0x55555555u) << 1)) >> (32u - 2u * k);
-        if (badf) return PG_INVALID_SLOT;
-        const int32_t slot = (c.rna ? W.table_u : W.table_t)[code];
-        // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
-        const uint32_t dur = W.sig_move_offset == 0 ? own_len : B.op_n[g + W.sig_move_offset];
-        // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
-        const bool ok = slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, c.n, 0u, c.rna, c.st_k, c.end_k, 0u, 0u);
-        return ok ? (uint32_t)slot : PG_INVALID_SLOT;
+            for (int j = 0; j < 4; ++j) {
+                if (g0 + j >= N) break;
+                const uint32_t e = idx[j], fl = t_fl[e];
+                if ((fl & 3u) != 1u) continue;
+                const bool rna = (fl >> 2) & 1u;
+                const uint64_t s0 = (uint64_t)t_s0lo[e] | ((uint64_t)t_s0hi[e] << 32);
+                const uint32_t i = (uint32_t)((int32_t)(x + j) - t_o0[e]);
+                const uint8_t bc = base_code(B.seq[rna ? s0 + t_slen[e] - 1u - i : s0 + i], rna);
+                code8 |= ((uint32_t)bc & 3u) << (2 * j);
+                if (bc <= 3) bad4 &= ~(1u << j);
+            }
+        }
     };
 
 #pragma unroll 1
     for (uint32_t q = 0; q < 4; ++q) {
-        const uint64_t g0 = (uint64_t)(tile0 + q) * PG_SORT_TILE + (uint64_t)tid * 4u;
+        const uint64_t T0 = (uint64_t)(tile0 + q) * PG_SORT_TILE;
+        if (T0 >= N) break; // block-uniform
+        const uint64_t g0 = T0 + (uint64_t)tid * 4u;
         uint32_t out[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
         uint32_t opn[4] = {0, 0, 0, 0}; // op_n of the group's own ops
         if (g0 + 4 <= N) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_n + g0); opn[0] = v.x; opn[1] = v.y; opn[2] = v.z; opn[3] = v.w; }
         else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
-        }
-        // the reads of the group: A owns g0; B (few threads per tile) is the next read with ops, if it starts inside the group. Both are
-        // opened side by side, stage by stage, so that a group on a read boundary costs no extra dependent round trip.
-        uint32_t rA = 0, rB = 0; uint64_t o1A = ~0ull; bool needB = false, needC = false;
-        if (g0 < N) {
-            rA = O.blk_read[g0 >> 6];
-            if (rA >= B.n_reads) rA = B.n_reads - 1; // only with a broken op_off (the batch fails anyway)
-            o1A = B.op_off[rA + 1];
-            while (o1A <= g0 && rA + 1 < B.n_reads) { ++rA; o1A = B.op_off[rA + 1]; }
-            needB = o1A < g0 + 4 && o1A < N;
-            if (needB) {
-                rB = rA + 1;
-                uint64_t o1B = rB < B.n_reads ? B.op_off[rB + 1] : N;
-                while (o1B <= o1A && rB + 1 < B.n_reads) { ++rB; o1B = B.op_off[rB + 1]; } // reads without ops
-                needC = o1B < g0 + 4 && o1B < N; // a third read inside the group (reads of 1-2 ops): the slow way below
-            }
         }
         // sums of op_n over the wave's 256-op block (all 64 lanes take part): cum at 4-op granularity, the block total, and for a
         // read that starts in this group the sum in front of its first op (PgReadMeta::pcum0). Ops of ANY kind count: the emit
@@ -596,44 +611,84 @@ template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_w
         if (g0 < N) {
             O.cum[g0 >> 2] = pre[0];
             if (lane == WAVE - 1 || g0 + 4 >= N) O.btot[g0 >> 8] = inc;
-            EvRead A, Bq; EvOpen wA, wB;
-            read_record(A, wA, rA, g0, g0);
-            if (needB) read_record(Bq, wB, rB, g0, o1A);
-            else { Bq.r = 0; Bq.n = 0; Bq.kind = 0; Bq.i0 = 0; Bq.jb = 0; Bq.rna = false; Bq.st_k = Bq.end_k = 0; Bq.code2 = 0; Bq.bad = 0xffffu; }
-            uint32_t dA[5], dB[5], shA = 0, shB = 0;
-            const bool winA = A.kind == 1u, winB = needB && Bq.kind == 1u;
-            if (winA) shA = window_load(A, wA, dA);
-            if (winB) shB = window_load(Bq, wB, dB);
-            if (winA) window_codes(A, dA, shA);
-            if (winB) window_codes(Bq, dB, shB);
-            if (A.i0 == 0) O.meta[rA].pcum0 = pre[0];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t g = g0 + j;
-                if (g >= N) break;
-                const bool inB = needB && g >= o1A;
-                if (inB && g == o1A) O.meta[rB].pcum0 = pre[j];
-                if (opn[j] >= PG_OP_N_LIMIT && (inB ? Bq.kind : A.kind) == 1u) report_error(O, inB ? Bq.r : A.r, PGR_ERR_RANGE);
-                if (inB) out[j] = event_slot(Bq, g, (uint32_t)j, opn[j]); // (two inlined copies: a reference chosen at run time would
-                else out[j] = event_slot(A, g, (uint32_t)j, opn[j]);      //  put both records into scratch memory)
+        }
+        // ---- the table of the tile's reads ---------------------------------------------------------------------------------
+        const uint32_t rFirst = sh_rf[q];
+        const uint64_t halo_end = T0 + PG_SORT_TILE + 16 < N ? T0 + PG_SORT_TILE + 16 : N;
+        bool valid = false, over = false;
+        {
+            const uint32_t r = rFirst + tid;
+            uint64_t o0 = 0;
+            if (r < B.n_reads) { o0 = B.op_off[r]; valid = tid == 0 || o0 < halo_end; }
+            if (valid) {
+                const PgReadMeta *mp = O.meta + r;
+                const uint32_t flags = mp->flags;
+                const uint64_t s0 = mp->s0;
+                const bool generic = O.gen_flag[r] == O.batch_id;
+                const bool skip = O.oor && O.oor[r];
+                // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has
+                // no events here and fails the batch on the host (pg_api.hip: check_read_errors)
+                const uint32_t kind = (!(flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((flags & PG_RM_DIRECT_OK) ? 1u : 0u));
+                t_o0[tid] = (int32_t)((int64_t)mp->o0 - (int64_t)T0); t_n[tid] = mp->nops; t_fl[tid] = kind | ((flags & PG_RM_RNA) ? 4u : 0u);
+                t_s0lo[tid] = (uint32_t)s0; t_s0hi[tid] = (uint32_t)(s0 >> 32); t_slen[tid] = mp->slen; t_stk[tid] = mp->st_k; t_endk[tid] = mp->end_k;
+                if (tid == TBL - 1) over = r + 1 < B.n_reads && B.op_off[r + 1] < halo_end; // more reads than the table holds
             }
-            if (needC) { // three or more reads inside four ops (reads of one or two ops): every later op opens its read on its own
-                const uint64_t o1B = B.op_off[rB + 1];
+        }
+        const uint32_t R = (uint32_t)__syncthreads_count(valid); // valid threads are 0 .. R-1 (op_off is monotone)
+        if (__syncthreads_or(over)) { // (block-uniform) reads of a few ops each: every thread looks its reads up on its own
 #pragma unroll
-                for (int j = 2; j < 4; ++j) { // a third read cannot start in front of op 2
-                    const uint64_t g = g0 + j;
-                    if (g < N && g >= o1B) {
-                        uint32_t rc = rB + 1;
-                        while (rc + 1 < B.n_reads && B.op_off[rc + 1] <= g) ++rc;
-                        EvRead c; EvOpen wc; uint32_t d[5];
-                        read_record(c, wc, rc, g0, B.op_off[rc]);
-                        if (B.op_off[rc] == g) O.meta[rc].pcum0 = pre[j];
-                        if (c.kind == 1u) { const uint32_t sh = window_load(c, wc, d); window_codes(c, d, sh); }
-                        if (opn[j] >= PG_OP_N_LIMIT && c.kind == 1u) report_error(O, c.r, PGR_ERR_RANGE);
-                        out[j] = event_slot(c, g, (uint32_t)j, opn[j]);
-                    }
+            for (int j = 0; j < 4; ++j) if (g0 + j < N) out[j] = event_slot_scalar(B, W, O, g0 + j, opn[j], pre[j]);
+        } else {
+            uint32_t idx[4] = {0, 0, 0, 0};
+#pragma unroll 1
+            for (uint32_t pass = 0; pass < 2; ++pass) { // pass 1 (threads 0..3 only): the halo, the 16 ops behind the tile, whose
+                if (pass && tid >= 4) break;            // bases the tile's last events reach
+                const uint32_t slot_g = pass ? 1024u + tid : tid;
+                uint32_t gi[4] = {0, 0, 0, 0}, code8 = 0, bad4 = 0xfu;
+                if (T0 + slot_g * 4u < N) group_codes(T0, slot_g * 4u, R, gi, code8, bad4);
+                codeb[slot_g] = (uint8_t)code8; badb[slot_g] = (uint8_t)bad4;
+                if (!pass) { idx[0] = gi[0]; idx[1] = gi[1]; idx[2] = gi[2]; idx[3] = gi[3]; }
+            }
+            __syncthreads();
+            if (g0 < N) {
+                // bases of ops g0 .. g0+15 (op g0+p at bits 2p) and their "not A C G T/U" bits
+                const uint32_t c2 = (uint32_t)codeb[tid] | ((uint32_t)codeb[tid + 1] << 8) | ((uint32_t)codeb[tid + 2] << 16) | ((uint32_t)codeb[tid + 3] << 24);
+                const uint32_t bad16 = (uint32_t)badb[tid] | ((uint32_t)badb[tid + 1] << 4) | ((uint32_t)badb[tid + 2] << 8) | ((uint32_t)badb[tid + 3] << 12);
+                uint32_t cur = 0xffffffffu, n = 0, fl = 0; int32_t o0r = 0, stk = 0, endk = 0;
+                bool any_generic = (t_fl[idx[0]] & 3u) == 2u;
+                if (idx[3] != idx[0]) any_generic = any_generic || (t_fl[idx[1]] & 3u) == 2u || (t_fl[idx[2]] & 3u) == 2u || (t_fl[idx[3]] & 3u) == 2u;
+                uint4 walked = make_uint4(PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT);
+                if (any_generic) { // events of generic reads come from k_walk
+                    if (g0 + 4 <= N) walked = *reinterpret_cast<const uint4 *>(O.ev_slot + g0);
+                    else { uint32_t wv[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT}; for (int j = 0; j < 4 && g0 + j < N; ++j) wv[j] = O.ev_slot[g0 + j]; walked = make_uint4(wv[0], wv[1], wv[2], wv[3]); }
+                }
+                const uint32_t wk[4] = {walked.x, walked.y, walked.z, walked.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (g0 + j >= N) break;
+                    if (idx[j] != cur) { cur = idx[j]; o0r = t_o0[cur]; n = t_n[cur]; fl = t_fl[cur]; stk = t_stk[cur]; endk = t_endk[cur]; }
+                    const uint32_t kind = fl & 3u;
+                    const bool rna = (fl >> 2) & 1u;
+                    const uint32_t i = (uint32_t)((int32_t)(tid * 4u + j) - o0r), e = i + W.sig_move_offset;
+                    if (i == 0) O.meta[rFirst + cur].pcum0 = pre[j];
+                    if (opn[j] >= PG_OP_N_LIMIT && kind == 1u) report_error(O, rFirst + cur, PGR_ERR_RANGE);
+                    if (kind == 2u) { out[j] = wk[j]; continue; }
+                    if (kind != 1u || !(i <= n - k && e < n)) continue; // not an event of its read (gmove.cpp:891-894); n >= k for direct reads
+                    // matches i .. i+k-1 at bits 2j ..: a field of k 2-bit groups with the FIRST base lowest -- the code the reference
+                    // looks up on RNA-oriented records (mirrored k-mer, gmove.cpp:883, 899); its groups reversed on DNA-oriented ones
+                    const uint32_t field = (c2 >> (2u * j)) & ((1u << (2u * k)) - 1u), badf = (bad16 >> j) & ((1u << k) - 1u);
+                    const uint32_t xr = __builtin_bitreverse32(field);
+                    const uint32_t fwd = (((xr & 0xAAAAAAAAu) >> 1) | ((xr & 0x55555555u) << 1)) >> (32u - 2u * k);
+                    if (badf) continue;
+                    const int32_t slot = rna ? W.table_u[field] : W.table_t[fwd];
+                    // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
+                    const uint32_t dur = W.sig_move_offset == 0 ? opn[j] : B.op_n[g0 + j + W.sig_move_offset];
+                    // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
+                    if (slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, n, 0u, rna, stk, endk, 0u, 0u)) out[j] = (uint32_t)slot;
                 }
             }
+        }
+        if (g0 < N) {
             if (g0 + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
             else { for (int j = 0; j < 4 && g0 + j < N; ++j) O.ev_slot[g0 + j] = out[j]; }
         }
@@ -642,6 +697,7 @@ template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_w
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (out[j] != PG_INVALID_SLOT) atomicAdd(&cnt[q][out[j] & mask], 1u);
         }
+        __syncthreads(); // the table and the code bytes are rewritten for the next tile
     }
     if (COUNT) {
         __syncthreads();
