@@ -278,9 +278,11 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
-    CTRY(c->table_t.ensure(tb)); CTRY(c->table_u.ensure(tb));
+    // one allocation, the U-spelled table right behind the T-spelled one: a kernel reaches both from ONE uniform base with a 32-bit
+    // lane offset (PgWalkParams::table_u == table_t + n_codes)
+    CTRY(c->table_t.ensure(2 * tb));
     CTRY(hipMemcpy(c->table_t.p, p->table_t, tb, hipMemcpyHostToDevice));
-    CTRY(hipMemcpy(c->table_u.p, p->table_u, tb, hipMemcpyHostToDevice));
+    CTRY(hipMemcpy(c->table_t.as<char>() + tb, p->table_u, tb, hipMemcpyHostToDevice));
     c->prm.table_t = nullptr; c->prm.table_u = nullptr;
     const uint32_t ns = p->n_slots;
     CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
@@ -476,7 +478,7 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.max_dur = c->prm.max_dur; W.min_dur = c->prm.min_dur; W.pick_margin = c->prm.kmer_pick_margin; W.allow_rna = c->prm.allow_rna;
     W.short_ok = (c->prm.flags & PG_FLAG_SHORT_READS_OK) ? 1 : 0;
     W.no_generic = c->batch_all_matches ? 1 : 0;
-    W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_u.as<int32_t>();
+    W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_t.as<int32_t>() + c->n_codes;
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
     O.m_tix = c->m_tix.as<uint32_t>() + PG_TIX_FRONT(c->prm.kmer_pick_margin); O.ev_slot = c->ev_slot.as<uint32_t>();
     O.meta = c->meta.as<PgReadMeta>();

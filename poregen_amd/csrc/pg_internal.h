@@ -23,7 +23,7 @@ struct PgWalkParams {
     int32_t pick_margin, allow_rna, short_ok;
     int32_t no_generic; // PG_BATCH_ALL_MATCHES: k_walk is not launched, a read that needs it has no events and fails the batch
     uint32_t n_codes; // 4^k
-    const int32_t *table_t, *table_u;
+    const int32_t *table_t, *table_u; // table_u == table_t + n_codes (one allocation)
 };
 
 // per-read status codes written by k_walk_events (negative = error, reported through the C ABI)
@@ -42,8 +42,7 @@ enum {
     PGR_ERR_LAYOUT = -10      // the read's ops end behind pg_batch.n_ops, or op_off is not monotone (device batches)
 };
 
-// per-read record (64 bytes) written by k_batch_init for EVERY read; the generic walk refines n / m of the reads it walks, the
-// op-parallel event kernel adds pcum0 for the reads it handles
+// per-read record (64 bytes) written by k_batch_init for EVERY read; the generic walk refines n / m of the reads it walks
 struct __attribute__((aligned(16))) PgReadMeta {
     uint64_t o0;     // op_off[r]
     uint64_t s0;     // seq_off[r]
@@ -56,8 +55,7 @@ struct __attribute__((aligned(16))) PgReadMeta {
     uint32_t L;      // len_raw_signal (clamped to 2^32 - 1; > INT32_MAX is an error)
     int32_t qs;      // query_start
     uint32_t flags;  // PG_RM_*
-    uint32_t pcum0;  // direct reads: sum of op_n over [first op of the 256-op block of o0, o0) (see PgWalkOut::cum)
-    uint32_t pad[2];
+    uint32_t pad[3];
 };
 enum {
     PG_RM_RNA = 1u,       // target_start > target_end

@@ -179,7 +179,7 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
     mt.nops = layout_ok ? (uint32_t)(o1 - o0) : 0u;
     mt.slen = (uint32_t)(s1 - s0 > 0xffffffffull ? 0xffffffffull : s1 - s0);
     mt.n = 0; mt.m = 0; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
-    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pcum0 = 0; mt.pad[0] = mt.pad[1] = 0;
+    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pad[0] = mt.pad[1] = mt.pad[2] = 0;
     int status = PGR_OK;
     if (!layout_ok) status = PGR_ERR_LAYOUT;
     // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
@@ -201,7 +201,7 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
 // k_walk: the generic walk (gmove.cpp:831-871) and event loop (891-927) of one read by one wave
 // ---------------------------------------------------------------------------------------------------------------------
 #define PG_EV_PER_THREAD 4 // four consecutive op indices per thread / lane
-#define PG_EV_TBL 1024       // reads per tile k_events keeps in LDS
+#define PG_EV_TBL 128        // reads per tile (and its 16-op halo) k_events keeps in LDS
 // LDS window of a read's per-match values: what the event loop needs besides the window starts -- base code, window length, I/D ops
 // in front. A read of at most PG_WALK_LDS_OPS ss ops never writes them to global memory; a longer one re-fills the window per tile.
 #define PG_WALK_LDS_OPS 512
@@ -489,13 +489,12 @@ __device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, ui
 }
 
 // One op's event with every look-up done by the thread itself and the k bases fetched one by one: k_events' way for a tile that
-// more than PG_EV_TBL reads touch (reads of a few ops each). Small, not fast. pre_g = sum of op_n in front of g inside its 256-op block.
-__device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint64_t g, uint32_t own_len, uint32_t pre_g) {
+// more than PG_EV_TBL reads touch (reads of a few ops each). Small, not fast.
+__device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint64_t g, uint32_t own_len) {
     const uint32_t r = owner_search(B, g), k = W.k;
     const PgReadMeta *mp = O.meta + r;
     const uint32_t flags = mp->flags, n = mp->nops;
     const uint64_t o0 = mp->o0;
-    if (o0 == g) O.meta[r].pcum0 = pre_g;
     const bool generic = O.gen_flag[r] == O.batch_id, skip = O.oor && O.oor[r];
     if (!(flags & PG_RM_LIVE) || skip) return PG_INVALID_SLOT;
     if (generic) return W.no_generic ? PG_INVALID_SLOT : O.ev_slot[g]; // computed by k_walk
@@ -518,192 +517,244 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
     return ok ? (uint32_t)slot : PG_INVALID_SLOT;
 }
 
-// COUNT: direct ranking -- also per-(tile, slot) counts of the accepted events into hist[slot][tile..tile+3]
+// k_events: a workgroup of 1024 threads takes 4 tiles of 4096 op indices side by side, 256 threads per tile, 16 CONSECUTIVE ops per
+// thread; every stage runs once per workgroup:
+//   1. the tile's reads go into an LDS table (entry e = read rFirst + e, built by thread e of the tile): first op relative to the
+//      tile, class | orientation, sequence offset / length, and the range [ilo, ihi] of event indices that pass the position tests
+//      of the reference (gmove.cpp:891-894: a window exists; 204-211 without I/D ops: the two ends of indel_pos) -- worked out
+//      once per read instead of once per event;
+//   2. every thread finds the read(s) of its 16 ops in the table (a guess from the tile's mean read length, then a probe), fetches
+//      their 16 bases as one or two 16-byte windows of the sequence and leaves 2-bit codes (match order) + "not A C G T/U" bits
+//      in LDS; its own op_n give the window lengths and, summed along DPP rows of 16 lanes (= 256 ops), cum / btot;
+//   3. an event is k consecutive codes starting at its op (its own thread's and the next one's) -> slot table -> duration and
+//      position tests. COUNT (direct ranking): the accepted events are counted per (tile, slot) into hist[slot][tile..tile+3].
+// A tile touched by more than PG_EV_TBL reads, and a thread whose 16 ops span more than two reads, take event_slot_scalar.
 template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS : 1];
-    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k;
+    constexpr int TBL = PG_EV_TBL;
+    __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
+    __shared__ int32_t t_o0[4][TBL], t_ilo[4][TBL], t_ihi[4][TBL];
+    __shared__ uint32_t t_fl[4][TBL], t_s0lo[4][TBL], t_s0hi[4][TBL], t_slen[4][TBL];
+    __shared__ uint32_t codew[4][256 + 4], badw[4][256 + 4]; // [256]: the halo, the 16 ops behind the tile
+    // the thread's 16 slots wait here for the end of the kernel (transposed: op j of thread lt at [j][lt]): a global store between two
+    // slot-table look-ups would serialise them (on this part a wait for a load also waits for every store issued in front of it), and
+    // 16 more live registers cost a wave per SIMD. 16 bits per slot in direct mode (<= 1024 slots), 32 otherwise.
+    typedef typename std::conditional<COUNT, uint16_t, uint32_t>::type stage_t;
+    __shared__ stage_t stage[4][16][256];
+    constexpr uint32_t STAGE_INVALID = COUNT ? 0xFFFFu : PG_INVALID_SLOT;
+    __shared__ uint32_t sh_rf[5], sh_R[4], sh_over[4];
+    const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k, tq = tid >> 8, lt = tid & 255u;
     const int lane = lane_id();
     const uint64_t N = B.n_ops;
-    if (COUNT) { for (uint32_t i = tid; i < 4 * PG_RANK_MAX_DIGITS; i += 1024) (&cnt[0][0])[i] = 0; __syncthreads(); }
+    const uint64_t T0 = (uint64_t)(tile0 + tq) * PG_SORT_TILE, g0 = T0 + (uint64_t)lt * 16u;
+    const bool tile_live = T0 < N; // wave-uniform
+    if (COUNT) for (uint32_t i = tid; i < 4 * (PG_RANK_MAX_DIGITS + 32); i += 1024) (&cnt[0][0])[i] = 0;
+    if (tid < 5) { const uint64_t T = (uint64_t)(tile0 + tid) * PG_SORT_TILE; sh_rf[tid] = T < N ? owner_of(B, O, T) : B.n_reads; }
+    if (tid < 4) { sh_R[tid] = 0; sh_over[tid] = 0; }
+    // the thread's own op_n: four 16-byte loads in flight in front of everything else
+    uint32_t opn[16];
+    if (g0 + 16 <= N) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); opn[4 * v] = x.x; opn[4 * v + 1] = x.y; opn[4 * v + 2] = x.z; opn[4 * v + 3] = x.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
+    }
     const uint64_t seq_total = B.seq_off[B.n_reads];
     const uint32_t *__restrict__ seq32 = reinterpret_cast<const uint32_t *>(B.seq); // 4-byte aligned (checked by the host)
     const int64_t seq_last_dw = seq_total ? (int64_t)((seq_total - 1) >> 2) : 0;
-
-    // ---- the tile's reads, once per tile, in LDS (the usual case: <= PG_EV_TBL reads touch the tile and its 16-op halo) ----------
-    // entry e = read rFirst + e: first op relative to the tile, ops, class | orientation, sequence offset and length, target range.
-    // A thread finds the read of an op by a binary search over t_o0 (the LAST entry whose first op is not behind it owns it: reads
-    // without ops share their o0 with the read behind them) and takes everything else of the read from its entry: no per-thread
-    // global look-ups. The bases come in once per op: every thread turns the 4 bases of its OWN ops into a code byte (match order),
-    // the 16 bases an event group needs are the bytes of four neighbouring threads.
-    constexpr int TBL = PG_EV_TBL;
-    __shared__ int32_t t_o0[TBL], t_stk[TBL], t_endk[TBL];
-    __shared__ uint32_t t_n[TBL], t_fl[TBL], t_s0lo[TBL], t_s0hi[TBL], t_slen[TBL];
-    __shared__ uint8_t codeb[1024 + 8], badb[1024 + 8];
-    __shared__ uint32_t sh_rf[5];
-    if (tid < 5) { const uint64_t T = (uint64_t)(tile0 + tid) * PG_SORT_TILE; sh_rf[tid] = T < N ? owner_of(B, O, T) : B.n_reads; }
+    PG_PROBE_BEGIN(1);
     __syncthreads();
+    PG_MARK(1, 0); // first reads of the tiles, op_n
 
-    // the four base codes (match order: op j of the group at bits 2j) and "not A C G T/U" bits of the group of 4 ops that starts at
-    // tile-relative op index x; idx[j] = table entry of op j's read
-    auto group_codes = [&](uint64_t T0, uint32_t x, uint32_t R, uint32_t (&idx)[4], uint32_t &code8, uint32_t &bad4) {
-        uint32_t lo = 0, hi = R;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (t_o0[mid] <= (int32_t)x) lo = mid; else hi = mid; }
-        idx[0] = lo;
+    // ---- stage 1: the table entry of read rFirst + lt ------------------------------------------------------------------------------
+    const uint32_t rFirst = sh_rf[tq];
+    const uint64_t halo_end = T0 + PG_SORT_TILE + 16 < N ? T0 + PG_SORT_TILE + 16 : N;
+    if (tile_live) {
+        const uint32_t r = rFirst + lt;
+        if (lt < TBL && r < B.n_reads && (lt == 0 || B.op_off[r] < halo_end)) {
+            const PgReadMeta *mp = O.meta + r;
+            const uint32_t flags = mp->flags;
+            const uint64_t s0 = mp->s0;
+            const bool generic = O.gen_flag[r] == O.batch_id, skip = O.oor && O.oor[r], rna = (flags & PG_RM_RNA) != 0;
+            // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has no
+            // events here and fails the batch on the host (pg_api.hip: check_read_errors)
+            const uint32_t kind = (!(flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((flags & PG_RM_DIRECT_OK) ? 1u : 0u));
+            // event i of a read of n matches and no I/D op is a candidate iff i <= n-k and i+off < n (gmove.cpp:891-894) and is picked
+            // iff left >= M - st_k and left + k <= end_k, left = i (DNA-oriented) or n-i-k (RNA-oriented): pick_kmer with m = 0
+            const int64_t n = mp->nops, M = W.pick_margin, stk = mp->st_k, endk = mp->end_k, kk = k, off = W.sig_move_offset;
+            int64_t ilo = rna ? n - endk : M - stk, ihi = rna ? n - kk - M + stk : endk - kk;
+            if (ilo < 0) ilo = 0;
+            if (ihi > n - kk) ihi = n - kk;
+            if (ihi > n - off - 1) ihi = n - off - 1;
+            if (ihi < -1) ihi = -1;
+            if (ilo > 0x7fffffff) ilo = 0x7fffffff;
+            t_o0[tq][lt] = (int32_t)((int64_t)mp->o0 - (int64_t)T0); t_ilo[tq][lt] = (int32_t)ilo; t_ihi[tq][lt] = (int32_t)ihi;
+            t_fl[tq][lt] = kind | (rna ? 4u : 0u); t_s0lo[tq][lt] = (uint32_t)s0; t_s0hi[tq][lt] = (uint32_t)(s0 >> 32); t_slen[tq][lt] = mp->slen;
+            atomicMax(&sh_R[tq], lt + 1u);
+            if (lt == TBL - 1 && r + 1 < B.n_reads && B.op_off[r + 1] < halo_end) sh_over[tq] = 1; // more reads than the table holds
+        }
+    }
+    // ---- sums of op_n over 256-op blocks = DPP rows of 16 lanes: cum at 4-op granularity, the block totals ----------------------------
+    uint32_t s16 = 0;
 #pragma unroll
-        for (int j = 1; j < 4; ++j) { uint32_t e = idx[j - 1]; while (e + 1 < R && t_o0[e + 1] <= (int32_t)(x + j)) ++e; idx[j] = e; }
-        code8 = 0; bad4 = 0xfu;
-        const uint64_t g0 = T0 + x;
-        if (idx[3] == idx[0] && g0 + 4 <= N) { // one read owns the whole group: its 4 bases are 4 consecutive sequence bytes
-            const uint32_t e = idx[0], fl = t_fl[e];
-            if ((fl & 3u) == 1u) {
-                const bool rna = (fl >> 2) & 1u;
-                const uint64_t s0 = (uint64_t)t_s0lo[e] | ((uint64_t)t_s0hi[e] << 32);
-                const uint32_t i0 = (uint32_t)((int32_t)x - t_o0[e]);
-                const uint64_t a = rna ? s0 + t_slen[e] - 4u - i0 : s0 + i0; // RNA-oriented: match p is byte s0+slen-1-p
-                const int64_t adw = (int64_t)(a >> 2);
-                const uint32_t d0 = seq32[adw], d1 = seq32[adw + 1 > seq_last_dw ? seq_last_dw : adw + 1];
-                const uint32_t sh = (uint32_t)(a & 3) * 8u;
-                uint32_t v = sh ? (d0 >> sh) | (d1 << (32u - sh)) : d0;
-                if (rna) v = __builtin_bswap32(v);
-                uint32_t y = (v >> 1) & 0x03030303u;
-                y ^= (y >> 1) & 0x01010101u;
-                const uint32_t b0 = y & 0x01010101u, b1 = (y >> 1) & 0x01010101u, b01 = b0 & b1;
-                uint32_t d = v ^ (0x41414141u + 2u * b0 + 6u * b1 + 11u * b01); // see codes_of_16
-                if (rna) d &= ~b01;
-                const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
-                code8 = (y * 0x01041040u) >> 24;
-                bad4 = (((nz >> 7) * 0x00204081u) >> 21) & 0xfu;
-            }
-        } else { // a read boundary (or the batch's end) inside the group: op by op
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (g0 + j >= N) break;
-                const uint32_t e = idx[j], fl = t_fl[e];
-                if ((fl & 3u) != 1u) continue;
-                const bool rna = (fl >> 2) & 1u;
-                const uint64_t s0 = (uint64_t)t_s0lo[e] | ((uint64_t)t_s0hi[e] << 32);
-                const uint32_t i = (uint32_t)((int32_t)(x + j) - t_o0[e]);
-                const uint8_t bc = base_code(B.seq[rna ? s0 + t_slen[e] - 1u - i : s0 + i], rna);
-                code8 |= ((uint32_t)bc & 3u) << (2 * j);
-                if (bc <= 3) bad4 &= ~(1u << j);
-            }
+    for (int j = 0; j < 16; ++j) s16 += opn[j];
+    uint32_t rowinc = s16;
+    rowinc += dpp_zero<0x111, 0xF>(rowinc); rowinc += dpp_zero<0x112, 0xF>(rowinc); rowinc += dpp_zero<0x114, 0xF>(rowinc); rowinc += dpp_zero<0x118, 0xF>(rowinc);
+    const uint32_t rowex = rowinc - s16; // sum of op_n over [g0 & ~255, g0)
+    if (g0 < N) {
+        const uint32_t c1 = rowex + opn[0] + opn[1] + opn[2] + opn[3], c2_ = c1 + opn[4] + opn[5] + opn[6] + opn[7], c3 = c2_ + opn[8] + opn[9] + opn[10] + opn[11];
+        *reinterpret_cast<uint4 *>(O.cum + (g0 >> 2)) = make_uint4(rowex, c1, c2_, c3); // entries behind n_ops are padding
+        if ((lane & 15) == 15 || g0 + 16 >= N) O.btot[g0 >> 8] = rowinc;
+    }
+    PG_MARK(1, 1); // table entry, block sums
+    __syncthreads();
+    PG_MARK(1, 2); // barrier
+    const uint32_t R = sh_R[tq];
+    const bool over = sh_over[tq] != 0; // wave-uniform
+
+    // ---- stage 2: the reads of the thread's 16 ops, their bases ---------------------------------------------------------------------
+    // A = the read of op x0, B = the read (with ops) that starts inside the group at op jb (16 = none), more = a third read starts inside
+    struct Seg { uint32_t e; int32_t o0; uint32_t fl; };
+    auto find_reads = [&](uint32_t x0, Seg &A, Seg &Bs, uint32_t &jb, bool &more) {
+        uint32_t e = R > 1 ? (uint32_t)(((uint64_t)x0 * R) >> 12) : 0u; // reads of about equal length: a guess, then a probe
+        if (e >= R) e = R - 1;
+        while (e > 0 && t_o0[tq][e] > (int32_t)x0) --e;
+        while (e + 1 < R && t_o0[tq][e + 1] <= (int32_t)x0) ++e;
+        A.e = e; A.o0 = t_o0[tq][e]; A.fl = t_fl[tq][e];
+        jb = 16; more = false; Bs = A;
+        uint32_t f = e + 1;
+        if (f < R && t_o0[tq][f] < (int32_t)(x0 + 16)) {
+            while (f + 1 < R && t_o0[tq][f + 1] == t_o0[tq][f]) ++f; // reads without ops
+            Bs.e = f; Bs.o0 = t_o0[tq][f]; Bs.fl = t_fl[tq][f];
+            jb = (uint32_t)(Bs.o0 - (int32_t)x0);
+            more = f + 1 < R && t_o0[tq][f + 1] < (int32_t)(x0 + 16);
         }
     };
+    // 16 bases of read entry e starting at its event index i, as 2-bit codes (base i+p at bits 2p) + bad bits; 0 / all bad if no window
+    auto window = [&](const Seg &sg, uint32_t i, uint32_t &code, uint32_t &bad) {
+        code = 0; bad = 0xffffu;
+        if ((sg.fl & 3u) != 1u) return;
+        const bool rna = (sg.fl >> 2) & 1u;
+        const uint64_t s0 = (uint64_t)t_s0lo[tq][sg.e] | ((uint64_t)t_s0hi[tq][sg.e] << 32);
+        // DNA-oriented: base i+p is sequence byte s0+i+p; RNA-oriented: match p is byte s0+slen-1-p, so the window is the 16 bytes
+        // that END at s0+slen-1-i. Bytes outside the read (or the buffer: clamped) belong to non-candidates.
+        const int64_t a = rna ? (int64_t)(s0 + t_slen[tq][sg.e]) - 16 - (int64_t)i : (int64_t)(s0 + i);
+        const int64_t adw = a >> 2;
+        uint32_t d[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
+        const uint32_t sh = (uint32_t)(a & 3) * 8u;
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
+        if (rna) { // byte q of the window is match i+15-q: into match order
+            const uint32_t a0 = __builtin_bswap32(w[3]), a1 = __builtin_bswap32(w[2]), a2 = __builtin_bswap32(w[1]), a3 = __builtin_bswap32(w[0]);
+            w[0] = a0; w[1] = a1; w[2] = a2; w[3] = a3;
+        }
+        codes_of_16(w, rna, code, bad);
+    };
+    Seg A{0, 0, 0}, Bs{0, 0, 0}; uint32_t jb = 16; bool more = false;
+    if (tile_live && !over) {
+#pragma unroll 1
+        for (uint32_t pass = 0; pass < 2; ++pass) { // pass 1 (thread 0 of the tile): the halo
+            if (pass && lt != 0) break;
+            const uint32_t slot_g = pass ? 256u : lt, x0 = slot_g * 16u;
+            uint32_t code = 0, bad = 0xffffu;
+            if (T0 + x0 < N) {
+                Seg a, b; uint32_t j2; bool m2;
+                find_reads(x0, a, b, j2, m2);
+                uint32_t cA, bA, cB = 0, bB = 0xffffu;
+                window(a, (uint32_t)((int32_t)x0 - a.o0), cA, bA);
+                if (j2 < 16) window(b, 0u, cB, bB);
+                const uint32_t keep = j2 < 16 ? (1u << (2u * j2)) - 1u : 0xffffffffu, keepb = j2 < 16 ? (1u << j2) - 1u : 0xffffu;
+                code = (cA & keep) | (j2 < 16 ? cB << (2u * j2) : 0u);
+                bad = (bA & keepb) | (j2 < 16 ? (bB << j2) & 0xffffu : 0u);
+                if (!pass) { A = a; Bs = b; jb = j2; more = m2; }
+            }
+            codew[tq][slot_g] = code; badw[tq][slot_g] = bad;
+        }
+    }
+    PG_MARK(1, 3); // reads of the group, base codes
+    __syncthreads();
+    PG_MARK(1, 4); // barrier
 
+    // ---- stage 3: the events ------------------------------------------------------------------------------------------------------------
+    const uint32_t cmask = (1u << nbits) - 1u;
+    if (tile_live && g0 < N && (over || more)) { // every op on its own (rare): its read, its k bases, its window length
 #pragma unroll 1
-    for (uint32_t q = 0; q < 4; ++q) {
-        const uint64_t T0 = (uint64_t)(tile0 + q) * PG_SORT_TILE;
-        if (T0 >= N) break; // block-uniform
-        const uint64_t g0 = T0 + (uint64_t)tid * 4u;
-        uint32_t out[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
-        uint32_t opn[4] = {0, 0, 0, 0}; // op_n of the group's own ops
-        if (g0 + 4 <= N) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_n + g0); opn[0] = v.x; opn[1] = v.y; opn[2] = v.z; opn[3] = v.w; }
-        else {
+        for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
+            const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, B.op_n[g0 + j]);
+            O.ev_slot[g0 + j] = sl;
+            if (COUNT && sl != PG_INVALID_SLOT) atomicAdd(&cnt[tq][sl & cmask], 1u);
+        }
+    } else if (tile_live && g0 < N) {
+        const uint32_t x0 = lt * 16u;
+        const uint64_t c64 = (uint64_t)codew[tq][lt] | ((uint64_t)codew[tq][lt + 1] << 32); // bases of ops x0 .. x0+31, op x0+p at bits 2p
+        const uint32_t bad32 = (badw[tq][lt] & 0xffffu) | (badw[tq][lt + 1] << 16);
+        const int32_t iloA = t_ilo[tq][A.e], ihiA = t_ihi[tq][A.e];
+        int32_t iloB = 0, ihiB = -1;
+        if (jb < 16) { iloB = t_ilo[tq][Bs.e]; ihiB = t_ihi[tq][Bs.e]; }
+        const bool any_generic = (A.fl & 3u) == 2u || (jb < 16 && (Bs.fl & 3u) == 2u);
+        bool too_long = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
-        }
-        // sums of op_n over the wave's 256-op block (all 64 lanes take part): cum at 4-op granularity, the block total, and for a
-        // read that starts in this group the sum in front of its first op (PgReadMeta::pcum0). Ops of ANY kind count: the emit
-        // kernels only take differences inside one read.
-        const uint32_t s4 = opn[0] + opn[1] + opn[2] + opn[3];
-        const uint32_t inc = wave_incl_scan_u32(s4);
-        const uint32_t pre[4] = {inc - s4, inc - s4 + opn[0], inc - s4 + opn[0] + opn[1], inc - opn[3]};
-        if (g0 < N) {
-            O.cum[g0 >> 2] = pre[0];
-            if (lane == WAVE - 1 || g0 + 4 >= N) O.btot[g0 >> 8] = inc;
-        }
-        // ---- the table of the tile's reads ---------------------------------------------------------------------------------
-        const uint32_t rFirst = sh_rf[q];
-        const uint64_t halo_end = T0 + PG_SORT_TILE + 16 < N ? T0 + PG_SORT_TILE + 16 : N;
-        bool valid = false, over = false;
-        {
-            const uint32_t r = rFirst + tid;
-            uint64_t o0 = 0;
-            if (r < B.n_reads) { o0 = B.op_off[r]; valid = tid == 0 || o0 < halo_end; }
-            if (valid) {
-                const PgReadMeta *mp = O.meta + r;
-                const uint32_t flags = mp->flags;
-                const uint64_t s0 = mp->s0;
-                const bool generic = O.gen_flag[r] == O.batch_id;
-                const bool skip = O.oor && O.oor[r];
-                // W.no_generic: the caller vouched for a batch of matches only and k_walk was not launched; a listed read then has
-                // no events here and fails the batch on the host (pg_api.hip: check_read_errors)
-                const uint32_t kind = (!(flags & PG_RM_LIVE) || skip) ? 0u : (generic ? (W.no_generic ? 0u : 2u) : ((flags & PG_RM_DIRECT_OK) ? 1u : 0u));
-                t_o0[tid] = (int32_t)((int64_t)mp->o0 - (int64_t)T0); t_n[tid] = mp->nops; t_fl[tid] = kind | ((flags & PG_RM_RNA) ? 4u : 0u);
-                t_s0lo[tid] = (uint32_t)s0; t_s0hi[tid] = (uint32_t)(s0 >> 32); t_slen[tid] = mp->slen; t_stk[tid] = mp->st_k; t_endk[tid] = mp->end_k;
-                if (tid == TBL - 1) over = r + 1 < B.n_reads && B.op_off[r + 1] < halo_end; // more reads than the table holds
+        for (int v = 0; v < 4; ++v) {
+            uint32_t wk[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
+            if (any_generic) { // events of generic reads come from k_walk
+                if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(O.ev_slot + g0 + 4 * v); wk[0] = x.x; wk[1] = x.y; wk[2] = x.z; wk[3] = x.w; }
+                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) wk[u] = O.ev_slot[g0 + 4 * v + u]; }
             }
-        }
-        const uint32_t R = (uint32_t)__syncthreads_count(valid); // valid threads are 0 .. R-1 (op_off is monotone)
-        if (__syncthreads_or(over)) { // (block-uniform) reads of a few ops each: every thread looks its reads up on its own
+            // the window lengths: the thread's own op_n again (they were summed long ago; registers are worth more than cache hits)
+            uint32_t len[4] = {0, 0, 0, 0};
+            if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
+            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) len[u] = B.op_n[g0 + 4 * v + u]; }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (g0 + j < N) out[j] = event_slot_scalar(B, W, O, g0 + j, opn[j], pre[j]);
-        } else {
-            uint32_t idx[4] = {0, 0, 0, 0};
-#pragma unroll 1
-            for (uint32_t pass = 0; pass < 2; ++pass) { // pass 1 (threads 0..3 only): the halo, the 16 ops behind the tile, whose
-                if (pass && tid >= 4) break;            // bases the tile's last events reach
-                const uint32_t slot_g = pass ? 1024u + tid : tid;
-                uint32_t gi[4] = {0, 0, 0, 0}, code8 = 0, bad4 = 0xfu;
-                if (T0 + slot_g * 4u < N) group_codes(T0, slot_g * 4u, R, gi, code8, bad4);
-                codeb[slot_g] = (uint8_t)code8; badb[slot_g] = (uint8_t)bad4;
-                if (!pass) { idx[0] = gi[0]; idx[1] = gi[1]; idx[2] = gi[2]; idx[3] = gi[3]; }
-            }
-            __syncthreads();
-            if (g0 < N) {
-                // bases of ops g0 .. g0+15 (op g0+p at bits 2p) and their "not A C G T/U" bits
-                const uint32_t c2 = (uint32_t)codeb[tid] | ((uint32_t)codeb[tid + 1] << 8) | ((uint32_t)codeb[tid + 2] << 16) | ((uint32_t)codeb[tid + 3] << 24);
-                const uint32_t bad16 = (uint32_t)badb[tid] | ((uint32_t)badb[tid + 1] << 4) | ((uint32_t)badb[tid + 2] << 8) | ((uint32_t)badb[tid + 3] << 12);
-                uint32_t cur = 0xffffffffu, n = 0, fl = 0; int32_t o0r = 0, stk = 0, endk = 0;
-                bool any_generic = (t_fl[idx[0]] & 3u) == 2u;
-                if (idx[3] != idx[0]) any_generic = any_generic || (t_fl[idx[1]] & 3u) == 2u || (t_fl[idx[2]] & 3u) == 2u || (t_fl[idx[3]] & 3u) == 2u;
-                uint4 walked = make_uint4(PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT);
-                if (any_generic) { // events of generic reads come from k_walk
-                    if (g0 + 4 <= N) walked = *reinterpret_cast<const uint4 *>(O.ev_slot + g0);
-                    else { uint32_t wv[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT}; for (int j = 0; j < 4 && g0 + j < N; ++j) wv[j] = O.ev_slot[g0 + j]; walked = make_uint4(wv[0], wv[1], wv[2], wv[3]); }
-                }
-                const uint32_t wk[4] = {walked.x, walked.y, walked.z, walked.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (g0 + j >= N) break;
-                    if (idx[j] != cur) { cur = idx[j]; o0r = t_o0[cur]; n = t_n[cur]; fl = t_fl[cur]; stk = t_stk[cur]; endk = t_endk[cur]; }
-                    const uint32_t kind = fl & 3u;
-                    const bool rna = (fl >> 2) & 1u;
-                    const uint32_t i = (uint32_t)((int32_t)(tid * 4u + j) - o0r), e = i + W.sig_move_offset;
-                    if (i == 0) O.meta[rFirst + cur].pcum0 = pre[j];
-                    if (opn[j] >= PG_OP_N_LIMIT && kind == 1u) report_error(O, rFirst + cur, PGR_ERR_RANGE);
-                    if (kind == 2u) { out[j] = wk[j]; continue; }
-                    if (kind != 1u || !(i <= n - k && e < n)) continue; // not an event of its read (gmove.cpp:891-894); n >= k for direct reads
-                    // matches i .. i+k-1 at bits 2j ..: a field of k 2-bit groups with the FIRST base lowest -- the code the reference
-                    // looks up on RNA-oriented records (mirrored k-mer, gmove.cpp:883, 899); its groups reversed on DNA-oriented ones
-                    const uint32_t field = (c2 >> (2u * j)) & ((1u << (2u * k)) - 1u), badf = (bad16 >> j) & ((1u << k) - 1u);
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * v + u;
+                const bool inB = (uint32_t)j >= jb;
+                const int32_t o0r = inB ? Bs.o0 : A.o0, ilo = inB ? iloB : iloA, ihi = inB ? ihiB : ihiA;
+                const uint32_t fl = inB ? Bs.fl : A.fl, kind = fl & 3u;
+                const int32_t i = (int32_t)(x0 + j) - o0r;
+                uint32_t sl = kind == 2u ? wk[u] : PG_INVALID_SLOT;
+                if (kind == 1u && i >= ilo && i <= ihi && g0 + j < N) {
+                    // matches i .. i+k-1 at bits 2j ..: k 2-bit groups with the FIRST base lowest -- the code the reference looks up on
+                    // RNA-oriented records (mirrored k-mer, gmove.cpp:883, 899); its groups reversed on DNA-oriented ones
+                    const uint32_t field = (uint32_t)(c64 >> (2 * j)) & ((1u << (2u * k)) - 1u), badf = (uint32_t)(((uint64_t)bad32 >> j) & ((1u << k) - 1u));
                     const uint32_t xr = __builtin_bitreverse32(field);
                     const uint32_t fwd = (((xr & 0xAAAAAAAAu) >> 1) | ((xr & 0x55555555u) << 1)) >> (32u - 2u * k);
-                    if (badf) continue;
-                    const int32_t slot = rna ? W.table_u[field] : W.table_t[fwd];
-                    // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read: e < n)
-                    const uint32_t dur = W.sig_move_offset == 0 ? opn[j] : B.op_n[g0 + j + W.sig_move_offset];
-                    // pick_this_kmer without I/D ops: no interior entry (gmove.cpp:204-211 with indel_pos = [-st_k, end_k + M])
-                    if (slot >= 0 && dur <= W.max_dur && dur >= W.min_dur && pick_kmer(i, k, W.pick_margin, n, 0u, rna, stk, endk, 0u, 0u)) out[j] = (uint32_t)slot;
+                    const bool rna = (fl >> 2) & 1u;
+                    // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read): gmove.cpp:916-921
+                    const uint32_t dur = W.sig_move_offset == 0 ? len[u] : B.op_n[g0 + j + W.sig_move_offset];
+                    if (!badf && dur <= W.max_dur && dur >= W.min_dur) sl = (uint32_t)W.table_t[rna ? field + W.n_codes : fwd]; // table_u sits behind table_t; -1 = not in the slice = PG_INVALID_SLOT
                 }
+                if (kind == 1u && len[u] >= PG_OP_N_LIMIT && g0 + j < N) too_long = true;
+                stage[tq][j][lt] = (stage_t)(sl == PG_INVALID_SLOT ? STAGE_INVALID : sl);
+                if (COUNT && sl != PG_INVALID_SLOT && g0 + j < N) atomicAdd(&cnt[tq][sl & cmask], 1u);
             }
         }
-        if (g0 < N) {
-            if (g0 + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0) = make_uint4(out[0], out[1], out[2], out[3]);
-            else { for (int j = 0; j < 4 && g0 + j < N; ++j) O.ev_slot[g0 + j] = out[j]; }
+        // ---- everything that stores to global memory: behind the last look-up -------------------------------------------------------
+        if (too_long) { // an op of 2^24 samples or more in a direct read (PG_OP_N_LIMIT): any fails the batch, the lowest read is reported
+            for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
+                const bool inB = j >= jb;
+                if (((inB ? Bs.fl : A.fl) & 3u) == 1u && B.op_n[g0 + j] >= PG_OP_N_LIMIT) report_error(O, rFirst + (inB ? Bs.e : A.e), PGR_ERR_RANGE);
+            }
         }
-        if (COUNT) {
-            const uint32_t mask = (1u << nbits) - 1u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (out[j] != PG_INVALID_SLOT) atomicAdd(&cnt[q][out[j] & mask], 1u);
+        for (int v = 0; v < 4; ++v) {
+            uint32_t o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t x = stage[tq][4 * v + u][lt]; o4[u] = x == STAGE_INVALID ? PG_INVALID_SLOT : x; }
+            if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
         }
-        __syncthreads(); // the table and the code bytes are rewritten for the next tile
     }
+    PG_MARK(1, 5); // events, stores, counts
     if (COUNT) {
         __syncthreads();
         for (uint32_t d = tid; d < (1u << nbits); d += 1024)
             *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
     }
+    PG_MARK(1, 6); // barrier + histogram rows
+    PG_PROBE_END(1, blockIdx.x * 16u + (tid >> 6));
 }
 
 // SAM/BAM front-end (gmove.cpp:1149-1160): a read with an out-of-range sample is a skipped read (no events, no ':')
@@ -713,10 +764,10 @@ __global__ __launch_bounds__(256) void k_apply_oor(uint32_t n_reads, PgWalkOut O
 }
 
 // what the emit kernels need of the read of a kept event
-struct KeptRead { uint64_t o0; uint32_t qs, pcum0, L; bool generic; };
+struct KeptRead { uint64_t o0; uint32_t qs, L; bool generic; };
 __device__ __forceinline__ KeptRead kept_read(const PgWalkOut &O, uint32_t rd) {
     const PgReadMeta *mt = O.meta + rd;
-    KeptRead k; k.o0 = mt->o0; k.qs = (uint32_t)mt->qs; k.pcum0 = mt->pcum0; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
+    KeptRead k; k.o0 = mt->o0; k.qs = (uint32_t)mt->qs; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
     return k;
 }
 // window start and length of a kept event (gmove.cpp:854-855) at op index g of read rd: from the generic walk's arrays, or, for a
@@ -725,13 +776,22 @@ __device__ __forceinline__ bool kept_window(const PgDevBatch &B, const PgWalkPar
     const uint64_t ge = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
     if (kr.generic) { start = O.m_start[ge]; len = O.m_len[ge]; return true; }
     len = B.op_n[ge];
-    uint32_t pge = O.cum[ge >> 2]; // P(ge) = sum of op_n over [ge & ~255, ge)
-    for (uint64_t y = ge & ~3ull; y < ge; ++y) pge += B.op_n[y];
+    // P(x) = sum of op_n over [x & ~255, x) = cum at the 4-op group + the ops of the group in front of x; the window starts at
+    // query_start + sum of op_n over [o0, ge) = P differences + whole blocks in between
+    auto P = [&](uint64_t x) {
+        uint32_t s = O.cum[x >> 2];
+        const uint64_t y = x & ~3ull;
+        const uint32_t a = B.op_n[y], b = B.op_n[y + 1 < B.n_ops ? y + 1 : y], c = B.op_n[y + 2 < B.n_ops ? y + 2 : y]; // (unconditional: 3 loads in flight)
+        const uint32_t m = (uint32_t)(x & 3);
+        s += (m > 0 ? a : 0u) + (m > 1 ? b : 0u) + (m > 2 ? c : 0u);
+        return s;
+    };
+    const uint32_t p0 = P(kr.o0), pge = P(ge);
     uint64_t sum;
     const uint64_t b0 = kr.o0 >> 8, b1 = ge >> 8;
-    if (b0 == b1) sum = (uint64_t)(pge - kr.pcum0);
+    if (b0 == b1) sum = (uint64_t)(pge - p0);
     else {
-        sum = (uint64_t)(O.btot[b0] - kr.pcum0) + pge;
+        sum = (uint64_t)(O.btot[b0] - p0) + pge;
         for (uint64_t b = b0 + 1; b < b1; ++b) sum += O.btot[b];
     }
     const uint64_t st = (uint64_t)kr.qs + sum;

@@ -26,7 +26,8 @@ eng.sync()
 lib.pg_debug_phases(buf.ctypes.data, 0, 1)
 eng.reset(); eng.submit(shard); eng.sync()
 names = {0: ("k_read_stats", ["record load", "samples arrive", "binning", "prefix scan", "selection + stores"]),
-         1: ("k_walk<true>", ["header loads", "ops arrive", "scans + bases arrive", "walk stores", "event loop"])}
+         1: ("k_events<true> (per wave, 4 tiles)", ["first reads of the tiles + op_n", "table entry + block sums", "barrier", "reads of the group + base codes",
+                                                   "barrier", "events + stores + counts", "barrier + histogram rows"])}
 for k, (name, ph) in names.items():
     lib.pg_debug_phases(buf.ctypes.data, k, 0)
     live = buf[:, 7] > 0
