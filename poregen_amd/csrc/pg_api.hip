@@ -85,6 +85,9 @@ struct pg_ctx {
     DevBuf meta, huge_scratch, oor;
     DevBuf blk_read, gen_flag, gen_list, cum, btot; // PgWalkOut: owner index, generic-read list, block sums of op_n
     uint32_t batch_id = 0;  // serial number of the batch being counted (tags gen_flag entries and the error word)
+    PgRareArgs rare{};      // the rare statistics launch of the current batch ...
+    bool rare_pending = false; // ... still to be issued: with the sample-offset scan of pg_collect
+    bool in_submit = false, plan_done = false; // pg_submit: the sample_limit cut was applied inside the tile scan's launch (no k_slot_plan)
     uint32_t gen_reads = 0; // generic reads of the last settled batch
     bool batch_all_matches = false; // PG_BATCH_ALL_MATCHES of the current batch (and not PG_FLAG_DEBUG_SPLIT_WALK)
     DevBuf job_total, job_freq; bool have_job_totals = false; // pg_collect_gathered / pg_job_totals_device
@@ -290,7 +293,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->job_total.ensure(ns * 8ull)); CTRY(c->job_freq.ensure(ns * 8ull)); // allocated once: callers may cache the pointers
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(32));
-    CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut)
+    CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut), [24] u32 ticket (k_rank_scan)
     CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
 #undef CTRY
@@ -445,7 +448,7 @@ static pg_status ensure_stats_buffers(pg_ctx *c) {
 // statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
 // handles the reads whose in-range code interval fits it (no host decision, no sync)
 // plan_done: the records (and the flag reset) were written by this batch's k_batch_init
-static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, bool forked_behind_init = false, bool plan_done = false) {
+static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, bool forked_behind_init = false, bool plan_done = false, bool rare_with_scan = false) {
     // by this batch's k_batch_init, on the same stream (or on the stream this one was forked from, behind that kernel)
     const bool flags_are_reset = (st == c->st || forked_behind_init) && c->stat_flags_reset;
     c->stat_flags_reset = false;
@@ -463,13 +466,21 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     }
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
-    HIP_TRY(c, pg_launch_read_stats(st, c->B, 1024, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, nullptr, oor, range_only));
+    HIP_TRY(c, pg_launch_read_stats(st, c->B, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, oor, range_only));
     prof_end(c, st);
-    prof_begin(c, "k_read_stats_rare", st);
-    HIP_TRY(c, pg_launch_read_stats(st, c->B, 65536, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, c->huge_scratch.as<uint32_t>(), oor, range_only, c->wide_blocks));
-    prof_end(c, st);
+    // the rare reads (in-range interval wider than 1024 codes; usually none): their workers ride in the launch of the sample-offset
+    // scan when that comes next on the same stream (rare_pending); otherwise a launch of their own, here
+    PgRareArgs &A = c->rare;
+    A.B = c->B; A.plan = c->read_plan[sl].as<PgStatRec>(); A.med = c->med[sl].as<double>(); A.mad = c->mad[sl].as<double>();
+    A.status = c->stat_status[sl].as<int32_t>(); A.err = flags; A.win = win; A.wide_list = c->wide_list[sl].as<uint32_t>(); A.wide_count = flags + 1;
+    A.scratch = c->huge_scratch.as<uint32_t>(); A.oor = oor; A.range_only = range_only; A.wide_blocks = c->wide_blocks;
+    if (rare_with_scan && st == c->st) c->rare_pending = true;
+    else {
+        prof_begin(c, "k_read_stats_rare", st);
+        HIP_TRY(c, pg_launch_read_stats_rare(st, A));
+        prof_end(c, st);
+    }
     return PG_OK;
 }
 
@@ -503,7 +514,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     pg_status s = download_last(c);
     if (s != PG_OK) return s;
     if (c->have_batch_result) { c->reads_before += c->B.n_reads; c->have_batch_result = false; }
-    c->have_count = false;
+    c->have_count = false; c->rare_pending = false; c->plan_done = false;
     const uint32_t n = b->n_reads;
 
     c->batch_is_host = b->location == PG_LOC_HOST;
@@ -613,8 +624,11 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     uint64_t *acc_copy = (counts_out && counts_location == PG_LOC_DEVICE) ? counts_out : nullptr; // written by the counting kernels
     if (direct) {
         prof_begin(c, "rank_scan", c->st);
+        // pg_submit (base = this context's running counts): the sample_limit cut rides in the tile scan's launch
+        const bool fuse_plan = c->in_submit;
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
-                                    c->tile_last.as<int32_t>(), acc_copy));
+                                    c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
+                                    c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done));
         prof_end(c, c->st);
     } else {
         prof_begin(c, "sort_events", c->st);
@@ -641,7 +655,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
             HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
             HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
         }
-        pg_status s2 = launch_stats(c, ss, nullptr, tail, c->plan_in_init);
+        pg_status s2 = launch_stats(c, ss, nullptr, tail, c->plan_in_init, /*rare_with_scan=*/ss == c->st);
         if (s2 != PG_OK) return s2;
         if (overlap || tail) HIP_TRY(c, hipEventRecord(c->ev_join[c->slot], c->st2));
         c->stats_in_flight = overlap || tail;
@@ -663,7 +677,7 @@ pg_status pg_stats(pg_ctx *c) {
     if (!c->stats_deferred) return PG_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     c->stats_deferred = false;
-    return launch_stats(c, c->st, nullptr, false, c->plan_in_init);
+    return launch_stats(c, c->st, nullptr, false, c->plan_in_init, true);
 }
 
 pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0, 0); }
@@ -680,7 +694,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stats_deferred) { // PG_FLAG_DEFER_STATS and the caller did not place them with pg_stats
         c->stats_deferred = false;
-        pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init);
+        pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init, true);
         if (s2 != PG_OK) return s2;
     }
     const uint32_t ns = c->prm.n_slots;
@@ -707,12 +721,16 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st)); // chained-scan state
     }
     if (!direct) HIP_TRY(c, c->keep32.ensure(ns * 4ull));
+    const bool plan_in_scan = c->plan_done && !all_counts && !base;
+    c->plan_done = false;
+    if (!plan_in_scan) {
     prof_begin(c, "k_slot_plan", c->st);
     HIP_TRY(c, pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
                         pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
                         (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr, G));
     prof_end(c, c->st);
+    }
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
@@ -740,10 +758,12 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     // lazy statistics: only the reads that own a kept event (flags written above)
     const bool lazy = c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE);
-    if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>()); if (s2 != PG_OK) return s2; }
+    if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>(), false, false, true); if (s2 != PG_OK) return s2; }
 
     prof_begin(c, "scan_ev_len", c->st);
-    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>()));
+    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
+                                      c->rare_pending ? &c->rare : nullptr));
+    c->rare_pending = false;
     prof_end(c, c->st);
 
     uint64_t gather_cap = ke_cap;
@@ -790,7 +810,10 @@ static pg_status settle_batch(pg_ctx *c) {
 }
 
 pg_status pg_submit(pg_ctx *c, const pg_batch *b) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    c->in_submit = true;
     pg_status s = pg_count(c, b, nullptr, PG_LOC_HOST);
+    c->in_submit = false;
     if (s != PG_OK) return s;
     return pg_collect(c, nullptr, PG_LOC_HOST);
 }

@@ -173,8 +173,11 @@ hipError_t pg_launch_apply_oor(hipStream_t st, const PgDevBatch &B, const PgWalk
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): tile prefix of the per-tile per-slot counts pg_launch_events left in S.hist;
 // acc_cnt = events per slot
 hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last,
-                                 uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */);
+                                 uint64_t *acc_cnt, uint64_t *running, uint32_t limit, int32_t *tile_last,
+                                 uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */,
+                                 // plan_keep != null (pg_submit: base = the context's running counts): the sample_limit cut rides in the same
+                                 // launch (its last workgroup does pg_launch_slot_plan's work); *plan_done says whether it did
+                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done);
 hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
@@ -196,21 +199,35 @@ hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const ui
                          const uint32_t *hist, uint32_t n_tiles, uint32_t *keep32, uint64_t *scan_scratch,
                          const int32_t *tile_last /* direct mode, base == running: from pg_launch_rank_direct_count; else null */,
                          const PgGathered &G /* all_counts != null: base = the rows below G.rank, summed in the same pass */);
+// the rare statistics (reads whose in-range interval needs more than 1024 bins): workers stride over the two lists the main launch
+// has filled -- wide_list from the front (<= PG_STATS_BINS codes: LDS histogram), from the back (more: 65536 bins in global memory)
+struct PgRareArgs {
+    PgDevBatch B;
+    const PgStatRec *plan;
+    double *med, *mad;
+    int32_t *status, *err;
+    int win;                   // half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search
+    const uint32_t *wide_list;
+    const int32_t *wide_count; // [0] / [1]: lengths of the wide / huge list
+    uint32_t *scratch;         // PG_HUGE_SCRATCH_WORDS words
+    uint8_t *oor;
+    int range_only;
+    uint32_t wide_blocks;      // hint: wide-list length of the last settled batch (64 .. 2048 workers)
+};
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
-// entries ZERO before the first use (every launch leaves them zero again)
-hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch);
+// entries ZERO before the first use (every launch leaves them zero again). rare (may be null): the rare statistics ride in the
+// same launch (short inputs) or get their own launch in front of the scan kernels
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
+                                  const PgRareArgs *rare);
+hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
 // plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset);
-// bins: 1024 (one workgroup per read) or anything larger = the rare reads (wide list: PG_STATS_BINS LDS bins; huge list:
-// 65536 bins in global memory), one launch for both lists
-// win: half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search often
-hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list /* filled by the 1024-bin launch */,
-                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only,
-                          uint32_t wide_blocks_hint = 0 /* rare launch: workgroups for the wide list (64 .. 2048) */);
+// the main statistics launch (one wave per read, 1024 LDS bins); reads that need more put themselves on wide_list
+hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only);
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

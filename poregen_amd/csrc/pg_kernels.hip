@@ -861,46 +861,103 @@ __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__
 // collects with -- the last tile that still places an event of this slot falls out of the same pass: keep = min(cnt,
 // room), room = limit - base; it is the largest tile whose exclusive prefix is < room when cnt >= room, else the last
 // non-empty tile (k_tile_max finds the same by searching the finished prefix rows when the base arrives later).
-__global__ __launch_bounds__(64) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
-                                                  uint64_t *__restrict__ acc_cnt, uint32_t n_slots, const uint64_t *__restrict__ running,
-                                                  uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy) {
-    const uint32_t d = blockIdx.x;
+// plan (plan.keep != null; direct mode, base = the context's own running counts: pg_submit): the workgroup that finishes LAST also applies
+// the sample_limit cut (k_slot_plan's work: gmove.cpp:925-927, 945-950) -- one launch less per batch. Hand-over without fences (a
+// device-scope release writes the XCD's whole L2 back: 7 -> 34 us when every workgroup did one): each workgroup's two results leave
+// as sc1 stores (agent-scope relaxed atomics), the wave waits for them (vmcnt(0)) and then adds to ONE counter; the workgroup whose
+// add returns the last ticket reads all results back with sc1 loads (MI355X_MICROARCH.md, cross-workgroup hand-offs, first row).
+struct PgScanPlan {
+    uint64_t *keep, *ev_off, *plan_totals, *running_out;
+    uint32_t *ticket;
+};
+#define PG_SCAN_WAVES 16 // digits (= waves) per workgroup of k_rank_scan: 64 workgroups for 1024 slots, 64 adds to the ticket
+__global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
+                                                  uint64_t *__restrict__ acc_cnt, uint32_t n_slots, uint32_t n_digits, const uint64_t *running,
+                                                  uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy, PgScanPlan plan) {
+    const uint32_t d = blockIdx.x * PG_SCAN_WAVES + (threadIdx.x >> 6); // one wave per digit
     const int lane = lane_id();
-    uint32_t run = 0;
-    const bool want_last = tile_last && d < n_slots;
-    const uint64_t base0 = want_last ? running[d] : 0;
-    const uint32_t room = base0 >= limit ? 0u : limit - (uint32_t)base0;
-    int candA = -1, candB = -1;
-    uint32_t *__restrict__ row = hist + (uint64_t)d * n_tiles;
-    for (uint32_t c0 = 0; c0 < n_tiles; c0 += 8 * WAVE) { // eight independent loads in flight, then the (ALU-only) scans
-        uint32_t v[8];
+    if (d < n_digits) {
+        uint32_t run = 0;
+        const bool want_last = tile_last && d < n_slots;
+        const uint64_t base0 = want_last ? running[d] : 0;
+        const uint32_t room = base0 >= limit ? 0u : limit - (uint32_t)base0;
+        int candA = -1, candB = -1;
+        uint32_t *__restrict__ row = hist + (uint64_t)d * n_tiles;
+        for (uint32_t c0 = 0; c0 < n_tiles; c0 += 8 * WAVE) { // eight independent loads in flight, then the (ALU-only) scans
+            uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const uint32_t i = c0 + u * WAVE + lane; v[u] = i < n_tiles ? row[i] : 0u; }
+            for (int u = 0; u < 8; ++u) { const uint32_t i = c0 + u * WAVE + lane; v[u] = i < n_tiles ? row[i] : 0u; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = c0 + u * WAVE + lane;
-            const uint32_t inc = wave_incl_scan_u32(v[u]);
-            const uint32_t excl = run + inc - v[u];
-            if (i < n_tiles) {
-                row[i] = excl;
-                if (excl < room) candA = (int)i; // i grows along the loop: the last assignment is the largest
-                if (v[u] > 0) candB = (int)i;
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t i = c0 + u * WAVE + lane;
+                const uint32_t inc = wave_incl_scan_u32(v[u]);
+                const uint32_t excl = run + inc - v[u];
+                if (i < n_tiles) {
+                    row[i] = excl;
+                    if (excl < room) candA = (int)i; // i grows along the loop: the last assignment is the largest
+                    if (v[u] > 0) candB = (int)i;
+                }
+                run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             }
-            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        }
+        int last = -1;
+        if (want_last) {
+            last = run >= room ? candA : candB;
+            if (room == 0 || run == 0) last = -1;
+            for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(last, o, WAVE); last = t > last ? t : last; }
+        }
+        if (lane == 0) {
+            totals[d] = run;
+            if (acc_copy && d < n_slots) acc_copy[d] = run; // pg_count's device output (a rank's row of the all_gather buffer): no copy kernel
+            if (plan.keep) { // sc1: read back by the last workgroup
+                if (d < n_slots) {
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(acc_cnt + d), (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(tile_last + d, last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (want_last) tile_last[d] = last;
+                if (acc_cnt && d < n_slots) acc_cnt[d] = run; // direct mode: digit == slot, so this is the batch's accepted-event count
+            }
         }
     }
-    if (want_last) {
-        int last = run >= room ? candA : candB;
-        if (room == 0 || run == 0) last = -1;
-        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(last, o, WAVE); last = t > last ? t : last; }
-        if (lane == 0) tile_last[d] = last;
-    }
-    if (lane == 0) {
-        totals[d] = run;
-        if (acc_cnt && d < n_slots) { // direct mode: digit == slot, so this is the batch's accepted-event count
-            acc_cnt[d] = run;
-            if (acc_copy) acc_copy[d] = run; // pg_count's device output (a rank's row of the all_gather buffer): no copy kernel
+    if (!plan.keep) return; // (block-uniform)
+    __shared__ uint32_t sh_ticket, wsum[PG_SCAN_WAVES], wfull[PG_SCAN_WAVES]; __shared__ int wmax[PG_SCAN_WAVES];
+    __builtin_amdgcn_s_waitcnt(0); // every storing wave: its two stores have left ...
+    __syncthreads();               // ... before the one lane that signals for the workgroup adds to the counter
+    if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(plan.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_ticket != gridDim.x - 1) return;
+    // ---- the last workgroup: keep = min(cnt, limit - running), offsets, totals (as k_slot_plan with base == running) ---------------
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    uint32_t carry = 0, full = 0; int tmax = -1;
+    for (uint32_t c = 0; c < n_slots; c += PG_SCAN_WAVES * WAVE) {
+        const uint32_t s_ = c + tid;
+        uint32_t kp = 0; bool isfull = false; int tl = -1;
+        if (s_ < n_slots) {
+            const uint64_t cnt = __hip_atomic_load(reinterpret_cast<unsigned long long *>(acc_cnt + s_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tl = __hip_atomic_load(tile_last + s_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t b = running[s_];
+            const uint64_t rm = b >= limit ? 0 : (uint64_t)limit - b;
+            kp = (uint32_t)(cnt < rm ? cnt : rm);
+            isfull = limit > 0 && b + cnt >= limit; // at limit 0 no k-mer ever completes (gmove.cpp:925-927 skips every event)
+            plan.running_out[s_] = b + cnt;
+            plan.keep[s_] = kp;
         }
+        const uint32_t inc = wave_incl_scan_u32(kp); // kept events of a batch number < 2^31
+        const uint32_t nf = (uint32_t)__popcll(__ballot(isfull));
+        for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(tl, o, WAVE); tl = t > tl ? t : tl; }
+        if (lane == WAVE - 1) { wsum[w] = inc; wfull[w] = nf; wmax[w] = tl; }
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+        for (uint32_t ww = 0; ww < PG_SCAN_WAVES; ++ww) { if (ww < w) off += wsum[ww]; tot += wsum[ww]; full += wfull[ww]; tmax = wmax[ww] > tmax ? wmax[ww] : tmax; }
+        if (s_ < n_slots) plan.ev_off[s_] = (uint64_t)carry + off + inc - kp;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        plan.ev_off[n_slots] = carry; plan.plan_totals[0] = carry; plan.plan_totals[1] = full;
+        plan.plan_totals[3] = (uint64_t)(int64_t)tmax; // read as a signed tile index by k_rank_emit
+        __hip_atomic_store(plan.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next batch
     }
 }
 
@@ -1307,8 +1364,20 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 // order = order of arrival, so a block only ever waits for blocks that already run), state[1] = blocks done,
 // state[2 + b] = (value << 2) | flag, flag 1 = sum of block b, 2 = inclusive prefix up to block b. The block that
 // finishes last clears the state for the next launch (the buffer is zeroed when it is allocated).
-__global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
-                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ state) {
+#define PG_RARE_LDS_WORDS (PG_STATS_BINS + WAVE + 32 + 4) // = StatsGeom<PG_STATS_BINS>::LDS_WORDS (checked where that is defined)
+__device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, uint32_t *hist, const PgRareArgs &A); // with the statistics kernels
+// RARE: blocks [n_scan, gridDim.x) are not part of the scan: each of their 4 waves is a worker of the rare statistics launch
+// (reads whose in-range interval needs more than 1024 bins; usually none) -- an empty launch of its own costs a kernel boundary.
+template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
+                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ state, uint32_t n_scan, PgRareArgs A) {
+    if (RARE) {
+        __shared__ __attribute__((aligned(16))) uint32_t rare_hist[4][PG_RARE_LDS_WORDS];
+        if (blockIdx.x >= n_scan) {
+            const uint32_t workers = (gridDim.x - n_scan) * 4u;
+            rare_worker((blockIdx.x - n_scan) * 4u + (threadIdx.x >> 6), workers - PG_HUGE_BLOCKS, rare_hist[threadIdx.x >> 6], A);
+            return;
+        }
+    }
     __shared__ uint64_t wsum[4];
     __shared__ uint64_t sh_prefix;
     __shared__ uint32_t sh_block;
@@ -1364,11 +1433,11 @@ __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(state + 1), 1ull);
-        sh_block = done + 1 == gridDim.x;
+        sh_block = done + 1 == n_scan;
     }
     __syncthreads();
     if (sh_block) // last block out: nobody reads the state any more
-        for (uint32_t i = threadIdx.x; i < gridDim.x + 2; i += 256) __hip_atomic_store(state + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t i = threadIdx.x; i < n_scan + 2; i += 256) __hip_atomic_store(state + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =====================================================================================================
@@ -1908,29 +1977,30 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) void k_read_stats(PgDevBatch B, 
 // empty launch still costs a kernel boundary): blocks [0, gridDim.x - PG_HUGE_BLOCKS) stride over the wide list
 // (<= PG_STATS_BINS codes: LDS histogram), the last PG_HUGE_BLOCKS blocks over the huge list (any interval: a 65536-bin
 // histogram in global memory, one scratch histogram per block).
-__global__ __launch_bounds__(64) void k_read_stats_rare(PgDevBatch B, const PgStatRec *__restrict__ plan, double *__restrict__ med,
-                                                        double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
-                                                        int win, const uint32_t *__restrict__ wide_list,
-                                                        const int32_t *__restrict__ wide_count, uint32_t *__restrict__ scratch,
-                                                        uint8_t *__restrict__ oor, int range_only) {
-    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
-    const uint32_t n_wide_blocks = gridDim.x - PG_HUGE_BLOCKS;
-    if (blockIdx.x < n_wide_blocks) {
-        const uint32_t n_list = (uint32_t)wide_count[0];
-        for (uint32_t it = blockIdx.x; it < n_list; it += n_wide_blocks) {
-            stats_one_read<PG_STATS_BINS>(hist, B, wide_list[it], plan, med, mad, status, err, win, oor, range_only);
+static_assert(PG_RARE_LDS_WORDS == StatsGeom<PG_STATS_BINS>::LDS_WORDS, "k_scan_chained's rare histogram");
+// one rare-read worker (= one wave): workers [0, n_wide) stride over the wide list (LDS histogram `hist` of PG_STATS_BINS bins), workers
+// [n_wide, n_wide + PG_HUGE_BLOCKS) over the huge list (a 65536-bin histogram in global memory, one scratch histogram per worker)
+__device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, uint32_t *hist, const PgRareArgs &A) {
+    if (worker < n_wide) {
+        const uint32_t n_list = (uint32_t)A.wide_count[0];
+        for (uint32_t it = worker; it < n_list; it += n_wide) {
+            stats_one_read<PG_STATS_BINS>(hist, A.B, A.wide_list[it], A.plan, A.med, A.mad, A.status, A.err, A.win, A.oor, A.range_only);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
         }
-    } else {
-        const uint32_t hb = blockIdx.x - n_wide_blocks, n_list = (uint32_t)wide_count[1];
-        uint32_t *gh = scratch + (size_t)hb * PG_HUGE_WORDS;
+    } else if (worker < n_wide + PG_HUGE_BLOCKS) {
+        const uint32_t hb = worker - n_wide, n_list = (uint32_t)A.wide_count[1];
+        uint32_t *gh = A.scratch + (size_t)hb * PG_HUGE_WORDS;
         for (uint32_t it = hb; it < n_list; it += PG_HUGE_BLOCKS) {
-            stats_one_read<PG_HUGE_BINS>(gh, B, wide_list[B.n_reads - 1 - it], plan, med, mad, status, err, win, oor, range_only);
+            stats_one_read<PG_HUGE_BINS>(gh, A.B, A.wide_list[A.B.n_reads - 1 - it], A.plan, A.med, A.mad, A.status, A.err, A.win, A.oor, A.range_only);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+__global__ __launch_bounds__(64) void k_read_stats_rare(PgRareArgs A) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist[StatsGeom<PG_STATS_BINS>::LDS_WORDS];
+    rare_worker(blockIdx.x, gridDim.x - PG_HUGE_BLOCKS, hist, A);
 }
 
 // =====================================================================================================
@@ -2099,11 +2169,16 @@ hipError_t pg_launch_apply_oor(hipStream_t st, const PgDevBatch &B, const PgWalk
 static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
 hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
-                                 uint64_t *acc_cnt, const uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy) {
+                                 uint64_t *acc_cnt, uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy,
+                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
+    *plan_done = false;
     if (n_tiles) { // the counts are in S.hist (k_events<true>)
-        PG_LAUNCH(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, running, limit, tile_last, acc_copy);
+        PgScanPlan P{};
+        if (plan_keep) { P.keep = plan_keep; P.ev_off = plan_ev_off; P.plan_totals = plan_totals; P.running_out = running; P.ticket = plan_ticket; *plan_done = true; }
+        PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
+                  (const uint64_t *)running, limit, tile_last, acc_copy, P);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
         if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));
@@ -2136,8 +2211,8 @@ hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64
         const int nbits = (int)((key_bits - shift) < per ? (key_bits - shift) : per);
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         PG_LAUNCH(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
-        PG_LAUNCH(k_rank_scan, dim3(1u << nbits), dim3(64), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, (const uint64_t *)nullptr, 0u,
-                           (int32_t *)nullptr, (uint64_t *)nullptr);
+        PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, 1u << nbits,
+                  (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{});
         PG_LAUNCH(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         PG_LAUNCH(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
@@ -2166,7 +2241,7 @@ hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const ui
     if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
         PG_HIP(hipMemsetAsync(totals, 0, 32, st));
         PG_LAUNCH(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
-        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch));
+        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch, nullptr));
         PG_LAUNCH(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
         return hipSuccess;
     }
@@ -2184,18 +2259,33 @@ hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint3
     return hipSuccess;
 }
 
-hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch) {
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
+                                  const PgRareArgs *rare) {
     const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK), nbl = nb ? nb : 1;
     if (nbl <= 64) { // one look-back round: a single launch wins (11 vs 17 us at 25 blocks)
-        PG_LAUNCH(k_scan_chained, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch);
+        if (rare) { // the rare statistics ride in this launch: 4 workers per extra block, PG_HUGE_BLOCKS of them for the huge list
+            const uint32_t want = rare->wide_blocks < 64 ? 64u : (rare->wide_blocks > 2048 ? 2048u : rare->wide_blocks);
+            const uint32_t extra = (want + PG_HUGE_BLOCKS + 3) / 4;
+            PG_LAUNCH(k_scan_chained<true>, dim3(nbl + extra), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, *rare);
+        } else PG_LAUNCH(k_scan_chained<false>, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, PgRareArgs{});
         return hipSuccess;
     }
+    if (rare) PG_HIP(pg_launch_read_stats_rare(st, *rare));
     // long inputs: the look-back chain (one round per 64 blocks) costs more than two extra launches (52 vs 33 us at 523
     // blocks); the partial sums live behind the chained scan's state, which has to stay zero
     uint64_t *partial = scratch + 72;
     PG_LAUNCH(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
     PG_LAUNCH(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
     PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
+    if (A.B.n_reads == 0) return hipSuccess;
+    // the workers stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
+    const uint32_t want = A.wide_blocks < 64 ? 64u : (A.wide_blocks > 2048 ? 2048u : A.wide_blocks);
+    const uint32_t wide_blocks = A.B.n_reads < want ? A.B.n_reads : want;
+    PG_LAUNCH(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, A);
     return hipSuccess;
 }
 
@@ -2208,20 +2298,11 @@ hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_
     return hipSuccess;
 }
 
-hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, int bins, const void *plan_buf,
-                          double *med, double *mad, int32_t *status, int32_t *err, int win, uint32_t *wide_list,
-                          int32_t *wide_count, uint32_t *huge_scratch, uint8_t *oor, int range_only, uint32_t wide_blocks_hint) {
+hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only) {
     if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
-    if (bins <= 1024) {
-        PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
-    } else { // the wide and huge lists are usually empty: a small grid strides over them
-        // the blocks stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
-        const uint32_t want = wide_blocks_hint < 64 ? 64u : (wide_blocks_hint > 2048 ? 2048u : wide_blocks_hint);
-        const uint32_t wide_blocks = B.n_reads < want ? B.n_reads : want;
-        PG_LAUNCH(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, B, plan, med, mad, status, err, win,
-                           (const uint32_t *)wide_list, (const int32_t *)wide_count, huge_scratch, oor, range_only);
-    }
+    PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
     return hipSuccess;
 }
 
