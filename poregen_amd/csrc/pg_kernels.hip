@@ -529,8 +529,10 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
 //   3. an event is k consecutive codes starting at its op (its own thread's and the next one's) -> slot table -> duration and
 //      position tests. COUNT (direct ranking): the accepted events are counted per (tile, slot) into hist[slot][tile..tile+3].
 // A tile touched by more than PG_EV_TBL reads, and a thread whose 16 ops span more than two reads, take event_slot_scalar.
-template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
+// LT: both slot tables (<= 1024 codes each: k <= 5; <= 1024 slots: COUNT) as 16-bit entries in LDS -- 16 look-ups per thread at LDS latency
+template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
     constexpr int TBL = PG_EV_TBL;
+    __shared__ uint16_t ltab[LT ? 2048 : 2];
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
     __shared__ int32_t t_o0[4][TBL], t_ilo[4][TBL], t_ihi[4][TBL];
     __shared__ uint32_t t_fl[4][TBL], t_s0lo[4][TBL], t_s0hi[4][TBL], t_slen[4][TBL];
@@ -550,6 +552,10 @@ template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_w
     if (COUNT) for (uint32_t i = tid; i < 4 * (PG_RANK_MAX_DIGITS + 32); i += 1024) (&cnt[0][0])[i] = 0;
     if (tid < 5) { const uint64_t T = (uint64_t)(tile0 + tid) * PG_SORT_TILE; sh_rf[tid] = T < N ? owner_of(B, O, T) : B.n_reads; }
     if (tid < 4) { sh_R[tid] = 0; sh_over[tid] = 0; }
+    if (LT) for (uint32_t i = tid; i < 2048; i += 1024) { // [0, 1024): T-spelled codes, [1024, 2048): U-spelled; -1 (not in the slice) -> 0xFFFF
+        const uint32_t code = i & 1023u, which = i >> 10;
+        ltab[i] = code < W.n_codes ? (uint16_t)W.table_t[which * W.n_codes + code] : (uint16_t)0xFFFFu;
+    }
     // the thread's own op_n: four 16-byte loads in flight in front of everything else
     uint32_t opn[16];
     if (g0 + 16 <= N) {
@@ -724,7 +730,10 @@ template <bool COUNT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_w
                     const bool rna = (fl >> 2) & 1u;
                     // the window length of event i is that of match i + sig_move_offset (op index g + offset, inside the read): gmove.cpp:916-921
                     const uint32_t dur = W.sig_move_offset == 0 ? len[u] : B.op_n[g0 + j + W.sig_move_offset];
-                    if (!badf && dur <= W.max_dur && dur >= W.min_dur) sl = (uint32_t)W.table_t[rna ? field + W.n_codes : fwd]; // table_u sits behind table_t; -1 = not in the slice = PG_INVALID_SLOT
+                    if (!badf && dur <= W.max_dur && dur >= W.min_dur) {
+                        if (LT) { const uint32_t t16 = ltab[rna ? 1024u + field : fwd]; sl = t16 == 0xFFFFu ? PG_INVALID_SLOT : t16; }
+                        else sl = (uint32_t)W.table_t[rna ? field + W.n_codes : fwd]; // table_u sits behind table_t; -1 = not in the slice = PG_INVALID_SLOT
+                    }
                 }
                 if (kind == 1u && len[u] >= PG_OP_N_LIMIT && g0 + j < N) too_long = true;
                 stage[tq][j][lt] = (stage_t)(sl == PG_INVALID_SLOT ? STAGE_INVALID : sl);
@@ -1916,14 +1925,22 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 #ifndef PG_STATS_WPB
 #define PG_STATS_WPB 1 // reads (= independent waves, no barrier between them) per workgroup
 #endif
-__global__ __launch_bounds__(64 * PG_STATS_WPB) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
+#ifndef PG_STATS_WAVES_PER_EU
+#define PG_STATS_WAVES_PER_EU 6 // measured on one box (tools/ab_lib.sh): 8 waves per SIMD 82 us, 6: 76.7, 5: 77.7, 4: 78.2 -- the memory system queues less behind fewer waves
+#endif
+__global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_eu(PG_STATS_WAVES_PER_EU, PG_STATS_WAVES_PER_EU))) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
                                                    int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
                                                    int32_t *__restrict__ wide_count) {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[PG_STATS_WPB][StatsGeom<1024>::LDS_WORDS];
+#if PG_STATS_WPB == 1
+    uint32_t *hist = hist_all[0];
+    const uint32_t r = blockIdx.x; // uniform: the record and everything derived from it stay in scalar registers
+#else
     uint32_t *hist = hist_all[threadIdx.x >> 6];
-    const uint32_t r = blockIdx.x * PG_STATS_WPB + (threadIdx.x >> 6);
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PG_STATS_WPB + (threadIdx.x >> 6)));
     if (r >= B.n_reads) return;
+#endif
     const int lane = lane_id();
     PG_PROBE_BEGIN(0);
     const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
@@ -2155,8 +2172,9 @@ hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkPar
     const uint32_t n_tiles = pg_tiles(B.n_ops, hist != nullptr);
     const uint32_t blocks = (n_tiles + 3) / 4;
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
-    if (hist) PG_LAUNCH(k_events<true>, dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
-    else PG_LAUNCH(k_events<false>, dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, (uint32_t *)nullptr);
+    if (hist && W.n_codes <= 1024) PG_LAUNCH((k_events<true, true>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
+    else if (hist) PG_LAUNCH((k_events<true, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
+    else PG_LAUNCH((k_events<false, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, (uint32_t *)nullptr);
     return hipSuccess;
 }
 

@@ -9,5 +9,5 @@ python3 - $out <<'PY'
 import json, sys, glob
 for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
     d = json.loads(open(f).read().strip().splitlines()[-1]); k = d["kernels_ms_per_step"]
-    print(f.split("/")[-1].ljust(18), "%.4f" % d["ms_per_step"], "k_walk %.1f" % (k["k_walk"] * 1e3), "k_read_stats %.1f" % (k["k_read_stats"] * 1e3))
+    print(f.split("/")[-1].ljust(18), "%.4f" % d["ms_per_step"], " ".join("%s %.1f" % (n, v * 1e3) for n, v in k.items()))
 PY
