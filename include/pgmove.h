@@ -36,7 +36,7 @@
  * / _finish / _all_slots_full /    parallel driver, work_db (a batch split over worker threads)   src/thread.c:119-132,
  * _model / _destroy                plugged in at the same seam as pg_submit                       src/gmove.cpp:515
  * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
- * pg_last_batch_device / pg_kernel_stats*
+ * pg_runtime_init / pg_poll / pg_all_slots_full_settled / pg_last_batch_device / pg_kernel_stats*
  */
 #ifndef PGMOVE_H
 #define PGMOVE_H
@@ -203,6 +203,9 @@ const char *pg_version(void);
 pg_status pg_build_slot_tables(uint32_t kmer_size, const char *const *kmers, uint32_t n_slots,
                                int32_t *table_t, int32_t *table_u);
 
+/* Brings the HIP runtime up on `device` (the first call in a process takes 0.1-0.2 s): a host that has other start-up work -- file
+ * indices, parsing -- calls this on a thread of its own first; pg_create afterwards finds the runtime ready. Optional. */
+pg_status pg_runtime_init(int32_t device);
 pg_status pg_create(const pg_params *params, pg_ctx **out);
 void      pg_destroy(pg_ctx *ctx);
 pg_status pg_reset(pg_ctx *ctx); /* forget all reads/events, keep parameters and buffers */
@@ -239,7 +242,13 @@ pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work
  * synchronisation. NULL restores the context's own stream. */
 pg_status pg_set_stream(pg_ctx *ctx, void *hip_stream);
 pg_status pg_finish(pg_ctx *ctx, pg_result *out);    /* sync, copy results to host, merge batches */
-int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events */
+int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events (waits for the device) */
+/* The same as of the last batch the context has already waited for (pg_submit / pg_count wait for the PREVIOUS batch): no wait.
+ * A host that parses batch i+1 while batch i is on the device asks this after submitting i+1 and learns about batch i. */
+int32_t   pg_all_slots_full_settled(const pg_ctx *ctx);
+/* Has the device finished the last submitted batch? 1 = yes (the batch is then settled: its per-read errors are returned as a
+ * negative pg_status, pg_all_slots_full_settled speaks about it), 0 = still running. Never waits. */
+int32_t   pg_poll(pg_ctx *ctx);
 
 /* device-resident view of the LAST collected batch (for callers that keep results on the GPU) */
 typedef struct {
@@ -321,6 +330,8 @@ const char *pg_job_last_error(const pg_job *job);       /* job may be NULL: erro
 pg_status   pg_job_submit(pg_job *job, const pg_batch *host_batch);
 pg_status   pg_job_sync(pg_job *job);                   /* wait for every device; surfaces per-read errors (lowest shard first) */
 int32_t     pg_job_all_slots_full(pg_job *job);         /* src/gmove.cpp:733-735 for the job */
+int32_t     pg_job_all_slots_full_settled(const pg_job *job); /* as pg_all_slots_full_settled */
+int32_t     pg_job_poll(pg_job *job);                    /* as pg_poll, for every device of the job */
 pg_status   pg_job_finish(pg_job *job, pg_result *out); /* merged view, owned by the job until the next submit / destroy */
 /* 1 when the last pg_job_create chose RCCL for this job's exchange, 0 = host memory */
 int32_t     pg_job_uses_rccl(const pg_job *job);

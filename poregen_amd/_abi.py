@@ -34,7 +34,7 @@ EXPORTS = [
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
     "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
-    "pg_job_uses_rccl", "pg_job_model",
+    "pg_job_uses_rccl", "pg_job_model", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
 ]
 PG_JOB_EXCHANGE_AUTO, PG_JOB_EXCHANGE_HOST, PG_JOB_EXCHANGE_RCCL = 0, 1, 2
 
@@ -152,6 +152,11 @@ def load():
     lib.pg_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_model.restype = i32
     lib.pg_model_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, C.POINTER(PgModelResult)]; lib.pg_model_device.restype = i32
     lib.pg_model_format.argtypes = [C.POINTER(PgModelResult), u32, i32, C.c_char_p, C.c_size_t]; lib.pg_model_format.restype = C.c_size_t
+    lib.pg_runtime_init.argtypes = [i32]; lib.pg_runtime_init.restype = i32
+    lib.pg_all_slots_full_settled.argtypes = [vp]; lib.pg_all_slots_full_settled.restype = i32
+    lib.pg_job_all_slots_full_settled.argtypes = [vp]; lib.pg_job_all_slots_full_settled.restype = i32
+    lib.pg_poll.argtypes = [vp]; lib.pg_poll.restype = i32
+    lib.pg_job_poll.argtypes = [vp]; lib.pg_job_poll.restype = i32
     lib.pg_job_create.argtypes = [C.POINTER(PgParams), C.POINTER(C.c_int32), u32, u32, C.POINTER(vp)]; lib.pg_job_create.restype = i32
     lib.pg_job_destroy.argtypes = [vp]; lib.pg_job_destroy.restype = None
     lib.pg_job_last_error.argtypes = [vp]; lib.pg_job_last_error.restype = C.c_char_p

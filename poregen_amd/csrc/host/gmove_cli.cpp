@@ -128,7 +128,9 @@ struct Backend {
     bool ok() const { return ctx || job; }
     pg_status submit(const pg_batch *b) { return job ? pg_job_submit(job, b) : pg_submit(ctx, b); }
     pg_status sync() { return job ? pg_job_sync(job) : pg_sync(ctx); }
-    bool all_full() { return job ? pg_job_all_slots_full(job) != 0 : pg_all_slots_full(ctx) != 0; }
+    bool all_full() { return job ? pg_job_all_slots_full(job) != 0 : pg_all_slots_full(ctx) != 0; }            // waits for the device
+    int32_t poll() { return job ? pg_job_poll(job) : pg_poll(ctx); } // 1: the device has finished the last batch (errors < 0), 0: not yet; no wait
+    bool all_full_settled() const { return job ? pg_job_all_slots_full_settled(job) != 0 : pg_all_slots_full_settled(ctx) != 0; } // as of the batch already waited for
     pg_status finish(pg_result *r) { return job ? pg_job_finish(job, r) : pg_finish(ctx, r); }
     pg_status model(pg_model_result *m) { return job ? pg_job_model(job, 0, m) : pg_model(ctx, 0, m); }
     const char *error() const { return job ? pg_job_last_error(job) : pg_last_error(ctx); }
@@ -193,6 +195,10 @@ int gmove_main(int argc, char **argv) {
         return fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE;
     }
     const char *slow5file = argv[optind], *move_table = argv[optind + 1], *output_dir = argv[optind + 2];
+    // the HIP runtime takes 0.1-0.2 s to come up: it starts NOW, on a thread of its own, next to the directory set-up, the k-mer list,
+    // the file indices and the parsing of the first batch; the context is created behind it
+    const int first_device = devices.empty() ? device : devices[0];
+    std::future<pg_status> rt_ready = std::async(std::launch::async, [first_device]() { return pg_runtime_init(first_device); });
     if (opt.kmer_size <= opt.sig_move_offset) fprintf(stderr, "[gmove::WARNING] signal move offset value should be less than the kmer length\n");
 
     if (raw_model_path && opt.delimit_files) return die("--raw_model cannot be combined with -d: the ':' delimiters are not numbers (datamash stops on them)");
@@ -282,7 +288,7 @@ int gmove_main(int argc, char **argv) {
     const std::chrono::steady_clock::time_point t_setup0 = std::chrono::steady_clock::now();
     std::future<pg_status> ctx_ready = std::async(std::launch::async, [&]() {
         const std::chrono::steady_clock::time_point a = std::chrono::steady_clock::now();
-        pg_status st;
+        pg_status st = rt_ready.get(); // (an error is reported again, with its text, by pg_create below)
         if (devices.empty()) { st = pg_create(&prm, &dev.ctx); if (st != PG_OK) ctx_err = pg_last_error(nullptr); } // the text lives in the creating thread
         else { st = pg_job_create(&prm, devices.data(), (uint32_t)devices.size(), exchange, &dev.job); if (st != PG_OK) ctx_err = pg_job_last_error(nullptr); }
         t_ctx = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
@@ -314,7 +320,8 @@ int gmove_main(int argc, char **argv) {
     };
 
     // ---- the read loop (src/gmove.cpp:732-969), batched ---------------------------------------------------
-    HostBatch hb;
+    HostBatch hbs[2]; // two batches: one is parsed while the other is on its way through the device
+    int cur = 0;
     pgh::Slow5Rec rec;
     std::string seq;
     char *line = nullptr; size_t cap = 0; ssize_t got;
@@ -327,24 +334,27 @@ int gmove_main(int argc, char **argv) {
     double t_device = 0, t_finish = 0, t_dump = 0, t_lines = 0, t_decode = 0, t_concat = 0;
     const clk::time_point t_loop0 = clk::now();
     auto flush = [&]() -> bool {
-        if (hb.n() == 0) return true;
+        if (hbs[cur].n() == 0) return true;
         const clk::time_point tf0 = clk::now();
         pg_batch b; memset(&b, 0, sizeof b);
-        b.struct_size = sizeof b; b.location = PG_LOC_HOST; b.n_reads = hb.n();
-        b.sig = hb.sig.data(); b.sig_off = hb.sig_off.data(); b.digitisation = hb.dig.data(); b.offset = hb.off.data(); b.range = hb.range.data();
-        b.query_start = hb.qs.data(); b.target_start = hb.ts.data(); b.target_end = hb.te.data(); b.seq = hb.seq.data(); b.seq_off = hb.seq_off.data();
-        b.op_n = hb.op_n.data(); b.op_t = hb.op_t.data(); b.op_off = hb.op_off.data();
+        b.struct_size = sizeof b; b.location = PG_LOC_HOST; b.n_reads = hbs[cur].n();
+        b.sig = hbs[cur].sig.data(); b.sig_off = hbs[cur].sig_off.data(); b.digitisation = hbs[cur].dig.data(); b.offset = hbs[cur].off.data(); b.range = hbs[cur].range.data();
+        b.query_start = hbs[cur].qs.data(); b.target_start = hbs[cur].ts.data(); b.target_end = hbs[cur].te.data(); b.seq = hbs[cur].seq.data(); b.seq_off = hbs[cur].seq_off.data();
+        b.op_n = hbs[cur].op_n.data(); b.op_t = hbs[cur].op_t.data(); b.op_off = hbs[cur].op_off.data();
         if (batch_all_matches) b.flags |= PG_BATCH_ALL_MATCHES; // no I / D op in the batch (every ss string `reform` writes): verified on the device
         batch_all_matches = true;
         if (!need_ctx()) return false;
+        // Queued, not awaited: the next batch is parsed meanwhile. pg_submit itself waits for the batch BEFORE this one (and hands its
+        // per-read errors back), so the buffers of that batch -- hbs[cur ^ 1], about to be refilled -- are no longer read by anyone.
         pg_status s = dev.submit(&b);
-        if (s == PG_OK) s = dev.sync();
         if (s != PG_OK) { fprintf(stderr, "[gmove] %s\n", dev.error()); return false; }
-        hb.clear();
         t_device += secs(tf0, clk::now());
-        // every k-mer of the WHOLE list complete: the reference stops reading (gmove.cpp:733-735). With a slice it reads on
-        // (and would still fail on a malformed later line), so we do too.
-        if (whole_list && dev.all_full()) stop = true;
+        cur ^= 1;
+        hbs[cur].clear();
+        // every k-mer of the WHOLE list complete: the reference stops reading (gmove.cpp:733-735). With a slice it reads on (and would
+        // still fail on a malformed later line), so we do too. Asked without waiting: this is the state behind the batch before the one
+        // just queued; a batch too many changes nothing in the output (its events rank behind the complete files').
+        if (whole_list && dev.all_full_settled()) stop = true;
         return true;
     };
     // Move-table style records (table file and SAM/BAM, gmove.cpp:557-700 / 1080-1261): resolve -m (first window starts
@@ -357,7 +367,7 @@ int gmove_main(int argc, char **argv) {
         if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
             fprintf(stderr, "move record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", read_id); status = EXIT_FAILURE; return false;
         }
-        hb.sig.append(rec.raw.data() + trim, rec.raw.data() + rec.raw.size()); // gmove.cpp:591-598: only the trimmed signal is used
+        hbs[cur].sig.append(rec.raw.data() + trim, rec.raw.data() + rec.raw.size()); // gmove.cpp:591-598: only the trimmed signal is used
         total_samples += rec.raw.size();
         seq.clear();
         uint32_t qstart = 0;
@@ -372,18 +382,18 @@ int gmove_main(int argc, char **argv) {
             size_t n_seg = 0, prev = start_idx;
             for (size_t i = start_idx + 1; i < move_len; i++) // the last move is never closed (gmove.cpp:632, 1195)
                 if (is_one[i]) {
-                    if (n_seg < seq.size()) { hb.op_n.push_back((uint32_t)((i - prev) * (size_t)stride)); hb.op_t.push_back(0); }
+                    if (n_seg < seq.size()) { hbs[cur].op_n.push_back((uint32_t)((i - prev) * (size_t)stride)); hbs[cur].op_t.push_back(0); }
                     n_seg++; prev = i;
                 }
             // event j pairs segment j with the k-mer at base j even when fewer than k segments follow it: pad with
             // zero-length matches (never used as windows) so that the collector sees k matched bases for it
             const size_t real = n_seg < seq.size() ? n_seg : seq.size();
             size_t pad = seq.size() > n_seg ? seq.size() - n_seg : 0; if (pad > opt.kmer_size - 1) pad = opt.kmer_size - 1;
-            for (size_t i = 0; i < pad; i++) { hb.op_n.push_back(0); hb.op_t.push_back(0); }
+            for (size_t i = 0; i < pad; i++) { hbs[cur].op_n.push_back(0); hbs[cur].op_t.push_back(0); }
             seq.resize(real + pad);
             if (seq.size() < opt.kmer_size) seq.append(opt.kmer_size - seq.size(), 'N'); // not "skipped": the read still gets its ':' with -d
         }
-        hb.qs.push_back((int32_t)qstart); hb.ts.push_back(0); hb.te.push_back((int32_t)seq.size());
+        hbs[cur].qs.push_back((int32_t)qstart); hbs[cur].ts.push_back(0); hbs[cur].te.push_back((int32_t)seq.size());
         return true;
     };
     // ---- PAF front-end: a batch of lines is read, then every thread of a pool parses / decodes a contiguous run of them
@@ -413,6 +423,14 @@ int gmove_main(int argc, char **argv) {
             if (n_lines == 0) break;
             const clk::time_point tp1 = clk::now();
             t_lines += secs(tp0, tp1);
+            // the batch in flight may have completed every k-mer by now: then the reference would not have read these lines
+            auto job_complete = [&]() -> bool {
+                if (!whole_list || !dev.ok()) return false;
+                const int32_t pr = dev.poll();
+                if (pr < 0) { fprintf(stderr, "[gmove] %s\n", dev.error()); status = EXIT_FAILURE; return true; }
+                return pr == 1 && dev.all_full_settled();
+            };
+            if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
             on_threads([&](unsigned t) {
                 Run &r = runs[t];
                 r.b.clear(); r.bad = false; r.msg.clear();
@@ -439,6 +457,7 @@ int gmove_main(int argc, char **argv) {
                 }
             });
             t_decode += secs(tp1, clk::now());
+            if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
             // runs in file order up to the first failing line; one device batch unless that would exceed 2^29 samples
             unsigned last_run = nt; // first run that stopped early
             for (unsigned t = 0; t < nt; t++) if (runs[t].bad) { last_run = t; break; }
@@ -451,33 +470,43 @@ int gmove_main(int argc, char **argv) {
                 uint64_t ns = 0, nq = 0, no = 0, nb = 0;
                 for (unsigned t = t0; t < t1; t++) { ns += runs[t].b.sig_off.back(); nq += runs[t].b.seq_off.back(); no += runs[t].b.op_off.back(); nb += runs[t].b.n(); }
                 const clk::time_point tc0 = clk::now();
-                hb.sig.resize(ns); hb.seq.resize(nq); hb.op_n.resize(no); hb.op_t.resize(no);
-                hb.sig_off.resize(nb + 1); hb.seq_off.resize(nb + 1); hb.op_off.resize(nb + 1);
-                hb.dig.resize(nb); hb.off.resize(nb); hb.range.resize(nb); hb.qs.resize(nb); hb.ts.resize(nb); hb.te.resize(nb);
+                hbs[cur].sig.resize(ns); hbs[cur].seq.resize(nq); hbs[cur].op_n.resize(no); hbs[cur].op_t.resize(no);
+                hbs[cur].sig_off.resize(nb + 1); hbs[cur].seq_off.resize(nb + 1); hbs[cur].op_off.resize(nb + 1);
+                hbs[cur].dig.resize(nb); hbs[cur].off.resize(nb); hbs[cur].range.resize(nb); hbs[cur].qs.resize(nb); hbs[cur].ts.resize(nb); hbs[cur].te.resize(nb);
                 std::vector<uint64_t> bs(nt + 1, 0), bq(nt + 1, 0), bo(nt + 1, 0), bn(nt + 1, 0);
                 for (unsigned t = t0; t < t1; t++) { bs[t + 1] = bs[t] + runs[t].b.sig_off.back(); bq[t + 1] = bq[t] + runs[t].b.seq_off.back(); bo[t + 1] = bo[t] + runs[t].b.op_off.back(); bn[t + 1] = bn[t] + runs[t].b.n(); }
                 on_threads([&](unsigned t) {
                     if (t < t0 || t >= t1) return;
                     const HostBatch &b = runs[t].b;
                     const size_t n = b.n();
-                    if (b.sig_off.back()) memcpy(hb.sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t));
-                    if (b.seq_off.back()) memcpy(hb.seq.data() + bq[t], b.seq.data(), b.seq_off.back());
-                    if (b.op_off.back()) { memcpy(hb.op_n.data() + bo[t], b.op_n.data(), b.op_off.back() * sizeof(uint32_t)); memcpy(hb.op_t.data() + bo[t], b.op_t.data(), b.op_off.back()); } // a failed line may have left ops behind op_off.back()
+                    if (b.sig_off.back()) memcpy(hbs[cur].sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t));
+                    if (b.seq_off.back()) memcpy(hbs[cur].seq.data() + bq[t], b.seq.data(), b.seq_off.back());
+                    if (b.op_off.back()) { memcpy(hbs[cur].op_n.data() + bo[t], b.op_n.data(), b.op_off.back() * sizeof(uint32_t)); memcpy(hbs[cur].op_t.data() + bo[t], b.op_t.data(), b.op_off.back()); } // a failed line may have left ops behind op_off.back()
                     if (std::any_of(b.op_t.begin(), b.op_t.begin() + (ptrdiff_t)b.op_off.back(), [](uint8_t x) { return x != 0; })) batch_all_matches = false;
                     for (size_t k = 0; k < n; k++) {
                         const size_t g = bn[t] + k;
-                        hb.sig_off[g] = bs[t] + b.sig_off[k]; hb.seq_off[g] = bq[t] + b.seq_off[k]; hb.op_off[g] = bo[t] + b.op_off[k];
-                        hb.dig[g] = b.dig[k]; hb.off[g] = b.off[k]; hb.range[g] = b.range[k]; hb.qs[g] = b.qs[k]; hb.ts[g] = b.ts[k]; hb.te[g] = b.te[k];
+                        hbs[cur].sig_off[g] = bs[t] + b.sig_off[k]; hbs[cur].seq_off[g] = bq[t] + b.seq_off[k]; hbs[cur].op_off[g] = bo[t] + b.op_off[k];
+                        hbs[cur].dig[g] = b.dig[k]; hbs[cur].off[g] = b.off[k]; hbs[cur].range[g] = b.range[k]; hbs[cur].qs[g] = b.qs[k]; hbs[cur].ts[g] = b.ts[k]; hbs[cur].te[g] = b.te[k];
                     }
                 });
-                hb.sig_off[nb] = ns; hb.seq_off[nb] = nq; hb.op_off[nb] = no;
+                hbs[cur].sig_off[nb] = ns; hbs[cur].seq_off[nb] = nq; hbs[cur].op_off[nb] = no;
                 t_concat += secs(tc0, clk::now());
                 total_samples += ns;
                 for (uint64_t k = 0; k < nb; k++) if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
                 if (nb && !flush()) { status = EXIT_FAILURE; break; }
                 t0 = t1;
             }
-            if (status == EXIT_SUCCESS && !stop && last_run < nt) { fprintf(stderr, "%s\n", runs[last_run].msg.c_str()); status = EXIT_FAILURE; }
+            if (status == EXIT_SUCCESS && !stop && last_run < nt) {
+                // a line the reference may never have read: it stops once every k-mer of the whole list is complete. Wait for the batches
+                // in flight and look before failing.
+                bool complete = false;
+                if (whole_list && dev.ok()) {
+                    if (dev.sync() != PG_OK) { fprintf(stderr, "[gmove] %s\n", dev.error()); status = EXIT_FAILURE; }
+                    else complete = dev.all_full();
+                }
+                if (complete) stop = true;
+                else if (status == EXIT_SUCCESS) { fprintf(stderr, "%s\n", runs[last_run].msg.c_str()); status = EXIT_FAILURE; }
+            }
         }
     } else
     for (;;) {
@@ -507,12 +536,12 @@ int gmove_main(int argc, char **argv) {
             for (size_t i = 0; i < move_len; i++) is_one[i] = moves[i] == '1';
             if (!add_move_record(col[0], atoi(col[1]), col[2], atoi(col[3]), strtoull(col[5], nullptr, 10), atoll(col[6]))) break;
         }
-        hb.sig_off.push_back(hb.sig.size());
-        hb.dig.push_back(rec.digitisation); hb.off.push_back(rec.offset); hb.range.push_back(rec.range);
-        hb.seq.insert(hb.seq.end(), seq.begin(), seq.end()); hb.seq_off.push_back(hb.seq.size());
-        hb.op_off.push_back(hb.op_n.size());
+        hbs[cur].sig_off.push_back(hbs[cur].sig.size());
+        hbs[cur].dig.push_back(rec.digitisation); hbs[cur].off.push_back(rec.offset); hbs[cur].range.push_back(rec.range);
+        hbs[cur].seq.insert(hbs[cur].seq.end(), seq.begin(), seq.end()); hbs[cur].seq_off.push_back(hbs[cur].seq.size());
+        hbs[cur].op_off.push_back(hbs[cur].op_n.size());
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
-        if (hb.n() >= batch_reads || hb.sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
+        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
     }
     if (status == EXIT_SUCCESS && !flush()) status = EXIT_FAILURE;
     free(line); fclose(paf_fp);

@@ -247,6 +247,17 @@ void pg_destroy(pg_ctx *c) {
     delete c;
 }
 
+pg_status pg_runtime_init(int32_t device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, PG_ERR_NO_DEVICE, "no HIP device available (%s); libpgmove has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, PG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipFree(nullptr); // creates the device's primary context
+    if (e != hipSuccess) return fail(nullptr, PG_ERR_NO_DEVICE, "HIP runtime on device %d: %s", device, hipGetErrorString(e));
+    return PG_OK;
+}
+
 pg_status pg_create(const pg_params *p, pg_ctx **out) {
     if (!p || !out) return fail(nullptr, PG_ERR_INVALID_ARG, "pg_create: null argument");
     *out = nullptr;
@@ -852,6 +863,17 @@ int32_t pg_all_slots_full(pg_ctx *c) {
     if (settle_batch(c) != PG_OK) return 0;
     return c->full_slots == c->prm.n_slots;
 }
+
+int32_t pg_poll(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_batch_result || c->totals_known) return 1;
+    if (hipSetDevice(c->device) != hipSuccess) return PG_ERR_HIP;
+    if (hipStreamQuery(c->st) != hipSuccess || hipStreamQuery(c->st2) != hipSuccess) { (void)hipGetLastError(); return 0; } // hipErrorNotReady
+    const pg_status s = settle_batch(c);
+    return s == PG_OK ? 1 : s;
+}
+
+int32_t pg_all_slots_full_settled(const pg_ctx *c) { return c && c->full_slots == c->prm.n_slots; }
 
 pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     if (!c || !v) return PG_ERR_INVALID_ARG;

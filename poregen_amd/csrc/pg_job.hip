@@ -333,6 +333,21 @@ int32_t pg_job_all_slots_full(pg_job *j) {
     return pg_all_slots_full(j->ctx[j->n - 1]);
 }
 
+int32_t pg_job_poll(pg_job *j) {
+    if (!j) return PG_ERR_INVALID_ARG;
+    for (uint32_t g = 0; g < j->n; ++g) {
+        const int32_t r = pg_poll(j->ctx[g]);
+        if (r == 0) return 0;
+        if (r < 0) return jfail(j, r, "shard %u (device %d): %s", g, j->devices[g], pg_last_error(j->ctx[g]));
+    }
+    return 1;
+}
+
+int32_t pg_job_all_slots_full_settled(const pg_job *j) {
+    if (!j || !j->have_batch) return 0;
+    return pg_all_slots_full_settled(j->ctx[j->n - 1]);
+}
+
 pg_status pg_job_finish(pg_job *j, pg_result *out) {
     if (!j || !out) return PG_ERR_INVALID_ARG;
     if (j->merged) { *out = j->merged_view; return PG_OK; }

@@ -530,7 +530,7 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
 //      position tests. COUNT (direct ranking): the accepted events are counted per (tile, slot) into hist[slot][tile..tile+3].
 // A tile touched by more than PG_EV_TBL reads, and a thread whose 16 ops span more than two reads, take event_slot_scalar.
 // LT: both slot tables (<= 1024 codes each: k <= 5; <= 1024 slots: COUNT) as 16-bit entries in LDS -- 16 look-ups per thread at LDS latency
-template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
+template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT ? 8 : 4, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
     constexpr int TBL = PG_EV_TBL;
     __shared__ uint16_t ltab[LT ? 2048 : 2];
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
