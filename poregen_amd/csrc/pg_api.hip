@@ -922,25 +922,52 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         c->merged_valid = true; c->m_events = n_events; c->m_samples = n_samples; c->m_reads = n_reads;
         return PG_OK;
     }
-    c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.assign(n_events + 1, 0);
+    c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.resize(n_events + 1);
     c->r_ev_len.resize(n_events); c->r_ev_read.resize(n_events); c->r_samples.resize(n_samples);
     c->r_skipped.resize(n_reads);
-    uint64_t e = 0, sp = 0;
+    // pass 1 (cheap): where every slot's events and samples start in the merged arrays
+    std::vector<uint64_t> slot_e(ns + 1, 0), slot_s(ns + 1, 0);
     for (uint32_t sl = 0; sl < ns; sl++) {
-        c->r_ev_off[sl] = e;
-        uint64_t rbase = 0;
-        for (auto &h : c->batches) {
-            const uint64_t a = h.ev_off[sl], b = h.ev_off[sl + 1];
-            for (uint64_t i = a; i < b; i++) {
-                c->r_ev_len[e] = h.ev_len[i]; c->r_ev_read[e] = (uint32_t)(rbase + h.ev_read[i]); c->r_samp_off[e] = sp;
-                const uint64_t so = h.samp_off[i], len = h.ev_len[i];
-                if (len) memcpy(&c->r_samples[sp], &h.samples[so], len * sizeof(double));
-                sp += len; e++;
+        uint64_t ne = 0, nsmp = 0;
+        for (auto &h : c->batches) { const uint64_t a = h.ev_off[sl], b = h.ev_off[sl + 1]; ne += b - a; nsmp += h.samp_off[b] - h.samp_off[a]; }
+        slot_e[sl + 1] = slot_e[sl] + ne; slot_s[sl + 1] = slot_s[sl] + nsmp;
+        c->r_counts[sl] = ne; c->r_ev_off[sl] = slot_e[sl];
+    }
+    // pass 2: the copies (hundreds of MB at large limits), slot ranges side by side on a few threads
+    auto merge_slots = [&](uint32_t s0, uint32_t s1) {
+        for (uint32_t sl = s0; sl < s1; sl++) {
+            uint64_t e = slot_e[sl], sp = slot_s[sl], rbase = 0;
+            for (auto &h : c->batches) {
+                const uint64_t a = h.ev_off[sl], b = h.ev_off[sl + 1];
+                if (b > a) {
+                    const uint64_t s_a = h.samp_off[a], s_b = h.samp_off[b];
+                    memcpy(&c->r_samples[sp], &h.samples[s_a], (s_b - s_a) * sizeof(double)); // a slot's events of one batch are contiguous
+                    for (uint64_t i = a; i < b; i++, e++) {
+                        c->r_ev_len[e] = h.ev_len[i]; c->r_ev_read[e] = (uint32_t)(rbase + h.ev_read[i]); c->r_samp_off[e] = sp + (h.samp_off[i] - s_a);
+                    }
+                    sp += s_b - s_a;
+                }
+                rbase += h.n_reads;
             }
-            c->r_counts[sl] += b - a;
-            rbase += h.n_reads;
+        }
+    };
+    {
+        const unsigned nt = n_samples >= (8u << 20) ? 8u : 1u;
+        if (nt == 1) merge_slots(0, ns);
+        else {
+            std::vector<std::thread> pool;
+            uint32_t s0 = 0;
+            for (unsigned t = 0; t < nt; t++) { // equal shares of the samples
+                uint32_t s1 = s0;
+                const uint64_t want = slot_s[ns] / nt * (t + 1);
+                while (s1 < ns && (t + 1 == nt || slot_s[s1 + 1] <= want)) s1++;
+                if (s1 > s0) pool.emplace_back(merge_slots, s0, s1);
+                s0 = s1;
+            }
+            for (auto &th : pool) th.join();
         }
     }
+    const uint64_t e = slot_e[ns], sp = slot_s[ns];
     c->r_ev_off[ns] = e; c->r_samp_off[n_events] = sp;
     uint64_t rb = 0;
     for (auto &h : c->batches) { if (h.n_reads) memcpy(&c->r_skipped[rb], h.skipped.data(), h.n_reads); rb += h.n_reads; }

@@ -50,13 +50,22 @@ for case in range(n_cases):
         skipped += 1
         continue
     slice_kmers = kmers[sl["index_start"] - 1:sl["index_end"]] if sl else kmers  # the engine takes the slice itself
-    eng = GmoveEngine(GmoveParams(kmers=slice_kmers, lazy_stats=bool(rng.integers(0, 2)), debug_narrow=bool(rng.random() < 0.15), **p))
+    # the op-parallel event kernel or (forced) the wave-per-read walk for every read; host batches or device-resident ones (which carry
+    # pg_batch.n_ops and, without indels, PG_BATCH_ALL_MATCHES: no k_walk launch at all)
+    eng = GmoveEngine(GmoveParams(kmers=slice_kmers, lazy_stats=bool(rng.integers(0, 2)), debug_narrow=bool(rng.random() < 0.15),
+                                  split_walk=bool(rng.random() < 0.2), **p))
+    on_device = rng.random() < 0.4
+    def put(x):
+        if on_device:
+            import torch
+            return x.to_device(torch.device("cuda:0"))
+        return x
     try:
         cut = int(rng.integers(0, n_reads + 1))
         if cut and cut < n_reads:
-            eng.submit(b.slice_reads(0, cut)); eng.submit(b.slice_reads(cut, n_reads))
+            eng.submit(put(b.slice_reads(0, cut))); eng.submit(put(b.slice_reads(cut, n_reads)))
         else:
-            eng.submit(b)
+            eng.submit(put(b))
         res = eng.finish()
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=p["sample_limit"])
         if len(slice_kmers) <= 1024:  # the k-mer model (pg_model) against tr | tail | datamash restated on the oracle's dump files
