@@ -79,11 +79,11 @@ struct pg_ctx {
     DevBuf m_start, m_len, m_base, m_tix, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage, tile_last;
-    DevBuf ev_len, ev_read, ev_start, read_needed, samp_off, scan_scratch, samples;
+    DevBuf ev_len, ev_read, ev_src, read_needed, samp_off, scan_scratch, samples;
     DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf meta, huge_scratch, oor;
-    DevBuf blk_read, gen_flag, gen_list, cum, btot; // PgWalkOut: owner index, generic-read list, block sums of op_n
+    DevBuf blk_read, gen_flag, gen_list, cum, btot, tile_read; // PgWalkOut: owner index, generic-read list, block sums of op_n
     uint32_t batch_id = 0;  // serial number of the batch being counted (tags gen_flag entries and the error word)
     PgRareArgs rare{};      // the rare statistics launch of the current batch ...
     bool rare_pending = false; // ... still to be issued: with the sample-offset scan of pg_collect
@@ -232,10 +232,10 @@ void pg_destroy(pg_ctx *c) {
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_start, &c->read_needed,
+                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_src, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
-                      &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot,
+                      &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
     for (DevBuf *b : bufs) b->release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -507,7 +507,7 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     O.status = c->status.as<int32_t>();
     O.err = c->errflag.as<unsigned long long>(); O.layout_err = c->errflag.as<int32_t>() + 2; O.gen_count = c->errflag.as<uint32_t>() + 4;
     O.blk_read = c->blk_read.as<uint32_t>(); O.gen_flag = c->gen_flag.as<uint32_t>(); O.gen_list = c->gen_list.as<uint32_t>();
-    O.cum = c->cum.as<uint32_t>(); O.btot = c->btot.as<uint32_t>(); O.batch_id = c->batch_id;
+    O.cum = c->cum.as<uint32_t>(); O.btot = c->btot.as<uint32_t>(); O.batch_id = c->batch_id; O.tile_read = c->tile_read.as<uint32_t>();
     O.oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) ? c->oor.as<uint8_t>() : nullptr;
 }
 
@@ -563,7 +563,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->m_tix.ensure((Nn + 64 + c->prm.kmer_size + 2 * PG_TIX_FRONT(c->prm.kmer_pick_margin)) * 4));
     HIP_TRY(c, c->ev_slot.ensure((Nn + 32) * 4));
     HIP_TRY(c, c->blk_read.ensure((Nn / 64 + 2) * 4)); HIP_TRY(c, c->cum.ensure((Nn / 4 + 64) * 4)); HIP_TRY(c, c->btot.ensure((Nn / 256 + 2) * 4));
-    HIP_TRY(c, c->gen_list.ensure((n + 1) * 4ull));
+    HIP_TRY(c, c->gen_list.ensure((n + 1) * 4ull)); HIP_TRY(c, c->tile_read.ensure((Nn / PG_SORT_TILE + 8) * 4));
     { // gen_flag entries are compared with the batch's serial number: fresh memory must not hold one by accident
         const size_t before = c->gen_flag.cap;
         HIP_TRY(c, c->gen_flag.ensure((n + 1) * 4ull));
@@ -745,13 +745,13 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
-    HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_start.ensure((ke_cap + 1) * 4));
+    HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_src.ensure((ke_cap + 1) * 8));
     HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8));
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     PgKeptOut K{};
-    K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_start = c->ev_start.as<uint32_t>();
+    K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_src = c->ev_src.as<uint64_t>();
     // the per-read "owns a kept event" flags are only consumed by the lazy statistics: no scattered byte stores otherwise
     K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
     if (direct) {
@@ -793,7 +793,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     }
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", c->st);
-    HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_start.as<uint32_t>(),
+    HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_src.as<uint64_t>(),
                      c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>()));
     prof_end(c, c->st);

@@ -55,7 +55,8 @@ struct __attribute__((aligned(16))) PgReadMeta {
     uint32_t L;      // len_raw_signal (clamped to 2^32 - 1; > INT32_MAX is an error)
     int32_t qs;      // query_start
     uint32_t flags;  // PG_RM_*
-    uint32_t pad[3];
+    uint32_t pad;
+    uint64_t sig0;   // sig_off[r]: first sample of the read in the batch's signal
 };
 enum {
     PG_RM_RNA = 1u,       // target_start > target_end
@@ -91,7 +92,13 @@ struct PgWalkOut {
     // cum[g >> 2] = sum of op_n over [g & ~255, g & ~3), btot[g >> 8] = sum over the whole 256-op block (ops < 2^24: no overflow)
     uint32_t *cum;   // [n_ops / 4 + 64]
     uint32_t *btot;  // [n_ops / 256 + 1]
+    // direct ranking (<= 1024 slots): an accepted event's ev_slot entry also names its read, relative to the first read of its tile of
+    // 4096 op indices: slot | (read - tile_read[tile]) << PG_SLOT_BITS, PG_REL_UNKNOWN in the upper bits = look the read up (owner_of)
+    uint32_t *tile_read; // [n_tiles + 1]
 };
+#define PG_SLOT_BITS 10
+#define PG_SLOT_MASK ((1u << PG_SLOT_BITS) - 1u)
+#define PG_REL_UNKNOWN ((1u << (32 - PG_SLOT_BITS)) - 1u)
 
 #define PG_INVALID_SLOT 0xFFFFFFFFu
 #define PG_TIX_FRONT(margin) (((uint64_t)((margin) > 0 ? (margin) : 0) + 3) & ~3ull)
@@ -141,7 +148,7 @@ struct PgGathered {
 struct PgKeptOut {
     uint32_t *ev_len;     // [n_kept] window length incl. margin, clamped to the signal
     uint32_t *ev_read;    // [n_kept] read index inside the batch
-    uint32_t *ev_start;   // [n_kept] window start inside the read
+    uint64_t *ev_src;     // [n_kept] window start as a sample index of the BATCH (sig_off[read] + start inside the read)
     uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
 };
 // resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
@@ -229,5 +236,5 @@ hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
                                 uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only);
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
-                      const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
+                      const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

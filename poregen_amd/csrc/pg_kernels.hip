@@ -179,7 +179,7 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
     mt.nops = layout_ok ? (uint32_t)(o1 - o0) : 0u;
     mt.slen = (uint32_t)(s1 - s0 > 0xffffffffull ? 0xffffffffull : s1 - s0);
     mt.n = 0; mt.m = 0; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
-    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pad[0] = mt.pad[1] = mt.pad[2] = 0;
+    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pad = 0; mt.sig0 = B.sig_off[r];
     int status = PGR_OK;
     if (!layout_ok) status = PGR_ERR_LAYOUT;
     // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
@@ -490,8 +490,9 @@ __device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, ui
 
 // One op's event with every look-up done by the thread itself and the k bases fetched one by one: k_events' way for a tile that
 // more than PG_EV_TBL reads touch (reads of a few ops each). Small, not fast.
-__device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint64_t g, uint32_t own_len) {
-    const uint32_t r = owner_search(B, g), k = W.k;
+__device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint64_t g, uint32_t own_len, uint32_t &r) {
+    r = owner_search(B, g);
+    const uint32_t k = W.k;
     const PgReadMeta *mp = O.meta + r;
     const uint32_t flags = mp->flags, n = mp->nops;
     const uint64_t o0 = mp->o0;
@@ -575,6 +576,7 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
     // ---- stage 1: the table entry of read rFirst + lt ------------------------------------------------------------------------------
     const uint32_t rFirst = sh_rf[tq];
     const uint64_t halo_end = T0 + PG_SORT_TILE + 16 < N ? T0 + PG_SORT_TILE + 16 : N;
+    if (COUNT && tile_live && lt == 0) O.tile_read[tile0 + tq] = rFirst;
     if (tile_live) {
         const uint32_t r = rFirst + lt;
         if (lt < TBL && r < B.n_reads && (lt == 0 || B.op_off[r] < halo_end)) {
@@ -689,8 +691,10 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
     if (tile_live && g0 < N && (over || more)) { // every op on its own (rare): its read, its k bases, its window length
 #pragma unroll 1
         for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
-            const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, B.op_n[g0 + j]);
-            O.ev_slot[g0 + j] = sl;
+            uint32_t rd;
+            const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, B.op_n[g0 + j], rd);
+            const uint32_t rel = rd - rFirst < PG_REL_UNKNOWN ? rd - rFirst : PG_REL_UNKNOWN;
+            O.ev_slot[g0 + j] = COUNT && sl != PG_INVALID_SLOT ? sl | (rel << PG_SLOT_BITS) : sl; // COUNT: the read rides in the upper bits (PgWalkOut::tile_read)
             if (COUNT && sl != PG_INVALID_SLOT) atomicAdd(&cnt[tq][sl & cmask], 1u);
         }
     } else if (tile_live && g0 < N) {
@@ -751,7 +755,12 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
         for (int v = 0; v < 4; ++v) {
             uint32_t o4[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t x = stage[tq][4 * v + u][lt]; o4[u] = x == STAGE_INVALID ? PG_INVALID_SLOT : x; }
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t x = stage[tq][4 * v + u][lt];
+                // COUNT: the event's read rides in the upper bits, as its table entry = read - first read of the tile (PgWalkOut::tile_read)
+                const uint32_t rel = (uint32_t)(4 * v + u) >= jb ? Bs.e : A.e;
+                o4[u] = x == STAGE_INVALID ? PG_INVALID_SLOT : (COUNT ? x | (rel << PG_SLOT_BITS) : x);
+            }
             if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
             else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
         }
@@ -773,10 +782,10 @@ __global__ __launch_bounds__(256) void k_apply_oor(uint32_t n_reads, PgWalkOut O
 }
 
 // what the emit kernels need of the read of a kept event
-struct KeptRead { uint64_t o0; uint32_t qs, L; bool generic; };
+struct KeptRead { uint64_t o0, sig0; uint32_t qs, L; bool generic; };
 __device__ __forceinline__ KeptRead kept_read(const PgWalkOut &O, uint32_t rd) {
     const PgReadMeta *mt = O.meta + rd;
-    KeptRead k; k.o0 = mt->o0; k.qs = (uint32_t)mt->qs; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
+    KeptRead k; k.o0 = mt->o0; k.sig0 = mt->sig0; k.qs = (uint32_t)mt->qs; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
     return k;
 }
 // window start and length of a kept event (gmove.cpp:854-855) at op index g of read rd: from the generic walk's arrays, or, for a
@@ -1038,7 +1047,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
     // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
     if (W.print_margin > start || we <= ws) { report_error(O, rd, PGR_ERR_WINDOW); ws = we = 0; }
     K.ev_len[e] = we - ws;
-    K.ev_start[e] = ws;
+    K.ev_src[e] = kr.sig0 + ws;
     K.ev_read[e] = rd;
     if (K.read_needed) K.read_needed[rd] = 1;
 }
@@ -1059,6 +1068,7 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
     if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
+    const uint32_t tile_first = O.tile_read[tile];
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
     // phase 0: everything the ordered loop needs from global memory, all rows in flight at once. The slots of the tile's events
     // are requested in front of the "any room left?" test: a tile up to the last useful one nearly always passes it, and the
@@ -1079,8 +1089,8 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const bool valid = kv[row] != PG_INVALID_SLOT;
-        kp[row] = valid ? (uint32_t)keep[kv[row]] : 0u;   // <= sample_limit
-        eo[row] = valid ? (uint32_t)ev_off[kv[row]] : 0u; // < number of kept events of the batch (< 2^32)
+        kp[row] = valid ? (uint32_t)keep[kv[row] & PG_SLOT_MASK] : 0u;   // <= sample_limit
+        eo[row] = valid ? (uint32_t)ev_off[kv[row] & PG_SLOT_MASK] : 0u; // < number of kept events of the batch (< 2^32)
     }
     // events of each slot in each wave of this tile (k_rank_count_direct keeps only the tile totals), then the rank of
     // each wave's first event of a slot = tile prefix + earlier waves
@@ -1113,7 +1123,10 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     // sums), then the stores.
     uint32_t rd[PG_EMIT_ROWS];
 #pragma unroll
-    for (int row = 0; row < PG_EMIT_ROWS; ++row) rd[row] = dst[row] != 0xFFFFFFFFu ? owner_of(B, O, base + (uint64_t)row * WAVE + lane) : 0u;
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) { // the read rides in the key's upper bits (k_events), relative to the tile's first read
+        const uint32_t rel = kv[row] >> PG_SLOT_BITS;
+        rd[row] = dst[row] == 0xFFFFFFFFu ? 0u : (rel != PG_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, base + (uint64_t)row * WAVE + lane));
+    }
     KeptRead kr[PG_EMIT_ROWS];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) if (dst[row] != 0xFFFFFFFFu) kr[row] = kept_read(O, rd[row]);
@@ -1134,7 +1147,7 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
         if (W.print_margin > ws[row] || we <= start) { report_error(O, rd[row], PGR_ERR_WINDOW); start = we = 0; }
         K.ev_len[dst[row]] = we - start;
-        K.ev_start[dst[row]] = start;
+        K.ev_src[dst[row]] = kr[row].sig0 + start;
         K.ev_read[dst[row]] = rd[row];
         if (K.read_needed) K.read_needed[rd[row]] = 1;
     }
@@ -2034,7 +2047,7 @@ __global__ __launch_bounds__(64) void k_read_stats_rare(PgRareArgs A) {
 #endif
 template <int G>
 __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const uint32_t *__restrict__ ev_len,
-                                              const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
+                                              const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
                                               const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                               const double *__restrict__ med, const double *__restrict__ mad, double *__restrict__ samples) {
     const int lane = lane_id();
@@ -2049,51 +2062,70 @@ __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_ke
         return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
     };
     for (uint64_t e = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G); e < n_kept; e += stride) {
-        const uint32_t *p1 = sub == 0 ? ev_read + e : (sub == 1 ? ev_len + e : (sub == 2 ? ev_start + e
-                             : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub == 3 ? 0 : 1)));
-        const uint32_t f = sub < 5 ? *p1 : 0u;
+        // round 1: the event's six dwords by six lanes -- read, length, window start in the batch's signal (the emit kernels have
+        // added the read's sample offset: the window loads below need no second hop), output offset
+        const uint32_t *p1 = sub == 0 ? ev_read + e : (sub == 1 ? ev_len + e : (sub < 4 ? reinterpret_cast<const uint32_t *>(ev_src + e) + (sub - 2)
+                             : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub - 4)));
+        const uint32_t f = sub < 6 ? *p1 : 0u;
         const uint32_t rd = (uint32_t)__shfl((int)f, g0, WAVE), len = (uint32_t)__shfl((int)f, g0 + 1, WAVE);
-        const uint32_t st0 = (uint32_t)__shfl((int)f, g0 + 2, WAVE);
-        const uint64_t dst = pair64(f, 3);
-        const uint64_t *arr = sub == 0 ? B.sig_off + rd : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.off + rd)
-                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.range + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(B.dig + rd)
-                              : (sub == 4 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd)))));
-        const uint64_t h = sub < (scaling ? 6u : 4u) ? *arr : 0ull;
-        const uint64_t src = from(h, 0) + st0;
-        const double offset = __longlong_as_double((long long)from(h, 1));
-        const double scale = __longlong_as_double((long long)from(h, 2)) / __longlong_as_double((long long)from(h, 3));
-        const double md = scaling ? __longlong_as_double((long long)from(h, 4)) : 0.0;
-        const double ma = scaling ? __longlong_as_double((long long)from(h, 5)) : 1.0;
+        const uint64_t src = pair64(f, 2), dst = pair64(f, 4);
+        // round 2, all in flight together: the read's calibration and statistics by five lanes, the window's samples by every lane
+        const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
+                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
+        const uint64_t h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
+        const uint32_t odd = (uint32_t)(src & 1u);
+        const uint64_t d0 = src >> 1; // dword that holds sample src
+        constexpr int PASSES = 4; // windows of up to 2 * G * PASSES samples have all their loads in flight (longer ones: the loop below)
+        uint2 q[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const uint32_t t = 2 * sub + 2 * G * ps;
+            const uint64_t d = d0 + (t >> 1);
+            q[ps] = make_uint2(0u, 0u);
+            if (t < len) {
+                if (2 * d + 3 < total) q[ps] = *reinterpret_cast<const uint2 *>(sig32 + d); // 8 bytes, 4-byte aligned
+                else { // the last dwords of the batch: no read beyond the buffer
+                    const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
+                    q[ps] = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
+                }
+            }
+        }
+        const double offset = __longlong_as_double((long long)from(h, 0));
+        const double scale = __longlong_as_double((long long)from(h, 1)) / __longlong_as_double((long long)from(h, 2));
+        const double md = scaling ? __longlong_as_double((long long)from(h, 3)) : 0.0;
+        const double ma = scaling ? __longlong_as_double((long long)from(h, 4)) : 1.0;
         auto conv = [&](int raw) {
             const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
             double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
             if (scaling) x = (x - md) / ma;                               // gmove.cpp:774
             return x;
         };
-        const uint32_t odd = (uint32_t)(src & 1u);
-        const uint64_t d0 = src >> 1; // dword that holds sample src
-        for (uint32_t t = 2 * sub; t < len; t += 2 * G) { // this lane's two samples t, t+1 = halves of dwords d, d+1
-            const uint64_t d = d0 + (t >> 1);
-            int s0, s1;
-            if (2 * d + 3 < total) {
-                const uint2 q = *reinterpret_cast<const uint2 *>(sig32 + d); // 8 bytes, 4-byte aligned
-                s0 = odd ? (int)q.x >> 16 : (int)(short)(q.x & 0xffffu);
-                s1 = odd ? (int)(short)(q.y & 0xffffu) : (int)q.x >> 16;
-            } else { // the last dwords of the batch: no read beyond the buffer
-                s0 = (int)B.sig[src + t];
-                s1 = t + 1 < len ? (int)B.sig[src + t + 1] : 0;
-            }
+        auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1
+            const int s0 = odd ? (int)qq.x >> 16 : (int)(short)(qq.x & 0xffffu);
+            const int s1 = odd ? (int)(short)(qq.y & 0xffffu) : (int)qq.x >> 16;
             const double x0 = conv(s0);
             if (t + 1 < len) {
                 const double x1 = conv(s1);
                 *reinterpret_cast<double2 *>(samples + dst + t) = make_double2(x0, x1); // 16 bytes, 8-byte aligned
             } else samples[dst + t] = x0;
+        };
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) { const uint32_t t = 2 * sub + 2 * G * ps; if (t < len) emit2(t, q[ps]); }
+        for (uint32_t t = 2 * sub + 2 * G * PASSES; t < len; t += 2 * G) { // very long windows (--margin, --max_dur)
+            const uint64_t d = d0 + (t >> 1);
+            uint2 qq;
+            if (2 * d + 3 < total) qq = *reinterpret_cast<const uint2 *>(sig32 + d);
+            else {
+                const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
+                qq = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
+            }
+            emit2(t, qq);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const uint32_t *__restrict__ ev_len,
-                                                const uint32_t *__restrict__ ev_read, const uint32_t *__restrict__ ev_start,
+                                                const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
                                                 double *__restrict__ samples) {
@@ -2102,8 +2134,8 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
     const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
     // mean kept window (from the scan's total): 8 lanes per event (16 samples per pass) up to a mean of PG_GATHER8_MEAN samples --
     // half the waves of the 16-lane form; two passes over a 28-sample window still win (A/B on one box: 20.7 -> 19.5 us)
-    if (samp_off[n_kept] <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_start, samp_off, scaling, pa_min, pa_max, med, mad, samples);
-    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_start, samp_off, scaling, pa_min, pa_max, med, mad, samples);
+    if (samp_off[n_kept] <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
+    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
 }
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *__restrict__ read_needed,
@@ -2325,12 +2357,12 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
 }
 
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
-                      const uint32_t *ev_read, const uint32_t *ev_start, const uint64_t *samp_off, int scaling, double pa_min,
+                      const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples) {
     if (n_kept_cap == 0) return hipSuccess;
     uint64_t blocks = (n_kept_cap + 15) / 16;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
-    PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_start, samp_off, scaling,
+    PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_src, samp_off, scaling,
                        pa_min, pa_max, med, mad, samples);
     return hipSuccess;
 }

@@ -3,11 +3,13 @@
 # trace of the same command and the HBM-traffic counters of the dominant kernel (separate --pmc passes).
 # usage (from the repo root, on the GPU box): bash tools/round_artifacts.sh <tag>   -> gpurun_out/<tag>/
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag; mkdir -p $out
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -20 $out/pytest_gpu.txt; exit 1; }
-tail -2 $out/pytest_gpu.txt
+if [ "$2" != "nopytest" ]; then
+  timeout -k 10 900 python -m pytest tests -x -q -m gpu > $out/pytest_gpu.txt 2>&1 || { tail -20 $out/pytest_gpu.txt; exit 1; }
+  tail -2 $out/pytest_gpu.txt
+fi
 python3 bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-lazy-extra --no-extras > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 for pass in FETCH_SIZE WRITE_SIZE; do
@@ -30,6 +32,7 @@ tot = sum(r[2] for r in rows)
 with open(f"{out}/kernel_stats.csv", "w", newline="") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows: w.writerow([r[0], r[1], r[2], round(r[3], 1), round(100 * r[2] / tot, 2), r[4], r[5]])
-print("k_read_stats FETCH KB", res["FETCH_SIZE"].get("k_read_stats"), "WRITE KB", res["WRITE_SIZE"].get("k_read_stats"))
+for kn in res["FETCH_SIZE"]:
+    print(kn[:60].ljust(60), "FETCH KB %.0f (x2 on gfx950 for wide streaming reads)" % res["FETCH_SIZE"][kn], "WRITE KB %.0f" % res["WRITE_SIZE"].get(kn, 0))
 PY
 cat $out/bench.json
