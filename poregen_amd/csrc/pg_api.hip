@@ -288,7 +288,20 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)); // "least" and "greatest" priority (numerically high / low)
     CTRY(hipStreamCreateWithPriority(&c->own_st, hipStreamNonBlocking, prio_high));
     c->st = c->own_st;
-    CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
+    {
+        // experiment hook: PGMOVE_STATS_CU_WITHHELD=N keeps N compute units (spread over the XCDs: the mask's bits go round the
+        // XCDs) out of the statistics stream's reach, so that the small launches next to it (PG_FLAG_OVERLAP_TAIL) find room
+        const char *wh = getenv("PGMOVE_STATS_CU_WITHHELD");
+        const int withheld = wh ? atoi(wh) : 0;
+        hipDeviceProp_t prop;
+        CTRY(hipGetDeviceProperties(&prop, p->device));
+        const int cus = prop.multiProcessorCount;
+        if (withheld > 0 && withheld < cus) {
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int i = 0; i < cus - withheld; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+            CTRY(hipExtStreamCreateWithCUMask(&c->st2, (uint32_t)mask.size(), mask.data()));
+        } else CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
+    }
     for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
