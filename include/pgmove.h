@@ -68,8 +68,11 @@ enum {
                                      (legal: event acceptance is signal-independent in the PAF path);
                                      default is to touch every read's signal like the reference does */
     PG_FLAG_PROFILE = 1u << 1,    /* record HIP events around every kernel (pg_kernel_stats) */
-    PG_FLAG_OVERLAP = 1u << 2,    /* run the statistics kernels on a second stream next to the walk/rank chain (measured: no gain
-                                     on MI355X, both sides are occupancy-bound; default is one stream) */
+    PG_FLAG_OVERLAP = 1u << 2,    /* two-stream mode: the statistics kernels of batch i+1 run on a second stream next to the event /
+                                     rank / emit chain of batches i and i+1; that stream is created with a quarter of the compute
+                                     units (of every XCD) withheld, so that the chain's workgroups find room. Pays when batches
+                                     follow each other (measured on configs[1]: 0.181 -> 0.157 ms per batch); every kernel then
+                                     shares the chip, so the default stays one stream with clean per-kernel timings. */
     PG_FLAG_SHORT_READS_OK = 1u << 4, /* a read with fewer than k matched bases simply has no events (move-table front-end,
                                         where that is well defined); default: PG_ERR_INPUT, because the PAF path of the
                                         reference has undefined behaviour there (src/gmove.cpp:891) */

@@ -289,18 +289,24 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipStreamCreateWithPriority(&c->own_st, hipStreamNonBlocking, prio_high));
     c->st = c->own_st;
     {
-        // experiment hook: PGMOVE_STATS_CU_WITHHELD=N keeps N compute units (spread over the XCDs: the mask's bits go round the
-        // XCDs) out of the statistics stream's reach, so that the small launches next to it (PG_FLAG_OVERLAP_TAIL) find room
+        // PG_FLAG_OVERLAP: the statistics stream may use three quarters of the compute units (the mask's bits go round the XCDs, so
+        // every XCD keeps a quarter of its CUs free of it). Without the reservation the streaming kernel's one-wave workgroups refill
+        // every wave slot they free and the chain's 16-wave workgroups wait for it to drain (measured, profiles/r02_two_stream_ab.txt:
+        // 0.181 ms per step with the whole chip, 0.172 with 32 CUs withheld, 0.157 with 64, 0.159 with 96, 0.174 with 128).
+        // PGMOVE_STATS_CU_WITHHELD=N overrides the number (measurements).
         const char *wh = getenv("PGMOVE_STATS_CU_WITHHELD");
-        const int withheld = wh ? atoi(wh) : 0;
         hipDeviceProp_t prop;
         CTRY(hipGetDeviceProperties(&prop, p->device));
         const int cus = prop.multiProcessorCount;
+        const int withheld = wh ? atoi(wh) : ((p->flags & PG_FLAG_OVERLAP) ? cus / 4 : 0);
+        bool masked = false;
         if (withheld > 0 && withheld < cus) {
             std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
             for (int i = 0; i < cus - withheld; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-            CTRY(hipExtStreamCreateWithCUMask(&c->st2, (uint32_t)mask.size(), mask.data()));
-        } else CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
+            masked = hipExtStreamCreateWithCUMask(&c->st2, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) (void)hipGetLastError(); // a runtime that refuses masks: the plain stream below
+        }
+        if (!masked) CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
     }
     for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
