@@ -98,7 +98,7 @@ struct PgWalkOut {
 };
 #define PG_SLOT_BITS 10
 #define PG_SLOT_MASK ((1u << PG_SLOT_BITS) - 1u)
-#define PG_REL_UNKNOWN ((1u << (32 - PG_SLOT_BITS)) - 1u)
+#define PG_REL_UNKNOWN ((1u << (32 - PG_SLOT_BITS)) - 2u) // not all ones: slot 1023 with an unknown read must not read as PG_INVALID_SLOT
 
 #define PG_INVALID_SLOT 0xFFFFFFFFu
 #define PG_TIX_FRONT(margin) (((uint64_t)((margin) > 0 ? (margin) : 0) + 3) & ~3ull)

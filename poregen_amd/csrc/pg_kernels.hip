@@ -471,10 +471,11 @@ template <int E, bool TIXG> __device__ __forceinline__ void walk_events_tile(con
 // 16 sequence bytes -> 2-bit codes (byte q at bits 2q) + one "not A C G T/U" bit per byte, four bytes at a time:
 // code = ((x >> 1) & 3) ^ (((x >> 1) & 3) >> 1) maps A C G T U to 0 1 2 3 3; the letter a code stands for is rebuilt
 // (0x41 + 2 b0 + 6 b1 + 11 b0 b1) and compared with the byte, 'U' (= 'T' ^ 1) passing on RNA-oriented records only.
-__device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, uint32_t &code2, uint32_t &bad) {
+// NW words of sequence bytes -> 2-bit codes (byte p at bits 2p) + one "not A C G T/U" bit per byte
+template <int NW> __device__ __forceinline__ void codes_of(const uint32_t (&w)[NW], bool rna, uint64_t &code2, uint32_t &bad) {
     code2 = 0; bad = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NW; ++q) {
         const uint32_t x = w[q];
         uint32_t y = (x >> 1) & 0x03030303u;
         y ^= (y >> 1) & 0x01010101u;
@@ -483,7 +484,7 @@ __device__ __forceinline__ void codes_of_16(const uint32_t (&w)[4], bool rna, ui
         uint32_t d = x ^ expect;
         if (rna) d &= ~b01; // 'U' against the 'T' of code 3
         const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u; // 0x80 in every non-zero byte
-        code2 |= ((y * 0x01041040u) >> 24) << (8 * q);
+        code2 |= (uint64_t)((y * 0x01041040u) >> 24) << (8 * q);
         bad |= ((((nz >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * q);
     }
 }
@@ -533,11 +534,10 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
 // LT: both slot tables (<= 1024 codes each: k <= 5; <= 1024 slots: COUNT) as 16-bit entries in LDS -- 16 look-ups per thread at LDS latency
 template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT ? 8 : 4, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
     constexpr int TBL = PG_EV_TBL;
-    __shared__ uint16_t ltab[LT ? 2048 : 2];
+    __shared__ uint16_t ltab[LT ? 2048 + 2 : 2]; // [2048]: 0xFFFF, where a position that is no candidate looks itself up
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
     __shared__ int32_t t_o0[4][TBL], t_ilo[4][TBL], t_ihi[4][TBL];
     __shared__ uint32_t t_fl[4][TBL], t_s0lo[4][TBL], t_s0hi[4][TBL], t_slen[4][TBL];
-    __shared__ uint32_t codew[4][256 + 4], badw[4][256 + 4]; // [256]: the halo, the 16 ops behind the tile
     // the thread's 16 slots wait here for the end of the kernel (transposed: op j of thread lt at [j][lt]): a global store between two
     // slot-table look-ups would serialise them (on this part a wait for a load also waits for every store issued in front of it), and
     // 16 more live registers cost a wave per SIMD. 16 bits per slot in direct mode (<= 1024 slots), 32 otherwise.
@@ -553,6 +553,7 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
     if (COUNT) for (uint32_t i = tid; i < 4 * (PG_RANK_MAX_DIGITS + 32); i += 1024) (&cnt[0][0])[i] = 0;
     if (tid < 5) { const uint64_t T = (uint64_t)(tile0 + tid) * PG_SORT_TILE; sh_rf[tid] = T < N ? owner_of(B, O, T) : B.n_reads; }
     if (tid < 4) { sh_R[tid] = 0; sh_over[tid] = 0; }
+    if (LT && tid == 0) ltab[2048] = (uint16_t)0xFFFFu;
     if (LT) for (uint32_t i = tid; i < 2048; i += 1024) { // [0, 1024): T-spelled codes, [1024, 2048): U-spelled; -1 (not in the slice) -> 0xFFFF
         const uint32_t code = i & 1023u, which = i >> 10;
         ltab[i] = code < W.n_codes ? (uint16_t)W.table_t[which * W.n_codes + code] : (uint16_t)0xFFFFu;
@@ -638,53 +639,48 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
             more = f + 1 < R && t_o0[tq][f + 1] < (int32_t)(x0 + 16);
         }
     };
-    // 16 bases of read entry e starting at its event index i, as 2-bit codes (base i+p at bits 2p) + bad bits; 0 / all bad if no window
-    auto window = [&](const Seg &sg, uint32_t i, uint32_t &code, uint32_t &bad) {
-        code = 0; bad = 0xffffu;
+    // NB = 4 NW bases of read entry e starting at its event index i, as 2-bit codes (base i+p at bits 2p) + bad bits; 0 / all bad if no
+    // window. NB >= 16 + k - 1: 20 with both tables in LDS (k <= 5), 28 otherwise (k <= 13)
+    constexpr int NW = LT ? 5 : 7, NB = 4 * NW;
+    auto window = [&](const Seg &sg, uint32_t i, uint64_t &code, uint32_t &bad) {
+        code = 0; bad = (1u << NB) - 1u;
         if ((sg.fl & 3u) != 1u) return;
         const bool rna = (sg.fl >> 2) & 1u;
         const uint64_t s0 = (uint64_t)t_s0lo[tq][sg.e] | ((uint64_t)t_s0hi[tq][sg.e] << 32);
-        // DNA-oriented: base i+p is sequence byte s0+i+p; RNA-oriented: match p is byte s0+slen-1-p, so the window is the 16 bytes
+        // DNA-oriented: base i+p is sequence byte s0+i+p; RNA-oriented: match p is byte s0+slen-1-p, so the window is the NB bytes
         // that END at s0+slen-1-i. Bytes outside the read (or the buffer: clamped) belong to non-candidates.
-        const int64_t a = rna ? (int64_t)(s0 + t_slen[tq][sg.e]) - 16 - (int64_t)i : (int64_t)(s0 + i);
+        const int64_t a = rna ? (int64_t)(s0 + t_slen[tq][sg.e]) - NB - (int64_t)i : (int64_t)(s0 + i);
         const int64_t adw = a >> 2;
-        uint32_t d[5];
+        uint32_t d[NW + 1];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
+        for (int q = 0; q < NW + 1; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
         const uint32_t sh = (uint32_t)(a & 3) * 8u;
-        uint32_t w[4];
+        uint32_t w[NW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
-        if (rna) { // byte q of the window is match i+15-q: into match order
-            const uint32_t a0 = __builtin_bswap32(w[3]), a1 = __builtin_bswap32(w[2]), a2 = __builtin_bswap32(w[1]), a3 = __builtin_bswap32(w[0]);
-            w[0] = a0; w[1] = a1; w[2] = a2; w[3] = a3;
+        for (int q = 0; q < NW; ++q) w[q] = sh ? (d[q] >> sh) | (d[q + 1] << (32u - sh)) : d[q];
+        if (rna) { // byte q of the window is match i+NB-1-q: into match order
+            uint32_t t[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) t[q] = __builtin_bswap32(w[NW - 1 - q]);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) w[q] = t[q];
         }
-        codes_of_16(w, rna, code, bad);
+        codes_of<NW>(w, rna, code, bad);
     };
+    // every thread fetches the bases of its own 16 ops AND of the k-1 ops behind them (the events that start in the group end
+    // there): no exchange between threads, no halo, no barrier between this stage and the events
     Seg A{0, 0, 0}, Bs{0, 0, 0}; uint32_t jb = 16; bool more = false;
-    if (tile_live && !over) {
-#pragma unroll 1
-        for (uint32_t pass = 0; pass < 2; ++pass) { // pass 1 (thread 0 of the tile): the halo
-            if (pass && lt != 0) break;
-            const uint32_t slot_g = pass ? 256u : lt, x0 = slot_g * 16u;
-            uint32_t code = 0, bad = 0xffffu;
-            if (T0 + x0 < N) {
-                Seg a, b; uint32_t j2; bool m2;
-                find_reads(x0, a, b, j2, m2);
-                uint32_t cA, bA, cB = 0, bB = 0xffffu;
-                window(a, (uint32_t)((int32_t)x0 - a.o0), cA, bA);
-                if (j2 < 16) window(b, 0u, cB, bB);
-                const uint32_t keep = j2 < 16 ? (1u << (2u * j2)) - 1u : 0xffffffffu, keepb = j2 < 16 ? (1u << j2) - 1u : 0xffffu;
-                code = (cA & keep) | (j2 < 16 ? cB << (2u * j2) : 0u);
-                bad = (bA & keepb) | (j2 < 16 ? (bB << j2) & 0xffffu : 0u);
-                if (!pass) { A = a; Bs = b; jb = j2; more = m2; }
-            }
-            codew[tq][slot_g] = code; badw[tq][slot_g] = bad;
-        }
+    uint64_t c64 = 0; uint32_t bad32 = (1u << NB) - 1u; // bases of ops x0 .. x0+NB-1, op x0+p at bits 2p
+    if (tile_live && !over && g0 < N) {
+        const uint32_t x0 = lt * 16u;
+        find_reads(x0, A, Bs, jb, more);
+        uint64_t cA, cB = 0; uint32_t bA, bB = (1u << NB) - 1u;
+        window(A, (uint32_t)((int32_t)x0 - A.o0), cA, bA);
+        if (jb < 16) window(Bs, 0u, cB, bB);
+        c64 = jb < 16 ? (cA & ((1ull << (2u * jb)) - 1ull)) | (cB << (2u * jb)) : cA;
+        bad32 = jb < 16 ? (bA & ((1u << jb) - 1u)) | (bB << jb) : bA;
     }
     PG_MARK(1, 3); // reads of the group, base codes
-    __syncthreads();
-    PG_MARK(1, 4); // barrier
 
     // ---- stage 3: the events ------------------------------------------------------------------------------------------------------------
     const uint32_t cmask = (1u << nbits) - 1u;
@@ -697,10 +693,125 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
             O.ev_slot[g0 + j] = COUNT && sl != PG_INVALID_SLOT ? sl | (rel << PG_SLOT_BITS) : sl; // COUNT: the read rides in the upper bits (PgWalkOut::tile_read)
             if (COUNT && sl != PG_INVALID_SLOT) atomicAdd(&cnt[tq][sl & cmask], 1u);
         }
+    } else if (COUNT && LT && tile_live && g0 < N && W.sig_move_offset == 0 &&
+               !((A.fl & 3u) == 1u && jb < 16 && (Bs.fl & 3u) == 1u && ((A.fl ^ Bs.fl) & 4u))) {
+        // ---- the straight-line form (direct ranking, both tables in LDS, window of an event = its own op; the two reads of the group,
+        // if both direct, of one orientation): the position, base and duration tests of the 16 events become three 16-bit masks, every
+        // event then costs one shift of the thread's code word, one LDS look-up (a position that fails a test looks up the 0xFFFF entry),
+        // one LDS count; the 16 slots stay in eight registers until the stores. No branch and no wait per event.
+        const uint32_t x0 = lt * 16u;
+        const uint32_t kindA = A.fl & 3u, kindB = jb < 16 ? (Bs.fl & 3u) : 0u;
+        auto bits = [](int32_t lo, int32_t hi) -> uint32_t { // bits lo .. hi (0 <= lo <= 16, -1 <= hi <= 15), none if lo > hi
+            const uint32_t h = (uint32_t)(hi < 0 ? 0 : hi), l = (uint32_t)(lo > 15 ? 15 : lo);
+            return lo <= hi ? ((2u << h) - 1u) & ~((1u << l) - 1u) : 0u;
+        };
+        // candidates by position (gmove.cpp:891-894, 204-211 through the per-read range [ilo, ihi]); gm: ops of generic reads (k_walk's events)
+        uint32_t pos = 0, gm = 0;
+        {
+            const int32_t jbi = (int32_t)jb, iA0 = (int32_t)x0 - A.o0; // event index of op x0 in read A
+            if (kindA == 1u) {
+                int32_t lo = t_ilo[tq][A.e] - iA0, hi = t_ihi[tq][A.e] - iA0; // ilo >= 0, ihi >= -1, iA0 >= 0: no overflow
+                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo); hi = hi > jbi - 1 ? jbi - 1 : (hi < -1 ? -1 : hi);
+                pos = bits(lo, hi);
+            } else if (kindA == 2u) gm = bits(0, jbi - 1);
+            if (kindB == 1u) { // event index of op x0 + j in read B: j - jb
+                int32_t lo = t_ilo[tq][Bs.e], hi = t_ihi[tq][Bs.e];
+                lo = jbi + (lo > 16 ? 16 : lo); hi = hi > 15 ? 15 : jbi + hi; hi = hi > 15 ? 15 : hi;
+                pos |= bits(lo > 16 ? 16 : lo, hi);
+            } else if (kindB == 2u) gm |= bits(jbi, 15);
+        }
+        const uint32_t nvalid = g0 + 16 <= N ? 16u : (uint32_t)(N - g0);
+        const uint32_t vmask = (2u << (nvalid - 1u)) - 1u;
+        // a base that is not A C G T/U anywhere in the k-mer: k <= 5 here (both tables fit 1024 codes)
+        const uint32_t km1 = k - 1u;
+        const uint32_t bm = bad32 | (bad32 >> (km1 < 1u ? km1 : 1u)) | (bad32 >> (km1 < 2u ? km1 : 2u)) | (bad32 >> (km1 < 3u ? km1 : 3u)) | (bad32 >> (km1 < 4u ? km1 : 4u));
+        // durations (gmove.cpp:916-921): the thread's own op_n again (they were summed long ago; registers are worth more than cache hits)
+        uint32_t dm = 0, orv = 0;
+        {
+            const uint32_t range = W.max_dur - W.min_dur;
+#pragma unroll
+            for (int v = 3; v >= 0; --v) {
+                uint32_t len[4] = {0, 0, 0, 0};
+                if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
+                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) len[u] = B.op_n[g0 + 4 * v + u]; }
+#pragma unroll
+                for (int u = 3; u >= 0; --u) { dm = (dm << 1) | ((len[u] - W.min_dur <= range) ? 1u : 0u); orv |= len[u]; }
+            }
+            if (W.max_dur < W.min_dur) dm = 0;
+        }
+        const uint32_t cm = pos & ~bm & dm & vmask;
+        PG_MARK(1, 5); // straight-line form: the three masks (op_n arrives)
+        // the code word in look-up order, times two (byte offsets into ltab): RNA-oriented records look the mirrored k-mer up (first base
+        // lowest: a right shift by 2j of the word as it is, gmove.cpp:883, 899); DNA-oriented ones the k-mer itself (first base highest:
+        // the word with its 2-bit groups in reverse order, base p at bits 62-2p, shifted right by 64-2k-2j)
+        const bool rna = ((kindA == 1u ? A.fl : Bs.fl) >> 2) & 1u;
+        uint64_t S64; uint32_t sh, tb2; int32_t step;
+        if (rna) { S64 = c64 << 1; sh = 0u; step = 2; tb2 = 2048u; } // op 31 loses a bit: events only reach op 15 + k - 1
+        else {
+            const uint32_t lo = __builtin_bitreverse32((uint32_t)(c64 >> 32)), hi = __builtin_bitreverse32((uint32_t)c64);
+            const uint64_t r = (uint64_t)lo | ((uint64_t)hi << 32);
+            S64 = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
+            sh = 63u - 2u * k; step = -2; tb2 = 0u;
+        }
+        const uint32_t mask2 = ((1u << (2u * k)) - 1u) << 1;
+        const char *lbase = reinterpret_cast<const char *>(ltab);
+        uint32_t *cbase = &cnt[tq][0];
+        const uint32_t dummy = PG_RANK_MAX_DIGITS + ((uint32_t)lane & 31u);
+        uint32_t pk[8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { // four look-ups in flight, then their four counts
+            uint32_t t16[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * v + u;
+                const uint32_t off = ((uint32_t)(S64 >> (sh + (uint32_t)(step * j))) & mask2) | tb2;
+                const uint32_t m = (uint32_t)((int32_t)(cm << (31 - j)) >> 31);
+                t16[u] = *reinterpret_cast<const volatile uint16_t *>(lbase + ((off & m) | (4096u & ~m)));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(cbase + (t16[u] < dummy ? t16[u] : dummy), 1u);
+            pk[2 * v] = t16[0] | (t16[1] << 16); pk[2 * v + 1] = t16[2] | (t16[3] << 16);
+        }
+        PG_MARK(1, 6); // straight-line form: look-ups and counts
+        if (gm & vmask) { // the events of generic reads come from k_walk (plain slots < 1024, or PG_INVALID_SLOT)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                uint32_t wk[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
+                if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(O.ev_slot + g0 + 4 * v); wk[0] = x.x; wk[1] = x.y; wk[2] = x.z; wk[3] = x.w; }
+                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) wk[u] = O.ev_slot[g0 + 4 * v + u]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = 4 * v + u;
+                    if ((gm & vmask) >> j & 1u) {
+                        const uint32_t x = wk[u] & 0xFFFFu; // PG_INVALID_SLOT -> 0xFFFF
+                        pk[j >> 1] = (j & 1) ? (pk[j >> 1] & 0xFFFFu) | (x << 16) : (pk[j >> 1] & 0xFFFF0000u) | x;
+                        if (x != 0xFFFFu) atomicAdd(cbase + x, 1u);
+                    }
+                }
+            }
+        }
+        if (orv >= PG_OP_N_LIMIT) { // an op of 2^24 samples or more in a direct read: any fails the batch, the lowest read is reported
+            for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
+                const bool inB = j >= jb;
+                if (((inB ? Bs.fl : A.fl) & 3u) == 1u && B.op_n[g0 + j] >= PG_OP_N_LIMIT) report_error(O, rFirst + (inB ? Bs.e : A.e), PGR_ERR_RANGE);
+            }
+        }
+        // the stores: slot | read << PG_SLOT_BITS (read = its table entry); 0xFFFF sign-extends to PG_INVALID_SLOT and stays it under the OR
+        const uint32_t relA = A.e << PG_SLOT_BITS, relB = Bs.e << PG_SLOT_BITS;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            uint32_t o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * v + u;
+                const int32_t x = (j & 1) ? (int32_t)pk[j >> 1] >> 16 : (int32_t)(int16_t)(pk[j >> 1] & 0xFFFFu);
+                o4[u] = (uint32_t)x | ((uint32_t)j >= jb ? relB : relA);
+            }
+            if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
+        }
     } else if (tile_live && g0 < N) {
         const uint32_t x0 = lt * 16u;
-        const uint64_t c64 = (uint64_t)codew[tq][lt] | ((uint64_t)codew[tq][lt + 1] << 32); // bases of ops x0 .. x0+31, op x0+p at bits 2p
-        const uint32_t bad32 = (badw[tq][lt] & 0xffffu) | (badw[tq][lt + 1] << 16);
         const int32_t iloA = t_ilo[tq][A.e], ihiA = t_ihi[tq][A.e];
         int32_t iloB = 0, ihiB = -1;
         if (jb < 16) { iloB = t_ilo[tq][Bs.e]; ihiB = t_ihi[tq][Bs.e]; }
@@ -765,13 +876,12 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
             else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
         }
     }
-    PG_MARK(1, 5); // events, stores, counts
+    PG_MARK(1, 4); // stores (straight-line form), or the whole of the events (the other forms)
     if (COUNT) {
         __syncthreads();
         for (uint32_t d = tid; d < (1u << nbits); d += 1024)
             *reinterpret_cast<uint4 *>(hist + (uint64_t)d * n_tiles + tile0) = make_uint4(cnt[0][d], cnt[1][d], cnt[2][d], cnt[3][d]);
     }
-    PG_MARK(1, 6); // barrier + histogram rows
     PG_PROBE_END(1, blockIdx.x * 16u + (tid >> 6));
 }
 

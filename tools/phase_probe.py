@@ -26,8 +26,9 @@ eng.sync()
 lib.pg_debug_phases(buf.ctypes.data, 0, 1)
 eng.reset(); eng.submit(shard); eng.sync()
 names = {0: ("k_read_stats", ["record load", "samples arrive", "binning", "prefix scan", "selection + stores"]),
-         1: ("k_events<true> (per wave, 4 tiles)", ["first reads of the tiles + op_n", "table entry + block sums", "barrier", "reads of the group + base codes",
-                                                   "barrier", "events + stores + counts", "barrier + histogram rows"])}
+         1: ("k_events<true> (per wave, 4 tiles)", ["first reads of the tiles + op_n", "table entry + block sums", "the two barriers", "reads of the group + base codes",
+                                                   "stores (or events, other forms)", "masks (op_n arrives)", "look-ups + counts"])}
+# k_events: the last barrier and the histogram rows are the rest of the lifetime
 for k, (name, ph) in names.items():
     lib.pg_debug_phases(buf.ctypes.data, k, 0)
     live = buf[:, 7] > 0
