@@ -792,7 +792,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     prof_begin(c, "scan_ev_len", c->st);
     HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
-                                      c->rare_pending ? &c->rare : nullptr));
+                                      c->rare_pending ? &c->rare : nullptr, totals + 2));
     c->rare_pending = false;
     prof_end(c, c->st);
 

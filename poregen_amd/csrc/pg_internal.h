@@ -224,8 +224,9 @@ struct PgRareArgs {
 // out[i] = sum_{j<i} in[j] for i in [0, n], n = *n_ptr <= n_cap; scratch >= ceil(n_cap/4096)+80 uint64, its first 72
 // entries ZERO before the first use (every launch leaves them zero again). rare (may be null): the rare statistics ride in the
 // same launch (short inputs) or get their own launch in front of the scan kernels
+// total_out (may be null): the total (= out[n]) once more, where the consumer of the offsets finds it next to n
 hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
-                                  const PgRareArgs *rare);
+                                  const PgRareArgs *rare, uint64_t *total_out);
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
 // plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
@@ -235,6 +236,7 @@ hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_
 // the main statistics launch (one wave per read, 1024 LDS bins); reads that need more put themselves on wide_list
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
                                 uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only);
+// n_kept_ptr: [0] kept events, [2] their samples (the offset scan's total_out)
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples);

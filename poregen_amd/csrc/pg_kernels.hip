@@ -1167,6 +1167,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 // Geometry: only the few tiles in front of the last useful one do any work, so the tile is spread over 16 waves of 4
 // rows (a 1024-thread workgroup): the ordered loop, the one serial part, is 4 steps instead of 16.
 #define PG_EMIT_WAVES 16
+#define PG_EMIT_GRID 512 // two 64 KB workgroups per CU
 #define PG_EMIT_ROWS (PG_SORT_TILE / (PG_EMIT_WAVES * WAVE))
 __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
                                                    const uint32_t *__restrict__ hist,
@@ -1174,10 +1175,17 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
                                                    const uint64_t *__restrict__ totals, PgDevBatch B, PgWalkParams W, PgWalkOut O,
                                                    PgKeptOut K) {
     __shared__ uint32_t wbase[PG_EMIT_WAVES][PG_RANK_MAX_DIGITS];
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x, w = tid >> 6;
+    __shared__ uint32_t s_keep[PG_RANK_MAX_DIGITS], s_off[PG_RANK_MAX_DIGITS];
+    static_assert(PG_RANK_MAX_DIGITS <= PG_EMIT_WAVES * WAVE, "one digit per thread");
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
-    if ((int64_t)tile > (int64_t)totals[3]) return; // beyond the last tile that can still place an event (k_slot_plan)
+    // the workgroups share the tiles round robin: at most PG_EMIT_GRID of them are started, and only the ones with a tile up to the
+    // last that can still place an event (k_slot_plan: usually a few dozen of thousands) stay -- 1024-thread workgroups with 64 KB of
+    // LDS that start only to leave are not free, least of all next to another stream's kernel
+    const int64_t last_tile = (int64_t)totals[3];
+    for (uint32_t tile = blockIdx.x; tile < n_tiles && (int64_t)tile <= last_tile; tile += gridDim.x) {
+    if (tile != blockIdx.x) __syncthreads(); // the previous tile's ranks are read out of wbase until its last wave is through
     const uint32_t tile_first = O.tile_read[tile];
     const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
     // phase 0: everything the ordered loop needs from global memory, all rows in flight at once. The slots of the tile's events
@@ -1189,27 +1197,35 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         const uint64_t idx = base + (uint64_t)row * WAVE + lane;
         kv[row] = idx < n ? keys[idx] : PG_INVALID_SLOT;
     }
+    // thread d (ndig <= 1024 = the workgroup: one digit each) brings slot d's column entry, keep and offset: the column entry stays
+    // in its register for the wave bases below, the other two go to LDS, where the events look them up -- no second round to memory
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
-    for (uint32_t d = tid; d < ndig; d += PG_EMIT_WAVES * WAVE) {
-        if (d < n_slots && (uint64_t)hist[(uint64_t)d * n_tiles + tile] < keep[d]) any = 1;
+    uint32_t hcol = 0;
+    if (tid < ndig) {
+        const uint32_t d = tid;
+        uint64_t kd = 0, od = 0;
+        if (d < n_slots) { hcol = hist[(uint64_t)d * n_tiles + tile]; kd = keep[d]; od = ev_off[d]; }
+        if (d < n_slots && (uint64_t)hcol < kd) any = 1;
+        s_keep[d] = (uint32_t)kd; // <= sample_limit
+        s_off[d] = (uint32_t)od;  // < number of kept events of the batch (< 2^32)
         for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) wbase[ww][d] = 0;
     }
-    if (!__syncthreads_or(any)) return; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
+    if (!__syncthreads_or(any)) continue; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
     volatile uint32_t *mybase = wbase[w];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         const bool valid = kv[row] != PG_INVALID_SLOT;
-        kp[row] = valid ? (uint32_t)keep[kv[row] & PG_SLOT_MASK] : 0u;   // <= sample_limit
-        eo[row] = valid ? (uint32_t)ev_off[kv[row] & PG_SLOT_MASK] : 0u; // < number of kept events of the batch (< 2^32)
+        kp[row] = valid ? s_keep[kv[row] & (ndig - 1u)] : 0u;
+        eo[row] = valid ? s_off[kv[row] & (ndig - 1u)] : 0u;
     }
     // events of each slot in each wave of this tile (k_rank_count_direct keeps only the tile totals), then the rank of
     // each wave's first event of a slot = tile prefix + earlier waves
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) if (kv[row] != PG_INVALID_SLOT) atomicAdd(&wbase[w][kv[row] & (ndig - 1u)], 1u);
     __syncthreads();
-    for (uint32_t d = tid; d < ndig; d += PG_EMIT_WAVES * WAVE) {
-        uint32_t b = hist[(uint64_t)d * n_tiles + tile];
-        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) { const uint32_t cw = wbase[ww][d]; wbase[ww][d] = b; b += cw; }
+    if (tid < ndig) {
+        uint32_t b = hcol;
+        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) { const uint32_t cw = wbase[ww][tid]; wbase[ww][tid] = b; b += cw; }
     }
     __syncthreads();
     // phase 1: the ordered part -- LDS and ALU only: rank = tile prefix + earlier waves + earlier rows + in-row rank
@@ -1261,6 +1277,7 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         K.ev_read[dst[row]] = rd[row];
         if (K.read_needed) K.read_needed[rd[row]] = 1;
     }
+    } // tiles of this workgroup
 }
 
 // =====================================================================================================
@@ -1467,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_scan_partials_scan(uint64_t *__restrict
 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, uint64_t n_scalar,
                                                     const uint64_t *__restrict__ n_ptr, const uint64_t *__restrict__ partial,
-                                                    uint64_t *__restrict__ out) {
+                                                    uint64_t *__restrict__ out, uint64_t *__restrict__ total_out) {
     __shared__ uint64_t wsum[4];
     const uint64_t n = n_ptr ? *n_ptr : n_scalar;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * 16;
@@ -1486,9 +1503,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
         const uint64_t a = base + i;
         if (a < n) out[a] = run;
         run += v[i];
-        if (a + 1 == n) out[n] = run;
+        if (a + 1 == n) { out[n] = run; if (total_out) *total_out = run; }
     }
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) { out[0] = 0; if (total_out) *total_out = 0; }
 }
 
 // The same scan in ONE launch (chained scan with decoupled look-back): block b publishes the sum of its 4096 elements,
@@ -1501,7 +1518,8 @@ __device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, ui
 // RARE: blocks [n_scan, gridDim.x) are not part of the scan: each of their 4 waves is a worker of the rare statistics launch
 // (reads whose in-range interval needs more than 1024 bins; usually none) -- an empty launch of its own costs a kernel boundary.
 template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
-                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ state, uint32_t n_scan, PgRareArgs A) {
+                                                      uint64_t *__restrict__ out, uint64_t *__restrict__ state, uint32_t n_scan, PgRareArgs A,
+                                                      uint64_t *__restrict__ total_out) {
     if (RARE) {
         __shared__ __attribute__((aligned(16))) uint32_t rare_hist[4][PG_RARE_LDS_WORDS];
         if (blockIdx.x >= n_scan) {
@@ -1559,9 +1577,9 @@ template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const
         const uint64_t a = base + i;
         if (a < n) out[a] = run;
         run += v[i];
-        if (a + 1 == n) out[n] = run;
+        if (a + 1 == n) { out[n] = run; if (total_out) *total_out = run; }
     }
-    if (n == 0 && b == 0 && threadIdx.x == 0) out[0] = 0;
+    if (n == 0 && b == 0 && threadIdx.x == 0) { out[0] = 0; if (total_out) *total_out = 0; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(state + 1), 1ull);
@@ -2239,12 +2257,12 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
                                                 double *__restrict__ samples) {
-    const uint64_t n_kept = *n_kept_ptr;
+    const uint64_t n_kept = n_kept_ptr[0], n_samples = n_kept_ptr[2]; // [2]: the offset scan's total (= samp_off[n_kept]), one round trip earlier
     if (n_kept == 0) return;
     const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
     // mean kept window (from the scan's total): 8 lanes per event (16 samples per pass) up to a mean of PG_GATHER8_MEAN samples --
     // half the waves of the 16-lane form; two passes over a 28-sample window still win (A/B on one box: 20.7 -> 19.5 us)
-    if (samp_off[n_kept] <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
+    if (n_samples <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
     else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
 }
 
@@ -2353,7 +2371,7 @@ hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, u
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     if (!n_tiles) return hipSuccess;
-    PG_LAUNCH(k_rank_emit, dim3(n_tiles), dim3(PG_EMIT_WAVES * WAVE), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
+    PG_LAUNCH(k_rank_emit, dim3(n_tiles < PG_EMIT_GRID ? n_tiles : PG_EMIT_GRID), dim3(PG_EMIT_WAVES * WAVE), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, (const uint32_t *)S.hist,
                        keep, ev_off, totals, B, W, O, K);
     return hipSuccess;
 }
@@ -2401,7 +2419,7 @@ hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const ui
     if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
         PG_HIP(hipMemsetAsync(totals, 0, 32, st));
         PG_LAUNCH(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
-        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch, nullptr));
+        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch, nullptr, nullptr));
         PG_LAUNCH(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
         return hipSuccess;
     }
@@ -2420,14 +2438,14 @@ hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint3
 }
 
 hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
-                                  const PgRareArgs *rare) {
+                                  const PgRareArgs *rare, uint64_t *total_out) {
     const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK), nbl = nb ? nb : 1;
     if (nbl <= 64) { // one look-back round: a single launch wins (11 vs 17 us at 25 blocks)
         if (rare) { // the rare statistics ride in this launch: 4 workers per extra block, PG_HUGE_BLOCKS of them for the huge list
             const uint32_t want = rare->wide_blocks < 64 ? 64u : (rare->wide_blocks > 2048 ? 2048u : rare->wide_blocks);
             const uint32_t extra = (want + PG_HUGE_BLOCKS + 3) / 4;
-            PG_LAUNCH(k_scan_chained<true>, dim3(nbl + extra), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, *rare);
-        } else PG_LAUNCH(k_scan_chained<false>, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, PgRareArgs{});
+            PG_LAUNCH(k_scan_chained<true>, dim3(nbl + extra), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, *rare, total_out);
+        } else PG_LAUNCH(k_scan_chained<false>, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, PgRareArgs{}, total_out);
         return hipSuccess;
     }
     if (rare) PG_HIP(pg_launch_read_stats_rare(st, *rare));
@@ -2436,7 +2454,7 @@ hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n
     uint64_t *partial = scratch + 72;
     PG_LAUNCH(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
     PG_LAUNCH(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
-    PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out);
+    PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out, total_out);
     return hipSuccess;
 }
 
