@@ -1,14 +1,16 @@
 // pg_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the gmove hot path.
 //
 // Pipeline per batch (reference lines are src/gmove.cpp of hiruna72/poregen):
-//   k_walk          ss walk (lines 822-871), one wave per read, prefix sums by DPP wave scans
-//   k_events        event filters (lines 891-927, 204-211), four consecutive events per thread
+//   k_batch_init    per-read records (walk head 822-830, statistics plan 754-760), classification of the reads, flag resets
+//   k_walk          reads with I / D ops only: ss walk (lines 822-871) + their event loop, one wave per listed read
+//   k_events        op-parallel: the events of the match-only reads (lines 891-927, 204-211), 16 consecutive ops per thread,
+//                   and the per-(tile, slot) counts of the direct ranking
 //   k_rank_*        stable ranking of accepted events inside their k-mer slot: the deterministic stand-in for
 //                   "first sample_limit events in PAF-line order, then event order" (lines 732, 891, 925-927);
-//                   direct for <= 1024 slots (k_rank_count_direct / k_rank_scan / k_rank_emit), LSD radix sort
-//                   (k_rank_count / k_sort_* / k_kept_meta) beyond
-//   k_slot_plan (+ k_tile_max) or k_slot_keep, k_scan_*   the sample_limit cut and the output offsets
-//   k_read_plan + k_read_stats (+ k_read_stats_rare)     pA conversion, zero-fill, exact median and MAD (lines 754-771)
+//                   direct for <= 1024 slots (k_rank_scan with the sample_limit cut in its last workgroup / k_rank_emit),
+//                   LSD radix sort (k_rank_count / k_sort_* / k_kept_meta) beyond
+//   k_slot_plan (+ k_tile_max) or k_slot_keep, k_scan_*   the cut as a launch of its own (base from other ranks), output offsets
+//   k_read_stats (+ the rare workers riding in k_scan_chained)   pA conversion, zero-fill, exact median and MAD (lines 754-771)
 //   k_gather        window copy + normalisation of the kept events (lines 773-775, 928-944)
 // All of this is HBM/LDS-bound integer and FP64 work: there is no contraction here, so no MFMA.
 #include "pg_internal.h"
@@ -27,10 +29,10 @@ __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) -
 // outstanding memory operations, then the time since the previous mark goes to phase i) and stores them once, at its end, into
 // its own record g_pg_phase[kernel][wave][phase] -- no atomics, nothing shared between waves.
 #define PG_PROBE_WAVES 65536
-__device__ unsigned long long g_pg_phase[2][PG_PROBE_WAVES][8];
+__device__ unsigned long long g_pg_phase[3][PG_PROBE_WAVES][8]; // 0 k_read_stats, 1 k_events, 2 k_rank_emit
 extern "C" void pg_debug_phases(unsigned long long *out, int kernel, int reset) { // out: [PG_PROBE_WAVES][8]
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pg_phase), sizeof(unsigned long long) * PG_PROBE_WAVES * 8, sizeof(unsigned long long) * PG_PROBE_WAVES * 8 * kernel);
-    if (reset) { void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pg_phase)); (void)hipMemset(p, 0, sizeof(unsigned long long) * 2 * PG_PROBE_WAVES * 8); }
+    if (reset) { void *p = nullptr; (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_pg_phase)); (void)hipMemset(p, 0, sizeof(unsigned long long) * 3 * PG_PROBE_WAVES * 8); }
 }
 #define PG_PROBE_BEGIN(k) unsigned long long pg_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pg_t_ = __builtin_readcyclecounter(); const unsigned long long pg_t0_ = pg_t_
 #define PG_MARK(k, i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long n_ = __builtin_readcyclecounter(); pg_acc_[i] += n_ - pg_t_; pg_t_ = n_; } while (0)
@@ -914,12 +916,13 @@ __device__ __forceinline__ bool kept_window(const PgDevBatch &B, const PgWalkPar
         s += (m > 0 ? a : 0u) + (m > 1 ? b : 0u) + (m > 2 ? c : 0u);
         return s;
     };
+    const uint64_t b0 = kr.o0 >> 8, b1 = ge >> 8;
+    const uint32_t t0 = O.btot[b0]; // unconditional: in flight with P's loads, not behind them (a read rarely ends in the block it starts in)
     const uint32_t p0 = P(kr.o0), pge = P(ge);
     uint64_t sum;
-    const uint64_t b0 = kr.o0 >> 8, b1 = ge >> 8;
     if (b0 == b1) sum = (uint64_t)(pge - p0);
     else {
-        sum = (uint64_t)(O.btot[b0] - p0) + pge;
+        sum = (uint64_t)(t0 - p0) + pge;
         for (uint64_t b = b0 + 1; b < b1; ++b) sum += O.btot[b];
     }
     const uint64_t st = (uint64_t)kr.qs + sum;
@@ -1167,7 +1170,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
 // Geometry: only the few tiles in front of the last useful one do any work, so the tile is spread over 16 waves of 4
 // rows (a 1024-thread workgroup): the ordered loop, the one serial part, is 4 steps instead of 16.
 #define PG_EMIT_WAVES 16
-#define PG_EMIT_GRID 512 // two 64 KB workgroups per CU
+#define PG_EMIT_GRID 512
 #define PG_EMIT_ROWS (PG_SORT_TILE / (PG_EMIT_WAVES * WAVE))
 __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
                                                    const uint32_t *__restrict__ hist,
@@ -1181,16 +1184,20 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     const int lane = lane_id();
     const uint32_t ndig = 1u << nbits;
     // the workgroups share the tiles round robin: at most PG_EMIT_GRID of them are started, and only the ones with a tile up to the
-    // last that can still place an event (k_slot_plan: usually a few dozen of thousands) stay -- 1024-thread workgroups with 64 KB of
-    // LDS that start only to leave are not free, least of all next to another stream's kernel
+    // last that can still place an event (k_slot_plan: usually a few dozen of thousands) stay -- 1024-thread workgroups with 72 KB of
+    // LDS that start only to leave are not free, least of all next to another stream's kernel. Measured and lost (22 -> 25..26 us):
+    // asking for the tile's data in front of that test, and dropping the test for "stop at the first tile without room" -- either way
+    // every started workgroup first gathers its 1024-line column of the [slot][tile] table.
+    PG_PROBE_BEGIN(2);
     const int64_t last_tile = (int64_t)totals[3];
     for (uint32_t tile = blockIdx.x; tile < n_tiles && (int64_t)tile <= last_tile; tile += gridDim.x) {
     if (tile != blockIdx.x) __syncthreads(); // the previous tile's ranks are read out of wbase until its last wave is through
-    const uint32_t tile_first = O.tile_read[tile];
-    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
+    PG_MARK(2, 0); // the last useful tile is known
     // phase 0: everything the ordered loop needs from global memory, all rows in flight at once. The slots of the tile's events
     // are requested in front of the "any room left?" test: a tile up to the last useful one nearly always passes it, and the
-    // test's own loads and barrier then cost no round trip of their own
+    // test's own loads and barrier then cost no round trip of their own.
+    const uint32_t tile_first = O.tile_read[tile];
+    const uint64_t base = (uint64_t)tile * PG_SORT_TILE + (uint64_t)w * PG_EMIT_ROWS * WAVE;
     uint32_t kv[PG_EMIT_ROWS], kp[PG_EMIT_ROWS], eo[PG_EMIT_ROWS];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
@@ -1199,18 +1206,27 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
     }
     // thread d (ndig <= 1024 = the workgroup: one digit each) brings slot d's column entry, keep and offset: the column entry stays
     // in its register for the wave bases below, the other two go to LDS, where the events look them up -- no second round to memory
+    uint32_t hcol = 0; uint64_t kd = 0, od = 0;
+    if (tid < n_slots) { hcol = hist[(uint64_t)tid * n_tiles + tile]; kd = keep[tid]; od = ev_off[tid]; }
+    PG_MARK(2, 1); // keys, column, keep, offsets have arrived
     int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
-    uint32_t hcol = 0;
     if (tid < ndig) {
-        const uint32_t d = tid;
-        uint64_t kd = 0, od = 0;
-        if (d < n_slots) { hcol = hist[(uint64_t)d * n_tiles + tile]; kd = keep[d]; od = ev_off[d]; }
-        if (d < n_slots && (uint64_t)hcol < kd) any = 1;
-        s_keep[d] = (uint32_t)kd; // <= sample_limit
-        s_off[d] = (uint32_t)od;  // < number of kept events of the batch (< 2^32)
-        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) wbase[ww][d] = 0;
+        if (tid < n_slots && (uint64_t)hcol < kd) any = 1;
+        s_keep[tid] = (uint32_t)kd; // <= sample_limit
+        s_off[tid] = (uint32_t)od;  // < number of kept events of the batch (< 2^32)
+        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) wbase[ww][tid] = 0;
     }
-    if (!__syncthreads_or(any)) continue; // every k-mer this tile could feed is already full (gmove.cpp:925-927)
+    // the records of the events' reads (the read rides in the key's upper bits, relative to the tile's first read): requested now,
+    // for every event of the tile, so that they arrive while the ranks are worked out in LDS
+    uint32_t rd[PG_EMIT_ROWS]; KeptRead kr[PG_EMIT_ROWS]; bool have[PG_EMIT_ROWS];
+#pragma unroll
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) {
+        const uint32_t rel = kv[row] >> PG_SLOT_BITS;
+        have[row] = kv[row] != PG_INVALID_SLOT && rel != PG_REL_UNKNOWN;
+        rd[row] = tile_first + rel;
+        if (have[row]) kr[row] = kept_read(O, rd[row]);
+    }
+    if (!__syncthreads_or(any)) break; // every k-mer this tile could feed is already full (gmove.cpp:925-927), and -- the column entries only grow along the tiles -- so are the tiles behind it
     volatile uint32_t *mybase = wbase[w];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
@@ -1223,11 +1239,16 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) if (kv[row] != PG_INVALID_SLOT) atomicAdd(&wbase[w][kv[row] & (ndig - 1u)], 1u);
     __syncthreads();
-    if (tid < ndig) {
+    if (tid < ndig) { // sixteen independent reads, the prefix in registers, sixteen writes: not a read-write chain through LDS
+        uint32_t cw[PG_EMIT_WAVES];
+#pragma unroll
+        for (int ww = 0; ww < PG_EMIT_WAVES; ++ww) cw[ww] = wbase[ww][tid];
         uint32_t b = hcol;
-        for (uint32_t ww = 0; ww < PG_EMIT_WAVES; ++ww) { const uint32_t cw = wbase[ww][tid]; wbase[ww][tid] = b; b += cw; }
+#pragma unroll
+        for (int ww = 0; ww < PG_EMIT_WAVES; ++ww) { wbase[ww][tid] = b; b += cw[ww]; }
     }
     __syncthreads();
+    PG_MARK(2, 2); // any-room test, per-wave counts, wave bases (three barriers)
     // phase 1: the ordered part -- LDS and ALU only: rank = tile prefix + earlier waves + earlier rows + in-row rank
     uint32_t dst[PG_EMIT_ROWS];
 #pragma unroll
@@ -1244,24 +1265,20 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         const uint32_t rank = b + (uint32_t)__popcll(peers & lanemask_lt());
         dst[row] = (valid && rank < kp[row]) ? eo[row] + rank : 0xFFFFFFFFu;
     }
-    // phase 2: the kept events' windows (gmove.cpp:928-937). Staged across rows so that every stage is one set of independent
-    // loads: the owning read, then its record, then the window (start / length arrays of the generic walk, or op_n and k_events' block
-    // sums), then the stores.
-    uint32_t rd[PG_EMIT_ROWS];
+    // phase 2: the kept events' windows (gmove.cpp:928-937), staged across rows so that every stage is one set of independent loads: the
+    // window (start / length arrays of the generic walk, or op_n and k_events' block sums) from the records that have arrived by now,
+    // then the stores.
+    PG_MARK(2, 3); // the ordered rows (and the read records, requested long ago)
 #pragma unroll
-    for (int row = 0; row < PG_EMIT_ROWS; ++row) { // the read rides in the key's upper bits (k_events), relative to the tile's first read
-        const uint32_t rel = kv[row] >> PG_SLOT_BITS;
-        rd[row] = dst[row] == 0xFFFFFFFFu ? 0u : (rel != PG_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, base + (uint64_t)row * WAVE + lane));
-    }
-    KeptRead kr[PG_EMIT_ROWS];
-#pragma unroll
-    for (int row = 0; row < PG_EMIT_ROWS; ++row) if (dst[row] != 0xFFFFFFFFu) kr[row] = kept_read(O, rd[row]);
+    for (int row = 0; row < PG_EMIT_ROWS; ++row) // a kept event whose key does not name its read (k_events' per-op form in a crowded tile): look it up
+        if (dst[row] != 0xFFFFFFFFu && !have[row]) { rd[row] = owner_of(B, O, base + (uint64_t)row * WAVE + lane); kr[row] = kept_read(O, rd[row]); }
     uint32_t ws[PG_EMIT_ROWS], wl[PG_EMIT_ROWS]; bool okr[PG_EMIT_ROWS];
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         ws[row] = 0; wl[row] = 0; okr[row] = true;
         if (dst[row] != 0xFFFFFFFFu) okr[row] = kept_window(B, W, O, kr[row], base + (uint64_t)row * WAVE + lane, ws[row], wl[row]);
     }
+    PG_MARK(2, 4); // the windows
 #pragma unroll
     for (int row = 0; row < PG_EMIT_ROWS; ++row) {
         if (dst[row] == 0xFFFFFFFFu) continue;
@@ -1277,6 +1294,8 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         K.ev_read[dst[row]] = rd[row];
         if (K.read_needed) K.read_needed[rd[row]] = 1;
     }
+    PG_MARK(2, 5); // stores
+    if (tile == blockIdx.x) PG_PROBE_END(2, tile * PG_EMIT_WAVES + w);
     } // tiles of this workgroup
 }
 

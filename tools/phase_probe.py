@@ -29,6 +29,8 @@ names = {0: ("k_read_stats", ["record load", "samples arrive", "binning", "prefi
          1: ("k_events<true> (per wave, 4 tiles)", ["first reads of the tiles + op_n", "table entry + block sums", "the two barriers", "reads of the group + base codes",
                                                    "stores (or events, other forms)", "masks (op_n arrives)", "look-ups + counts"])}
 # k_events: the last barrier and the histogram rows are the rest of the lifetime
+names[2] = ("k_rank_emit (waves of the tiles that place events)", ["last useful tile known", "keys + column + keep + offsets arrive", "any-room test, counts, wave bases",
+                                                                    "ordered rows (+ read records)", "windows", "stores"])
 for k, (name, ph) in names.items():
     lib.pg_debug_phases(buf.ctypes.data, k, 0)
     live = buf[:, 7] > 0
