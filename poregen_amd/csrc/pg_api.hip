@@ -790,13 +790,13 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     const bool lazy = c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE);
     if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>(), false, false, true); if (s2 != PG_OK) return s2; }
 
+    uint64_t gather_cap = ke_cap;
     prof_begin(c, "scan_ev_len", c->st);
     HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
                                       c->rare_pending ? &c->rare : nullptr, totals + 2));
     c->rare_pending = false;
     prof_end(c, c->st);
 
-    uint64_t gather_cap = ke_cap;
     if (samp_cap * 8 > c->samples.cap) {
         // grow once to the worst case if that is moderate; otherwise size exactly from the device total (one sync)
         if (samp_cap * 8 <= (4ull << 30)) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));

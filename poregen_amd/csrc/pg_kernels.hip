@@ -2192,6 +2192,84 @@ __global__ __launch_bounds__(64) void k_read_stats_rare(PgRareArgs A) {
 #ifndef PG_GATHER8_MEAN
 #define PG_GATHER8_MEAN 32
 #endif
+// one kept event by a group of G lanes (sub = lane within the group, g0 = the group's first lane), in two halves so that a caller
+// can have the loads of several events in flight: gather_load -- the read's calibration and statistics by five lanes and the
+// window's samples by every lane, all requested together; gather_finish -- conversion and 16-byte stores
+#define PG_GATHER_PASSES 4 // windows of up to 2 * G * PASSES samples have all their loads in flight (longer ones: the loop in gather_finish)
+struct GatherRegs { uint64_t h; uint2 q[PG_GATHER_PASSES]; };
+template <int G>
+__device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, uint32_t rd, uint32_t len, uint64_t src, uint64_t total, int scaling,
+                                            const double *__restrict__ med, const double *__restrict__ mad, GatherRegs &R) {
+    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
+    const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
+                          : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
+    R.h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
+    const uint32_t odd = (uint32_t)(src & 1u);
+    const uint64_t d0 = src >> 1; // dword that holds sample src
+#pragma unroll
+    for (int ps = 0; ps < PG_GATHER_PASSES; ++ps) {
+        const uint32_t t = 2 * sub + 2 * G * ps;
+        const uint64_t d = d0 + (t >> 1);
+        R.q[ps] = make_uint2(0u, 0u);
+        if (t < len) {
+            if (2 * d + 3 < total) R.q[ps] = *reinterpret_cast<const uint2 *>(sig32 + d); // 8 bytes, 4-byte aligned
+            else { // the last dwords of the batch: no read beyond the buffer
+                const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
+                R.q[ps] = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
+            }
+        }
+    }
+}
+template <int G>
+__device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub, int g0, uint32_t len, uint64_t src, uint64_t dst, uint64_t total,
+                                              int scaling, double pa_min, double pa_max, double *__restrict__ samples, const GatherRegs &R) {
+    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
+    auto from = [&](uint64_t v, int k) { // the 64-bit value held by lane g0+k
+        return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
+    };
+    const uint32_t odd = (uint32_t)(src & 1u);
+    const uint64_t d0 = src >> 1;
+    const double offset = __longlong_as_double((long long)from(R.h, 0));
+    const double scale = __longlong_as_double((long long)from(R.h, 1)) / __longlong_as_double((long long)from(R.h, 2));
+    const double md = scaling ? __longlong_as_double((long long)from(R.h, 3)) : 0.0;
+    const double ma = scaling ? __longlong_as_double((long long)from(R.h, 4)) : 1.0;
+    auto conv = [&](int raw) {
+        const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
+        double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
+        if (scaling) x = (x - md) / ma;                               // gmove.cpp:774
+        return x;
+    };
+    auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1
+        const int s0 = odd ? (int)qq.x >> 16 : (int)(short)(qq.x & 0xffffu);
+        const int s1 = odd ? (int)(short)(qq.y & 0xffffu) : (int)qq.x >> 16;
+        const double x0 = conv(s0);
+        if (t + 1 < len) {
+            const double x1 = conv(s1);
+            *reinterpret_cast<double2 *>(samples + dst + t) = make_double2(x0, x1); // 16 bytes, 8-byte aligned (streaming "nt" stores: measured, slower -- 21.0 -> 23.5 us, 260 -> 368 us at 2.1 M events)
+        } else samples[dst + t] = x0;
+    };
+#pragma unroll
+    for (int ps = 0; ps < PG_GATHER_PASSES; ++ps) { const uint32_t t = 2 * sub + 2 * G * ps; if (t < len) emit2(t, R.q[ps]); }
+    for (uint32_t t = 2 * sub + 2 * G * PG_GATHER_PASSES; t < len; t += 2 * G) { // very long windows (--margin, --max_dur)
+        const uint64_t d = d0 + (t >> 1);
+        uint2 qq;
+        if (2 * d + 3 < total) qq = *reinterpret_cast<const uint2 *>(sig32 + d);
+        else {
+            const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
+            qq = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
+        }
+        emit2(t, qq);
+    }
+}
+template <int G>
+__device__ __forceinline__ void gather_one(const PgDevBatch &B, uint32_t sub, int g0, uint32_t rd, uint32_t len, uint64_t src, uint64_t dst,
+                                           uint64_t total, int scaling, double pa_min, double pa_max,
+                                           const double *__restrict__ med, const double *__restrict__ mad, double *__restrict__ samples) {
+    GatherRegs R;
+    gather_load<G>(B, sub, rd, len, src, total, scaling, med, mad, R);
+    gather_finish<G>(B, sub, g0, len, src, dst, total, scaling, pa_min, pa_max, samples, R);
+}
+
 template <int G>
 __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const uint32_t *__restrict__ ev_len,
                                               const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
@@ -2201,73 +2279,19 @@ __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_ke
     const int g0 = lane & ~(G - 1);
     const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
     const uint64_t stride = (uint64_t)gridDim.x * (256 / G);
-    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
     auto pair64 = [&](uint32_t v, int k) { // dwords held by lanes g0+k, g0+k+1 of this group as one 64-bit value
         return (uint64_t)(uint32_t)__shfl((int)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)v, g0 + k + 1, WAVE) << 32);
     };
-    auto from = [&](uint64_t v, int k) { // the 64-bit value held by lane g0+k
-        return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
-    };
     for (uint64_t e = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G); e < n_kept; e += stride) {
         // round 1: the event's six dwords by six lanes -- read, length, window start in the batch's signal (the emit kernels have
-        // added the read's sample offset: the window loads below need no second hop), output offset
+        // added the read's sample offset: the window loads need no second hop), output offset
         const uint32_t *p1 = sub == 0 ? ev_read + e : (sub == 1 ? ev_len + e : (sub < 4 ? reinterpret_cast<const uint32_t *>(ev_src + e) + (sub - 2)
                              : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub - 4)));
         const uint32_t f = sub < 6 ? *p1 : 0u;
         const uint32_t rd = (uint32_t)__shfl((int)f, g0, WAVE), len = (uint32_t)__shfl((int)f, g0 + 1, WAVE);
         const uint64_t src = pair64(f, 2), dst = pair64(f, 4);
         // round 2, all in flight together: the read's calibration and statistics by five lanes, the window's samples by every lane
-        const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
-                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
-        const uint64_t h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
-        const uint32_t odd = (uint32_t)(src & 1u);
-        const uint64_t d0 = src >> 1; // dword that holds sample src
-        constexpr int PASSES = 4; // windows of up to 2 * G * PASSES samples have all their loads in flight (longer ones: the loop below)
-        uint2 q[PASSES];
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const uint32_t t = 2 * sub + 2 * G * ps;
-            const uint64_t d = d0 + (t >> 1);
-            q[ps] = make_uint2(0u, 0u);
-            if (t < len) {
-                if (2 * d + 3 < total) q[ps] = *reinterpret_cast<const uint2 *>(sig32 + d); // 8 bytes, 4-byte aligned
-                else { // the last dwords of the batch: no read beyond the buffer
-                    const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
-                    q[ps] = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
-                }
-            }
-        }
-        const double offset = __longlong_as_double((long long)from(h, 0));
-        const double scale = __longlong_as_double((long long)from(h, 1)) / __longlong_as_double((long long)from(h, 2));
-        const double md = scaling ? __longlong_as_double((long long)from(h, 3)) : 0.0;
-        const double ma = scaling ? __longlong_as_double((long long)from(h, 4)) : 1.0;
-        auto conv = [&](int raw) {
-            const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
-            double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
-            if (scaling) x = (x - md) / ma;                               // gmove.cpp:774
-            return x;
-        };
-        auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1
-            const int s0 = odd ? (int)qq.x >> 16 : (int)(short)(qq.x & 0xffffu);
-            const int s1 = odd ? (int)(short)(qq.y & 0xffffu) : (int)qq.x >> 16;
-            const double x0 = conv(s0);
-            if (t + 1 < len) {
-                const double x1 = conv(s1);
-                *reinterpret_cast<double2 *>(samples + dst + t) = make_double2(x0, x1); // 16 bytes, 8-byte aligned
-            } else samples[dst + t] = x0;
-        };
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) { const uint32_t t = 2 * sub + 2 * G * ps; if (t < len) emit2(t, q[ps]); }
-        for (uint32_t t = 2 * sub + 2 * G * PASSES; t < len; t += 2 * G) { // very long windows (--margin, --max_dur)
-            const uint64_t d = d0 + (t >> 1);
-            uint2 qq;
-            if (2 * d + 3 < total) qq = *reinterpret_cast<const uint2 *>(sig32 + d);
-            else {
-                const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
-                qq = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
-            }
-            emit2(t, qq);
-        }
+        gather_one<G>(B, sub, g0, rd, len, src, dst, total, scaling, pa_min, pa_max, med, mad, samples);
     }
 }
 
