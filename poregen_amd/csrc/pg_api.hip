@@ -758,7 +758,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     HIP_TRY(c, pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
                         pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
-                        (direct && d_base == c->running.as<uint64_t>()) ? c->tile_last.as<int32_t>() : nullptr, G));
+                        direct ? c->tile_last.as<int32_t>() : nullptr, G));
     prof_end(c, c->st);
     }
 

@@ -1349,11 +1349,17 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     uint64_t carry = 0, full = 0;
+    // tile_last (k_rank_scan) was worked out with the context's running count as the base. The base used here may be larger (events of
+    // lower ranks, of other contexts): the last useful tile can then only lie earlier, and k_rank_emit's own "any room?" test ends
+    // the tiles in between -- no k_tile_max launch. A SMALLER base (a caller's pg_collect with a base of its own) would make it too
+    // early: then every tile counts as useful.
+    int base_below_running = 0;
     for (uint32_t c = 0; c < n_slots; c += 1024) {
         const uint32_t s = c + tid;
         uint64_t kp = 0, isfull = 0;
         if (s < n_slots) {
             const uint64_t cnt = acc_cnt[s], b = slot_base(G, base, s, n_slots, limit);
+            if (tile_last && running && b < running[s]) base_below_running = 1;
             const uint64_t room = b >= limit ? 0 : (uint64_t)limit - b;
             kp = cnt < room ? cnt : room;
             isfull = (limit > 0 && b + cnt >= limit) ? 1 : 0; // at limit 0 no k-mer ever completes: the test at gmove.cpp:925-927 skips every event before 945-950 can count it
@@ -1380,9 +1386,10 @@ __global__ __launch_bounds__(1024) void k_slot_plan(const uint64_t *__restrict__
         __syncthreads();
         if (tid == 0) for (int ww = 0; ww < 16; ++ww) last = wlast[ww] > last ? wlast[ww] : last;
     }
+    base_below_running = __syncthreads_or(base_below_running);
     if (tid == 0) { // totals[3]: read as a signed tile index by k_rank_emit; ~0 = -1: k_tile_max raises it
         ev_off[n_slots] = carry; totals[0] = carry; totals[1] = full;
-        totals[3] = tile_last ? (uint64_t)(int64_t)last : (hist ? ~0ull : ~0ull >> 1);
+        totals[3] = tile_last ? (base_below_running ? ~0ull >> 1 : (uint64_t)(int64_t)last) : (hist ? ~0ull : ~0ull >> 1);
     }
 }
 
