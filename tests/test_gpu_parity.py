@@ -96,6 +96,27 @@ def test_two_phase_shards_equal_single_run():
         e.close()
 
 
+def test_collect_with_a_base_below_the_running_count():
+    """k_rank_scan works the last useful tile out against the context's running count; pg_collect with a SMALLER base of the caller's
+    own (here: zero, after a first batch has filled the running count) must still place every event that base allows."""
+    b1 = synth.make_batch(300, kind="rna004", seed=31)
+    b2 = synth.make_batch(300, kind="rna004", seed=32)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=12)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b2)                                # the second batch on its own, base 0
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b1); eng.sync()                     # running counts: most k-mers full
+    eng.count(b2)
+    eng.collect(np.zeros(len(kmers), dtype=np.uint64))
+    res = eng.finish()
+    for s in range(len(kmers)):                    # batch 1's events come first in every slot; batch 2's must be the oracle's
+        want = o.values(s)
+        got = res.slot_values(s)
+        assert np.array_equal(got[got.size - want.size:].view(np.uint64), want.view(np.uint64)), s
+    eng.close()
+
+
 def test_device_resident_batch_and_reset():
     import torch
     b = synth.make_batch(300, kind="rna004", seed=14)
