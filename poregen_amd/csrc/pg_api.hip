@@ -247,13 +247,21 @@ void pg_destroy(pg_ctx *c) {
     delete c;
 }
 
+// PGMOVE_TIMING=1: wall-clock marks of the host side of a batch on stderr (where does the first batch's time go?)
+static double wall_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static bool timing_on() { static const bool on = getenv("PGMOVE_TIMING") != nullptr; return on; }
+#define PG_TMARK(label) do { if (timing_on()) { const double n_ = wall_now(); fprintf(stderr, "[pgmove timing] %-34s %8.3f ms\n", label, (n_ - tmark_) * 1e3); tmark_ = n_; } } while (0)
+
 pg_status pg_runtime_init(int32_t device) {
+    double tmark_ = timing_on() ? wall_now() : 0.0;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
+    PG_TMARK("runtime: hipGetDeviceCount");
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, PG_ERR_NO_DEVICE, "no HIP device available (%s); libpgmove has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (device < 0 || device >= ndev) return fail(nullptr, PG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipFree(nullptr); // creates the device's primary context
+    PG_TMARK("runtime: hipSetDevice + hipFree(0)");
     if (e != hipSuccess) return fail(nullptr, PG_ERR_NO_DEVICE, "HIP runtime on device %d: %s", device, hipGetErrorString(e));
     return PG_OK;
 }
@@ -274,6 +282,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     e = hipSetDevice(p->device);
     if (e != hipSuccess) return fail(nullptr, PG_ERR_NO_DEVICE, "hipSetDevice(%d): %s", p->device, hipGetErrorString(e));
 
+    double tmark_ = timing_on() ? wall_now() : 0.0;
     pg_ctx *c = new pg_ctx();
     c->prm = *p;
     c->device = p->device;
@@ -288,6 +297,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)); // "least" and "greatest" priority (numerically high / low)
     CTRY(hipStreamCreateWithPriority(&c->own_st, hipStreamNonBlocking, prio_high));
     c->st = c->own_st;
+    if (p->flags & (PG_FLAG_OVERLAP | PG_FLAG_OVERLAP_TAIL)) // the second stream only exists in the modes that use it: a hardware queue costs 15-20 ms to create
     {
         // PG_FLAG_OVERLAP: the statistics stream may use three quarters of the compute units (the mask's bits go round the XCDs, so
         // every XCD keeps a quarter of its CUs free of it). Without the reservation the streaming kernel's one-wave workgroups refill
@@ -308,6 +318,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
         }
         if (!masked) CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
     }
+    PG_TMARK("create: streams");
     for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
     CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
@@ -326,6 +337,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut), [24] u32 ticket (k_rank_scan)
     CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
+    PG_TMARK("create: events, tables, first buffers");
 #undef CTRY
     *out = c;
     return PG_OK;
@@ -336,7 +348,7 @@ pg_status pg_reset(pg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->prm.flags & PG_FLAG_PROFILE) {
         HIP_TRY(c, hipStreamSynchronize(c->st));
-        HIP_TRY(c, hipStreamSynchronize(c->st2));
+        if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
         prof_drain(c);
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
@@ -547,11 +559,14 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     c->have_count = false; c->rare_pending = false; c->plan_done = false;
     const uint32_t n = b->n_reads;
 
+    double tmark_ = timing_on() ? wall_now() : 0.0;
     c->batch_is_host = b->location == PG_LOC_HOST;
     c->batch_all_matches = (b->flags & PG_BATCH_ALL_MATCHES) != 0 && !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK);
     if (b->location == PG_LOC_HOST) {
         s = stage_host_batch(c, b);
         if (s != PG_OK) return s;
+        PG_TMARK("count: staging copies queued");
+        if (timing_on()) { HIP_TRY(c, hipStreamSynchronize(c->st)); PG_TMARK("count: staging copies done (sync)"); }
     } else if (b->location == PG_LOC_DEVICE) {
         PgDevBatch &B = c->B;
         B.sig = b->sig; B.sig_off = b->sig_off; B.dig = b->digitisation; B.off = b->offset; B.range = b->range;
@@ -603,6 +618,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     if (!direct) HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16)); // per-wave counts: only the radix sort keeps them
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
+    PG_TMARK("count: work buffers");
     c->full_before_batch = c->full_slots == c->prm.n_slots && c->prm.n_slots > 0;
     c->slot ^= 1; // this batch's statistics buffers
     const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0; // statistics first: the walk needs their verdict
@@ -696,6 +712,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         HIP_TRY(c, hipStreamSynchronize(c->st));
     }
     c->have_count = true;
+    PG_TMARK("count: kernels queued");
+    if (timing_on()) { HIP_TRY(c, hipStreamSynchronize(c->st)); PG_TMARK("count: kernels done (sync)"); }
     return PG_OK;
 }
 
@@ -722,6 +740,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_count) return fail(c, PG_ERR_STATE, "pg_collect without a preceding pg_count");
     HIP_TRY(c, hipSetDevice(c->device));
+    double tmark_ = timing_on() ? wall_now() : 0.0;
     if (c->stats_deferred) { // PG_FLAG_DEFER_STATS and the caller did not place them with pg_stats
         c->stats_deferred = false;
         pg_status s2 = launch_stats(c, c->st, nullptr, false, c->plan_in_init, true);
@@ -817,6 +836,8 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
                      c->samples.as<double>()));
     prof_end(c, c->st);
     HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], c->st));
+    PG_TMARK("collect: buffers + kernels queued");
+    if (timing_on()) { HIP_TRY(c, hipStreamSynchronize(c->st)); PG_TMARK("collect: kernels done (sync)"); }
     c->slot_used[c->slot] = true;
     c->have_count = false; c->have_batch_result = true; c->downloaded = false; c->totals_known = false;
     return PG_OK;
@@ -826,7 +847,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 static pg_status settle_batch(pg_ctx *c) {
     if (!c->have_batch_result || c->totals_known) return PG_OK;
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     pg_status s = check_read_errors(c);
     if (s != PG_OK) { c->have_batch_result = false; c->downloaded = true; return s; }
     uint64_t tot[2] = {0, 0};
@@ -860,7 +881,7 @@ pg_status pg_sync(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     return settle_batch(c);
 }
 
@@ -868,7 +889,7 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
     if (!c) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
     c->user_stream = hip_stream != nullptr;
     return PG_OK;
@@ -887,7 +908,7 @@ int32_t pg_poll(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_batch_result || c->totals_known) return 1;
     if (hipSetDevice(c->device) != hipSuccess) return PG_ERR_HIP;
-    if (hipStreamQuery(c->st) != hipSuccess || hipStreamQuery(c->st2) != hipSuccess) { (void)hipGetLastError(); return 0; } // hipErrorNotReady
+    if (hipStreamQuery(c->st) != hipSuccess || (c->st2 && hipStreamQuery(c->st2) != hipSuccess)) { (void)hipGetLastError(); return 0; } // hipErrorNotReady
     const pg_status s = settle_batch(c);
     return s == PG_OK ? 1 : s;
 }
@@ -1097,7 +1118,7 @@ pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t
     if (!c || !n_out) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     prof_drain(c);
     uint32_t n = 0;
     for (auto &name : c->prof_names) {
@@ -1111,7 +1132,7 @@ pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t
 pg_status pg_kernel_stats_reset(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     prof_drain(c);
     c->prof_acc.clear(); c->prof_names.clear();
     return PG_OK;
