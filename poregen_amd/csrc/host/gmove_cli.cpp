@@ -402,8 +402,15 @@ int gmove_main(int argc, char **argv) {
     // outcome, as in the reference's one-line-at-a-time loop.
     if (is_paf) {
         unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16; if (nt < 1) nt = 1;
-        struct Run { HostBatch b; std::string line_buf, seq, e2, msg; pgh::Slow5Rec rec; size_t lo = 0, hi = 0, n_ok = 0; bool bad = false; };
+        struct Run { HostBatch b; std::string line_buf, seq, e2, msg; pgh::Slow5Rec rec; size_t lo = 0, hi = 0, n_ok = 0; bool bad = false;
+                     std::vector<pgh::Slow5File::RawView> views; std::vector<pgh::PafRec> pafs; };
         std::vector<Run> runs(nt);
+        // Uncompressed BLOW5: a read's samples are copied ONCE, from the mapped file to their place in the batch. Pass 1 (per run) parses
+        // the lines and looks the records up -- their lengths give every run its place; pass 2 copies the samples there and does the rest
+        // (ss tokens, sequence). Otherwise a run decodes into its own buffers, which are copied into the batch (two more passes over the
+        // signal and as many more resident pages). The lines kept are a prefix of the file order either way: everything behind the first
+        // failing line is dropped, so the samples of the kept reads are a prefix of what was placed.
+        const bool can_place = s5.has_raw_views();
         std::vector<std::string> lines;
         auto on_threads = [&](const std::function<void(unsigned)> &fn) {
             if (nt == 1) { fn(0); return; }
@@ -431,39 +438,80 @@ int gmove_main(int argc, char **argv) {
                 return pr == 1 && dev.all_full_settled();
             };
             if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
-            on_threads([&](unsigned t) {
+            // the rest of a line once its record is at hand: ss tokens, sequence, the per-read scalars
+            auto finish_line = [&](Run &r, const pgh::PafRec &paf, double dig, double off, double range) -> bool {
+                    if (!pgh::tokenize_ss(paf.ss, paf.ss_len, r.b.op_n, r.b.op_t, r.e2)) { r.bad = true; r.msg = r.e2; return false; }
+                    // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
+                    const int64_t a = paf.target_start, b2 = paf.target_end;
+                    const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
+                    fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), r.seq); // absent name: empty sequence -> the read is skipped on the device
+                    r.b.seq.insert(r.b.seq.end(), r.seq.begin(), r.seq.end()); r.b.seq_off.push_back(r.b.seq.size());
+                    r.b.op_off.push_back(r.b.op_n.size());
+                    r.b.dig.push_back(dig); r.b.off.push_back(off); r.b.range.push_back(range);
+                    r.b.qs.push_back(paf.query_start); r.b.ts.push_back(paf.target_start); r.b.te.push_back(paf.target_end);
+                    return true;
+            };
+            bool placing = can_place;
+            auto pass1 = [&](unsigned t) {
                 Run &r = runs[t];
-                r.b.clear(); r.bad = false; r.msg.clear();
+                r.b.clear(); r.bad = false; r.msg.clear(); r.views.clear(); r.pafs.clear();
                 r.lo = n_lines * t / nt; r.hi = n_lines * (t + 1) / nt; r.n_ok = 0;
                 for (size_t i = r.lo; i < r.hi; i++) {
                     pgh::PafRec paf;
                     const int pr = pgh::parse_paf_line(&lines[i][0], lines[i].size(), paf);
                     if (pr == 1) { r.bad = true; r.msg = "malformed PAF record (fewer than 12 columns)"; return; }
                     if (pr == 2) { r.bad = true; r.msg = "ss:Z: tag not found in paf record for " + paf.rid; return; }    // gmove.cpp:1046-1049
+                    if (placing) {
+                        pgh::Slow5File::RawView v;
+                        if (!s5.raw_view(paf.rid, v, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read"; return; } // gmove.cpp:745-749
+                        r.b.sig_off.push_back(r.b.sig_off.back() + v.n);
+                        r.views.push_back(v); r.pafs.push_back(std::move(paf));
+                        r.n_ok++;
+                        continue;
+                    }
                     if (!s5.get(paf.rid, r.rec, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read"; return; } // gmove.cpp:745-749
-                    if (!pgh::tokenize_ss(paf.ss, paf.ss_len, r.b.op_n, r.b.op_t, r.e2)) { r.bad = true; r.msg = r.e2; return; }
-                    // faidx_fetch_seq(m_fai, tid, st_k, end_k-1, &len) with st_k/end_k = min/max of the target columns (gmove.cpp:792-805)
-                    const int64_t a = paf.target_start, b2 = paf.target_end;
-                    const int64_t st_k = (uint64_t)a > (uint64_t)b2 ? b2 : a, end_k = (uint64_t)a > (uint64_t)b2 ? a : b2;
-                    fai.fetch(paf.tid, (int)st_k, (int)(end_k - 1), r.seq); // absent name: empty sequence -> the read is skipped on the device
+                    if (!finish_line(r, paf, r.rec.digitisation, r.rec.offset, r.rec.range)) return;
                     if (i == r.lo) r.b.sig.reserve((r.hi - r.lo) * (r.rec.raw.size() + r.rec.raw.size() / 8)); // reads of a run are of similar length
                     r.b.sig.append(r.rec.raw.data(), r.rec.raw.data() + r.rec.raw.size());
                     r.b.sig_off.push_back(r.b.sig.size());
-                    r.b.seq.insert(r.b.seq.end(), r.seq.begin(), r.seq.end()); r.b.seq_off.push_back(r.b.seq.size());
-                    r.b.op_off.push_back(r.b.op_n.size());
-                    r.b.dig.push_back(r.rec.digitisation); r.b.off.push_back(r.rec.offset); r.b.range.push_back(r.rec.range);
-                    r.b.qs.push_back(paf.query_start); r.b.ts.push_back(paf.target_start); r.b.te.push_back(paf.target_end);
                     r.n_ok++;
                 }
-            });
-            t_decode += secs(tp1, clk::now());
-            if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
+            };
+            on_threads(pass1);
             // runs in file order up to the first failing line; one device batch unless that would exceed 2^29 samples
             unsigned last_run = nt; // first run that stopped early
-            for (unsigned t = 0; t < nt; t++) if (runs[t].bad) { last_run = t; break; }
-            const unsigned n_runs = last_run < nt ? last_run + 1 : nt;
             uint64_t tot = 0;
-            for (unsigned t = 0; t < n_runs; t++) tot += runs[t].b.sig_off.back();
+            auto kept_runs = [&]() {
+                last_run = nt;
+                for (unsigned t = 0; t < nt; t++) if (runs[t].bad) { last_run = t; break; }
+                const unsigned k = last_run < nt ? last_run + 1 : nt;
+                tot = 0;
+                for (unsigned t = 0; t < k; t++) tot += runs[t].b.sig_off.back();
+                return k;
+            };
+            unsigned n_runs = kept_runs();
+            if (placing && tot > ((uint64_t)1 << 29)) { placing = false; on_threads(pass1); n_runs = kept_runs(); } // several device batches: the runs keep their own samples
+            if (placing) { // pass 2: every run's samples to their place, then the rest of its lines
+                hbs[cur].sig.resize(tot);
+                std::vector<uint64_t> base(nt + 1, 0);
+                for (unsigned t = 0; t < n_runs; t++) base[t + 1] = base[t] + runs[t].b.sig_off.back();
+                on_threads([&](unsigned t) {
+                    if (t >= n_runs) return;
+                    Run &r = runs[t];
+                    int16_t *dst = hbs[cur].sig.data() + base[t];
+                    for (size_t k = 0; k < r.n_ok; k++) {
+                        const pgh::Slow5File::RawView &v = r.views[k];
+                        if (v.n) memcpy(dst + r.b.sig_off[k], v.samples, v.n * sizeof(int16_t));
+                        if (!finish_line(r, r.pafs[k], v.digitisation, v.offset, v.range)) { // "Bad ss": the run ends in front of this line
+                            r.n_ok = k; r.b.sig_off.resize(k + 1);
+                            return;
+                        }
+                    }
+                });
+                n_runs = kept_runs();
+            }
+            t_decode += secs(tp1, clk::now());
+            if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
             unsigned t0 = 0;
             while (t0 < n_runs && !stop && status == EXIT_SUCCESS) {
                 const unsigned t1 = tot > ((uint64_t)1 << 29) ? t0 + 1 : n_runs; // too big for one batch: run by run
@@ -479,7 +527,7 @@ int gmove_main(int argc, char **argv) {
                     if (t < t0 || t >= t1) return;
                     const HostBatch &b = runs[t].b;
                     const size_t n = b.n();
-                    if (b.sig_off.back()) memcpy(hbs[cur].sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t));
+                    if (!placing && b.sig_off.back()) memcpy(hbs[cur].sig.data() + bs[t], b.sig.data(), b.sig_off.back() * sizeof(int16_t)); // (placed: already there)
                     if (b.seq_off.back()) memcpy(hbs[cur].seq.data() + bq[t], b.seq.data(), b.seq_off.back());
                     if (b.op_off.back()) { memcpy(hbs[cur].op_n.data() + bo[t], b.op_n.data(), b.op_off.back() * sizeof(uint32_t)); memcpy(hbs[cur].op_t.data() + bo[t], b.op_t.data(), b.op_off.back()); } // a failed line may have left ops behind op_off.back()
                     if (std::any_of(b.op_t.begin(), b.op_t.begin() + (ptrdiff_t)b.op_off.back(), [](uint8_t x) { return x != 0; })) batch_all_matches = false;

@@ -193,6 +193,25 @@ bool Slow5File::decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) cons
     return true;
 }
 
+bool Slow5File::raw_view(const std::string &read_id, RawView &v, std::string &err) const {
+    auto it = index_.find(read_id);
+    if (it == index_.end()) { err = "read " + read_id + " not found"; return false; }
+    if (!has_raw_views()) { err = "BLOW5 records are compressed"; return false; }
+    const unsigned char *body = (const unsigned char *)f_.data + it->second.off;
+    const size_t blen = it->second.len;
+    uint16_t il;
+    if (blen < 2) { err = "corrupt BLOW5 record"; return false; }
+    memcpy(&il, body, 2);
+    size_t p = 2 + (size_t)il;
+    if (p + 4 + 32 + 8 > blen) { err = "corrupt BLOW5 record"; return false; }
+    p += 4; // read_group
+    memcpy(&v.digitisation, body + p, 8); memcpy(&v.offset, body + p + 8, 8); memcpy(&v.range, body + p + 16, 8); p += 32;
+    memcpy(&v.n, body + p, 8); p += 8;
+    if (v.n > (blen - p) / 2) { err = "corrupt BLOW5 record (signal)"; return false; }
+    v.samples = body + p; // (2-byte alignment is not guaranteed: copy with memcpy)
+    return true;
+}
+
 bool Slow5File::get(const std::string &read_id, Slow5Rec &out, std::string &err) const {
     auto it = index_.find(read_id);
     if (it == index_.end()) { err = "read " + read_id + " not found"; return false; }

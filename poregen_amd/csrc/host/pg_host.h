@@ -27,6 +27,11 @@ class Slow5File {
 public:
     bool open(const std::string &path, std::string &err); // opens and indexes (read id -> record location)
     bool get(const std::string &read_id, Slow5Rec &out, std::string &err) const; // false if absent / malformed
+    // uncompressed BLOW5 (records and signals stored as they are): the samples of a read where they lie in the mapped file, so that a
+    // caller can copy them ONCE, straight to where they are needed. false if absent / malformed (err) -- only when has_raw_views()
+    struct RawView { const void *samples = nullptr; uint64_t n = 0; double digitisation = 0, offset = 0, range = 0; };
+    bool has_raw_views() const { return binary_ && rec_press_ == 0 && sig_press_ == 0; }
+    bool raw_view(const std::string &read_id, RawView &v, std::string &err) const;
     size_t n_reads() const { return index_.size(); }
     bool is_binary() const { return binary_; }
     const std::vector<std::string> &ids_in_file_order() const { return order_; }

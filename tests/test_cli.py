@@ -255,6 +255,14 @@ def test_malformed_line_behind_the_completing_read(tmp_path):
     sl = [x if x != "64" else "10" for x in whole]                  # --file_limit 10: a slice, the loop never ends early
     assert cli(sl + [tmp_path / "gpu2"]).returncode == 1
     assert oracle_cli(sl + [tmp_path / "cpu2"]).returncode != 0
+    # the same from an uncompressed BLOW5: the samples are placed straight into the batch, run by run, and a run that ends at a bad
+    # line leaves its later samples behind the kept prefix
+    synth.write_blow5(b, pre + ".blow5", compress=False)
+    wb = [pre + ".blow5"] + whole[1:]
+    for name, br in (("gpu3", "64"), ("gpu4", "1000"), ("gpu5", "7")):
+        r = cli(wb + [tmp_path / name, "--batch_reads", br]); assert r.returncode == 0, r.stderr
+        assert_same_dirs(tmp_path / name, tmp_path / "cpu")
+    assert cli([pre + ".blow5"] + sl[1:] + [tmp_path / "gpu6"]).returncode == 1
 
 
 @pytest.mark.gpu
