@@ -209,10 +209,21 @@ def main():
             break
         except Exception:
             pass
+    # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison -- the
+    # HIP-event pair used here adds its own 3-5 us to every launch it brackets, so `achieved` is the conservative figure of the two
+    trace_ms = None
+    try:
+        import csv
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))):
+            if row["Name"].startswith("k_read_stats(") and args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
+                trace_ms = float(row["AverageNs"]) * 1e-6
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
         "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
+        "committed_trace_avg_launch_ms": trace_ms, "committed_trace_frac": (stats_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if trace_ms else None,
     }
     kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
     # the COMPLETE step against the roofline: SURVEY 8(d)'s B_alg = every input byte once, every output byte once
