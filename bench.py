@@ -209,8 +209,9 @@ def main():
             break
         except Exception:
             pass
-    # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison -- the
-    # HIP-event pair used here adds its own 3-5 us to every launch it brackets, so `achieved` is the conservative figure of the two
+    # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison. The
+    # library's profile mode attaches the event pair to the dispatch itself (hipExtLaunchKernelGGL: the dispatch's own start / end time
+    # stamps, which is what the trace reads), so the two agree; kernels_sum_ms is below ms_per_step by the gaps between dispatches
     trace_ms = None
     try:
         import csv

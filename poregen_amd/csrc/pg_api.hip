@@ -56,7 +56,7 @@ struct HostBatchResult { // one collected batch, downloaded
     std::vector<uint8_t> skipped;
 };
 
-struct ProfEntry { const char *name; hipEvent_t a, b; };
+struct ProfEntry { const char *name; hipEvent_t a, b; bool bracket; };
 
 } // namespace
 
@@ -156,17 +156,24 @@ static const char *read_status_text(int code) {
 
 // ------------------------------------------------------------------------------------------------------
 // profiling helpers
-static void prof_begin(pg_ctx *c, const char *name, hipStream_t st) {
+// bracket: two recorded events around whatever is queued in between (several launches, launches that do not go through PG_LAUNCH);
+// otherwise the next kernel launch carries the pair itself
+static void prof_begin(pg_ctx *c, const char *name, hipStream_t st, bool bracket = false) {
     if (!(c->prm.flags & PG_FLAG_PROFILE)) return;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!c->prof_pool.empty()) { ev = c->prof_pool.back(); c->prof_pool.pop_back(); }
     else { (void)hipEventCreate(&ev.first); (void)hipEventCreate(&ev.second); }
-    (void)hipEventRecord(ev.first, st);
-    c->prof.push_back({name, ev.first, ev.second});
+    if (bracket) (void)hipEventRecord(ev.first, st);
+    else { pg_prof_start = ev.first; pg_prof_stop = ev.second; } // carried by the next kernel launch (PG_LAUNCH)
+    c->prof.push_back({name, ev.first, ev.second, bracket});
 }
 static void prof_end(pg_ctx *c, hipStream_t st) {
     if (!(c->prm.flags & PG_FLAG_PROFILE)) return;
-    (void)hipEventRecord(c->prof.back().b, st);
+    if (c->prof.back().bracket) { (void)hipEventRecord(c->prof.back().b, st); return; }
+    if (pg_prof_start) { // nothing was launched in between: an empty interval
+        (void)hipEventRecord(c->prof.back().a, st); (void)hipEventRecord(c->prof.back().b, st);
+        pg_prof_start = nullptr; pg_prof_stop = nullptr;
+    }
 }
 static void prof_drain(pg_ctx *c) { // requires the streams to be idle
     for (auto &p : c->prof) {
@@ -502,7 +509,7 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] / [2] lengths of the wide / huge list
     if (!plan_done) {
-        prof_begin(c, "k_read_plan", st);
+        prof_begin(c, "k_read_plan", st, true);
         HIP_TRY(c, pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset));
         prof_end(c, st);
     }
@@ -644,10 +651,12 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     const bool force_generic = (c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) != 0;
+    prof_begin(c, "k_batch_init", c->st);
     HIP_TRY(c, pg_launch_batch_init(c->st, n, c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
                          c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>(), c->B, c->prm.pa_min, c->prm.pa_max,
                          c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr,
                          W, O, force_generic ? 1 : 0));
+    prof_end(c, c->st);
     c->stat_flags_reset = !overlap;
     c->zero_running = false;
 
@@ -677,11 +686,11 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
                                     c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done));
         prof_end(c, c->st);
     } else {
-        prof_begin(c, "sort_events", c->st);
+        prof_begin(c, "sort_events", c->st, true);
         if (N) HIP_TRY(c, pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S, &c->sorted_idx));
         else { c->sorted_idx = 0; HIP_TRY(c, hipMemsetAsync(c->scount.p, 0, 8, c->st)); }
         prof_end(c, c->st);
-        prof_begin(c, "slot_bounds", c->st);
+        prof_begin(c, "slot_bounds", c->st, true);
         HIP_TRY(c, pg_launch_slot_bounds(c->st, S.keys[c->sorted_idx], S.count, N, c->slot_start.as<uint32_t>(), c->slot_end.as<uint32_t>(),
                               c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy));
         prof_end(c, c->st);
@@ -773,7 +782,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     const bool plan_in_scan = c->plan_done && !all_counts && !base;
     c->plan_done = false;
     if (!plan_in_scan) {
-    prof_begin(c, "k_slot_plan", c->st);
+    prof_begin(c, "k_slot_plan", c->st, true);
     HIP_TRY(c, pg_launch_slot_plan(c->st, c->acc_cnt.as<uint64_t>(), d_base, c->running.as<uint64_t>(), c->prm.sample_limit, ns,
                         c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, direct ? c->hist.as<uint32_t>() : nullptr,
                         pg_tiles(N ? N : 1, true), direct ? nullptr : c->keep32.as<uint32_t>(), c->scan_scratch.as<uint64_t>(),
@@ -810,7 +819,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>(), false, false, true); if (s2 != PG_OK) return s2; }
 
     uint64_t gather_cap = ke_cap;
-    prof_begin(c, "scan_ev_len", c->st);
+    prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
     HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
                                       c->rare_pending ? &c->rare : nullptr, totals + 2));
     c->rare_pending = false;
@@ -1023,7 +1032,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
 static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[3], const uint64_t *d_ev_off, const uint64_t *d_samp_off,
                            const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out) {
     HIP_TRY(c, c->md_out.ensure((ns + 1) * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure((ns + 1) * sizeof(PgSlotDwell)));
-    prof_begin(c, "k_slot_model", c->st);
+    prof_begin(c, "k_slot_model", c->st, true);
     HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_kind, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
                                     c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
     prof_end(c, c->st);

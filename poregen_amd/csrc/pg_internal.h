@@ -151,6 +151,8 @@ struct PgKeptOut {
     uint64_t *ev_src;     // [n_kept] window start as a sample index of the BATCH (sig_off[read] + start inside the read)
     uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
 };
+// profiling (PG_FLAG_PROFILE): the pair of events the NEXT kernel launch of this host thread carries (pg_kernels.hip: PG_LAUNCH); null = none
+extern thread_local hipEvent_t pg_prof_start, pg_prof_stop;
 // resets the per-batch flags of the main chain in one launch: err words, read_needed[n], and (if zero_running) the
 // context's running per-slot counts
 // stat_flags (may be null): the statistics flags of this batch (see pg_launch_read_plan), reset here to save a launch

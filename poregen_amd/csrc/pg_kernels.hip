@@ -14,6 +14,7 @@
 //   k_gather        window copy + normalisation of the kept events (lines 773-775, 928-944)
 // All of this is HBM/LDS-bound integer and FP64 work: there is no contraction here, so no MFMA.
 #include "pg_internal.h"
+#include <hip/hip_ext.h>
 #include "pg_select.h"
 #include <limits.h>
 #include <type_traits>
@@ -2353,7 +2354,14 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *_
 // a sticky earlier error) must fail the batch instead of leaving the previous batch's results in the buffers
 // =====================================================================================================
 // (hipGetLastError is per host thread and sticky: an unrelated earlier failure, e.g. a refused hipSetDevice, is cleared first)
-#define PG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+// PG_FLAG_PROFILE: the first launch behind prof_begin carries the pair of events ITSELF (hipExtLaunchKernelGGL: the dispatch's own
+// start / end time stamps, what rocprofv3's kernel trace reads) instead of standing between two recorded events, whose own cost
+// (3-5 us per pair) used to be counted into the kernel
+thread_local hipEvent_t pg_prof_start = nullptr, pg_prof_stop = nullptr;
+#define PG_LAUNCH(kernel, grid, block, shmem, stream, ...) do { (void)hipGetLastError(); \
+    if (pg_prof_start) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pg_prof_start, pg_prof_stop, 0, __VA_ARGS__); pg_prof_start = nullptr; pg_prof_stop = nullptr; } \
+    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
+    const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 #define PG_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
