@@ -2090,6 +2090,9 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 // streams at 5.9 TB/s whether the waves are launched per read or kept persistent with a rolling register prefetch of the
 // next read; the persistent form only added bookkeeping and registers (fewer resident waves), so the hardware
 // dispatcher does the load balancing and the overlap comes from eight resident waves per SIMD.
+#ifndef PG_STATS_NT_LOADS
+#define PG_STATS_NT_LOADS 1
+#endif
 #ifndef PG_STATS_WPB
 #define PG_STATS_WPB 1 // reads (= independent waves, no barrier between them) per workgroup
 #endif
@@ -2130,7 +2133,17 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
             const uint32_t last = n_vec - p > 8 * WAVE ? 8 * WAVE - 1 : (uint32_t)(n_vec - p) - 1;
             int4 q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
+            for (int u = 0; u < 8; ++u) {
+#if PG_STATS_NT_LOADS
+                // streaming ("nt") loads: the 400 MB of signal are read once; left to the default policy they push everything the small
+                // kernels around this one work on (ops, slots, records: ~100 MB) out of the L2s and the 256 MB Infinity Cache
+                typedef int pg_i4 __attribute__((ext_vector_type(4)));
+                const pg_i4 x = __builtin_nontemporal_load(reinterpret_cast<const pg_i4 *>(vp) + min((uint32_t)(u * WAVE + lane), last));
+                q[u] = make_int4(x.x, x.y, x.z, x.w);
+#else
+                q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
+#endif
+            }
             if (p == 0) stats_zero<1024>(hist, lane); // behind the first pass's loads: the histogram is cleared while they are in flight
             PG_MARK(0, 1); // the samples have arrived
 #ifdef PG_PROBE_NO_BIN // timing probe only: the samples are consumed, nothing is binned (results are garbage)
