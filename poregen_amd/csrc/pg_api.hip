@@ -509,7 +509,7 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] / [2] lengths of the wide / huge list
     if (!plan_done) {
-        prof_begin(c, "k_read_plan", st, true);
+        prof_begin(c, "k_read_plan", st);
         HIP_TRY(c, pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset));
         prof_end(c, st);
     }

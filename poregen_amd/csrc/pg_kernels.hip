@@ -1643,8 +1643,9 @@ __device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, c
 }
 
 __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
-                                                   PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status) {
+                                                   PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status, int32_t *__restrict__ reset_flags) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0 && reset_flags) { reset_flags[0] = INT_MAX; reset_flags[1] = 0; reset_flags[2] = 0; } // as k_stat_flags_init: the lists are k_read_stats' (a later launch)
     if (r < B.n_reads) read_plan_one(B, r, needed, pa_min, pa_max, rec, stat_status);
 }
 
@@ -2540,10 +2541,12 @@ hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
 
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
-    if (!flags_are_reset) PG_LAUNCH(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
-    if (B.n_reads == 0) return hipSuccess;
+    if (B.n_reads == 0) { // no record pass: the reset alone
+        if (!flags_are_reset) PG_LAUNCH(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
+        return hipSuccess;
+    }
     PG_LAUNCH(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
-                       reinterpret_cast<PgStatRec *>(plan_buf), stat_status);
+                       reinterpret_cast<PgStatRec *>(plan_buf), stat_status, flags_are_reset ? (int32_t *)nullptr : flags);
     return hipSuccess;
 }
 
