@@ -2094,6 +2094,9 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 #ifndef PG_STATS_NT_LOADS
 #define PG_STATS_NT_LOADS 1
 #endif
+#ifndef PG_STATS_CACHED_FRACTION
+#define PG_STATS_CACHED_FRACTION 8 // reads [0, n_reads / this) keep the default cache policy
+#endif
 #ifndef PG_STATS_WPB
 #define PG_STATS_WPB 1 // reads (= independent waves, no barrier between them) per workgroup
 #endif
@@ -2103,7 +2106,7 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_eu(PG_STATS_WAVES_PER_EU, PG_STATS_WAVES_PER_EU))) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
                                                    int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
-                                                   int32_t *__restrict__ wide_count) {
+                                                   int32_t *__restrict__ wide_count, uint32_t keep_cached) {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[PG_STATS_WPB][StatsGeom<1024>::LDS_WORDS];
 #if PG_STATS_WPB == 1
     uint32_t *hist = hist_all[0];
@@ -2133,17 +2136,23 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
             const int4 *__restrict__ vp = reinterpret_cast<const int4 *>(sig) + (va + p); // uniform base, 32-bit lane offsets
             const uint32_t last = n_vec - p > 8 * WAVE ? 8 * WAVE - 1 : (uint32_t)(n_vec - p) - 1;
             int4 q[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
 #if PG_STATS_NT_LOADS
-                // streaming ("nt") loads: the 400 MB of signal are read once; left to the default policy they push everything the small
-                // kernels around this one work on (ops, slots, records: ~100 MB) out of the L2s and the 256 MB Infinity Cache
+            // streaming ("nt") loads: the 400 MB of signal are read once; left to the default policy they push everything the small
+            // kernels around this one work on (ops, slots, records: ~100 MB) out of the L2s and the 256 MB Infinity Cache. The
+            // batch's FIRST reads are the exception (r < keep_cached, an eighth of the batch: the kept events -- the first
+            // sample_limit per k-mer in read order -- come from the front of a batch, and k_gather fetches their windows next)
+            if (r >= keep_cached) {
                 typedef int pg_i4 __attribute__((ext_vector_type(4)));
-                const pg_i4 x = __builtin_nontemporal_load(reinterpret_cast<const pg_i4 *>(vp) + min((uint32_t)(u * WAVE + lane), last));
-                q[u] = make_int4(x.x, x.y, x.z, x.w);
-#else
-                q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const pg_i4 x = __builtin_nontemporal_load(reinterpret_cast<const pg_i4 *>(vp) + min((uint32_t)(u * WAVE + lane), last));
+                    q[u] = make_int4(x.x, x.y, x.z, x.w);
+                }
+            } else
 #endif
+            {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = vp[min((uint32_t)(u * WAVE + lane), last)];
             }
             if (p == 0) stats_zero<1024>(hist, lane); // behind the first pass's loads: the histogram is cleared while they are in flight
             PG_MARK(0, 1); // the samples have arrived
@@ -2554,7 +2563,8 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
                                 uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only) {
     if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
-    PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count);
+    PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count,
+              B.n_reads / PG_STATS_CACHED_FRACTION);
     return hipSuccess;
 }
 
