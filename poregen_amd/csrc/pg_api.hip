@@ -808,9 +808,10 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         HIP_TRY(c, pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K));
         prof_end(c, c->st);
     } else {
-        prof_begin(c, "k_kept_meta", c->st);
+        prof_begin(c, "k_kept_meta", c->st, true);
         HIP_TRY(c, pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
-                            c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K));
+                            c->slot_start.as<uint32_t>(), c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), c->B, W, O, K,
+                            c->sv[c->sorted_idx ^ 1].as<uint32_t>()));
         prof_end(c, c->st);
     }
 

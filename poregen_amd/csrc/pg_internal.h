@@ -195,9 +195,10 @@ hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, u
 hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t key_bits, const PgSortBufs &S, int *sorted_idx);
 hipError_t pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uint32_t *m_ptr, uint64_t n_upper,
                            uint32_t *slot_start, uint32_t *slot_end, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy);
+// dst_scratch: uint32[n_ops] work space (the radix sort's spare value buffer)
 hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint32_t *sval, const uint32_t *m_ptr, uint64_t n_upper,
                          const uint32_t *slot_start, const uint64_t *keep, const uint64_t *ev_off,
-                         const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);
+                         const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K, uint32_t *dst_scratch);
 // keep[s] = min(cnt[s], max(0, limit - base[s])); ev_off = exclusive scan of keep ([n_slots+1]);
 // totals[0] = kept events, totals[1] = slots that are full after this batch; running[s] = base[s] + cnt[s]
 // hist/n_tiles (direct mode, else nullptr): also computes totals[3] = last tile that can still place an event
