@@ -80,7 +80,7 @@ struct pg_ctx {
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage, tile_last;
     DevBuf ev_len, ev_read, ev_src, read_needed, samp_off, scan_scratch, samples;
-    DevBuf med[2], mad[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
+    DevBuf med[2], mad[2], gcal[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf meta, huge_scratch, oor;
     DevBuf blk_read, gen_flag, gen_list, cum, btot, tile_read; // PgWalkOut: owner index, generic-read list, block sums of op_n
@@ -240,7 +240,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_src, &c->read_needed,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
@@ -489,6 +489,7 @@ static pg_status ensure_stats_buffers(pg_ctx *c) {
     const int sl = c->slot;
     if (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) HIP_TRY(c, c->oor.ensure(n + 1ull));
     HIP_TRY(c, c->med[sl].ensure((n + 1) * 8ull)); HIP_TRY(c, c->mad[sl].ensure((n + 1) * 8ull));
+    HIP_TRY(c, c->gcal[sl].ensure((n + 1) * 32ull));
     HIP_TRY(c, c->read_plan[sl].ensure((n + 1) * (size_t)PG_STAT_REC_BYTES)); HIP_TRY(c, c->wide_list[sl].ensure((n + 1) * 4ull));
     HIP_TRY(c, c->stat_status[sl].ensure((n + 2) * 4ull)); HIP_TRY(c, c->huge_scratch.ensure(PG_HUGE_SCRATCH_WORDS * 4));
     return PG_OK;
@@ -516,12 +517,13 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     HIP_TRY(c, pg_launch_read_stats(st, c->B, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
-                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, oor, range_only));
+                         c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, oor, range_only,
+                         c->gcal[sl].as<double>()));
     prof_end(c, st);
     // the rare reads (in-range interval wider than 1024 codes; usually none): their workers ride in the launch of the sample-offset
     // scan when that comes next on the same stream (rare_pending); otherwise a launch of their own, here
     PgRareArgs &A = c->rare;
-    A.B = c->B; A.plan = c->read_plan[sl].as<PgStatRec>(); A.med = c->med[sl].as<double>(); A.mad = c->mad[sl].as<double>();
+    A.B = c->B; A.plan = c->read_plan[sl].as<PgStatRec>(); A.med = c->med[sl].as<double>(); A.mad = c->mad[sl].as<double>(); A.gcal = c->gcal[sl].as<double>();
     A.status = c->stat_status[sl].as<int32_t>(); A.err = flags; A.win = win; A.wide_list = c->wide_list[sl].as<uint32_t>(); A.wide_count = flags + 1;
     A.scratch = c->huge_scratch.as<uint32_t>(); A.oor = oor; A.range_only = range_only; A.wide_blocks = c->wide_blocks;
     if (rare_with_scan && st == c->st) c->rare_pending = true;
@@ -843,7 +845,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     prof_begin(c, "k_gather", c->st);
     HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_src.as<uint64_t>(),
                      c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
-                     c->samples.as<double>()));
+                     c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr));
     prof_end(c, c->st);
     HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], c->st));
     PG_TMARK("collect: buffers + kernels queued");

@@ -214,7 +214,7 @@ hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const ui
 struct PgRareArgs {
     PgDevBatch B;
     const PgStatRec *plan;
-    double *med, *mad;
+    double *med, *mad, *gcal;
     int32_t *status, *err;
     int win;                   // half-width (<= 15) of the exact candidate window placed by the integer model; 0 forces the fallback search
     const uint32_t *wide_list;
@@ -237,9 +237,10 @@ hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset);
 // the main statistics launch (one wave per read, 1024 LDS bins); reads that need more put themselves on wide_list
+// gcal (may be null): double[4 * n_reads], per read {offset, scale, median, MAD} for k_gather
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
-                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only);
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal);
 // n_kept_ptr: [0] kept events, [2] their samples (the offset scan's total_out)
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
-                      double pa_max, const double *med, const double *mad, double *samples);
+                      double pa_max, const double *med, const double *mad, double *samples, const double *gcal);

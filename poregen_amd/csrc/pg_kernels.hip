@@ -2041,7 +2041,7 @@ __device__ __forceinline__ bool stats_select_sym(const uint32_t *hist, int lane,
 // everything after the histogram is complete: prefix, the out-of-range flag, the selection, the two stores
 template <int BINS>
 __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t r, const PgStatRec &m, double *__restrict__ med,
-                                             double *__restrict__ mad, int win, uint8_t *__restrict__ oor, int range_only PG_PROBE_PARAM) {
+                                             double *__restrict__ mad, double *__restrict__ gcal, int win, uint8_t *__restrict__ oor, int range_only PG_PROBE_PARAM) {
     using Pre = typename StatsCfg<BINS>::Pre;
     const uint64_t L = m.end - m.beg;
     const uint32_t lane_end = stats_prefix<BINS>(hist, lane, (uint32_t)m.span);
@@ -2074,14 +2074,20 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
 #endif
         stats_select<BINS>(hist, lane, pl, L, m.offset, m.scale, win, m0, m1);
     }
-    if (lane == 0) { med[r] = m0; mad[r] = m1; }
+    if (lane == 0) {
+        med[r] = m0; mad[r] = m1;
+        // everything k_gather needs of this read in ONE 32-byte record (offset, scale, median, MAD) instead of five arrays: a kept
+        // event's calibration is then one memory transaction, not five (they are random per event once events are in k-mer order)
+        if (gcal) *reinterpret_cast<double4 *>(gcal + 4ull * r) = make_double4(m.offset, m.scale, m0, m1);
+    }
 }
 
 // a read that gets no statistics: skipped, unusable calibration, or wider than the widest histogram
-__device__ __forceinline__ void stats_no_result(int lane, uint32_t r, int code, double *__restrict__ med, double *__restrict__ mad,
+__device__ __forceinline__ void stats_no_result(int lane, uint32_t r, int code, double *__restrict__ med, double *__restrict__ mad, double *__restrict__ gcal,
                                                 int32_t *__restrict__ status, int32_t *__restrict__ err) {
     if (lane == 0) {
         med[r] = __builtin_nan(""); mad[r] = __builtin_nan("");
+        if (gcal) *reinterpret_cast<double4 *>(gcal + 4ull * r) = make_double4(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
         if (code) { status[r] = code; atomicMin(&err[0], (int)r); }
     }
 }
@@ -2089,13 +2095,13 @@ __device__ __forceinline__ void stats_no_result(int lane, uint32_t r, int code, 
 // One read, start to finish, by one wave (the wide / huge launches: rare reads, no cross-read pipelining).
 template <int BINS>
 __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch &B, uint32_t r, const PgStatRec *__restrict__ rec,
-                                               double *__restrict__ med, double *__restrict__ mad, int32_t *__restrict__ status,
+                                               double *__restrict__ med, double *__restrict__ mad, double *__restrict__ gcal, int32_t *__restrict__ status,
                                                int32_t *__restrict__ err, int win, uint8_t *__restrict__ oor, int range_only) {
     using C = StatsCfg<BINS>;
     const int lane = lane_id();
     const PgStatRec m = rec[r];
     if (m.mode != PG_STAT_RUN) return; // reported by the main launch
-    if (m.span > BINS) { stats_no_result(lane, r, PGR_ERR_WIDE, med, mad, status, err); return; }
+    if (m.span > BINS) { stats_no_result(lane, r, PGR_ERR_WIDE, med, mad, gcal, status, err); return; }
     const uint64_t beg = m.beg, end = m.end;
     stats_zero<BINS>(hist, lane);
     const int c_lo = m.c_lo;
@@ -2129,7 +2135,7 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 #ifdef PG_PHASE_PROBE
     unsigned long long pg_t_ = 0, pg_acc_[8]; // the rare launches are not profiled
 #endif
-    stats_finish<BINS>(hist, lane, r, m, med, mad, win, oor, range_only PG_PROBE_ARG);
+    stats_finish<BINS>(hist, lane, r, m, med, mad, gcal, win, oor, range_only PG_PROBE_ARG);
 }
 
 #ifndef PG_STATS_SETPRIO
@@ -2155,7 +2161,7 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_eu(PG_STATS_WAVES_PER_EU, PG_STATS_WAVES_PER_EU))) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
                                                    int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
-                                                   int32_t *__restrict__ wide_count, uint32_t keep_cached) {
+                                                   int32_t *__restrict__ wide_count, uint32_t keep_cached, double *__restrict__ gcal) {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[PG_STATS_WPB][StatsGeom<1024>::LDS_WORDS];
 #if PG_STATS_WPB == 1
     uint32_t *hist = hist_all[0];
@@ -2169,7 +2175,7 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
     PG_PROBE_BEGIN(0);
     const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
     PG_MARK(0, 0); // the record
-    if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, status, err); return; }
+    if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, gcal, status, err); return; }
     if (m.span > 1024) { if (lane == 0) stats_list_wide(r, m.span, B.n_reads, wide_list, wide_count); return; } // for the wider launch
     const int16_t *__restrict__ sig = B.sig;
     const int c_lo = m.c_lo;
@@ -2225,7 +2231,7 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
         for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
     }
     if (PG_STATS_SETPRIO) __builtin_amdgcn_s_setprio(PG_STATS_SETPRIO); // the selection is a serial chain: let it through in front of the streaming waves
-    stats_finish<1024>(hist, lane, r, m, med, mad, win, oor, range_only PG_PROBE_ARG);
+    stats_finish<1024>(hist, lane, r, m, med, mad, gcal, win, oor, range_only PG_PROBE_ARG);
     PG_MARK(0, 4); // selection + stores (slot 3: the prefix scan, marked inside stats_finish)
     PG_PROBE_END(0, r);
 }
@@ -2241,7 +2247,7 @@ __device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, ui
     if (worker < n_wide) {
         const uint32_t n_list = (uint32_t)A.wide_count[0];
         for (uint32_t it = worker; it < n_list; it += n_wide) {
-            stats_one_read<PG_STATS_BINS>(hist, A.B, A.wide_list[it], A.plan, A.med, A.mad, A.status, A.err, A.win, A.oor, A.range_only);
+            stats_one_read<PG_STATS_BINS>(hist, A.B, A.wide_list[it], A.plan, A.med, A.mad, A.gcal, A.status, A.err, A.win, A.oor, A.range_only);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier(); // the LDS histogram is reused for the next read
         }
@@ -2249,7 +2255,7 @@ __device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, ui
         const uint32_t hb = worker - n_wide, n_list = (uint32_t)A.wide_count[1];
         uint32_t *gh = A.scratch + (size_t)hb * PG_HUGE_WORDS;
         for (uint32_t it = hb; it < n_list; it += PG_HUGE_BLOCKS) {
-            stats_one_read<PG_HUGE_BINS>(gh, A.B, A.wide_list[A.B.n_reads - 1 - it], A.plan, A.med, A.mad, A.status, A.err, A.win, A.oor, A.range_only);
+            stats_one_read<PG_HUGE_BINS>(gh, A.B, A.wide_list[A.B.n_reads - 1 - it], A.plan, A.med, A.mad, A.gcal, A.status, A.err, A.win, A.oor, A.range_only);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
         }
@@ -2279,11 +2285,15 @@ __global__ __launch_bounds__(64) void k_read_stats_rare(PgRareArgs A) {
 struct GatherRegs { uint64_t h; uint2 q[PG_GATHER_PASSES]; };
 template <int G>
 __device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, uint32_t rd, uint32_t len, uint64_t src, uint64_t total, int scaling,
-                                            const double *__restrict__ med, const double *__restrict__ mad, GatherRegs &R) {
+                                            const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, GatherRegs &R) {
     const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
-    const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
-                          : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
-    R.h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
+    if (gcal) { // offset, scale, median, MAD of the read as one 32-byte record (written by the statistics kernels): four lanes, one transaction
+        R.h = sub < 4u ? reinterpret_cast<const uint64_t *>(gcal)[4ull * rd + sub] : 0ull;
+    } else {
+        const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
+                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
+        R.h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
+    }
     const uint32_t odd = (uint32_t)(src & 1u);
     const uint64_t d0 = src >> 1; // dword that holds sample src
 #pragma unroll
@@ -2302,7 +2312,7 @@ __device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, u
 }
 template <int G>
 __device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub, int g0, uint32_t len, uint64_t src, uint64_t dst, uint64_t total,
-                                              int scaling, double pa_min, double pa_max, double *__restrict__ samples, const GatherRegs &R) {
+                                              int scaling, double pa_min, double pa_max, double *__restrict__ samples, const GatherRegs &R, bool gcal) {
     const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
     auto from = [&](uint64_t v, int k) { // the 64-bit value held by lane g0+k
         return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
@@ -2310,9 +2320,10 @@ __device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub,
     const uint32_t odd = (uint32_t)(src & 1u);
     const uint64_t d0 = src >> 1;
     const double offset = __longlong_as_double((long long)from(R.h, 0));
-    const double scale = __longlong_as_double((long long)from(R.h, 1)) / __longlong_as_double((long long)from(R.h, 2));
-    const double md = scaling ? __longlong_as_double((long long)from(R.h, 3)) : 0.0;
-    const double ma = scaling ? __longlong_as_double((long long)from(R.h, 4)) : 1.0;
+    // gcal: the record holds range / digitisation as the statistics used it (the same expression, PgStatRec::scale)
+    const double scale = gcal ? __longlong_as_double((long long)from(R.h, 1)) : __longlong_as_double((long long)from(R.h, 1)) / __longlong_as_double((long long)from(R.h, 2));
+    const double md = scaling ? __longlong_as_double((long long)from(R.h, gcal ? 2 : 3)) : 0.0;
+    const double ma = scaling ? __longlong_as_double((long long)from(R.h, gcal ? 3 : 4)) : 1.0;
     auto conv = [&](int raw) {
         const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
         double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
@@ -2344,17 +2355,17 @@ __device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub,
 template <int G>
 __device__ __forceinline__ void gather_one(const PgDevBatch &B, uint32_t sub, int g0, uint32_t rd, uint32_t len, uint64_t src, uint64_t dst,
                                            uint64_t total, int scaling, double pa_min, double pa_max,
-                                           const double *__restrict__ med, const double *__restrict__ mad, double *__restrict__ samples) {
+                                           const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, double *__restrict__ samples) {
     GatherRegs R;
-    gather_load<G>(B, sub, rd, len, src, total, scaling, med, mad, R);
-    gather_finish<G>(B, sub, g0, len, src, dst, total, scaling, pa_min, pa_max, samples, R);
+    gather_load<G>(B, sub, rd, len, src, total, scaling, med, mad, gcal, R);
+    gather_finish<G>(B, sub, g0, len, src, dst, total, scaling, pa_min, pa_max, samples, R, gcal != nullptr);
 }
 
 template <int G>
 __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const uint32_t *__restrict__ ev_len,
                                               const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
                                               const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
-                                              const double *__restrict__ med, const double *__restrict__ mad, double *__restrict__ samples) {
+                                              const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, double *__restrict__ samples) {
     const int lane = lane_id();
     const int g0 = lane & ~(G - 1);
     const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
@@ -2371,7 +2382,7 @@ __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_ke
         const uint32_t rd = (uint32_t)__shfl((int)f, g0, WAVE), len = (uint32_t)__shfl((int)f, g0 + 1, WAVE);
         const uint64_t src = pair64(f, 2), dst = pair64(f, 4);
         // round 2, all in flight together: the read's calibration and statistics by five lanes, the window's samples by every lane
-        gather_one<G>(B, sub, g0, rd, len, src, dst, total, scaling, pa_min, pa_max, med, mad, samples);
+        gather_one<G>(B, sub, g0, rd, len, src, dst, total, scaling, pa_min, pa_max, med, mad, gcal, samples);
     }
 }
 
@@ -2379,14 +2390,14 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
                                                 const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
-                                                double *__restrict__ samples) {
+                                                double *__restrict__ samples, const double *__restrict__ gcal) {
     const uint64_t n_kept = n_kept_ptr[0], n_samples = n_kept_ptr[2]; // [2]: the offset scan's total (= samp_off[n_kept]), one round trip earlier
     if (n_kept == 0) return;
     const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
     // mean kept window (from the scan's total): 8 lanes per event (16 samples per pass) up to a mean of PG_GATHER8_MEAN samples --
     // half the waves of the 16-lane form; two passes over a 28-sample window still win (A/B on one box: 20.7 -> 19.5 us)
-    if (n_samples <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
-    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, samples);
+    if (n_samples <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
+    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
 }
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *__restrict__ read_needed,
@@ -2609,21 +2620,21 @@ hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_
 }
 
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
-                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only) {
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal) {
     if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
     PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count,
-              B.n_reads / PG_STATS_CACHED_FRACTION);
+              B.n_reads / PG_STATS_CACHED_FRACTION, gcal);
     return hipSuccess;
 }
 
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
-                      double pa_max, const double *med, const double *mad, double *samples) {
+                      double pa_max, const double *med, const double *mad, double *samples, const double *gcal) {
     if (n_kept_cap == 0) return hipSuccess;
     uint64_t blocks = (n_kept_cap + 15) / 16;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
     PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_src, samp_off, scaling,
-                       pa_min, pa_max, med, mad, samples);
+                       pa_min, pa_max, med, mad, samples, gcal);
     return hipSuccess;
 }

@@ -261,7 +261,7 @@ int main(int argc, char **argv) {
         static_assert(sizeof(PgStatRec) == sizeof(Rec), "same record");
         for (int ro : {1, 0}) {
             char nm[96]; snprintf(nm, sizeof nm, "k_read_stats (product kernel), range_only=%d", ro);
-            time(nm, [&] { hipLaunchKernelGGL(k_read_stats, dim3((unsigned)n_chunks), dim3(64), 0, 0, PB, (const PgStatRec *)rec, medb, madb, stb, stb + n_chunks, 15, (uint8_t *)nullptr, ro, (uint32_t *)nullptr, stb + n_chunks + 4, 0u); });
+            time(nm, [&] { hipLaunchKernelGGL(k_read_stats, dim3((unsigned)n_chunks), dim3(64), 0, 0, PB, (const PgStatRec *)rec, medb, madb, stb, stb + n_chunks, 15, (uint8_t *)nullptr, ro, (uint32_t *)nullptr, stb + n_chunks + 4, 0u, (double *)nullptr); });
         }
         { // ... and timed the way bench.py times it: ONE launch between two events, another kernel in front
             float tot = 0; const int reps = 10;
