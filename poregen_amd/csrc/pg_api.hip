@@ -54,6 +54,9 @@ struct HostBatchResult { // one collected batch, downloaded
     std::vector<uint32_t> ev_len, ev_read;
     SampleVec samples;
     std::vector<uint8_t> skipped;
+    // more batches follow (or came before): the samples stay on the device, in a buffer of their own, until pg_finish merges the
+    // batches there and downloads the result ONCE -- no per-batch download in front of the next submit, no second copy on the host
+    DevBuf dsamples; bool on_device = false;
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; bool bracket; };
@@ -114,6 +117,7 @@ struct pg_ctx {
     std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
     std::vector<uint32_t> r_ev_len, r_ev_read;
     SampleVec r_samples;
+    DevBuf dmerged, dseg; // pg_finish over device-held batches: merged samples, segment descriptors
     std::vector<uint8_t> r_skipped;
     // pg_model
     std::vector<PgSlotModel> mo_raw;
@@ -239,12 +243,13 @@ void pg_destroy(pg_ctx *c) {
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->ev_len, &c->ev_read, &c->ev_src, &c->read_needed,
+                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->dmerged, &c->dseg, &c->ev_len, &c->ev_read, &c->ev_src, &c->read_needed,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
     for (DevBuf *b : bufs) b->release();
+    for (auto &hb : c->batches) hb.dsamples.release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &p : c->prof_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (int i = 0; i < 2; i++) { if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); if (c->ev_gathered[i]) (void)hipEventDestroy(c->ev_gathered[i]); }
@@ -360,6 +365,7 @@ pg_status pg_reset(pg_ctx *c) {
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
     c->zero_running = true;
+    for (auto &hb : c->batches) hb.dsamples.release();
     c->batches.clear(); c->single_moved = false; c->have_job_totals = false; c->merged_valid = false;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->full_before_batch = false; c->cur_n_kept = c->cur_n_samples = 0;
@@ -370,7 +376,8 @@ static pg_status settle_batch(pg_ctx *c);
 static pg_status check_read_errors(pg_ctx *c);
 
 // copy the finished batch's device results to the host (needed before its buffers are reused)
-static pg_status download_last(pg_ctx *c) {
+// more_coming: called in front of the next batch (pg_count); false: from pg_finish
+static pg_status download_last(pg_ctx *c, bool more_coming) {
     if (!c->have_batch_result || c->downloaded) return PG_OK;
     { pg_status s0 = settle_batch(c); if (s0 != PG_OK) return s0; }
     c->batches.emplace_back();
@@ -387,7 +394,15 @@ static pg_status download_last(pg_ctx *c) {
         HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
     } else h.samp_off[0] = 0;
-    if (h.n_samples) {
+    // one of several batches with a sizeable result: its samples stay on the device (see HostBatchResult)
+    if (h.n_samples * 8ull >= (8ull << 20) && (more_coming || c->batches.size() > 1) && !getenv("PGMOVE_HOST_MERGE")) {
+        if (h.dsamples.ensure(h.n_samples * 8ull) == hipSuccess &&
+            hipMemcpyAsync(h.dsamples.p, c->samples.p, h.n_samples * 8ull, hipMemcpyDeviceToDevice, c->st) == hipSuccess) {
+            h.on_device = true;
+            h.samples.clear(); h.samples.shrink_to_fit();
+        } else { (void)hipGetLastError(); h.dsamples.release(); h.samples.resize(h.n_samples); } // no room: through the host
+    }
+    if (h.n_samples && !h.on_device) {
         // pageable destination: the runtime stages the copy through pinned bounce buffers with one host thread per call;
         // several calls on slices run side by side (first touch of the fresh pages included)
         const uint64_t bytes = h.n_samples * 8ull;
@@ -562,7 +577,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     if (!c || !b) return PG_ERR_INVALID_ARG;
     if (b->struct_size != sizeof(pg_batch)) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch");
     HIP_TRY(c, hipSetDevice(c->device));
-    pg_status s = download_last(c);
+    pg_status s = download_last(c, true);
     if (s != PG_OK) return s;
     if (c->have_batch_result) { c->reads_before += c->B.n_reads; c->have_batch_result = false; }
     c->have_count = false; c->rare_pending = false; c->plan_done = false;
@@ -941,7 +956,7 @@ pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
 pg_status pg_finish(pg_ctx *c, pg_result *out) {
     if (!c || !out) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    pg_status s = download_last(c);
+    pg_status s = download_last(c, false);
     if (s != PG_OK) return s;
     const uint32_t ns = c->prm.n_slots;
     if (c->merged_valid) { // nothing was collected since the last call: the merged view is current
@@ -985,6 +1000,16 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         slot_e[sl + 1] = slot_e[sl] + ne; slot_s[sl + 1] = slot_s[sl] + nsmp;
         c->r_counts[sl] = ne; c->r_ev_off[sl] = slot_e[sl];
     }
+    // the samples: merged on the device when every batch's are still there (the usual case: download_last), else on the host
+    bool all_dev = true;
+    for (auto &h : c->batches) if (h.n_samples && !h.on_device) all_dev = false;
+    if (!all_dev)
+        for (auto &h : c->batches)
+            if (h.on_device) { // mixed (a pg_finish between batches, or a batch that found no room): this one through the host after all
+                h.samples.resize(h.n_samples);
+                HIP_TRY(c, hipMemcpy(h.samples.data(), h.dsamples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
+                h.dsamples.release(); h.on_device = false;
+            }
     // pass 2: the copies (hundreds of MB at large limits), slot ranges side by side on a few threads
     auto merge_slots = [&](uint32_t s0, uint32_t s1) {
         for (uint32_t sl = s0; sl < s1; sl++) {
@@ -993,7 +1018,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
                 const uint64_t a = h.ev_off[sl], b = h.ev_off[sl + 1];
                 if (b > a) {
                     const uint64_t s_a = h.samp_off[a], s_b = h.samp_off[b];
-                    memcpy(&c->r_samples[sp], &h.samples[s_a], (s_b - s_a) * sizeof(double)); // a slot's events of one batch are contiguous
+                    if (!all_dev) memcpy(&c->r_samples[sp], &h.samples[s_a], (s_b - s_a) * sizeof(double)); // a slot's events of one batch are contiguous
                     for (uint64_t i = a; i < b; i++, e++) {
                         c->r_ev_len[e] = h.ev_len[i]; c->r_ev_read[e] = (uint32_t)(rbase + h.ev_read[i]); c->r_samp_off[e] = sp + (h.samp_off[i] - s_a);
                     }
@@ -1018,6 +1043,40 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
             }
             for (auto &th : pool) th.join();
         }
+    }
+    if (all_dev && n_samples) {
+        std::vector<PgSeg> segs;
+        segs.reserve((size_t)ns * c->batches.size());
+        for (uint32_t sl = 0; sl < ns; sl++) {
+            uint64_t sp2 = slot_s[sl];
+            for (auto &h : c->batches) {
+                const uint64_t a2 = h.ev_off[sl], b2 = h.ev_off[sl + 1];
+                if (b2 > a2) {
+                    const uint64_t s_a = h.samp_off[a2], s_b = h.samp_off[b2];
+                    if (s_b > s_a) segs.push_back(PgSeg{h.dsamples.as<double>() + s_a, sp2, s_b - s_a});
+                    sp2 += s_b - s_a;
+                }
+            }
+        }
+        HIP_TRY(c, c->dseg.ensure(segs.size() * sizeof(PgSeg) + 16)); HIP_TRY(c, c->dmerged.ensure(n_samples * 8ull));
+        HIP_TRY(c, hipMemcpyAsync(c->dseg.p, segs.data(), segs.size() * sizeof(PgSeg), hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, pg_launch_merge_segments(c->st, c->dseg.as<PgSeg>(), (uint32_t)segs.size(), c->dmerged.as<double>()));
+        HIP_TRY(c, hipStreamSynchronize(c->st));
+        // one download of the merged samples, slices side by side (pageable destination, first touch included)
+        const uint64_t bytes = n_samples * 8ull;
+        const unsigned parts = bytes >= (64ull << 20) ? 8u : 1u;
+        std::vector<hipError_t> rc(parts, hipSuccess);
+        std::vector<std::thread> pool;
+        const uint64_t step = ((n_samples + parts - 1) / parts + 511) & ~511ull;
+        for (unsigned t = 0; t < parts; t++)
+            pool.emplace_back([&, t]() {
+                const uint64_t a2 = std::min<uint64_t>(n_samples, t * step), b2 = std::min<uint64_t>(n_samples, a2 + step);
+                if (b2 <= a2) return;
+                rc[t] = hipSetDevice(c->device);
+                if (rc[t] == hipSuccess) rc[t] = hipMemcpy(c->r_samples.data() + a2, c->dmerged.as<double>() + a2, (b2 - a2) * 8ull, hipMemcpyDeviceToHost);
+            });
+        for (auto &th : pool) th.join();
+        for (hipError_t e2 : rc) HIP_TRY(c, e2);
     }
     const uint64_t e = slot_e[ns], sp = slot_s[ns];
     c->r_ev_off[ns] = e; c->r_samp_off[n_events] = sp;

@@ -240,6 +240,10 @@ hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_
 // gcal (may be null): double[4 * n_reads], per read {offset, scale, median, MAD} for k_gather
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
                                 uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal);
+// pg_finish over several batches: a batch's kept samples stay on the device until then; (k-mer, batch) segments are copied into the
+// job's k-mer-major order by one launch and leave the device once
+struct PgSeg { const double *src; uint64_t dst_off, n; };
+hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst);
 // n_kept_ptr: [0] kept events, [2] their samples (the offset scan's total_out)
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,

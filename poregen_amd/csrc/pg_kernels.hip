@@ -2628,6 +2628,19 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
     return hipSuccess;
 }
 
+// several batches' kept samples into the k-mer-major order of the whole job, on the device: one workgroup per (k-mer, batch) segment
+__global__ __launch_bounds__(256) void k_merge_segments(const PgSeg *__restrict__ seg, double *__restrict__ dst) {
+    const PgSeg sg = seg[blockIdx.x];
+    const double *__restrict__ src = sg.src;
+    double *__restrict__ d = dst + sg.dst_off;
+    for (uint64_t i = threadIdx.x; i < sg.n; i += 256) d[i] = src[i];
+}
+hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst) {
+    if (!n_seg) return hipSuccess;
+    PG_LAUNCH(k_merge_segments, dim3(n_seg), dim3(256), 0, st, d_seg, dst);
+    return hipSuccess;
+}
+
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
                       const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples, const double *gcal) {
