@@ -395,7 +395,10 @@ static pg_status download_last(pg_ctx *c, bool more_coming) {
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
     } else h.samp_off[0] = 0;
     // one of several batches with a sizeable result: its samples stay on the device (see HostBatchResult)
-    if (h.n_samples * 8ull >= (8ull << 20) && (more_coming || c->batches.size() > 1) && !getenv("PGMOVE_HOST_MERGE")) {
+    // (PGMOVE_HOST_MERGE=1: never -- A/B; PGMOVE_HOLD_MIN_BYTES=n: from n bytes on instead of 8 MB -- tests run small jobs through the device merge)
+    const char *hm = getenv("PGMOVE_HOLD_MIN_BYTES");
+    const uint64_t hold_min = hm ? strtoull(hm, nullptr, 10) : (8ull << 20);
+    if (h.n_samples && h.n_samples * 8ull >= hold_min && (more_coming || c->batches.size() > 1) && !getenv("PGMOVE_HOST_MERGE")) {
         if (h.dsamples.ensure(h.n_samples * 8ull) == hipSuccess &&
             hipMemcpyAsync(h.dsamples.p, c->samples.p, h.n_samples * 8ull, hipMemcpyDeviceToDevice, c->st) == hipSuccess) {
             h.on_device = true;

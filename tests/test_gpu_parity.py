@@ -96,6 +96,29 @@ def test_two_phase_shards_equal_single_run():
         e.close()
 
 
+def test_batches_merged_on_the_device(monkeypatch):
+    """Several batches: their kept samples stay on the device and pg_finish merges them there (one download). Small jobs take the host
+    merge by default; PGMOVE_HOLD_MIN_BYTES=1 sends this one through the device path -- same result as one batch, and as the oracle."""
+    monkeypatch.setenv("PGMOVE_HOLD_MIN_BYTES", "1")
+    b = synth.make_batch(600, kind="rna004", seed=41)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    for cuts in ([0, 250, 600], [0, 100, 101, 380, 600], [0, 599, 600]):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            eng.submit(b.slice_reads(lo, hi))
+        res = eng.finish()
+        assert_result_equals_oracle(res, o, sample_limit=40)
+        res2 = eng.finish()                                   # the merged view again, nothing new collected
+        assert np.array_equal(res2.samples.view(np.uint64), res.samples.view(np.uint64))
+        eng.submit(b.slice_reads(0, 50))                      # a batch behind a finish: the mixed case (falls back to the host merge)
+        res3 = eng.finish()
+        assert res3.n_reads == 650 and int(res3.counts.sum()) >= int(res.counts.sum())
+        eng.close()
+
+
 def test_collect_with_a_base_below_the_running_count():
     """k_rank_scan works the last useful tile out against the context's running count; pg_collect with a SMALLER base of the caller's
     own (here: zero, after a first batch has filled the running count) must still place every event that base allows."""
