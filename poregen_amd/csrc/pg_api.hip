@@ -82,7 +82,12 @@ struct pg_ctx {
     DevBuf m_start, m_len, m_base, m_tix, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
     DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage, tile_last;
-    DevBuf ev_len, ev_read, ev_src, read_needed, samp_off, scan_scratch, samples;
+    DevBuf ev_rec, ev_len, ev_read, read_needed, samp_off, scan_scratch, samples; // ev_len / ev_read: unpacked from the records on demand (ensure_unpacked)
+    bool unpacked = false;
+    uint32_t win_hint = 0; // mean kept window of the last settled batch (samples): picks the gather's lanes per event
+    // partitioned ranking (1024 < slots <= 2^20; pg_place.hip)
+    bool part_mode = false; uint32_t part_hi = 0, part_lo = 0;
+    DevBuf part_elem, part_lodig, part_rbase, part_tile_region, part_ntiles, part_histB, part_Bp, chunk_part;
     DevBuf med[2], mad[2], gcal[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf meta, huge_scratch, oor;
@@ -243,7 +248,8 @@ void pg_destroy(pg_ctx *c) {
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->dmerged, &c->dseg, &c->ev_len, &c->ev_read, &c->ev_src, &c->read_needed,
+                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec, &c->ev_len, &c->ev_read, &c->read_needed,
+                      &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
@@ -300,6 +306,10 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     c->device = p->device;
     c->n_codes = 1u << (2 * p->kmer_size);
     c->key_bits = 1; while ((1ull << c->key_bits) < (uint64_t)p->n_slots) c->key_bits++;
+    // more than 1024 slots: partitioned ranking (two digits of <= 10 bits); beyond 2^20 slots (k >= 11 with the whole list) the LSD radix
+    // sort of round 1 stays (PGMOVE_LSD_SORT=1 forces it: tests, A/B)
+    c->part_mode = p->n_slots > PG_DIRECT_MAX_SLOTS && c->key_bits <= PG_PART_MAX_KEY_BITS && !getenv("PGMOVE_LSD_SORT");
+    if (c->part_mode) { c->part_hi = (c->key_bits + 1) / 2; c->part_lo = c->key_bits - c->part_hi; }
     auto bail = [&](pg_status s) { g_create_error = c->err; pg_destroy(c); return s; };
 #define CTRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, PG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(PG_ERR_HIP); } } while (0)
     // The main chain is a sequence of short, latency-bound kernels; the statistics kernel is one long throughput-bound
@@ -374,6 +384,7 @@ pg_status pg_reset(pg_ctx *c) {
 
 static pg_status settle_batch(pg_ctx *c);
 static pg_status check_read_errors(pg_ctx *c);
+static pg_status ensure_unpacked(pg_ctx *c);
 
 // copy the finished batch's device results to the host (needed before its buffers are reused)
 // more_coming: called in front of the next batch (pg_count); false: from pg_finish
@@ -390,6 +401,7 @@ static pg_status download_last(pg_ctx *c, bool more_coming) {
     HIP_TRY(c, hipMemcpy(h.keep.data(), c->keep.p, ns * 8ull, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(h.ev_off.data(), c->ev_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost));
     if (h.n_events) {
+        { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
         HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off.p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
@@ -488,6 +500,10 @@ static pg_status check_read_errors(pg_ctx *c) {
         if (tot[1] == c->prm.n_slots && tot[0] == 0) return PG_OK;
         if (tot[1] == c->prm.n_slots && tot[0] > 0) { // complete inside this batch: at the read of its last kept event
             std::vector<uint32_t> er(tot[0]);
+            const uint64_t kept_before = c->cur_n_kept; c->cur_n_kept = tot[0]; // (settle_batch sets it behind this check)
+            const pg_status su = ensure_unpacked(c);
+            c->cur_n_kept = kept_before; c->unpacked = false;
+            if (su != PG_OK) return su;
             HIP_TRY(c, hipMemcpy(er.data(), c->ev_read.p, tot[0] * 4ull, hipMemcpyDeviceToHost));
             uint32_t last = 0;
             for (uint32_t v : er) last = v > last ? v : last;
@@ -576,6 +592,31 @@ static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
     S.dbase = c->dbase.as<uint32_t>(); S.count = c->scount.as<uint32_t>(); S.n_tiles = n_tiles;
 }
 
+// lanes per kept event of the chunked gather: by the mean kept window of the last settled batch, else by a guess from the duration
+// filter (dwells lean towards min_dur). Every choice is correct for every window; PGMOVE_GATHER_LANES overrides (measurements).
+static int gather_lanes(const pg_ctx *c) {
+    static const char *ov = getenv("PGMOVE_GATHER_LANES");
+    if (ov) return atoi(ov);
+    const uint32_t mw = c->win_hint ? c->win_hint : c->prm.min_dur + (c->prm.max_dur > c->prm.min_dur ? (c->prm.max_dur - c->prm.min_dur) / 4 : 0) + 2 * c->prm.signal_print_margin;
+    return mw <= 6 ? 4 : (mw <= 36 ? 8 : 16); // (k = 9, mean window 12.4: 8 lanes 0.91-0.97 ms, 4 lanes 1.07-1.10 ms)
+}
+
+static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
+    P.elemA = c->part_elem.as<uint4>(); P.loA = c->part_lodig.as<uint16_t>(); P.hist = c->hist.as<uint32_t>(); P.totals = c->totals.as<uint32_t>(); P.rbase = c->part_rbase.as<uint32_t>();
+    P.tile_region = c->part_tile_region.as<uint32_t>(); P.n_tilesB = c->part_ntiles.as<uint32_t>(); P.histB = c->part_histB.as<uint32_t>();
+    P.Bp = c->part_Bp.as<uint32_t>(); P.hi_bits = c->part_hi; P.lo_bits = c->part_lo; P.tilesB_cap = pg_part_tiles_cap(n_ops, c->part_hi);
+}
+
+// the kept events' lengths and reads as arrays of their own (the device holds 16-byte records): for the download, the device view, the model
+static pg_status ensure_unpacked(pg_ctx *c) {
+    if (c->unpacked) return PG_OK;
+    HIP_TRY(c, c->ev_len.ensure((c->cur_n_kept + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((c->cur_n_kept + 1) * 4));
+    HIP_TRY(c, pg_launch_unpack_recs(c->st, c->ev_rec.as<PgKeptRec>(), c->cur_n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>()));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    c->unpacked = true;
+    return PG_OK;
+}
+
 pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t counts_location) {
     if (!c || !b) return PG_ERR_INVALID_ARG;
     if (b->struct_size != sizeof(pg_batch)) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch");
@@ -636,13 +677,20 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     const uint32_t n_tiles = pg_tiles(Nn, direct);
     uint32_t ndig;
     if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
-    else {
+    else if (c->part_mode) {
+        ndig = 1u << c->part_hi;
+        const uint32_t tcap = pg_part_tiles_cap(Nn, c->part_hi);
+        HIP_TRY(c, c->part_elem.ensure((size_t)tcap * PG_SORT_TILE * 16)); HIP_TRY(c, c->part_lodig.ensure((size_t)tcap * PG_SORT_TILE * 2)); HIP_TRY(c, c->part_rbase.ensure((ndig + 2) * 4ull));
+        HIP_TRY(c, c->part_tile_region.ensure((tcap + 1) * 4ull)); HIP_TRY(c, c->part_ntiles.ensure(16));
+        HIP_TRY(c, c->part_histB.ensure(((size_t)tcap << c->part_lo) * 4)); HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4));
+    } else {
         const uint32_t passes = (c->key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
         ndig = 1u << ((c->key_bits + passes - 1) / passes);
         for (int i = 0; i < 2; i++) { HIP_TRY(c, c->sk[i].ensure(Nn * 4)); HIP_TRY(c, c->sv[i].ensure(Nn * 4)); }
     }
-    HIP_TRY(c, c->hist.ensure((size_t)n_tiles * ndig * 4));
-    if (!direct) HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16)); // per-wave counts: only the radix sort keeps them
+    const uint32_t n_tiles_hist = c->part_mode ? pg_tiles(Nn, true) : n_tiles; // k_events writes a slot's counts of four tiles as one 16-byte store
+    HIP_TRY(c, c->hist.ensure((size_t)n_tiles_hist * ndig * 4));
+    if (!direct && !c->part_mode) HIP_TRY(c, c->wcnt.ensure((size_t)n_tiles * ndig * 16)); // per-wave counts: only the radix sort keeps them
     HIP_TRY(c, c->totals.ensure(ndig * 4ull)); HIP_TRY(c, c->dbase.ensure(ndig * 4ull));
 
     PG_TMARK("count: work buffers");
@@ -694,7 +742,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     PgSortBufs S{};
     fill_sort(c, S, n_tiles);
     prof_begin(c, "k_events", c->st);
-    HIP_TRY(c, pg_launch_events(c->st, c->B, W, O, c->prm.n_slots, direct ? S.hist : nullptr));
+    HIP_TRY(c, pg_launch_events(c->st, c->B, W, O, c->prm.n_slots, (direct || c->part_mode) ? S.hist : nullptr, c->part_mode ? c->part_hi : 0u, c->part_lo));
     prof_end(c, c->st);
     uint64_t *acc_copy = (counts_out && counts_location == PG_LOC_DEVICE) ? counts_out : nullptr; // written by the counting kernels
     if (direct) {
@@ -705,6 +753,28 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
                                     c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
                                     c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done));
         prof_end(c, c->st);
+    } else if (c->part_mode) {
+        // partitioned ranking, pass A and the counts of pass B (pg_place.hip): everything pg_count's result needs
+        PgPartBufs P{};
+        fill_part(c, P, Nn);
+        if (N) {
+            prof_begin(c, "part_tile_scan", c->st);
+            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot));
+            prof_end(c, c->st);
+            prof_begin(c, "k_part_bases", c->st);
+            HIP_TRY(c, pg_launch_part_bases(c->st, P, c->B, O));
+            prof_end(c, c->st);
+            prof_begin(c, "k_part_scatter", c->st);
+            HIP_TRY(c, pg_launch_part_scatter(c->st, P, O.ev_slot, N, c->B, W, O));
+            prof_end(c, c->st);
+            prof_begin(c, "region_counts", c->st, true);
+            HIP_TRY(c, pg_launch_region_counts(c->st, P, c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy));
+            prof_end(c, c->st);
+        } else {
+            HIP_TRY(c, hipMemsetAsync(c->acc_cnt.p, 0, c->prm.n_slots * 8ull, c->st));
+            if (acc_copy) HIP_TRY(c, hipMemsetAsync(acc_copy, 0, c->prm.n_slots * 8ull, c->st));
+            HIP_TRY(c, hipMemsetAsync(c->part_ntiles.p, 0, 4, c->st));
+        }
     } else {
         prof_begin(c, "sort_events", c->st, true);
         if (N) HIP_TRY(c, pg_launch_sort_events(c->st, O.ev_slot, N, c->key_bits, S, &c->sorted_idx));
@@ -812,21 +882,36 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
-    HIP_TRY(c, c->ev_len.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((ke_cap + 1) * 4)); HIP_TRY(c, c->ev_src.ensure((ke_cap + 1) * 8));
+    HIP_TRY(c, c->ev_rec.ensure((ke_cap + 1) * sizeof(PgKeptRec)));
     HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8));
+    c->unpacked = false;
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     PgKeptOut K{};
-    K.ev_len = c->ev_len.as<uint32_t>(); K.ev_read = c->ev_read.as<uint32_t>(); K.ev_src = c->ev_src.as<uint64_t>();
+    K.rec = c->ev_rec.as<PgKeptRec>();
     // the per-read "owns a kept event" flags are only consumed by the lazy statistics: no scattered byte stores otherwise
     K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
+    // Many kept events (nearly every accepted event kept: large sample_limit, k = 9): the offset scan happens inside the gather's
+    // workgroups (pg_place.hip). Few (the default limit: 10^5 events): the one-launch chained scan + the strided gather of round 2.
+    const bool chunked = ke_cap > 64ull * 4096 && (win_cap + 1) * 4096 < (1ull << 32);
+    bool sums_ready = false;
+    if (chunked) HIP_TRY(c, c->chunk_part.ensure(8200 * 8));
     if (direct) {
         PgSortBufs S{};
         fill_sort(c, S, 0);
         prof_begin(c, "k_rank_emit", c->st);
         HIP_TRY(c, pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K));
         prof_end(c, c->st);
+    } else if (c->part_mode) {
+        PgPartBufs P{};
+        fill_part(c, P, N ? N : 1);
+        if (N) {
+            prof_begin(c, "k_region_place", c->st);
+            HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part.as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
+            prof_end(c, c->st);
+            sums_ready = chunked;
+        }
     } else {
         prof_begin(c, "k_kept_meta", c->st, true);
         HIP_TRY(c, pg_launch_kept_meta(c->st, c->sk[c->sorted_idx].as<uint32_t>(), c->sv[c->sorted_idx].as<uint32_t>(), c->scount.as<uint32_t>(), N,
@@ -840,28 +925,42 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (lazy) { pg_status s2 = launch_stats(c, c->st, c->read_needed.as<uint8_t>(), false, false, true); if (s2 != PG_OK) return s2; }
 
     uint64_t gather_cap = ke_cap;
-    prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
-    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->ev_len.as<uint32_t>(), ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
-                                      c->rare_pending ? &c->rare : nullptr, totals + 2));
-    c->rare_pending = false;
-    prof_end(c, c->st);
+    if (chunked) {
+        if (c->rare_pending) { // the rare statistics have no scan launch to ride in
+            prof_begin(c, "k_read_stats_rare", c->st);
+            HIP_TRY(c, pg_launch_read_stats_rare(c->st, c->rare));
+            prof_end(c, c->st);
+            c->rare_pending = false;
+        }
+        prof_begin(c, "len_partials", c->st, true);
+        HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec.as<PgKeptRec>(), c->chunk_part.as<uint64_t>(), c->samp_off.as<uint64_t>(), totals + 2, sums_ready));
+        prof_end(c, c->st);
+    } else {
+        prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
+        HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec.p) + 2, 4, ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
+                                          c->rare_pending ? &c->rare : nullptr, totals + 2));
+        c->rare_pending = false;
+        prof_end(c, c->st);
+    }
 
     if (samp_cap * 8 > c->samples.cap) {
         // grow once to the worst case if that is moderate; otherwise size exactly from the device total (one sync)
         if (samp_cap * 8 <= (4ull << 30)) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));
         else {
-            uint64_t tot[1] = {0};
-            HIP_TRY(c, hipMemcpyAsync(tot, totals, 8, hipMemcpyDeviceToHost, c->st));
+            uint64_t tot[3] = {0, 0, 0};
+            HIP_TRY(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, c->st));
             HIP_TRY(c, hipStreamSynchronize(c->st));
-            uint64_t n_samples = 0;
-            HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off.as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
-            HIP_TRY(c, c->samples.ensure((n_samples + 1) * 8));
+            HIP_TRY(c, c->samples.ensure((tot[2] + 1) * 8)); // totals[2]: all kept samples (the offset scan's total)
             gather_cap = tot[0];
         }
     }
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", c->st);
-    HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>(), c->ev_src.as<uint64_t>(),
+    if (chunked)
+        HIP_TRY(c, pg_launch_gather_chunks(c->st, c->B, ke_cap, totals, c->ev_rec.as<PgKeptRec>(), c->chunk_part.as<uint64_t>(), c->samp_off.as<uint64_t>(), c->prm.scaling,
+                                           c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c)));
+    else
+        HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec.as<PgKeptRec>(),
                      c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr));
     prof_end(c, c->st);
@@ -886,6 +985,7 @@ static pg_status settle_batch(pg_ctx *c) {
     uint64_t n_samples = 0;
     HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off.as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
     c->cur_n_samples = n_samples;
+    if (tot[0]) c->win_hint = (uint32_t)((n_samples + tot[0] - 1) / tot[0]);
     c->totals_known = true;
     return PG_OK;
 }
@@ -949,6 +1049,7 @@ pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     if (!c || !v) return PG_ERR_INVALID_ARG;
     if (!c->have_batch_result) return fail(c, PG_ERR_STATE, "no collected batch");
     { pg_status s0 = settle_batch(c); if (s0 != PG_OK) return s0; }
+    { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
     v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
     v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
     v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off.as<uint64_t>(); v->d_samples = c->samples.as<double>();
@@ -1136,6 +1237,7 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
     const uint64_t *d_ev_off, *d_samp_off; const uint32_t *d_ev_len; const double *d_samples;
     if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
         // one batch: its kept events are still on the device, in the same order
+        { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
         d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off.as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
     } else { // several batches were merged on the host (slot-major): hand the merged arrays back
         HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));

@@ -55,13 +55,14 @@ struct __attribute__((aligned(16))) PgReadMeta {
     uint32_t L;      // len_raw_signal (clamped to 2^32 - 1; > INT32_MAX is an error)
     int32_t qs;      // query_start
     uint32_t flags;  // PG_RM_*
-    uint32_t pad;
+    uint32_t opsum0; // partitioned ranking only (k_part_bases): sum of op_n over all ops in front of o0, modulo 2^32 (pg_place.hip: op_prefix)
     uint64_t sig0;   // sig_off[r]: first sample of the read in the batch's signal
 };
 enum {
     PG_RM_RNA = 1u,       // target_start > target_end
     PG_RM_LIVE = 2u,      // passed the per-read checks: not skipped, no error so far
-    PG_RM_DIRECT_OK = 4u  // live, k <= nops <= fetched bases: takes the op-parallel event path unless one of its ops is an I or a D
+    PG_RM_DIRECT_OK = 4u, // live, k <= nops <= fetched bases: takes the op-parallel event path unless one of its ops is an I or a D
+    PG_RM_GENERIC = 8u    // partitioned ranking only (k_part_bases): the read is on the generic list (gen_flag[r] == batch_id), folded in here
 };
 
 struct PgWalkOut {
@@ -100,6 +101,10 @@ struct PgWalkOut {
 #define PG_SLOT_MASK ((1u << PG_SLOT_BITS) - 1u)
 #define PG_REL_UNKNOWN ((1u << (32 - PG_SLOT_BITS)) - 2u) // not all ones: slot 1023 with an unknown read must not read as PG_INVALID_SLOT
 
+// partitioned ranking: slots of up to PG_PART_MAX_KEY_BITS (20) bits, the read's table entry above them
+#define PG_PART_REL_SHIFT 20
+#define PG_PART_REL_UNKNOWN ((1u << (32 - PG_PART_REL_SHIFT)) - 2u)
+
 #define PG_INVALID_SLOT 0xFFFFFFFFu
 #define PG_TIX_FRONT(margin) (((uint64_t)((margin) > 0 ? (margin) : 0) + 3) & ~3ull)
 
@@ -120,6 +125,38 @@ struct PgSortBufs {
     uint32_t *count;  // [2] count[0] = number of keys entering the current pass, count[1] = scratch
     uint32_t n_tiles; // for the capacity N the buffers were sized for
 };
+
+// ---- partitioned ranking (PG_DIRECT_MAX_SLOTS < n_slots <= 2^PG_PART_MAX_KEY_BITS; pg_place.hip) ------------------------------
+#define PG_PART_MAX_KEY_BITS 20
+struct PgPartBufs {
+    uint4 *elemA;          // [n_ops + (R + 1) * PG_SORT_TILE] accepted events {slot, window start, length | start's high bits, read}, partitioned by the
+                           // high digit of the slot (region), stable; region r starts at rbase[r], a multiple of PG_SORT_TILE
+    uint16_t *loA;         // [as elemA] the low digit of every element once more (pass B's count kernel reads 2 bytes per element, not 16)
+    uint32_t *hist;        // [R][tiles of op indices] counts (k_events<2>) -> exclusive tile prefixes (k_rank_scan)
+    uint32_t *totals;      // [R] accepted events per region
+    uint32_t *rbase;       // [R + 1]
+    uint32_t *tile_region; // [tilesB_cap] region of every tile of elemA
+    uint32_t *n_tilesB;    // [1] tiles of elemA in use
+    uint32_t *histB;       // [tilesB_cap][1 << lo_bits] counts per low digit -> exclusive prefixes along the region
+    uint32_t *Bp;          // [n_ops / 256 + 2] exclusive prefix of PgWalkOut::btot, modulo 2^32
+    uint32_t hi_bits, lo_bits, tilesB_cap;
+};
+static inline uint32_t pg_part_tiles_cap(uint64_t n_ops, uint32_t hi_bits) { return (uint32_t)((n_ops + PG_SORT_TILE - 1) / PG_SORT_TILE) + (1u << hi_bits); }
+hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot);
+hipError_t pg_launch_part_bases(hipStream_t st, const PgPartBufs &P, const PgDevBatch &B, const PgWalkOut &O);
+hipError_t pg_launch_part_scatter(hipStream_t st, const PgPartBufs &P, const uint32_t *ev_slot, uint64_t n, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
+// acc_cnt / acc_copy (may be null): accepted events per slot
+hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy);
+struct PgKeptOut; struct PgKeptRec;
+// part / n_kept_cap: the chunked gather's per-chunk sums of kept window lengths are accumulated by this launch (n_kept_cap = 0: not wanted)
+hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, const uint32_t *keep32, const uint64_t *ev_off, const PgWalkOut &O, const PgKeptOut &K,
+                                  uint64_t *part, uint64_t n_kept_cap);
+// many kept events: sample offsets inside the gather's workgroups (part: >= 8192 entries of work space)
+hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
+                                  bool sums_ready);
+hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
+                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes);
+hipError_t pg_launch_unpack_recs(hipStream_t st, const PgKeptRec *rec, uint64_t n, uint32_t *ev_len, uint32_t *ev_read);
 
 // ---- stats ---------------------------------------------------------------------------------------
 #define PG_STATS_BINS 2048 // in-range codes the LDS histogram can hold; wider reads take the global-memory path
@@ -145,10 +182,16 @@ struct PgGathered {
     uint64_t *total, *freq; // [n_slots] the job's accepted events per slot and min(total, sample_limit) (pg_job_totals_device)
 };
 // ---- launchers (all asynchronous on `st`; the result is hipGetLastError() behind the launch / the queued copy's status) -----------------------------------------------------------
+// a kept event in the batch's final (k-mer-major) order: ONE 16-byte record, so that the kernels that place events -- each at a
+// position of its own -- pay one memory transaction per event, not three (round 2 kept three arrays: 3 x 32-byte write requests per
+// event, 1.47 GB of write traffic for 0.25 GB of data at k = 9)
+struct __attribute__((aligned(16))) PgKeptRec {
+    uint64_t src;  // window start as a sample index of the BATCH (sig_off[read] + start inside the read, margin applied)
+    uint32_t len;  // window length incl. margin, clamped to the signal
+    uint32_t read; // read index inside the batch
+};
 struct PgKeptOut {
-    uint32_t *ev_len;     // [n_kept] window length incl. margin, clamped to the signal
-    uint32_t *ev_read;    // [n_kept] read index inside the batch
-    uint64_t *ev_src;     // [n_kept] window start as a sample index of the BATCH (sig_off[read] + start inside the read)
+    PgKeptRec *rec;       // [n_kept]
     uint8_t *read_needed; // [n_reads] set to 1 for reads that own a kept event (may be nullptr)
 };
 // profiling (PG_FLAG_PROFILE): the pair of events the NEXT kernel launch of this host thread carries (pg_kernels.hip: PG_LAUNCH); null = none
@@ -176,7 +219,9 @@ hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_
 hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // the op-parallel event kernel over ALL op indices: computes the events of direct reads, passes the generic reads' through, and (hist
 // != null, direct ranking) counts the accepted events per tile and slot as pg_launch_rank_direct_count's first kernel would
-hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist);
+// part_hi_bits != 0 (partitioned ranking, pg_place.hip): hist = P.hist, counts per (tile, slot >> part_lo_bits)
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist,
+                            uint32_t part_hi_bits, uint32_t part_lo_bits);
 // SAM/BAM front-end: reads with an out-of-range sample become skipped reads (behind the statistics, in front of the walk)
 hipError_t pg_launch_apply_oor(hipStream_t st, const PgDevBatch &B, const PgWalkOut &O);
 // direct ranking (n_slots <= PG_DIRECT_MAX_SLOTS): tile prefix of the per-tile per-slot counts pg_launch_events left in S.hist;
@@ -228,7 +273,8 @@ struct PgRareArgs {
 // entries ZERO before the first use (every launch leaves them zero again). rare (may be null): the rare statistics ride in the
 // same launch (short inputs) or get their own launch in front of the scan kernels
 // total_out (may be null): the total (= out[n]) once more, where the consumer of the offsets finds it next to n
-hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
+// in[i * stride]: stride in dwords (1 = a plain array; 4 = the len field of PgKeptRec records)
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t stride, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
                                   const PgRareArgs *rare, uint64_t *total_out);
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
 // plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
@@ -245,6 +291,6 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
 struct PgSeg { const double *src; uint64_t dst_off, n; };
 hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst);
 // n_kept_ptr: [0] kept events, [2] their samples (the offset scan's total_out)
-hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
-                      const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
+hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec,
+                      const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples, const double *gcal);

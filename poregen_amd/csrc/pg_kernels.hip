@@ -13,16 +13,10 @@
 //   k_read_stats (+ the rare workers riding in k_scan_chained)   pA conversion, zero-fill, exact median and MAD (lines 754-771)
 //   k_gather        window copy + normalisation of the kept events (lines 773-775, 928-944)
 // All of this is HBM/LDS-bound integer and FP64 work: there is no contraction here, so no MFMA.
-#include "pg_internal.h"
-#include <hip/hip_ext.h>
+#include "pg_dev.h"
 #include "pg_select.h"
 #include <limits.h>
 #include <type_traits>
-
-#define WAVE 64
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
-__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 #ifdef PG_PHASE_PROBE
 // Measurement build only (make variant NAME=phase EXTRA=-DPG_PHASE_PROBE; tools/phase_probe.py): per-wave time stamps (s_memtime)
@@ -47,31 +41,6 @@ extern "C" void pg_debug_phases(unsigned long long *out, int kernel, int reset) 
 #define PG_PROBE_PARAM
 #define PG_PROBE_ARG
 #endif
-
-// Inclusive wave64 scan with DPP row shifts + row broadcasts (no LDS traffic, 6 VALU ops): rows of 16 lanes
-// are scanned with row_shr:1/2/4/8, then lane 15 of each row is broadcast into the next row (rows 1,3) and
-// lane 31 into rows 2,3.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_zero(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += dpp_zero<0x111, 0xF>(v); // row_shr:1
-    v += dpp_zero<0x112, 0xF>(v); // row_shr:2
-    v += dpp_zero<0x114, 0xF>(v); // row_shr:4
-    v += dpp_zero<0x118, 0xF>(v); // row_shr:8
-    v += dpp_zero<0x142, 0xA>(v); // row_bcast:15 -> rows 1 and 3
-    v += dpp_zero<0x143, 0xC>(v); // row_bcast:31 -> rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        uint64_t t = __shfl_up(v, d, WAVE);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
 
 // smallest t in [0, n) for which the monotone predicate holds, n if none. All 64 lanes call it together;
 // every round tests 64 candidates at once (two rounds cover n <= 4096).
@@ -144,30 +113,9 @@ __device__ __forceinline__ uint8_t base_code(uint8_t ch, bool rna_read) {
     return ok ? (uint8_t)((codes >> (2u * (idx & 31u))) & 3u) : (uint8_t)4;
 }
 
-__device__ __forceinline__ void report_error(const PgWalkOut &O, uint32_t r, int code) {
-    O.status[r] = code;
-    atomicMax(O.err, ((unsigned long long)O.batch_id << 32) | (unsigned long long)(0xFFFFFFFFu - r)); // PgWalkOut::err
-}
-
-// the read that owns op index g (g < n_ops): the read of the 64-op block's first op, then along op_off (reads without ops
-// are stepped over; a read of >= 64 ops ends the probe at once)
-__device__ __forceinline__ uint32_t owner_of(const PgDevBatch &B, const PgWalkOut &O, uint64_t g) {
-    uint32_t r = O.blk_read[g >> 6];
-    if (r >= B.n_reads) r = B.n_reads - 1; // only with a broken op_off (the batch fails anyway): stay inside the arrays
-    while (r + 1 < B.n_reads && B.op_off[r + 1] <= g) ++r;
-    return r;
-}
-// ... by binary search (k_batch_init's op-parallel part runs next to the threads that write blk_read)
-__device__ __forceinline__ uint32_t owner_search(const PgDevBatch &B, uint64_t g) {
-    uint32_t lo = 0, hi = B.n_reads; // first r with op_off[r + 1] > g
-    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (B.op_off[mid + 1] > g) hi = mid; else lo = mid + 1; }
-    return lo < B.n_reads ? lo : B.n_reads - 1;
-}
 __device__ __forceinline__ void list_generic(const PgWalkOut &O, uint32_t r) {
     if (atomicExch(&O.gen_flag[r], O.batch_id) != O.batch_id) O.gen_list[atomicAdd(&O.gen_count[O.batch_id & 1u], 1u)] = r;
 }
-
-#define PG_OP_N_LIMIT (1u << 24) // an op of 2^24 samples or more is refused (PGR_ERR_RANGE): 256 of them fit a 32-bit block sum
 
 // One read's record, checks and class (k_batch_init, one thread per read). The checks are those at the head of the reference's
 // loop body: gmove.cpp:752 (assert), 792-798 (orientation), 806-808 (short fetch).
@@ -182,7 +130,7 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
     mt.nops = layout_ok ? (uint32_t)(o1 - o0) : 0u;
     mt.slen = (uint32_t)(s1 - s0 > 0xffffffffull ? 0xffffffffull : s1 - s0);
     mt.n = 0; mt.m = 0; mt.st_k = rna ? te : ts; mt.end_k = rna ? ts : te;
-    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.pad = 0; mt.sig0 = B.sig_off[r];
+    mt.L = (uint32_t)(L > 0xffffffffull ? 0xffffffffull : L); mt.qs = qs; mt.opsum0 = 0; mt.sig0 = B.sig_off[r];
     int status = PGR_OK;
     if (!layout_ok) status = PGR_ERR_LAYOUT;
     // gmove.cpp:752 assert(query_start < len); negative columns convert to huge size_t in the reference
@@ -535,7 +483,9 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
 //      position tests. COUNT (direct ranking): the accepted events are counted per (tile, slot) into hist[slot][tile..tile+3].
 // A tile touched by more than PG_EV_TBL reads, and a thread whose 16 ops span more than two reads, take event_slot_scalar.
 // LT: both slot tables (<= 1024 codes each: k <= 5; <= 1024 slots: COUNT) as 16-bit entries in LDS -- 16 look-ups per thread at LDS latency
-template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT ? 8 : 4, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist) {
+// COUNT: 0 = slots only; 1 = direct ranking: counts per (tile, slot), the event's read in the upper bits of its slot word; 2 = partitioned
+// ranking (pg_place.hip): counts per (tile, high digit of the slot = slot >> cshift), plain slot words
+template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT == 1 ? 8 : 4, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist, uint32_t cshift) {
     constexpr int TBL = PG_EV_TBL;
     __shared__ uint16_t ltab[LT ? 2048 + 2 : 2]; // [2048]: 0xFFFF, where a position that is no candidate looks itself up
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
@@ -544,9 +494,9 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
     // the thread's 16 slots wait here for the end of the kernel (transposed: op j of thread lt at [j][lt]): a global store between two
     // slot-table look-ups would serialise them (on this part a wait for a load also waits for every store issued in front of it), and
     // 16 more live registers cost a wave per SIMD. 16 bits per slot in direct mode (<= 1024 slots), 32 otherwise.
-    typedef typename std::conditional<COUNT, uint16_t, uint32_t>::type stage_t;
+    typedef typename std::conditional<COUNT == 1, uint16_t, uint32_t>::type stage_t;
     __shared__ stage_t stage[4][16][256];
-    constexpr uint32_t STAGE_INVALID = COUNT ? 0xFFFFu : PG_INVALID_SLOT;
+    constexpr uint32_t STAGE_INVALID = COUNT == 1 ? 0xFFFFu : PG_INVALID_SLOT;
     __shared__ uint32_t sh_rf[5], sh_R[4], sh_over[4];
     const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k, tq = tid >> 8, lt = tid & 255u;
     const int lane = lane_id();
@@ -687,16 +637,18 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
 
     // ---- stage 3: the events ------------------------------------------------------------------------------------------------------------
     const uint32_t cmask = (1u << nbits) - 1u;
+    auto cdig = [&](uint32_t sl) { return (COUNT == 2 ? sl >> cshift : sl) & cmask; }; // the digit an accepted event is counted under
     if (tile_live && g0 < N && (over || more)) { // every op on its own (rare): its read, its k bases, its window length
 #pragma unroll 1
         for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
             uint32_t rd;
             const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, B.op_n[g0 + j], rd);
-            const uint32_t rel = rd - rFirst < PG_REL_UNKNOWN ? rd - rFirst : PG_REL_UNKNOWN;
-            O.ev_slot[g0 + j] = COUNT && sl != PG_INVALID_SLOT ? sl | (rel << PG_SLOT_BITS) : sl; // COUNT: the read rides in the upper bits (PgWalkOut::tile_read)
-            if (COUNT && sl != PG_INVALID_SLOT) atomicAdd(&cnt[tq][sl & cmask], 1u);
+            constexpr uint32_t UNK = COUNT == 2 ? PG_PART_REL_UNKNOWN : PG_REL_UNKNOWN, RSH = COUNT == 2 ? PG_PART_REL_SHIFT : PG_SLOT_BITS;
+            const uint32_t rel = rd - rFirst < UNK ? rd - rFirst : UNK;
+            O.ev_slot[g0 + j] = COUNT && sl != PG_INVALID_SLOT ? sl | (rel << RSH) : sl; // the read rides in the upper bits (PgWalkOut::tile_read)
+            if (COUNT && sl != PG_INVALID_SLOT) atomicAdd(&cnt[tq][cdig(sl)], 1u);
         }
-    } else if (COUNT && LT && tile_live && g0 < N && W.sig_move_offset == 0 &&
+    } else if (COUNT == 1 && LT && tile_live && g0 < N && W.sig_move_offset == 0 &&
                !((A.fl & 3u) == 1u && jb < 16 && (Bs.fl & 3u) == 1u && ((A.fl ^ Bs.fl) & 4u))) {
         // ---- the straight-line form (direct ranking, both tables in LDS, window of an event = its own op; the two reads of the group,
         // if both direct, of one orientation): the position, base and duration tests of the 16 events become three 16-bit masks, every
@@ -855,7 +807,7 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
                 }
                 if (kind == 1u && len[u] >= PG_OP_N_LIMIT && g0 + j < N) too_long = true;
                 stage[tq][j][lt] = (stage_t)(sl == PG_INVALID_SLOT ? STAGE_INVALID : sl);
-                if (COUNT && sl != PG_INVALID_SLOT && g0 + j < N) atomicAdd(&cnt[tq][sl & cmask], 1u);
+                if (COUNT && sl != PG_INVALID_SLOT && g0 + j < N) atomicAdd(&cnt[tq][cdig(sl)], 1u);
             }
         }
         // ---- everything that stores to global memory: behind the last look-up -------------------------------------------------------
@@ -873,7 +825,7 @@ template <bool COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__(
                 const uint32_t x = stage[tq][4 * v + u][lt];
                 // COUNT: the event's read rides in the upper bits, as its table entry = read - first read of the tile (PgWalkOut::tile_read)
                 const uint32_t rel = (uint32_t)(4 * v + u) >= jb ? Bs.e : A.e;
-                o4[u] = x == STAGE_INVALID ? PG_INVALID_SLOT : (COUNT ? x | (rel << PG_SLOT_BITS) : x);
+                o4[u] = x == STAGE_INVALID ? PG_INVALID_SLOT : (COUNT ? x | (rel << (COUNT == 2 ? PG_PART_REL_SHIFT : PG_SLOT_BITS)) : x);
             }
             if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
             else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
@@ -894,43 +846,6 @@ __global__ __launch_bounds__(256) void k_apply_oor(uint32_t n_reads, PgWalkOut O
     if (r < n_reads && O.oor[r] && O.status[r] == PGR_OK) O.status[r] = PGR_SKIPPED;
 }
 
-// what the emit kernels need of the read of a kept event
-struct KeptRead { uint64_t o0, sig0; uint32_t qs, L; bool generic; };
-__device__ __forceinline__ KeptRead kept_read(const PgWalkOut &O, uint32_t rd) {
-    const PgReadMeta *mt = O.meta + rd;
-    KeptRead k; k.o0 = mt->o0; k.sig0 = mt->sig0; k.qs = (uint32_t)mt->qs; k.L = mt->L; k.generic = O.gen_flag[rd] == O.batch_id;
-    return k;
-}
-// window start and length of a kept event (gmove.cpp:854-855) at op index g of read rd: from the generic walk's arrays, or, for a
-// direct read, op_n itself and the block sums k_events left. Returns false when the sample index leaves the reference's int range.
-__device__ __forceinline__ bool kept_window(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const KeptRead &kr, uint64_t g, uint32_t &start, uint32_t &len) {
-    const uint64_t ge = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
-    if (kr.generic) { start = O.m_start[ge]; len = O.m_len[ge]; return true; }
-    len = B.op_n[ge];
-    // P(x) = sum of op_n over [x & ~255, x) = cum at the 4-op group + the ops of the group in front of x; the window starts at
-    // query_start + sum of op_n over [o0, ge) = P differences + whole blocks in between
-    auto P = [&](uint64_t x) {
-        uint32_t s = O.cum[x >> 2];
-        const uint64_t y = x & ~3ull;
-        const uint32_t a = B.op_n[y], b = B.op_n[y + 1 < B.n_ops ? y + 1 : y], c = B.op_n[y + 2 < B.n_ops ? y + 2 : y]; // (unconditional: 3 loads in flight)
-        const uint32_t m = (uint32_t)(x & 3);
-        s += (m > 0 ? a : 0u) + (m > 1 ? b : 0u) + (m > 2 ? c : 0u);
-        return s;
-    };
-    const uint64_t b0 = kr.o0 >> 8, b1 = ge >> 8;
-    const uint32_t t0 = O.btot[b0]; // unconditional: in flight with P's loads, not behind them (a read rarely ends in the block it starts in)
-    const uint32_t p0 = P(kr.o0), pge = P(ge);
-    uint64_t sum;
-    if (b0 == b1) sum = (uint64_t)(pge - p0);
-    else {
-        sum = (uint64_t)(t0 - p0) + pge;
-        for (uint64_t b = b0 + 1; b < b1; ++b) sum += O.btot[b];
-    }
-    const uint64_t st = (uint64_t)kr.qs + sum;
-    start = (uint32_t)st;
-    return st + len <= 0x7fffffffull;
-}
-
 // =====================================================================================================
 // Stable ranking of accepted events by slot. One tile = 4 waves x ROWS rows x 64 keys; digits of up to
 // 10 bits (1024 LDS counters per wave). Two uses:
@@ -938,17 +853,6 @@ __device__ __forceinline__ bool kept_window(const PgDevBatch &B, const PgWalkPar
 //           k-mer; k_rank_emit applies the sample_limit cut and writes only the kept events;
 //   generic (more slots): LSD radix sort by slot in ceil(bits/10) passes, ranks from the sorted order.
 // =====================================================================================================
-
-// lanes holding the same digit (among valid lanes)
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbits) {
-    uint64_t peers = __ballot(valid);
-    for (int b = 0; b < nbits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t mset = __ballot(valid && bit);
-        peers &= bit ? mset : ~mset;
-    }
-    return peers;
-}
 
 __global__ __launch_bounds__(256) void k_rank_count(const uint32_t *__restrict__ keys, uint32_t n_scalar,
                                                     const uint32_t *__restrict__ n_ptr, uint32_t shift, int nbits,
@@ -1005,9 +909,45 @@ struct PgScanPlan {
 #define PG_SCAN_WAVES 16 // digits (= waves) per workgroup of k_rank_scan: 64 workgroups for 1024 slots, 64 adds to the ticket
 __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
                                                   uint64_t *__restrict__ acc_cnt, uint32_t n_slots, uint32_t n_digits, const uint64_t *running,
-                                                  uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy, PgScanPlan plan) {
+                                                  uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy, PgScanPlan plan,
+                                                  const uint32_t *__restrict__ bp_btot, uint32_t bp_nb, uint32_t *__restrict__ bp_out) {
     const uint32_t d = blockIdx.x * PG_SCAN_WAVES + (threadIdx.x >> 6); // one wave per digit
     const int lane = lane_id();
+    if (bp_out && blockIdx.x == gridDim.x - 1) { // partitioned ranking: one extra workgroup turns k_events' 256-op block sums into their
+        // exclusive prefix (pg_place.hip: op_prefix), next to the digit scans instead of in a launch of its own. 64 consecutive sums per
+        // thread, all 16 loads in flight, one workgroup-wide scan per 65 536 sums (k = 9, 50 000 reads: one trip)
+        __shared__ uint32_t bsum[PG_SCAN_WAVES];
+        uint32_t carry = 0;
+        for (uint32_t c = 0; c < bp_nb; c += PG_SCAN_WAVES * WAVE * 64) {
+            const uint32_t i0 = c + threadIdx.x * 64;
+            uint4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = i0 + 4 * u;
+                if (i + 4 <= bp_nb) v[u] = *reinterpret_cast<const uint4 *>(bp_btot + i);
+                else v[u] = make_uint4(i < bp_nb ? bp_btot[i] : 0u, i + 1 < bp_nb ? bp_btot[i + 1] : 0u, i + 2 < bp_nb ? bp_btot[i + 2] : 0u, 0u);
+            }
+            uint32_t sum = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const uint4 x = v[u]; v[u] = make_uint4(sum, sum + x.x, sum + x.x + x.y, sum + x.x + x.y + x.z); sum += x.x + x.y + x.z + x.w; }
+            const uint32_t inc = wave_incl_scan_u32(sum);
+            if (lane == WAVE - 1) bsum[threadIdx.x >> 6] = inc;
+            __syncthreads();
+            uint32_t off = carry + inc - sum, tot = 0;
+            for (uint32_t ww = 0; ww < PG_SCAN_WAVES; ++ww) { if (ww < (threadIdx.x >> 6)) off += bsum[ww]; tot += bsum[ww]; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t i = i0 + 4 * u;
+                const uint4 x = make_uint4(v[u].x + off, v[u].y + off, v[u].z + off, v[u].w + off);
+                if (i + 4 <= bp_nb) *reinterpret_cast<uint4 *>(bp_out + i) = x;
+                else { if (i < bp_nb) bp_out[i] = x.x; if (i + 1 < bp_nb) bp_out[i + 1] = x.y; if (i + 2 < bp_nb) bp_out[i + 2] = x.z; }
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) bp_out[bp_nb] = carry;
+        return;
+    }
     if (d < n_digits) {
         uint32_t run = 0;
         const bool want_last = tile_last && d < n_slots;
@@ -1199,9 +1139,7 @@ __device__ __forceinline__ void write_kept(const PgDevBatch &B, const PgWalkPara
     uint32_t we = (uint32_t)(we64 > L ? L : we64), ws = start - W.print_margin;
     // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
     if (W.print_margin > start || we <= ws) { report_error(O, rd, PGR_ERR_WINDOW); ws = we = 0; }
-    K.ev_len[e] = we - ws;
-    K.ev_src[e] = kr.sig0 + ws;
-    K.ev_read[e] = rd;
+    K.rec[e] = PgKeptRec{kr.sig0 + ws, we - ws, rd};
     if (K.read_needed) K.read_needed[rd] = 1;
 }
 
@@ -1329,9 +1267,7 @@ __global__ __launch_bounds__(PG_EMIT_WAVES * WAVE) void k_rank_emit(const uint32
         uint32_t we = (uint32_t)(we64 > Lr ? Lr : we64);
         // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
         if (W.print_margin > ws[row] || we <= start) { report_error(O, rd[row], PGR_ERR_WINDOW); start = we = 0; }
-        K.ev_len[dst[row]] = we - start;
-        K.ev_src[dst[row]] = kr[row].sig0 + start;
-        K.ev_read[dst[row]] = rd[row];
+        K.rec[dst[row]] = PgKeptRec{kr[row].sig0 + start, we - start, rd[row]}; // one 16-byte store
         if (K.read_needed) K.read_needed[rd[row]] = 1;
     }
     PG_MARK(2, 5); // stores
@@ -1454,6 +1390,90 @@ __global__ __launch_bounds__(256) void k_slot_keep(const uint64_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&totals[1]), (unsigned long long)(wfull[0] + wfull[1] + wfull[2] + wfull[3]));
 }
+#define SCAN_CHUNK 4096 // elements per workgroup of the scan kernels
+// The same cut and its offsets in ONE launch (round 3; k_slot_keep + a scan + k_slot_totals + a memset were four: 34 us at k = 9): a chained
+// scan (decoupled look-back, as k_scan_chained: state[0] ticket, [1] blocks done, [2 + b] block entries, [2 + n_scan] full slots) whose
+// elements are worked out on the way in. 16 consecutive slots per thread; the state is left zeroed for the next launch.
+__global__ __launch_bounds__(256) void k_slot_cut(const uint64_t *__restrict__ acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit, uint32_t n_slots,
+                                                  uint64_t *__restrict__ keep, uint32_t *__restrict__ keep32, uint64_t *__restrict__ ev_off, uint64_t *__restrict__ totals,
+                                                  uint64_t *__restrict__ state, uint32_t n_scan, PgGathered G) {
+    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t sh_prefix;
+    __shared__ uint32_t sh_block, wfull[4];
+    if (threadIdx.x == 0) sh_block = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(state), 1ull);
+    __syncthreads();
+    const uint32_t b = sh_block;
+    const uint64_t s0 = (uint64_t)b * SCAN_CHUNK + (uint64_t)threadIdx.x * 16;
+    uint32_t v[16]; uint64_t s = 0; uint32_t nfull = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t sl = s0 + i;
+        v[i] = 0;
+        if (sl < n_slots) {
+            const uint64_t cnt = acc_cnt[sl], bb = slot_base(G, base, (uint32_t)sl, n_slots, limit);
+            const uint64_t room = bb >= limit ? 0 : (uint64_t)limit - bb;
+            const uint64_t kp = cnt < room ? cnt : room;
+            nfull += (limit > 0 && bb + cnt >= limit) ? 1u : 0u; // see k_slot_plan
+            if (running) running[sl] = bb + cnt;
+            keep[sl] = kp; keep32[sl] = (uint32_t)kp; v[i] = (uint32_t)kp; // <= sample_limit
+        }
+        s += v[i];
+    }
+    const uint64_t inc = wave_incl_scan_u64(s);
+    for (int o = 32; o >= 1; o >>= 1) nfull += __shfl_xor(nfull, o, WAVE);
+    if (lane_id() == WAVE - 1) { wsum[threadIdx.x >> 6] = inc; wfull[threadIdx.x >> 6] = nfull; }
+    __syncthreads();
+    const uint64_t block_sum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint64_t *st = state + 2;
+    if (threadIdx.x < WAVE) { // wave 0: publish, then look back 64 blocks at a time (k_scan_chained)
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(st + b, (block_sum << 2) | (b == 0 ? 2ull : 1ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t excl = 0;
+        int64_t hi = (int64_t)b - 1;
+        while (hi >= 0) {
+            const int64_t j = hi - lane;
+            uint64_t wv = 0;
+            if (j >= 0) do { wv = __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((wv & 3ull) == 0);
+            const uint64_t pm = __ballot(j >= 0 && (wv & 3ull) == 2ull);
+            const int stop = pm ? __ffsll((long long)pm) - 1 : WAVE;
+            uint64_t part = (j >= 0 && lane <= stop) ? (wv >> 2) : 0ull;
+            part = wave_incl_scan_u64(part);
+            excl += (uint64_t)__shfl(part, WAVE - 1, WAVE);
+            if (pm) break;
+            hi -= WAVE;
+        }
+        if (lane == 0) {
+            if (b != 0) __hip_atomic_store(st + b, ((excl + block_sum) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_prefix = excl;
+        }
+    }
+    __syncthreads();
+    uint64_t run = sh_prefix + inc - s;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint64_t sl = s0 + i;
+        if (sl < n_slots) ev_off[sl] = run;
+        run += v[i];
+        if (sl + 1 == n_slots) { ev_off[n_slots] = run; totals[0] = run; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // this block's full slots are in the job's count before the block is counted as done (a returning atomic: its result is waited for)
+        const unsigned long long seen = atomicAdd(reinterpret_cast<unsigned long long *>(st + n_scan), (unsigned long long)(wfull[0] + wfull[1] + wfull[2] + wfull[3]));
+        const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(state + 1), 1ull + (seen >> 63)); // (seen >> 63 == 0: keeps the order)
+        sh_block = done + 1 == n_scan;
+    }
+    __syncthreads();
+    if (sh_block) { // last block out: the totals, and nobody reads the state any more
+        if (threadIdx.x == 0) {
+            totals[1] = __hip_atomic_load(st + n_scan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            totals[3] = ~0ull >> 1; // (read as a signed tile index by the direct ranking only)
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_scan + 3; i += 256) __hip_atomic_store(state + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 __global__ void k_slot_totals(const uint64_t *__restrict__ ev_off, uint32_t n_slots, uint64_t *__restrict__ totals) {
     totals[0] = ev_off[n_slots]; totals[3] = ~0ull >> 1;
 }
@@ -1526,15 +1546,14 @@ __global__ __launch_bounds__(256) void k_kept_fill(const uint32_t *__restrict__ 
 // =====================================================================================================
 // exclusive scan u32 -> u64 over n elements, out has n+1 entries
 // =====================================================================================================
-#define SCAN_CHUNK 4096
 
-__global__ __launch_bounds__(256) void k_scan_partials(const uint32_t *__restrict__ in, uint64_t n_scalar,
+__global__ __launch_bounds__(256) void k_scan_partials(const uint32_t *__restrict__ in, uint32_t stride, uint64_t n_scalar,
                                                        const uint64_t *__restrict__ n_ptr, uint64_t *__restrict__ partial) {
     __shared__ uint64_t wsum[4];
     const uint64_t n = n_ptr ? *n_ptr : n_scalar;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
     uint64_t s = 0;
-    for (uint32_t i = threadIdx.x; i < SCAN_CHUNK; i += 256) { const uint64_t a = base + i; if (a < n) s += in[a]; }
+    for (uint32_t i = threadIdx.x; i < SCAN_CHUNK; i += 256) { const uint64_t a = base + i; if (a < n) s += in[a * stride]; }
     const uint64_t inc = wave_incl_scan_u64(s);
     if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -1558,7 +1577,7 @@ __global__ __launch_bounds__(256) void k_scan_partials_scan(uint64_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, uint64_t n_scalar,
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__ in, uint32_t stride, uint64_t n_scalar,
                                                     const uint64_t *__restrict__ n_ptr, const uint64_t *__restrict__ partial,
                                                     uint64_t *__restrict__ out, uint64_t *__restrict__ total_out) {
     __shared__ uint64_t wsum[4];
@@ -1567,7 +1586,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
     uint32_t v[16];
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const uint64_t a = base + i; v[i] = a < n ? in[a] : 0u; s += v[i]; }
+    for (int i = 0; i < 16; ++i) { const uint64_t a = base + i; v[i] = a < n ? in[a * stride] : 0u; s += v[i]; }
     const uint64_t inc = wave_incl_scan_u64(s);
     if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -1593,7 +1612,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t *__restrict__
 __device__ __forceinline__ void rare_worker(uint32_t worker, uint32_t n_wide, uint32_t *hist, const PgRareArgs &A); // with the statistics kernels
 // RARE: blocks [n_scan, gridDim.x) are not part of the scan: each of their 4 waves is a worker of the rare statistics launch
 // (reads whose in-range interval needs more than 1024 bins; usually none) -- an empty launch of its own costs a kernel boundary.
-template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
+template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t *__restrict__ in, uint32_t stride, uint64_t n_scalar, const uint64_t *__restrict__ n_ptr,
                                                       uint64_t *__restrict__ out, uint64_t *__restrict__ state, uint32_t n_scan, PgRareArgs A,
                                                       uint64_t *__restrict__ total_out) {
     if (RARE) {
@@ -1615,7 +1634,7 @@ template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const
     uint32_t v[16];
     uint64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const uint64_t a = base + i; v[i] = a < n ? in[a] : 0u; s += v[i]; }
+    for (int i = 0; i < 16; ++i) { const uint64_t a = base + i; v[i] = a < n ? in[a * stride] : 0u; s += v[i]; }
     const uint64_t inc = wave_incl_scan_u64(s);
     if (lane_id() == WAVE - 1) wsum[threadIdx.x >> 6] = inc;
     __syncthreads();
@@ -2275,95 +2294,8 @@ __global__ __launch_bounds__(64) void k_read_stats_rare(PgRareArgs A) {
 // five lanes at once and the read's calibration and statistics by six (each lane one 8-byte value of a different
 // array), then handed round with ds_bpermute; the window comes in as one 8-byte load per lane (its two samples,
 // whatever the parity of the window start) and leaves as one 16-byte store.
-#ifndef PG_GATHER8_MEAN
-#define PG_GATHER8_MEAN 32
-#endif
-// one kept event by a group of G lanes (sub = lane within the group, g0 = the group's first lane), in two halves so that a caller
-// can have the loads of several events in flight: gather_load -- the read's calibration and statistics by five lanes and the
-// window's samples by every lane, all requested together; gather_finish -- conversion and 16-byte stores
-#define PG_GATHER_PASSES 4 // windows of up to 2 * G * PASSES samples have all their loads in flight (longer ones: the loop in gather_finish)
-struct GatherRegs { uint64_t h; uint2 q[PG_GATHER_PASSES]; };
 template <int G>
-__device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, uint32_t rd, uint32_t len, uint64_t src, uint64_t total, int scaling,
-                                            const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, GatherRegs &R) {
-    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
-    if (gcal) { // offset, scale, median, MAD of the read as one 32-byte record (written by the statistics kernels): four lanes, one transaction
-        R.h = sub < 4u ? reinterpret_cast<const uint64_t *>(gcal)[4ull * rd + sub] : 0ull;
-    } else {
-        const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
-                              : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
-        R.h = sub < (scaling ? 5u : 3u) ? *arr : 0ull;
-    }
-    const uint32_t odd = (uint32_t)(src & 1u);
-    const uint64_t d0 = src >> 1; // dword that holds sample src
-#pragma unroll
-    for (int ps = 0; ps < PG_GATHER_PASSES; ++ps) {
-        const uint32_t t = 2 * sub + 2 * G * ps;
-        const uint64_t d = d0 + (t >> 1);
-        R.q[ps] = make_uint2(0u, 0u);
-        if (t < len) {
-            if (2 * d + 3 < total) R.q[ps] = *reinterpret_cast<const uint2 *>(sig32 + d); // 8 bytes, 4-byte aligned
-            else { // the last dwords of the batch: no read beyond the buffer
-                const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
-                R.q[ps] = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
-            }
-        }
-    }
-}
-template <int G>
-__device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub, int g0, uint32_t len, uint64_t src, uint64_t dst, uint64_t total,
-                                              int scaling, double pa_min, double pa_max, double *__restrict__ samples, const GatherRegs &R, bool gcal) {
-    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
-    auto from = [&](uint64_t v, int k) { // the 64-bit value held by lane g0+k
-        return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), g0 + k, WAVE) << 32);
-    };
-    const uint32_t odd = (uint32_t)(src & 1u);
-    const uint64_t d0 = src >> 1;
-    const double offset = __longlong_as_double((long long)from(R.h, 0));
-    // gcal: the record holds range / digitisation as the statistics used it (the same expression, PgStatRec::scale)
-    const double scale = gcal ? __longlong_as_double((long long)from(R.h, 1)) : __longlong_as_double((long long)from(R.h, 1)) / __longlong_as_double((long long)from(R.h, 2));
-    const double md = scaling ? __longlong_as_double((long long)from(R.h, gcal ? 2 : 3)) : 0.0;
-    const double ma = scaling ? __longlong_as_double((long long)from(R.h, gcal ? 3 : 4)) : 1.0;
-    auto conv = [&](int raw) {
-        const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
-        double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
-        if (scaling) x = (x - md) / ma;                               // gmove.cpp:774
-        return x;
-    };
-    auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1
-        const int s0 = odd ? (int)qq.x >> 16 : (int)(short)(qq.x & 0xffffu);
-        const int s1 = odd ? (int)(short)(qq.y & 0xffffu) : (int)qq.x >> 16;
-        const double x0 = conv(s0);
-        if (t + 1 < len) {
-            const double x1 = conv(s1);
-            *reinterpret_cast<double2 *>(samples + dst + t) = make_double2(x0, x1); // 16 bytes, 8-byte aligned (streaming "nt" stores: measured, slower -- 21.0 -> 23.5 us, 260 -> 368 us at 2.1 M events)
-        } else samples[dst + t] = x0;
-    };
-#pragma unroll
-    for (int ps = 0; ps < PG_GATHER_PASSES; ++ps) { const uint32_t t = 2 * sub + 2 * G * ps; if (t < len) emit2(t, R.q[ps]); }
-    for (uint32_t t = 2 * sub + 2 * G * PG_GATHER_PASSES; t < len; t += 2 * G) { // very long windows (--margin, --max_dur)
-        const uint64_t d = d0 + (t >> 1);
-        uint2 qq;
-        if (2 * d + 3 < total) qq = *reinterpret_cast<const uint2 *>(sig32 + d);
-        else {
-            const uint32_t a = (uint32_t)(uint16_t)B.sig[src + t], b2 = t + 1 < len ? (uint32_t)(uint16_t)B.sig[src + t + 1] : 0u;
-            qq = odd ? make_uint2(a << 16, b2) : make_uint2(a | (b2 << 16), 0u);
-        }
-        emit2(t, qq);
-    }
-}
-template <int G>
-__device__ __forceinline__ void gather_one(const PgDevBatch &B, uint32_t sub, int g0, uint32_t rd, uint32_t len, uint64_t src, uint64_t dst,
-                                           uint64_t total, int scaling, double pa_min, double pa_max,
-                                           const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, double *__restrict__ samples) {
-    GatherRegs R;
-    gather_load<G>(B, sub, rd, len, src, total, scaling, med, mad, gcal, R);
-    gather_finish<G>(B, sub, g0, len, src, dst, total, scaling, pa_min, pa_max, samples, R, gcal != nullptr);
-}
-
-template <int G>
-__device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const uint32_t *__restrict__ ev_len,
-                                              const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
+__device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_kept, uint64_t total, const PgKeptRec *__restrict__ rec,
                                               const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                               const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, double *__restrict__ samples) {
     const int lane = lane_id();
@@ -2374,20 +2306,18 @@ __device__ __forceinline__ void gather_events(const PgDevBatch &B, uint64_t n_ke
         return (uint64_t)(uint32_t)__shfl((int)v, g0 + k, WAVE) | ((uint64_t)(uint32_t)__shfl((int)v, g0 + k + 1, WAVE) << 32);
     };
     for (uint64_t e = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G); e < n_kept; e += stride) {
-        // round 1: the event's six dwords by six lanes -- read, length, window start in the batch's signal (the emit kernels have
-        // added the read's sample offset: the window loads need no second hop), output offset
-        const uint32_t *p1 = sub == 0 ? ev_read + e : (sub == 1 ? ev_len + e : (sub < 4 ? reinterpret_cast<const uint32_t *>(ev_src + e) + (sub - 2)
-                             : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub - 4)));
+        // round 1: the event's six dwords by six lanes -- its record (window start in the batch's signal: the emit kernels have
+        // added the read's sample offset, the window loads need no second hop; length; read) and its output offset
+        const uint32_t *p1 = sub < 4 ? reinterpret_cast<const uint32_t *>(rec + e) + sub : reinterpret_cast<const uint32_t *>(samp_off + e) + (sub - 4);
         const uint32_t f = sub < 6 ? *p1 : 0u;
-        const uint32_t rd = (uint32_t)__shfl((int)f, g0, WAVE), len = (uint32_t)__shfl((int)f, g0 + 1, WAVE);
-        const uint64_t src = pair64(f, 2), dst = pair64(f, 4);
+        const uint32_t len = (uint32_t)__shfl((int)f, g0 + 2, WAVE), rd = (uint32_t)__shfl((int)f, g0 + 3, WAVE);
+        const uint64_t src = pair64(f, 0), dst = pair64(f, 4);
         // round 2, all in flight together: the read's calibration and statistics by five lanes, the window's samples by every lane
         gather_one<G>(B, sub, g0, rd, len, src, dst, total, scaling, pa_min, pa_max, med, mad, gcal, samples);
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const uint32_t *__restrict__ ev_len,
-                                                const uint32_t *__restrict__ ev_read, const uint64_t *__restrict__ ev_src,
+__global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
                                                 const uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                 const double *__restrict__ med, const double *__restrict__ mad,
                                                 double *__restrict__ samples, const double *__restrict__ gcal) {
@@ -2396,8 +2326,8 @@ __global__ __launch_bounds__(256) void k_gather(PgDevBatch B, const uint64_t *__
     const uint64_t total = B.sig_off[B.n_reads]; // samples in the batch: bounds the 8-byte reads
     // mean kept window (from the scan's total): 8 lanes per event (16 samples per pass) up to a mean of PG_GATHER8_MEAN samples --
     // half the waves of the 16-lane form; two passes over a 28-sample window still win (A/B on one box: 20.7 -> 19.5 us)
-    if (n_samples <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
-    else gather_events<16>(B, n_kept, total, ev_len, ev_read, ev_src, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
+    if (n_samples <= PG_GATHER8_MEAN * n_kept) gather_events<8>(B, n_kept, total, rec, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
+    else gather_events<16>(B, n_kept, total, rec, samp_off, scaling, pa_min, pa_max, med, mad, gcal, samples);
 }
 
 __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *__restrict__ read_needed,
@@ -2441,11 +2371,6 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *_
 // start / end time stamps, what rocprofv3's kernel trace reads) instead of standing between two recorded events, whose own cost
 // (3-5 us per pair) used to be counted into the kernel
 thread_local hipEvent_t pg_prof_start = nullptr, pg_prof_stop = nullptr;
-#define PG_LAUNCH(kernel, grid, block, shmem, stream, ...) do { (void)hipGetLastError(); \
-    if (pg_prof_start) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, pg_prof_start, pg_prof_stop, 0, __VA_ARGS__); pg_prof_start = nullptr; pg_prof_stop = nullptr; } \
-    else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
-    const hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
-#define PG_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf,
@@ -2468,14 +2393,16 @@ hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParam
     return hipSuccess;
 }
 
-hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist) {
+hipError_t pg_launch_events(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, uint32_t n_slots, uint32_t *hist,
+                            uint32_t part_hi_bits, uint32_t part_lo_bits) {
     if (B.n_reads == 0 || B.n_ops == 0) return hipSuccess;
     const uint32_t n_tiles = pg_tiles(B.n_ops, hist != nullptr);
     const uint32_t blocks = (n_tiles + 3) / 4;
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
-    if (hist && W.n_codes <= 1024) PG_LAUNCH((k_events<true, true>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
-    else if (hist) PG_LAUNCH((k_events<true, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist);
-    else PG_LAUNCH((k_events<false, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, (uint32_t *)nullptr);
+    if (hist && part_hi_bits) PG_LAUNCH((k_events<2, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, (int)part_hi_bits, n_tiles, hist, part_lo_bits);
+    else if (hist && W.n_codes <= 1024) PG_LAUNCH((k_events<1, true>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist, 0u);
+    else if (hist) PG_LAUNCH((k_events<1, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, hist, 0u);
+    else PG_LAUNCH((k_events<0, false>), dim3(blocks), dim3(1024), 0, st, B, W, O, nbits, n_tiles, (uint32_t *)nullptr, 0u);
     return hipSuccess;
 }
 
@@ -2497,12 +2424,21 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
         PgScanPlan P{};
         if (plan_keep) { P.keep = plan_keep; P.ev_off = plan_ev_off; P.plan_totals = plan_totals; P.running_out = running; P.ticket = plan_ticket; *plan_done = true; }
         PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
-                  (const uint64_t *)running, limit, tile_last, acc_copy, P);
+                  (const uint64_t *)running, limit, tile_last, acc_copy, P, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
         if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));
         if (tile_last) PG_HIP(hipMemsetAsync(tile_last, 0xff, sizeof(int32_t) * n_slots, st)); // -1: nothing to place
     }
+    return hipSuccess;
+}
+
+// partitioned ranking: exclusive tile prefixes per high digit (in place), region sizes, and -- one extra workgroup -- the prefix of the block sums
+hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot) {
+    const uint32_t n_tiles = pg_tiles(n_ops, true), R = 1u << P.hi_bits;
+    if (!n_tiles) { PG_HIP(hipMemsetAsync(P.totals, 0, sizeof(uint32_t) * R, st)); return hipSuccess; }
+    PG_LAUNCH(k_rank_scan, dim3((R + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES + 1), dim3(PG_SCAN_WAVES * WAVE), 0, st, P.hist, n_tiles, P.totals, (uint64_t *)nullptr, 0u, R,
+              (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, btot, (uint32_t)((n_ops + 255) / 256), P.Bp);
     return hipSuccess;
 }
 
@@ -2531,7 +2467,7 @@ hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         PG_LAUNCH(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
         PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, 1u << nbits,
-                  (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{});
+                  (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr);
         PG_LAUNCH(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         PG_LAUNCH(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);
@@ -2557,11 +2493,9 @@ hipError_t pg_launch_slot_bounds(hipStream_t st, const uint32_t *skey, const uin
 hipError_t pg_launch_slot_plan(hipStream_t st, const uint64_t *acc_cnt, const uint64_t *base, uint64_t *running, uint32_t limit,
                          uint32_t n_slots, uint64_t *keep, uint64_t *ev_off, uint64_t *totals, const uint32_t *hist, uint32_t n_tiles,
                          uint32_t *keep32, uint64_t *scan_scratch, const int32_t *tile_last, const PgGathered &G) {
-    if (!hist && n_slots > 4096 && keep32 && scan_scratch) {
-        PG_HIP(hipMemsetAsync(totals, 0, 32, st));
-        PG_LAUNCH(k_slot_keep, dim3((n_slots + 255) / 256), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, totals, G);
-        PG_HIP(pg_launch_scan_u32_u64(st, keep32, n_slots, nullptr, ev_off, scan_scratch, nullptr, nullptr));
-        PG_LAUNCH(k_slot_totals, dim3(1), dim3(1), 0, st, (const uint64_t *)ev_off, n_slots, totals);
+    if (!hist && keep32 && scan_scratch) { // every ranking but the direct one (k_region_place / k_kept_pos read keep32 or keep)
+        const uint32_t nb = (n_slots + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        PG_LAUNCH(k_slot_cut, dim3(nb), dim3(256), 0, st, acc_cnt, base, running, limit, n_slots, keep, keep32, ev_off, totals, scan_scratch, nb, G);
         return hipSuccess;
     }
     PG_LAUNCH(k_slot_plan, dim3(1), dim3(1024), 0, st, acc_cnt, base, running, limit, n_slots, keep, ev_off, totals, hist, n_tiles, tile_last, G);
@@ -2578,24 +2512,24 @@ hipError_t pg_launch_kept_meta(hipStream_t st, const uint32_t *skey, const uint3
     return hipSuccess;
 }
 
-hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
+hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t stride, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
                                   const PgRareArgs *rare, uint64_t *total_out) {
     const uint32_t nb = (uint32_t)((n_cap + SCAN_CHUNK - 1) / SCAN_CHUNK), nbl = nb ? nb : 1;
     if (nbl <= 64) { // one look-back round: a single launch wins (11 vs 17 us at 25 blocks)
         if (rare) { // the rare statistics ride in this launch: 4 workers per extra block, PG_HUGE_BLOCKS of them for the huge list
             const uint32_t want = rare->wide_blocks < 64 ? 64u : (rare->wide_blocks > 2048 ? 2048u : rare->wide_blocks);
             const uint32_t extra = (want + PG_HUGE_BLOCKS + 3) / 4;
-            PG_LAUNCH(k_scan_chained<true>, dim3(nbl + extra), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, *rare, total_out);
-        } else PG_LAUNCH(k_scan_chained<false>, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, out, scratch, nbl, PgRareArgs{}, total_out);
+            PG_LAUNCH(k_scan_chained<true>, dim3(nbl + extra), dim3(256), 0, st, in, stride, n_cap, n_ptr, out, scratch, nbl, *rare, total_out);
+        } else PG_LAUNCH(k_scan_chained<false>, dim3(nbl), dim3(256), 0, st, in, stride, n_cap, n_ptr, out, scratch, nbl, PgRareArgs{}, total_out);
         return hipSuccess;
     }
     if (rare) PG_HIP(pg_launch_read_stats_rare(st, *rare));
     // long inputs: the look-back chain (one round per 64 blocks) costs more than two extra launches (52 vs 33 us at 523
     // blocks); the partial sums live behind the chained scan's state, which has to stay zero
     uint64_t *partial = scratch + 72;
-    PG_LAUNCH(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, partial);
+    PG_LAUNCH(k_scan_partials, dim3(nbl), dim3(256), 0, st, in, stride, n_cap, n_ptr, partial);
     PG_LAUNCH(k_scan_partials_scan, dim3(1), dim3(256), 0, st, partial, nbl);
-    PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, n_cap, n_ptr, (const uint64_t *)partial, out, total_out);
+    PG_LAUNCH(k_scan_apply, dim3(nbl), dim3(256), 0, st, in, stride, n_cap, n_ptr, (const uint64_t *)partial, out, total_out);
     return hipSuccess;
 }
 
@@ -2641,13 +2575,13 @@ hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t
     return hipSuccess;
 }
 
-hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const uint32_t *ev_len,
-                      const uint32_t *ev_read, const uint64_t *ev_src, const uint64_t *samp_off, int scaling, double pa_min,
+hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec,
+                      const uint64_t *samp_off, int scaling, double pa_min,
                       double pa_max, const double *med, const double *mad, double *samples, const double *gcal) {
     if (n_kept_cap == 0) return hipSuccess;
     uint64_t blocks = (n_kept_cap + 15) / 16;
     if (blocks > 256ull * 32) blocks = 256ull * 32;
-    PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, ev_len, ev_read, ev_src, samp_off, scaling,
+    PG_LAUNCH(k_gather, dim3((uint32_t)blocks), dim3(256), 0, st, B, n_kept_ptr, rec, samp_off, scaling,
                        pa_min, pa_max, med, mad, samples, gcal);
     return hipSuccess;
 }

@@ -1,0 +1,589 @@
+// pg_place.hip -- hand-written gfx950 kernels that PLACE the accepted events of a batch in the reference's output order (k-mer-major,
+// inside a k-mer: PAF line, then event index; src/gmove.cpp:732, 891, 925-950) when there are more k-mers than the direct ranking of
+// pg_kernels.hip holds (> 1024: k = 9 has 262 144), and the consumers whose work scales with the number of KEPT events.
+//
+// Partitioned ranking (1024 < slots <= 2^20; round 3). Round 2 sorted (slot, op index) pairs with two LSD radix passes and then needed
+// three scattered 4..8-byte stores per kept event to bring window, length and read into k-mer order: 46 M write requests of 32 bytes at
+// k = 9, 0.91 ms of a 2.85 ms step (profiles/r03_base_k9_traffic.json). Now every accepted event travels as ONE 16-byte element that
+// already holds all a kept event needs -- worked out in source order, where the loads are shared by neighbouring ops:
+//   k_events<2>       slots of all ops + per-(tile, high digit) counts                                   (pg_kernels.hip)
+//   k_rank_scan       tile prefixes per high digit, region sizes; one extra workgroup: prefix of the 256-op block sums (Bp)
+//   k_part_bases      regions = high digits, each padded to whole tiles of 4096 elements; per read: op-sum in front of its first op
+//   k_part_scatter    pass A: elements {slot, window start, length, read} partitioned by high digit, stable, through an LDS stage
+//                     in digit order (runs of ~8 elements = 128 bytes leave together)
+//   k_region_count / k_region_scan   pass B counts: per (region tile, low digit), prefixes along each region -> accepted events per slot
+//   (the sample_limit cut: k_slot_keep + offsets, pg_kernels.hip; with a base from other ranks in a multi-GPU job)
+//   k_region_place    pass B: rank inside the slot = region-tile prefix + rank inside the tile; kept events (rank < keep) leave as
+//                     PgKeptRec records at ev_off[slot] + rank, again in runs through the LDS stage
+// Offsets + gather for many kept events (k_len_partials, k_partials_scan, k_gather_chunks): the exclusive scan of the kept window
+// lengths happens inside the gather's workgroups (chunks of 1024 events, chunk bases from a small reduction), so the lengths
+// are read once and the offsets written once, not read / written / read again by a scan kernel of their own.
+#include "pg_dev.h"
+
+// =====================================================================================================
+// op-sum prefixes: window starts of direct reads without a walk
+// =====================================================================================================
+// sum of op_n over ALL ops of the batch in front of op x, modulo 2^32 (differences inside one read are exact: a read's samples fit
+// 31 bits): Bp = exclusive prefix of k_events' 256-op block sums, cum = its in-block sums at 4-op granularity
+__device__ __forceinline__ uint32_t op_prefix(const PgDevBatch &B, const PgWalkOut &O, const uint32_t *__restrict__ Bp, uint64_t x) {
+    uint32_t s = Bp[x >> 8] + O.cum[x >> 2];
+    const uint64_t y = x & ~3ull, last = B.n_ops ? B.n_ops - 1 : 0;
+    const uint32_t a = B.op_n[y < last ? y : last], b = B.op_n[y + 1 < last ? y + 1 : last], c = B.op_n[y + 2 < last ? y + 2 : last]; // unconditional: in flight together
+    const uint32_t m = (uint32_t)(x & 3);
+    s += (m > 0 ? a : 0u) + (m > 1 ? b : 0u) + (m > 2 ? c : 0u);
+    return s;
+}
+
+// what travels with an accepted event: y = window start in the batch's signal (low 32 bits) or the error code of an event whose
+// window is not printable, z = length (24 bits; 0 = error) | high 8 bits of the start, w = read. A kept event's window must be
+// printable (gmove.cpp:928-944 is undefined for margin > start or an empty window); whether it is only matters once the event is
+// KEPT, so the verdict travels too and k_region_place reports it.
+// have_row (sig_move_offset == 0): the caller holds op_n[g] and the sum of the ops in front of g inside its group of four (from its
+// neighbouring lanes: no loads)
+__device__ __forceinline__ uint4 event_element(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const uint32_t *__restrict__ Bp,
+                                               uint32_t slot, uint64_t g, uint32_t rd, bool have_row, uint32_t row_len, uint32_t row_partial) {
+    const PgReadMeta *mt = O.meta + rd;
+    const uint2 lq = *reinterpret_cast<const uint2 *>(&mt->L);     // L, qs
+    const uint4 fs = *reinterpret_cast<const uint4 *>(&mt->flags); // flags, opsum0, sig0
+    const uint64_t sig0 = (uint64_t)fs.z | ((uint64_t)fs.w << 32);
+    const uint64_t ge = g + W.sig_move_offset; // the event's window is that of match i + sig_move_offset
+    uint32_t start, len; bool ok = true;
+    if (fs.x & PG_RM_GENERIC) { start = O.m_start[ge]; len = O.m_len[ge]; }
+    else {
+        len = have_row ? row_len : B.op_n[ge];
+        const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + row_partial : op_prefix(B, O, Bp, ge);
+        const uint64_t st = (uint64_t)lq.y + (uint32_t)(pre - fs.y);
+        start = (uint32_t)st;
+        ok = st + len <= 0x7fffffffull;
+    }
+    int code = ok ? 0 : PGR_ERR_RANGE;
+    const uint64_t we64 = (uint64_t)start + len + W.print_margin;
+    const uint32_t we = (uint32_t)(we64 > lq.x ? lq.x : we64), ws = start - W.print_margin;
+    if (ok && (W.print_margin > start || we <= ws)) code = PGR_ERR_WINDOW;
+    const uint64_t src = sig0 + ws;
+    const uint32_t wl = we - ws;
+    if (!code && (wl >= (1u << 24) || (src >> 40))) code = PGR_ERR_RANGE; // (a window of 2^24 samples, a batch of 2^40: not representable here)
+    if (code) return make_uint4(slot, (uint32_t)code, 0u, rd);
+    return make_uint4(slot, (uint32_t)src, wl | ((uint32_t)(src >> 32) << 24), rd);
+}
+
+// =====================================================================================================
+// a tile of 4096 elements in stable digit order (512 threads: 8 waves x 8 rows of 64)
+// =====================================================================================================
+#define PG_PART_WAVES 8
+#define PG_PART_THREADS (PG_PART_WAVES * WAVE)
+#define PG_PART_ROWS (PG_SORT_TILE / PG_PART_THREADS)
+static_assert(PG_PART_ROWS * PG_PART_THREADS == PG_SORT_TILE, "tile geometry");
+#define PG_PART_TILES_PER_WG 4 // consecutive tiles of pass A per workgroup: a digit's four tile prefixes are ONE 16-byte load of the [digit][tile] table
+
+struct PartLds {
+    uint4 *stage;    // [PG_SORT_TILE] the tile's elements in digit order
+    uint32_t *cnt;   // [PG_PART_WAVES][ndig / 2] per-wave counts, two 16-bit digits per word (a wave holds 512 elements, a tile 4096)
+    uint32_t *ls;    // [ndig + 1] first stage position of every digit; [ndig] = elements of the tile
+    uint32_t *aux;   // [2 * ndig]
+    uint32_t *wsum;  // [PG_PART_WAVES]
+};
+static inline size_t part_lds_bytes(uint32_t ndig) {
+    const uint32_t half = ndig / 2 ? ndig / 2 : 1;
+    return (size_t)PG_SORT_TILE * 16 + ((size_t)PG_PART_WAVES * half + (ndig + 4) + 2 * ndig + 16) * 4;
+}
+__device__ __forceinline__ PartLds part_lds(uint32_t ndig) {
+    extern __shared__ uint4 pg_part_smem[];
+    const uint32_t half = ndig / 2 ? ndig / 2 : 1;
+    PartLds L;
+    L.stage = pg_part_smem;
+    L.cnt = reinterpret_cast<uint32_t *>(pg_part_smem + PG_SORT_TILE);
+    L.ls = L.cnt + PG_PART_WAVES * half;
+    L.aux = L.ls + ndig + 4;
+    L.wsum = L.aux + 2 * ndig;
+    return L;
+}
+
+// dig / valid: the thread's PG_PART_ROWS elements (element of row r: w * 512 + r * 64 + lane of the tile, i.e. source order = wave,
+// row, lane). cnt zeroed and visible (barrier) on entry. On exit (behind a barrier): j[r] = place of the element among the tile's valid
+// elements in (digit, source order) order; ls as described above. One pass: the count and the rank inside the wave come from the
+// same ordered walk over the rows (ballots find the lanes of equal digit; the lowest of them advances the wave's counter).
+__device__ __forceinline__ void tile_digit_order(const uint32_t (&dig)[PG_PART_ROWS], const bool (&valid)[PG_PART_ROWS], int nbits, uint32_t ndig,
+                                                 const PartLds &L, uint32_t (&j)[PG_PART_ROWS]) {
+    const uint32_t tid = threadIdx.x, w = tid >> 6, half = ndig / 2 ? ndig / 2 : 1;
+    const int lane = lane_id();
+    uint32_t *mycnt = L.cnt + w * half;
+    uint32_t lrank[PG_PART_ROWS];
+#pragma unroll
+    for (int r = 0; r < PG_PART_ROWS; ++r) {
+        const uint32_t d = dig[r], sh = (d & 1u) * 16u;
+        const uint64_t peers = match_digit(d, valid[r], nbits);
+        uint32_t b = 0;
+        if (valid[r]) b = (reinterpret_cast<volatile uint32_t *>(mycnt)[d >> 1] >> sh) & 0xffffu; // every peer reads the running count of its digit ...
+        __builtin_amdgcn_wave_barrier();
+        if (valid[r] && lane == __ffsll((long long)peers) - 1) atomicAdd(&mycnt[d >> 1], (uint32_t)__popcll(peers) << sh); // ... then the lowest advances it (the other half of the word may belong to another digit's leader: an atomic)
+        __builtin_amdgcn_wave_barrier();
+        lrank[r] = b + (uint32_t)__popcll(peers & lanemask_lt());
+    }
+    __syncthreads();
+    // per digit: exclusive prefix over the waves (in place, both halves of a word at once: sums stay below 2^16), the tile's total
+    uint32_t te = 0, to = 0;
+    if (tid < half) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < PG_PART_WAVES; ++ww) { const uint32_t word = L.cnt[ww * half + tid]; L.cnt[ww * half + tid] = run; run += word; }
+        te = run & 0xffffu; to = run >> 16;
+    }
+    const uint32_t s = te + to, inc = wave_incl_scan_u32(s);
+    if (lane == WAVE - 1) L.wsum[w] = inc;
+    __syncthreads();
+    uint32_t off = inc - s;
+    for (uint32_t ww = 0; ww < w; ++ww) off += L.wsum[ww];
+    if (tid < half) { L.ls[2 * tid] = off; if (2 * tid + 1 < ndig) L.ls[2 * tid + 1] = off + te; }
+    if (tid == PG_PART_THREADS - 1) L.ls[ndig] = off + s; // threads behind the digits hold 0: the last thread's prefix is the total
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PG_PART_ROWS; ++r) {
+        const uint32_t d = dig[r], sh = (d & 1u) * 16u;
+        j[r] = valid[r] ? L.ls[d] + ((L.cnt[w * half + (d >> 1)] >> sh) & 0xffffu) + lrank[r] : 0u;
+    }
+}
+
+// =====================================================================================================
+// pass A
+// =====================================================================================================
+// workgroup 0: the regions. Region r = the accepted events whose slot has high digit r, padded to whole tiles, so that a tile of pass B
+// lies in ONE region: rbase[r] = first element, tile_region[t] = region of tile t, n_tilesB = tiles in use.
+// workgroups 1..: per read, the op-sum in front of its first op (op_prefix) and the "generic" flag folded into its record, so that an
+// event's element costs ONE record load besides the owner look-up.
+__global__ __launch_bounds__(1024) void k_part_bases(const uint32_t *__restrict__ totals, uint32_t R, uint32_t *__restrict__ rbase,
+                                                     uint32_t *__restrict__ tile_region, uint32_t *__restrict__ n_tilesB, uint32_t tilesB_cap,
+                                                     PgDevBatch B, PgWalkOut O, const uint32_t *__restrict__ Bp) {
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x > 0) {
+        const uint32_t r = (blockIdx.x - 1) * 1024 + tid;
+        if (r < B.n_reads) {
+            PgReadMeta *mt = O.meta + r;
+            uint32_t flags = mt->flags;
+            const bool gen = O.gen_flag[r] == O.batch_id;
+            if (gen) flags |= PG_RM_GENERIC;
+            mt->opsum0 = ((flags & PG_RM_DIRECT_OK) && !gen) ? op_prefix(B, O, Bp, mt->o0) : 0u;
+            mt->flags = flags;
+        }
+        return;
+    }
+    __shared__ uint32_t sb[PG_RANK_MAX_DIGITS + 1], wsum[16];
+    const uint32_t nt = tid < R ? (totals[tid] + PG_SORT_TILE - 1) / PG_SORT_TILE : 0u;
+    const uint32_t inc = wave_incl_scan_u32(nt);
+    if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t off = inc - nt, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < (tid >> 6)) off += wsum[w]; total += wsum[w]; }
+    if (tid < R) { sb[tid] = off; rbase[tid] = off * PG_SORT_TILE; }
+    if (tid == 0) { sb[R] = total; rbase[R] = total * PG_SORT_TILE; *n_tilesB = total; }
+    __syncthreads();
+    for (uint32_t t = tid; t < total && t < tilesB_cap; t += 1024) { // the region of tile t: the last r with sb[r] <= t (empty regions share their base with the next one)
+        uint32_t lo = 0, hi = R; // invariant: sb[lo] <= t < sb[hi]
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sb[mid] <= t) lo = mid; else hi = mid; }
+        tile_region[t] = lo;
+    }
+}
+
+// pass A proper: the elements of PG_PART_TILES_PER_WG consecutive tiles of op indices go to their regions
+__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_part_scatter(const uint32_t *__restrict__ ev_slot, uint32_t n, uint32_t shift, int nbits, uint32_t n_tiles_pad,
+                                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ rbase,
+                                                                   PgDevBatch B, PgWalkParams W, PgWalkOut O, const uint32_t *__restrict__ Bp, uint4 *__restrict__ elemA,
+                                                                   uint16_t *__restrict__ loA) {
+    const uint32_t ndig = 1u << nbits, tid = threadIdx.x, w = tid >> 6;
+    const int lane = lane_id();
+    const PartLds L = part_lds(ndig);
+    const uint32_t tile0 = blockIdx.x * PG_PART_TILES_PER_WG;
+    // the tile prefixes of digits tid and tid + 512 for the four tiles: [digit][tile] table, four tiles = one 16-byte load
+    uint4 hc[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}; uint32_t rb[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t d = tid + q * PG_PART_THREADS;
+        if (d < ndig) { hc[q] = *reinterpret_cast<const uint4 *>(hist + (uint64_t)d * n_tiles_pad + tile0); rb[q] = rbase[d]; }
+    }
+    for (uint32_t k = 0; k < PG_PART_TILES_PER_WG; ++k) {
+        const uint64_t T0 = (uint64_t)(tile0 + k) * PG_SORT_TILE;
+        if (T0 >= n) break; // (block-uniform)
+        if (k) __syncthreads(); // the previous tile's stage and tables are read until its last thread is through
+        const uint32_t tile_first = O.tile_read[tile0 + k];
+        for (uint32_t i = tid; i < PG_PART_WAVES * (ndig / 2 ? ndig / 2 : 1); i += PG_PART_THREADS) L.cnt[i] = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t d = tid + q * PG_PART_THREADS;
+            if (d < ndig) L.aux[d] = rb[q] + (k == 0 ? hc[q].x : (k == 1 ? hc[q].y : (k == 2 ? hc[q].z : hc[q].w)));
+        }
+        // the tile's slots, then -- all rows' loads in flight -- the elements of the accepted events
+        uint32_t key[PG_PART_ROWS]; bool valid[PG_PART_ROWS]; uint32_t dig[PG_PART_ROWS];
+#pragma unroll
+        for (int r = 0; r < PG_PART_ROWS; ++r) {
+            const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+            key[r] = g < n ? ev_slot[g] : PG_INVALID_SLOT;
+        }
+        // every lane's own op_n: the window length of its event, and -- handed along the lanes -- the ops in front of it inside its group of
+        // four, which is what the 4-op granularity of k_events' in-block sums leaves to add (a row starts at a multiple of 64 ops)
+        const bool have_row = W.sig_move_offset == 0;
+        uint32_t opn[PG_PART_ROWS];
+#pragma unroll
+        for (int r = 0; r < PG_PART_ROWS; ++r) {
+            const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+            opn[r] = (have_row && g < n) ? B.op_n[g] : 0u;
+        }
+        uint4 el[PG_PART_ROWS];
+#pragma unroll
+        for (int r = 0; r < PG_PART_ROWS; ++r) {
+            const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+            const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3
+            const uint32_t m = (uint32_t)lane & 3u, partial = (m > 0 ? v1 : 0u) + (m > 1 ? v2 : 0u) + (m > 2 ? v3 : 0u);
+            valid[r] = key[r] != PG_INVALID_SLOT;
+            dig[r] = (key[r] >> shift) & (ndig - 1u);
+            el[r] = make_uint4(0, 0, 0, 0);
+            if (valid[r]) { // the read: its entry in the tile's table rides in the slot word's upper bits (k_events<2>), else a look-up
+                const uint32_t rel = key[r] >> PG_PART_REL_SHIFT;
+                const uint32_t rd = rel != PG_PART_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, g);
+                el[r] = event_element(B, W, O, Bp, key[r] & ((1u << PG_PART_REL_SHIFT) - 1u), g, rd, have_row, opn[r], partial);
+            }
+        }
+        __syncthreads();
+        uint32_t j[PG_PART_ROWS];
+        tile_digit_order(dig, valid, nbits, ndig, L, j);
+#pragma unroll
+        for (int r = 0; r < PG_PART_ROWS; ++r) if (valid[r]) L.stage[j[r]] = el[r];
+        __syncthreads();
+        // consecutive threads store consecutive elements of a digit's run
+        const uint32_t total = L.ls[ndig];
+        for (uint32_t jj = tid; jj < total; jj += PG_PART_THREADS) {
+            const uint4 e = L.stage[jj];
+            const uint32_t d = (e.x >> shift) & (ndig - 1u);
+            const uint64_t dst = (uint64_t)L.aux[d] + (jj - L.ls[d]);
+            elemA[dst] = e;
+            loA[dst] = (uint16_t)(e.x & ((1u << shift) - 1u)); // the low digits once more, 2 bytes each: all that pass B's count kernel reads
+        }
+    }
+}
+
+// =====================================================================================================
+// pass B
+// =====================================================================================================
+#define PG_G2_SUB 1024   // events a workgroup of the chunked gather holds in LDS at once: records + offsets = 20 KB (4 per thread in the scan)
+#define PG_PLACE_CSPAN 64 // chunks of the gather a region tile's kept events usually span (LDS sums; beyond: global atomics)
+__device__ __forceinline__ bool region_tile(uint32_t t, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
+                                            const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, uint32_t &r, uint64_t &first, uint32_t &nv) {
+    if (t >= *n_tilesB) return false;
+    r = tile_region[t];
+    first = (uint64_t)t * PG_SORT_TILE;
+    const uint64_t end = (uint64_t)rbase[r] + totals[r];
+    nv = end - first < PG_SORT_TILE ? (uint32_t)(end - first) : PG_SORT_TILE;
+    return true;
+}
+
+// events per (region tile, low digit): histB[tile][digit] (one contiguous row per tile)
+__global__ __launch_bounds__(256) void k_region_count(const uint16_t *__restrict__ loA, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
+                                                      const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, int lo_bits, uint32_t *__restrict__ histB) {
+    __shared__ uint32_t cnt[PG_RANK_MAX_DIGITS];
+    uint32_t r, nv; uint64_t first;
+    if (!region_tile(blockIdx.x, n_tilesB, tile_region, rbase, totals, r, first, nv)) return;
+    const uint32_t ndig = 1u << lo_bits, tid = threadIdx.x;
+    for (uint32_t d = tid; d < ndig; d += 256) cnt[d] = 0;
+    __syncthreads();
+    // 8 digits (16 bytes) per thread and load
+    const uint4 *__restrict__ keys = reinterpret_cast<const uint4 *>(loA + first); // (first is a multiple of the tile: 16-byte aligned)
+    uint4 kv[PG_SORT_TILE / 256 / 8];
+#pragma unroll
+    for (int i = 0; i < PG_SORT_TILE / 256 / 8; ++i) kv[i] = keys[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < PG_SORT_TILE / 256 / 8; ++i) {
+        const uint32_t x0 = (i * 256 + tid) * 8u, wd[4] = {kv[i].x, kv[i].y, kv[i].z, kv[i].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (x0 + q < nv) atomicAdd(&cnt[(wd[q >> 1] >> (16 * (q & 1))) & (ndig - 1u)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < ndig; d += 256) histB[(uint64_t)blockIdx.x * ndig + d] = cnt[d];
+}
+
+// one workgroup per region, one thread per low digit: exclusive prefixes along the region's tiles (in place); the totals are the
+// accepted events of the slots (region << lo_bits | digit) -- what pg_count hands out
+__global__ __launch_bounds__(1024) void k_region_scan(uint32_t *__restrict__ histB, const uint32_t *__restrict__ rbase, int lo_bits, uint32_t n_slots,
+                                                      uint64_t *__restrict__ acc_cnt, uint64_t *__restrict__ acc_copy) {
+    const uint32_t r = blockIdx.x, d = threadIdx.x, ndig = 1u << lo_bits;
+    if (d >= ndig) return;
+    const uint32_t t0 = rbase[r] / PG_SORT_TILE, t1 = rbase[r + 1] / PG_SORT_TILE;
+    uint32_t run = 0;
+    uint32_t t = t0;
+    for (; t + 4 <= t1; t += 4) { // four independent loads in flight
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = histB[(uint64_t)(t + u) * ndig + d];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { histB[(uint64_t)(t + u) * ndig + d] = run; run += v[u]; }
+    }
+    for (; t < t1; ++t) { const uint32_t v = histB[(uint64_t)t * ndig + d]; histB[(uint64_t)t * ndig + d] = run; run += v; }
+    const uint64_t slot = ((uint64_t)r << lo_bits) | d;
+    if (slot < n_slots) { acc_cnt[slot] = run; if (acc_copy) acc_copy[slot] = run; }
+}
+
+// pass B proper: the kept events of a region tile leave as records, in k-mer-major order
+__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_region_place(const uint4 *__restrict__ elemA, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
+                                                                   const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, int lo_bits, uint32_t n_slots,
+                                                                   const uint32_t *__restrict__ histB, const uint32_t *__restrict__ keep32, const uint64_t *__restrict__ ev_off,
+                                                                   PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift) {
+    const uint32_t ndig = 1u << lo_bits, tid = threadIdx.x, w = tid >> 6;
+    const int lane = lane_id();
+    // the tile's elements are requested in front of the look-ups that say how many of them count (the buffer holds every tile of the grid)
+    uint32_t ex[PG_PART_ROWS], ey[PG_PART_ROWS], ez[PG_PART_ROWS], ew[PG_PART_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < PG_PART_ROWS; ++rr) {
+        const uint4 v = elemA[(uint64_t)blockIdx.x * PG_SORT_TILE + w * (PG_PART_ROWS * WAVE) + rr * WAVE + lane];
+        ex[rr] = v.x; ey[rr] = v.y; ez[rr] = v.z; ew[rr] = v.w;
+    }
+    uint32_t r, nv; uint64_t first;
+    if (!region_tile(blockIdx.x, n_tilesB, tile_region, rbase, totals, r, first, nv)) return;
+    const PartLds L = part_lds(ndig);
+    __shared__ uint32_t csum[PG_PLACE_CSPAN]; // window lengths of this tile's kept events per chunk of the gather (k_gather_chunks)
+    if (tid < PG_PLACE_CSPAN) csum[tid] = 0;
+    const uint64_t c_lo = ev_off[(uint64_t)r << lo_bits] >> chunk_shift; // first chunk the region's kept events can fall into
+    for (uint32_t i = tid; i < PG_PART_WAVES * (ndig / 2 ? ndig / 2 : 1); i += PG_PART_THREADS) L.cnt[i] = 0;
+    // per digit (= slot of this region): events of the slot in the region's earlier tiles, how many it still keeps, where they go
+    uint32_t tp[2] = {0, 0}, kp[2] = {0, 0}, eo[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t d = tid + q * PG_PART_THREADS;
+        const uint64_t slot = ((uint64_t)r << lo_bits) | d;
+        if (d < ndig && slot < n_slots) { tp[q] = histB[(uint64_t)blockIdx.x * ndig + d]; kp[q] = keep32[slot]; eo[q] = (uint32_t)ev_off[slot]; }
+    }
+    bool valid[PG_PART_ROWS]; uint32_t dig[PG_PART_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < PG_PART_ROWS; ++rr) {
+        const uint32_t x = w * (PG_PART_ROWS * WAVE) + rr * WAVE + lane;
+        valid[rr] = x < nv;
+        dig[rr] = ex[rr] & (ndig - 1u);
+    }
+    __syncthreads();
+    uint32_t j[PG_PART_ROWS];
+    tile_digit_order(dig, valid, lo_bits, ndig, L, j);
+#pragma unroll
+    for (int rr = 0; rr < PG_PART_ROWS; ++rr) if (valid[rr]) L.stage[j[rr]] = make_uint4(ex[rr], ey[rr], ez[rr], ew[rr]);
+    // element at stage position jj (digit d) has rank tp[d] + jj - ls[d] inside its slot: kept iff jj < ls[d] + (keep - tp), and then it
+    // goes to ev_off + rank = jj + (ev_off + tp - ls[d])
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t d = tid + q * PG_PART_THREADS;
+        if (d < ndig) { const uint32_t lsd = L.ls[d]; L.aux[d] = lsd + (kp[q] > tp[q] ? kp[q] - tp[q] : 0u); L.aux[ndig + d] = eo[q] + tp[q] - lsd; }
+    }
+    __syncthreads();
+    const uint32_t total = L.ls[ndig];
+    for (uint32_t jj = tid; jj < total; jj += PG_PART_THREADS) {
+        const uint4 e = L.stage[jj];
+        const uint32_t d = e.x & (ndig - 1u);
+        if (jj >= L.aux[d]) continue; // its k-mer is full (gmove.cpp:925-927)
+        const uint32_t dst = jj + L.aux[ndig + d], len = e.z & 0xffffffu;
+        if (len == 0) { report_error(O, e.w, (int)e.y); K.rec[dst] = PgKeptRec{0, 0, e.w}; } // the verdict event_element left
+        else K.rec[dst] = PgKeptRec{(uint64_t)e.y | ((uint64_t)(e.z >> 24) << 32), len, e.w};
+        if (K.read_needed) K.read_needed[e.w] = 1;
+        if (!part) continue;
+        const uint64_t ch = ((uint64_t)dst >> chunk_shift) - c_lo;
+        if (ch < PG_PLACE_CSPAN) atomicAdd(&csum[ch], len);
+        else atomicAdd(reinterpret_cast<unsigned long long *>(part + ((uint64_t)dst >> chunk_shift)), (unsigned long long)len); // a region that keeps more than 64 chunks of events
+    }
+    __syncthreads();
+    if (part && tid < PG_PLACE_CSPAN && csum[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(part + c_lo + tid), (unsigned long long)csum[tid]); // integer sums: any order
+}
+
+// =====================================================================================================
+// sample offsets + gather of many kept events in one kernel (gmove.cpp:773-775, 938-944)
+// =====================================================================================================
+
+// sum of the kept window lengths of every chunk of `chunk` events
+__global__ __launch_bounds__(256) void k_len_partials(const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ n_kept_ptr, uint32_t chunk, uint64_t *__restrict__ part) {
+    __shared__ uint64_t wsum[4];
+    const uint64_t n = n_kept_ptr[0], e0 = (uint64_t)blockIdx.x * chunk;
+    uint64_t s = 0;
+    if (e0 < n) {
+        const uint64_t cnt = n - e0 < chunk ? n - e0 : chunk;
+        const uint32_t *__restrict__ lens = reinterpret_cast<const uint32_t *>(rec + e0) + 2;
+        for (uint64_t i = threadIdx.x; i < cnt; i += 256) s += lens[4 * i];
+    }
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, WAVE);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the (<= 8192) chunk sums in place; the total goes where the batch's consumers expect it
+__global__ __launch_bounds__(1024) void k_partials_scan(uint64_t *__restrict__ part, uint32_t n_chunks, const uint64_t *__restrict__ n_kept_ptr,
+                                                        uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t wsum[16];
+    const uint32_t tid = threadIdx.x;
+    uint64_t v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint32_t c = tid * 8 + i; v[i] = c < n_chunks ? part[c] : 0; s += v[i]; }
+    const uint64_t inc = wave_incl_scan_u64(s);
+    if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint64_t run = inc - s, tot = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < (tid >> 6)) run += wsum[w]; tot += wsum[w]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const uint32_t c = tid * 8 + i; if (c < n_chunks) part[c] = run; run += v[i]; }
+    if (tid == 0) { samp_off[n_kept_ptr[0]] = tot; *total_out = tot; }
+}
+
+// one workgroup per chunk of sub_per_chunk * PG_G2_SUB kept events: the exclusive scan of their window lengths (chunk base from
+// k_partials_scan), the offsets written for the batch's other consumers, and the gather of the windows -- G lanes per event as k_gather.
+// The gather is a chain record -> window -> stores per event, and what bounds it is how many of those chains the chip has in flight
+// (random ~25..60-byte reads: scatter_probe): E events per lane group and trip have their loads requested together.
+#ifndef PG_GC_EVENTS
+#define PG_GC_EVENTS 2
+#endif
+// The sub-chunk's records sit in LDS (they came in with one coalesced pass, which also feeds the scan of their lengths): an event's
+// chain is then LDS -> window + calibration (one memory round) -> stores, not record -> window -> stores (two)
+template <int G, int P>
+__device__ __forceinline__ void gather_chunk(const PgDevBatch &B, uint64_t total, const uint4 *s_rec, uint32_t cnt, uint64_t base,
+                                             const uint32_t *s_off, int scaling, double pa_min, double pa_max, const double *__restrict__ gcal, double *__restrict__ samples) {
+    const int lane = lane_id();
+    const int g0 = lane & ~(G - 1);
+    const uint32_t sub = (uint32_t)lane & (uint32_t)(G - 1);
+    constexpr int E = PG_GC_EVENTS;
+    constexpr uint32_t STEP = 256 / G;
+    for (uint32_t i0 = threadIdx.x / G; i0 < cnt; i0 += E * STEP) {
+        uint32_t len[E], so[E]; uint64_t src[E]; GatherRegs<P> R[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t i = i0 + u * STEP;
+            const uint4 r = s_rec[i < cnt ? i : 0u]; // every lane of the group reads the same 16 bytes: a broadcast
+            so[u] = s_off[i < cnt ? i : 0u];
+            len[u] = i < cnt ? r.z : 0u; src[u] = (uint64_t)r.x | ((uint64_t)r.y << 32);
+            if (i < cnt) gather_load<G, P>(B, sub, r.w, len[u], src[u], total, scaling, nullptr, nullptr, gcal, R[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            if (i0 + u * STEP < cnt) gather_finish<G, P>(B, sub, g0, len[u], src[u], base + so[u], total, scaling, pa_min, pa_max, samples, R[u], gcal != nullptr);
+            __builtin_amdgcn_sched_barrier(0); // one event's conversions (FP64 divisions: ~20 registers each) at a time
+        }
+    }
+}
+template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gather_chunks(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ part,
+                                                       uint32_t sub_per_chunk, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+                                                       double *__restrict__ samples, const double *__restrict__ gcal) {
+    __shared__ uint4 s_rec[PG_G2_SUB];
+    __shared__ uint32_t s_off[PG_G2_SUB];
+    __shared__ uint32_t wsum[4];
+    const uint64_t n_kept = n_kept_ptr[0];
+    const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
+    if (c0 >= n_kept) return;
+    const uint64_t total = B.sig_off[B.n_reads];
+    const uint32_t tid = threadIdx.x;
+    uint64_t run = part[blockIdx.x];
+    for (uint32_t sc = 0; sc < sub_per_chunk; ++sc) {
+        const uint64_t e0 = c0 + (uint64_t)sc * PG_G2_SUB;
+        if (e0 >= n_kept) break;
+        const uint32_t cnt = n_kept - e0 < PG_G2_SUB ? (uint32_t)(n_kept - e0) : PG_G2_SUB;
+        if (sc) __syncthreads(); // the previous sub-chunk's gather reads the LDS arrays until its last thread is through
+        // the records: coalesced (event i * 256 + tid: a wave takes 1 KB), into LDS
+        const uint4 *__restrict__ rv = reinterpret_cast<const uint4 *>(rec + e0);
+        uint4 q[PG_G2_SUB / 256];
+#pragma unroll
+        for (int i = 0; i < PG_G2_SUB / 256; ++i) { const uint32_t x = i * 256 + tid; q[i] = x < cnt ? rv[x] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int i = 0; i < PG_G2_SUB / 256; ++i) s_rec[i * 256 + tid] = q[i];
+        __syncthreads();
+        // exclusive scan of the lengths, consecutive events per thread
+        constexpr int PT = PG_G2_SUB / 256;
+        uint32_t v[PT], s = 0;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { v[i] = s_rec[tid * PT + i].z; s += v[i]; }
+        const uint32_t inc = wave_incl_scan_u32(s); // (a sub-chunk's samples fit 32 bits: the caller's bound on the window length)
+        if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t off = inc - s, tot = 0;
+        for (uint32_t w = 0; w < 4; ++w) { if (w < (tid >> 6)) off += wsum[w]; tot += wsum[w]; }
+#pragma unroll
+        for (int i = 0; i < PT; ++i) { s_off[tid * PT + i] = off; off += v[i]; }
+        __syncthreads();
+#ifndef PG_PROBE_NO_SOFF // (timing probe: what the offsets' stores cost)
+#pragma unroll
+        for (int i = 0; i < PG_G2_SUB / 256; ++i) { const uint32_t x = i * 256 + tid; if (x < cnt) samp_off[e0 + x] = run + s_off[x]; }
+#endif
+        gather_chunk<G, P>(B, total, s_rec, cnt, run, s_off, scaling, pa_min, pa_max, gcal, samples);
+        run += tot;
+    }
+}
+
+// the kept events' lengths and reads as arrays of their own (pg_result / pg_device_view; off the step's path)
+__global__ __launch_bounds__(256) void k_unpack_recs(const PgKeptRec *__restrict__ rec, uint64_t n, uint32_t *__restrict__ ev_len, uint32_t *__restrict__ ev_read) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) { const PgKeptRec x = rec[e]; ev_len[e] = x.len; ev_read[e] = x.read; }
+}
+
+// =====================================================================================================
+// launchers
+// =====================================================================================================
+hipError_t pg_launch_part_bases(hipStream_t st, const PgPartBufs &P, const PgDevBatch &B, const PgWalkOut &O) {
+    PG_LAUNCH(k_part_bases, dim3(1 + (B.n_reads + 1023) / 1024), dim3(1024), 0, st, (const uint32_t *)P.totals, 1u << P.hi_bits, P.rbase, P.tile_region, P.n_tilesB,
+              P.tilesB_cap, B, O, (const uint32_t *)P.Bp);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_part_scatter(hipStream_t st, const PgPartBufs &P, const uint32_t *ev_slot, uint64_t n, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O) {
+    if (!n) return hipSuccess;
+    const uint32_t n_tiles = (uint32_t)((n + PG_SORT_TILE - 1) / PG_SORT_TILE), n_tiles_pad = pg_tiles(n, true);
+    const size_t lds = part_lds_bytes(1u << P.hi_bits);
+    // more than 64 KB of dynamic LDS needs the attribute (per device: set at every launch, a host-side table entry)
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PG_RANK_MAX_DIGITS)));
+    PG_LAUNCH(k_part_scatter, dim3((n_tiles + PG_PART_TILES_PER_WG - 1) / PG_PART_TILES_PER_WG), dim3(PG_PART_THREADS), lds, st, ev_slot, (uint32_t)n, P.lo_bits, (int)P.hi_bits, n_tiles_pad,
+              (const uint32_t *)P.hist, (const uint32_t *)P.rbase, B, W, O, (const uint32_t *)P.Bp, P.elemA, P.loA);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy) {
+    PG_LAUNCH(k_region_count, dim3(P.tilesB_cap), dim3(256), 0, st, (const uint16_t *)P.loA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
+              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, P.histB);
+    PG_LAUNCH(k_region_scan, dim3(1u << P.hi_bits), dim3((1u << P.lo_bits) < 64u ? 64u : (1u << P.lo_bits)), 0, st, P.histB, (const uint32_t *)P.rbase, (int)P.lo_bits, n_slots, acc_cnt, acc_copy);
+    return hipSuccess;
+}
+
+static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk);
+// part (n_kept_cap != 0): the chunked gather's per-chunk sums of kept window lengths, accumulated here (zeroed first) -- k_len_partials' pass
+// over the records is not needed behind this launch
+hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, const uint32_t *keep32, const uint64_t *ev_off, const PgWalkOut &O, const PgKeptOut &K,
+                                  uint64_t *part, uint64_t n_kept_cap) {
+    uint32_t m = 1, n_chunks = 1;
+    if (n_kept_cap) n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    uint32_t chunk_shift = 10; while ((1u << chunk_shift) < m * PG_G2_SUB) ++chunk_shift; // PG_G2_SUB * m, a power of two
+    if (part) PG_HIP(hipMemsetAsync(part, 0, (size_t)(n_chunks + 1) * 8, st));
+    const size_t lds = part_lds_bytes(1u << P.lo_bits);
+    PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PG_RANK_MAX_DIGITS)));
+    PG_LAUNCH(k_region_place, dim3(P.tilesB_cap), dim3(PG_PART_THREADS), lds, st, (const uint4 *)P.elemA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
+              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, n_slots, (const uint32_t *)P.histB, keep32, ev_off, O, K, part, chunk_shift);
+    return hipSuccess;
+}
+
+static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk) {
+    uint32_t m = 1;
+    while ((n_kept_cap + (uint64_t)m * PG_G2_SUB - 1) / ((uint64_t)m * PG_G2_SUB) > 8192) m *= 2; // k_partials_scan holds 8192 chunk sums
+    *sub_per_chunk = m;
+    return (uint32_t)((n_kept_cap + (uint64_t)m * PG_G2_SUB - 1) / ((uint64_t)m * PG_G2_SUB));
+}
+
+// chunk sums of the kept window lengths + their exclusive scan (part: >= 8192 entries); *total_out = samp_off[n_kept] = all kept samples
+hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
+                                  bool sums_ready /* by pg_launch_region_place */) {
+    if (n_kept_cap == 0) return hipSuccess;
+    uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    if (!sums_ready) PG_LAUNCH(k_len_partials, dim3(n_chunks), dim3(256), 0, st, rec, n_kept_ptr, m * PG_G2_SUB, part);
+    PG_LAUNCH(k_partials_scan, dim3(1), dim3(1024), 0, st, part, n_chunks, n_kept_ptr, samp_off, total_out);
+    return hipSuccess;
+}
+// lanes: lanes per kept event (4, 8 or 16): any value is correct for any window length; the caller picks by the mean window it expects
+hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
+                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes) {
+    if (n_kept_cap == 0) return hipSuccess;
+    uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+    else if (lanes <= 8) PG_LAUNCH((k_gather_chunks<8, 3>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+    else PG_LAUNCH((k_gather_chunks<16, 2>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_unpack_recs(hipStream_t st, const PgKeptRec *rec, uint64_t n, uint32_t *ev_len, uint32_t *ev_read) {
+    if (!n) return hipSuccess;
+    PG_LAUNCH(k_unpack_recs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, rec, n, ev_len, ev_read);
+    return hipSuccess;
+}
