@@ -3,21 +3,27 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 walk/filter events -> deterministic per-k-mer ranking -> (N>1: RCCL all-gather of per-k-mer counts) ->
-sample_limit cut -> med-MAD statistics of every read -> gather of the kept windows. Workload at N=1 is
+sample_limit cut -> med-MAD statistics of every read -> gather of the kept windows. The headline workload at N=1 is
 BASELINE.json configs[1]: synthetic RNA004, 50 000 reads x 4 000 samples, k=5, --rna --scaling 1,
 min/max_dur 20/40, sample_limit 100, all 1024 k-mers. At N>1 every rank holds its own 50 000-read shard of
-one PAF-ordered job (weak scaling); value = samples of all ranks / max-over-ranks time.
+one PAF-ordered job (weak scaling); value = samples of all ranks / max-over-ranks time. `config.workload` names the
+BASELINE config the chosen flags are (or says "custom").
 
 `python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its own
 `python -m torch.distributed.run --nproc-per-node N` child (before anything touches a GPU) and relays its JSON line.
 
-Prints ONE JSON line (rank 0). Extra objects: "roofline" (k_read_stats, the kernel that streams the signal, timed with
-HIP events on the library's stream), "whole_step" (SURVEY 8d's algorithmic bytes of the COMPLETE step over the step
-time), and at N=1: "cpu_baseline" (the CPU oracle, a port of the reference algorithm, on a bounded sample of the same
-workload on this host's cores), "all_kept_mode" (the same reads at sample_limit 5000, where nearly every accepted
-event is kept), "hbm_not_mall" (k_read_stats over a 3.2 GB batch: 12x the 256 MiB Infinity Cache),
-"pcie_inclusive" (the step fed from host memory) and "end_to_end" (`bin/poregen gmove` as a child process on the same
-workload as BLOW5 + PAF + FASTQ files in the page cache, until the dump files are closed).
+Prints ONE JSON line (rank 0). Objects besides the contract's fields:
+  roofline      k_read_stats, the kernel that streams the signal (dispatch time stamps on the library's stream)
+  whole_step    SURVEY 8(d)'s algorithmic bytes of the COMPLETE step over the step time
+  useful        which of the streamed samples the reference would have read at all: it stops at the read that completes
+                the last k-mer (src/gmove.cpp:733-735); per rank `samples` next to `useful_samples`
+  config3_mode  (N=1) BASELINE configs[3]: 50 000 DNA reads, k = 9 (262 144 k-mers), sample_limit 1000: ms/step, whole-step
+                fraction of the HBM roofline, per-kernel times
+  all_kept_mode (N=1) the headline reads at sample_limit 5000 (configs[2]'s limit: every accepted event is kept)
+  config2_mode  (N>1) BASELINE configs[2]: the same N x 50 000 reads as ONE job at sample_limit 5000, same weak-scaling step
+  job_layer     (N>1) the step through pg_job_* (one process, N host threads, ncclCommInitAll), the path `poregen gmove
+                --devices` uses; fed from host memory, so PCIe-inclusive and never `value`
+  hbm_not_mall, pcie_inclusive, end_to_end, lazy_statistics_mode, two_stream_mode, kmer_model_once_per_job, cpu_baseline (N=1)
 """
 import argparse
 import json
@@ -54,6 +60,27 @@ def relaunch_under_torchrun(args):
     raise SystemExit(r.returncode if r.returncode else (0 if line else 1))
 
 
+def workload_label(kind, reads, read_len, k, limit, world):
+    """Which BASELINE.json config the flags are."""
+    shape = f"synthetic {kind} SLOW5+PAF, {reads} reads x {read_len} samples per GPU, k={k}, scaling med-MAD, sample_limit={limit}"
+    shape += ", min/max_dur 20/40, --rna" if kind == "rna004" else ""
+    std = reads == 50000 and read_len == 4000
+    if std and kind == "rna004" and k == 5 and limit == 100:
+        name = "BASELINE configs[1]" + (f" as a weak-scaling shard per GPU (x{world})" if world > 1 else "")
+    elif std and kind == "rna004" and k == 5 and limit == 5000:
+        name = "BASELINE configs[2]" + (f" ({world} of its 8 shards)" if world != 8 else "") if world > 1 else "BASELINE configs[2]'s per-GPU shard (one of its 8)"
+    elif std and kind == "dna_r10" and k == 9 and limit == 1000 and world == 1:
+        name = "BASELINE configs[3]"
+    else:
+        name = "custom (no BASELINE config)"
+    return f"{name}: {shape}"
+
+
+def b_alg(n_samples, n_reads, n_ops, n_bases, kept_samples, kept_events, n_slots):
+    """every input byte once, every output byte once."""
+    return 2 * n_samples + 24 * n_reads + 5 * n_ops + n_bases + 8 * kept_samples + 12 * kept_events + 8 * n_slots
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,8 +93,8 @@ def main():
     ap.add_argument("--sample-limit", type=int, default=100)
     ap.add_argument("--lazy", action="store_true", help="statistics only for reads that own a kept event")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics measurement (profiling runs)")
-    ap.add_argument("--no-extras", action="store_true", help="skip all_kept_mode / hbm_not_mall / pcie_inclusive / end_to_end (profiling and A/B runs)")
+    ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics / two-stream measurements (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip config3_mode / all_kept_mode / config2_mode / job_layer / hbm_not_mall / pcie_inclusive / end_to_end (profiling and A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
     ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
@@ -105,6 +132,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist_step = world > 1 or args.force_dist
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -128,50 +156,92 @@ def main():
     shard = host.to_device(dev)
     n_samples = host.n_samples
     n_ops = int(host.op_off[-1])
+    n_bases = int(host.seq_off[-1])
 
-    # multi-GPU step: the statistics are queued between the issue of the all_gather and the wait for it (dist.sharded_step)
-    defer = dist_step and not args.no_defer and not args.lazy and not args.overlap
-    eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=defer, **p))
-    gather_buf = torch.empty(world * len(kmers), dtype=torch.int64, device=dev)  # receive buffer of the per-step all_gather
-    # pg_count writes this rank's counts straight into its row of the receive buffer: the all_gather runs in place
-    counts_buf = gather_buf[rank * len(kmers):(rank + 1) * len(kmers)] if backend == "nccl" else torch.empty(len(kmers), dtype=torch.int64, device=dev)
     stream_ordered = dist_step and backend == "nccl"
+    side = None
     if stream_ordered:  # count -> RCCL all_gather -> collect ordered on one stream, no host sync inside a step
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
-        eng.use_torch_stream(side)
+    # multi-GPU step: the statistics are queued between the issue of the all_gather and the wait for it (dist.sharded_step)
+    defer = dist_step and not args.no_defer and not args.lazy and not args.overlap
 
-    def step():
-        eng.reset()
-        if dist_step:
-            total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered, gather_buf=gather_buf)
-            pgdist.merged_freq(total, args.sample_limit, engine=eng)
-        else:
-            eng.submit(shard)
+    def timed(params, steps, warmup):
+        """warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both sides, MAX over ranks."""
+        eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=defer, **params))
+        if stream_ordered:
+            eng.use_torch_stream(side)
+        gather_buf = torch.empty(world * len(kmers), dtype=torch.int64, device=dev)  # receive buffer of the per-step all_gather
+        # pg_count writes this rank's counts straight into its row of the receive buffer: the all_gather runs in place
+        counts_buf = gather_buf[rank * len(kmers):(rank + 1) * len(kmers)] if backend == "nccl" else torch.empty(len(kmers), dtype=torch.int64, device=dev)
+        state = {}
 
-    def fence():
-        eng.sync()
-        torch.cuda.synchronize()
+        def step():
+            eng.reset()
+            if dist_step:
+                total = pgdist.sharded_step(eng, shard, counts_buf=counts_buf, stream_ordered=stream_ordered, gather_buf=gather_buf)
+                state["freq"] = pgdist.merged_freq(total, params["sample_limit"], engine=eng)
+            else:
+                eng.submit(shard)
+
+        def fence():
+            eng.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        enqueue_ms = (time.perf_counter() - t0) / steps * 1e3  # host time to queue a step: a step cannot be faster than this
+        fence()
+        dt = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return eng, dt / steps * 1e3, enqueue_ms, state
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3  # host time to queue a step: a step cannot be faster than this
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * n_samples / (dt / args.steps)
+    def useful_of(eng, state, limit):
+        """What the reference would have read: it stops at the read that completes the last k-mer of the WHOLE list (gmove.cpp:733-735).
+        Per rank: samples streamed, samples of the reads up to and including the job's completing read."""
+        counts, ev_len, _, ev_read = eng.kept_tensors(device=dev, with_reads=True)
+        n_kept = int(ev_len.numel())
+        last_read = int(ev_read.max().item()) if n_kept else -1
+        if dist_step:
+            freq = state["freq"]
+            full = bool((freq >= limit).all().item()) if limit > 0 else False
+        else:
+            full = eng.all_slots_full()
+        mine = [n_kept, last_read, host.n_reads, int(n_samples)]
+        if world > 1:
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+        else:
+            allr = [mine]
+        per_rank = []
+        if full:
+            r_star = max(g for g in range(world) if allr[g][0] > 0)  # the last shard that still placed an event
+        for g in range(world):
+            kept_g, last_g, reads_g, samples_g = allr[g]
+            if not full or g < r_star:
+                u = samples_g
+            elif g == r_star:
+                u = int(host.sig_off[last_g + 1]) if g == rank else (last_g + 1) * args.read_len
+            else:
+                u = 0
+            per_rank.append({"rank": g, "samples": samples_g, "useful_samples": u, "kept_events": kept_g})
+        tot, use = sum(x["samples"] for x in per_rank), sum(x["useful_samples"] for x in per_rank)
+        return {"all_kmers_complete": full, "samples": tot, "useful_samples": use, "useful_fraction": use / tot if tot else None, "per_rank": per_rank}
 
-    # ---- per-kernel times with HIP events on the library's own stream (separate, untimed passes) ----------
+    eng, ms_per_step, enqueue_ms, state = timed(p, args.steps, args.warmup)
+    value = world * n_samples / (ms_per_step * 1e-3)
+    useful = useful_of(eng, state, args.sample_limit)
+
+    # ---- per-kernel times: the dispatches' own time stamps (PG_FLAG_PROFILE), separate untimed passes ----------
     prof = GmoveEngine(GmoveParams(kmers=kmers, profile=True, **p))
     for _ in range(2):
         prof.reset(); prof.submit(shard)
@@ -195,31 +265,31 @@ def main():
                   "algorithmic_bytes": 8 * kept_samples + 4 * kept_events, "GB/s": (8 * kept_samples + 4 * kept_events) / (model_ms * 1e-3) / 1e9}
     prof.close()
     stats_ms = ks["k_read_stats"][1] / ks["k_read_stats"][0]
-    # algorithmic bytes of the statistics kernels per launch: every int16 sample once, the three
+    # algorithmic bytes of the statistics kernel per launch: every int16 sample once, the three
     # doubles + two offsets of each read in, median + MAD out
     stats_bytes = 2 * n_samples + (24 + 16 + 16) * host.n_reads
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950
-    # note of MI355X_MICROARCH.md): measured offline on this exact workload and committed under profiles/
-    traffic = None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    # note of MI355X_MICROARCH.md): measured offline on the headline workload and committed under profiles/
+    traffic = None; trace_ms = None
+    headline = args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004" and args.k == 5
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
+            if headline:
                 traffic = pmc["traffic_bytes_per_launch"]
             break
         except Exception:
             pass
-    # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison. The
-    # library's profile mode attaches the event pair to the dispatch itself (hipExtLaunchKernelGGL: the dispatch's own start / end time
-    # stamps, which is what the trace reads), so the two agree; kernels_sum_ms is below ms_per_step by the gaps between dispatches
-    trace_ms = None
-    try:
-        import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats.csv"))):
-            if row["Name"].startswith("k_read_stats(") and args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004":
-                trace_ms = float(row["AverageNs"]) * 1e-6
-    except Exception:
-        pass
+    # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison
+    for name in ("r03_kernel_stats.csv", "r02_kernel_stats.csv"):
+        try:
+            import csv
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+                if row["Name"].startswith("k_read_stats(") and headline:
+                    trace_ms = float(row["AverageNs"]) * 1e-6
+            break
+        except Exception:
+            pass
     roofline = {
         "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
@@ -227,29 +297,19 @@ def main():
         "committed_trace_avg_launch_ms": trace_ms, "committed_trace_frac": (stats_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if trace_ms else None,
     }
     kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
-    # the COMPLETE step against the roofline: SURVEY 8(d)'s B_alg = every input byte once, every output byte once
-    n_bases = int(host.seq_off[-1])
-    b_alg = 2 * n_samples + 24 * host.n_reads + 5 * n_ops + n_bases + 8 * kept_samples + 12 * kept_events + 8 * len(kmers)
-    whole_step = {"algorithmic_bytes": b_alg, "bytes_per_sample": b_alg / n_samples, "ms_per_step": ms_per_step,
-                  "achieved_GBs": b_alg / (ms_per_step * 1e-3) / 1e9, "frac": b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    balg = b_alg(n_samples, host.n_reads, n_ops, n_bases, kept_samples, kept_events, len(kmers))
+    whole_step = {"algorithmic_bytes": balg, "bytes_per_sample": balg / n_samples, "ms_per_step": ms_per_step,
+                  "achieved_GBs": balg / (ms_per_step * 1e-3) / 1e9, "frac": balg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "kernels_sum_ms": sum(kernels_ms.values())}
 
     # the same job with statistics only for the reads that own a kept event (legal: acceptance is signal-independent in
     # the PAF path); reported next to `value`, never as `value`
     lazy_info = None
-    if world == 1 and not args.lazy and not args.no_lazy_extra:
-        lz = GmoveEngine(GmoveParams(kmers=kmers, **dict(p, lazy_stats=True)))
-        for _ in range(args.warmup):
-            lz.reset(); lz.submit(shard)
-        lz.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            lz.reset(); lz.submit(shard)
-        lz.sync(); torch.cuda.synchronize()
-        ldt = (time.perf_counter() - t0) / args.steps
+    if world == 1 and not dist_step and not args.lazy and not args.no_lazy_extra:
+        lz, lms, _, _ = timed(dict(p, lazy_stats=True), args.steps, args.warmup)
         lres = lz.finish()
         touched = int(np.unique(lres.ev_read).size)
-        lazy_info = {"value": n_samples / ldt, "ms_per_step": ldt * 1e3, "reads_with_statistics": touched,
+        lazy_info = {"value": n_samples / (lms * 1e-3), "ms_per_step": lms, "reads_with_statistics": touched,
                      "samples_touched": int(touched * args.read_len)}
         lz.close()
 
@@ -257,20 +317,12 @@ def main():
     # may use three quarters of the CUs. Kernels then share the chip, so per-kernel timings are not clean: reported next to
     # `value`, which stays the one-stream figure the roofline object describes.
     two_stream = None
-    if world == 1 and not args.lazy and not args.overlap and not args.no_lazy_extra:
-        ts = GmoveEngine(GmoveParams(kmers=kmers, **dict(p, overlap=True)))
-        for _ in range(args.warmup):
-            ts.reset(); ts.submit(shard)
-        ts.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            ts.reset(); ts.submit(shard)
-        ts.sync(); torch.cuda.synchronize()
-        tdt = (time.perf_counter() - t0) / args.steps
+    if world == 1 and not dist_step and not args.lazy and not args.overlap and not args.no_lazy_extra:
+        ts, tms, _, _ = timed(dict(p, overlap=True), args.steps, args.warmup)
         tres = ts.finish()
         same = (np.array_equal(tres.samples, res.samples) and np.array_equal(tres.ev_read, res.ev_read)
                 and np.array_equal(tres.samp_off, res.samp_off))
-        two_stream = {"value": n_samples / tdt, "ms_per_step": tdt * 1e3, "whole_step_frac": b_alg / tdt / 1e9 / HBM_PEAK_GBS,
+        two_stream = {"value": n_samples / (tms * 1e-3), "ms_per_step": tms, "whole_step_frac": balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "stats_stream_cus": "3/4 of every XCD (CU mask)", "results_equal_one_stream": bool(same)}
         ts.close()
 
@@ -280,8 +332,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16 in / f64 arithmetic",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[1]: synthetic {args.kind} SLOW5+PAF, {args.reads} reads x {args.read_len} samples per GPU, "
-                        f"k={args.k}, scaling med-MAD, sample_limit={args.sample_limit}" + (", min/max_dur 20/40, --rna" if rna else ""),
+            "workload": workload_label(args.kind, args.reads, args.read_len, args.k, args.sample_limit, world),
             "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
             "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
             "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if dist_step else None,
@@ -291,6 +342,7 @@ def main():
         "roofline": roofline,
         "whole_step": whole_step,
         "whole_step_frac": whole_step["frac"],
+        "useful": useful,
         "kernels_ms_per_step": kernels_ms,
         "host_enqueue_ms_per_step": enqueue_ms,
         "lazy_statistics_mode": lazy_info,
@@ -298,20 +350,30 @@ def main():
         "kmer_model_once_per_job": model_info,
         "gen_seconds": gen_s,
     }
+    eng.close()
 
-    extras = rank == 0 and world == 1 and not args.no_extras and not args.force_dist
-    if extras:
+    extras = not args.no_extras and not args.force_dist
+    if extras and world > 1:
+        # BASELINE configs[2]: the same shards as ONE job at sample_limit 5000 (at N = 8: 400 000 reads sharded 8 ways)
+        e2, ms2, _, st2 = timed(dict(p, sample_limit=5000), max(5, args.steps // 4), 3)
+        u2 = useful_of(e2, st2, 5000)
+        out["config2_mode"] = {"workload": workload_label(args.kind, args.reads, args.read_len, args.k, 5000, world), "ms_per_step": ms2,
+                               "value": world * n_samples / (ms2 * 1e-3), "unit": "samples/s", "useful": u2}
+        e2.close()
+        out["job_layer"] = job_layer(host, kmers, p, world, rank, dist)
+    if extras and rank == 0 and world == 1:
         t0 = time.time()
-        out["all_kept_mode"] = all_kept_mode(shard, host, kmers, p, n_ops, n_bases)
+        out["all_kept_mode"] = mode_run(shard, host, kmers, dict(p, sample_limit=5000),
+                                        "BASELINE configs[2]'s limit on the headline reads: sample_limit 5000, every accepted event is kept")
         out["hbm_not_mall"] = hbm_not_mall(shard, kmers, p, dev)
         out["pcie_inclusive"] = pcie_inclusive(host, kmers, p)
         del shard
         torch.cuda.empty_cache()
+        out["config3_mode"] = config3_mode(dev)
         out["end_to_end"] = end_to_end(host, args)
         out["extras_seconds"] = time.time() - t0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, kmers, p, args.cpu_seconds)
-    eng.close()
     if rank == 0:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)  # the ONE line of the contract on the real stdout
@@ -320,12 +382,11 @@ def main():
         dist.destroy_process_group()
 
 
-def all_kept_mode(shard, host, kmers, p, n_ops, n_bases, steps=10):
-    """The same 50 000 reads at sample_limit 5000 (BASELINE configs[2]'s limit): no k-mer fills up, so nearly every accepted
-    event is kept and gathered -- the regime in which all of the streamed signal can reach an output."""
+def mode_run(shard, host, kmers, q, what, steps=10):
+    """One more workload on a device-resident batch: ms per step (one stream, plain pg_submit), the whole step against the HBM
+    roofline, per-kernel times from a separate profiled pass."""
     import torch
     from poregen_amd.engine import GmoveEngine, GmoveParams
-    q = dict(p, sample_limit=5000)
     e = GmoveEngine(GmoveParams(kmers=kmers, **q))
     for _ in range(3):
         e.reset(); e.submit(shard)
@@ -347,9 +408,55 @@ def all_kept_mode(shard, host, kmers, p, n_ops, n_bases, steps=10):
     pe.sync()
     ks = {k: v2[1] / 5 for k, v2 in pe.kernel_stats().items()}
     pe.close()
-    b_alg = 2 * host.n_samples + 24 * host.n_reads + 5 * n_ops + n_bases + 8 * ksm + 12 * ke + 8 * len(kmers)
-    return {"sample_limit": 5000, "ms_per_step": ms, "value": host.n_samples / (ms * 1e-3), "unit": "samples/s", "kept_events": ke, "kept_samples": ksm,
-            "algorithmic_bytes": b_alg, "whole_step_frac": b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_ms_per_step": ks}
+    n_ops, n_bases = int(host.op_off[-1]), int(host.seq_off[-1])
+    balg = b_alg(host.n_samples, host.n_reads, n_ops, n_bases, ksm, ke, len(kmers))
+    return {"workload": what, "sample_limit": q["sample_limit"], "ms_per_step": ms, "value": host.n_samples / (ms * 1e-3), "unit": "samples/s",
+            "kept_events": ke, "kept_samples": ksm, "algorithmic_bytes": balg, "whole_step_frac": balg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernels_ms_per_step": ks}
+
+
+def config3_mode(dev):
+    """BASELINE configs[3]: synthetic DNA (R10 dwell), 50 000 reads x 4 000 samples, k = 9: 262 144 k-mers, sample_limit 1000."""
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    host = synth.make_batch_fast(50000, read_len=4000, kind="dna_r10", seed=20251003 + 3)
+    shard = host.to_device(dev)
+    kmers = generate_kmers(9, rna=False)
+    q = dict(kmer_size=9, rna=False, scaling=1, sample_limit=1000, device=dev.index or 0)
+    r = mode_run(shard, host, kmers, q, workload_label("dna_r10", 50000, 4000, 9, 1000, 1))
+    r["n_slots"] = len(kmers)
+    return r
+
+
+def job_layer(host, kmers, p, world, rank, dist):
+    """The step through pg_job_* on rank 0: ONE process, `world` devices, a host thread and a context per device, the exchange over
+    ncclCommInitAll -- what `poregen gmove --devices 0,1,...` runs. The other ranks' processes idle at the barrier meanwhile. The job
+    layer stages its batch from host memory (rank 0's shard, cut `world` ways), so this is a PCIe-inclusive figure."""
+    import torch
+    from poregen_amd import _abi
+    from poregen_amd.engine import GmoveJob, GmoveParams
+    info = None
+    if rank == 0:
+        try:
+            q = {k: v for k, v in p.items() if k not in ("device",)}
+            job = GmoveJob(GmoveParams(kmers=kmers, **q), list(range(world)), _abi.PG_JOB_EXCHANGE_AUTO)
+            job.submit(host); job.sync()      # contexts, communicators, first buffers
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                job.submit(host)
+            job.sync()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            r = job.finish()
+            info = {"devices": world, "exchange": "rccl" if job.uses_rccl else "host", "rccl_ranks_seen": world if job.uses_rccl else 0,
+                    "ms_per_step_pcie_inclusive": ms, "reads_per_step": host.n_reads, "samples_per_step": int(host.n_samples),
+                    "kept_events": int(r.counts.sum()), "all_kmers_complete": job.all_slots_full()}
+            job.close()
+        except Exception as ex:  # the headline must not die with the extra
+            info = {"error": repr(ex)[:300]}
+    torch.cuda.synchronize()
+    dist.barrier()
+    return info
 
 
 def hbm_not_mall(shard, kmers, p, dev, copies=8):
@@ -404,7 +511,10 @@ def pcie_inclusive(host, kmers, p, steps=4):
 
 def end_to_end(host, args):
     """SURVEY 8(d) metric (i): `bin/poregen gmove` as a child process on the workload written as BLOW5 + PAF + FASTQ, input files in the
-    page cache, wall clock from process start until the dump files are closed and the process has exited."""
+    page cache, wall clock from process start until the dump files are closed and the process has exited. `value` divides the samples
+    the run actually READ (like the reference it stops reading once every k-mer is complete) by the wall time; the figure over all
+    samples of the input files stands next to it as value_over_all_input."""
+    import re
     import shutil
     import tempfile
     from poregen_amd import synth
@@ -429,12 +539,15 @@ def end_to_end(host, args):
                 if r.returncode != 0:
                     return {"error": r.stderr[-400:]}
                 stages = [ln[len("[gmove] "):] for ln in r.stderr.splitlines() if ln.startswith("[gmove] ")]
+                m = re.search(r"\[gmove\] (\d+) reads, (\d+) samples", r.stderr)
+                read_samples = int(m.group(2)) if m else int(host.n_samples)
                 if best is None or wall < best["wall_s"]:
-                    best = {"wall_s": wall, "value": host.n_samples / wall, "unit": "samples/s", "stages": stages}
+                    best = {"wall_s": wall, "reads_read": int(m.group(1)) if m else host.n_reads, "samples_read": read_samples,
+                            "value": read_samples / wall, "value_over_all_input": host.n_samples / wall, "unit": "samples/s", "stages": stages}
                 shutil.rmtree(o, ignore_errors=True)
             out["runs"][f"sample_limit_{lim}"] = best
         first = out["runs"][f"sample_limit_{args.sample_limit}"]
-        out.update(value=first["value"], wall_s=first["wall_s"], unit="samples/s", stages=first["stages"])
+        out.update(value=first["value"], value_over_all_input=first["value_over_all_input"], wall_s=first["wall_s"], unit="samples/s", stages=first["stages"])
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -341,7 +341,15 @@ int gmove_main(int argc, char **argv) {
         b.sig = hbs[cur].sig.data(); b.sig_off = hbs[cur].sig_off.data(); b.digitisation = hbs[cur].dig.data(); b.offset = hbs[cur].off.data(); b.range = hbs[cur].range.data();
         b.query_start = hbs[cur].qs.data(); b.target_start = hbs[cur].ts.data(); b.target_end = hbs[cur].te.data(); b.seq = hbs[cur].seq.data(); b.seq_off = hbs[cur].seq_off.data();
         b.op_n = hbs[cur].op_n.data(); b.op_t = hbs[cur].op_t.data(); b.op_off = hbs[cur].op_off.data();
-        if (batch_all_matches) b.flags |= PG_BATCH_ALL_MATCHES; // no I / D op in the batch (every ss string `reform` writes): verified on the device
+        // PG_BATCH_ALL_MATCHES vouches that no read of the batch needs the generic walk: no I / D op (every ss string `reform` writes) AND
+        // k <= ops <= fetched bases for every read -- a shorter or overlong read goes to that walk too (a basecall shorter than k on the
+        // move-table / SAM / BAM front-ends simply has no events there, PG_FLAG_SHORT_READS_OK). The device verifies the claim.
+        bool vouch = batch_all_matches;
+        for (size_t r = 0; vouch && r < hbs[cur].n(); r++) {
+            const uint64_t nops = hbs[cur].op_off[r + 1] - hbs[cur].op_off[r], slen = hbs[cur].seq_off[r + 1] - hbs[cur].seq_off[r];
+            if (slen >= (uint64_t)opt.kmer_size && (nops < (uint64_t)opt.kmer_size || nops > slen)) vouch = false; // (slen < k: a skipped read, no walk)
+        }
+        if (vouch) b.flags |= PG_BATCH_ALL_MATCHES;
         batch_all_matches = true;
         if (!need_ctx()) return false;
         // Queued, not awaited: the next batch is parsed meanwhile. pg_submit itself waits for the batch BEFORE this one (and hands its
@@ -591,7 +599,12 @@ int gmove_main(int argc, char **argv) {
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
         if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
     }
-    if (status == EXIT_SUCCESS && !flush()) status = EXIT_FAILURE;
+    if (status == EXIT_FAILURE && !is_paf && whole_list && dev.ok()) {
+        // a record the reference may never have read: it stops once every k-mer of the whole list is complete (gmove.cpp:733-735), and the
+        // batches in flight may have done that. Wait for them and look before failing (the PAF loop does the same above).
+        if (dev.sync() == PG_OK && dev.all_full()) { status = EXIT_SUCCESS; stop = true; }
+    }
+    if (status == EXIT_SUCCESS && !stop && !flush()) status = EXIT_FAILURE;
     free(line); fclose(paf_fp);
 
     const double t_loop = secs(t_loop0, clk::now());

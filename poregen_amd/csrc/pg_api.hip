@@ -601,6 +601,12 @@ static int gather_lanes(const pg_ctx *c) {
     return mw <= 6 ? 4 : (mw <= 36 ? 8 : 16); // (k = 9, mean window 12.4: 8 lanes 0.91-0.97 ms, 4 lanes 1.07-1.10 ms)
 }
 
+// direct ranking: will (nearly) every tile place events? Then the placing kernel built for that takes over (k_rank_emit2), and it wants
+// the prefix of the block sums. The bound is the same as the chunked gather's: more than 64 * 4096 events may be kept.
+static bool dense_direct(const pg_ctx *c, uint64_t n_ops) {
+    return c->prm.n_slots <= PG_DIRECT_MAX_SLOTS && std::min<uint64_t>(n_ops, (uint64_t)c->prm.n_slots * c->prm.sample_limit) > 64ull * 4096 && !getenv("PGMOVE_EMIT1");
+}
+
 static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
     P.elemA = c->part_elem.as<uint4>(); P.loA = c->part_lodig.as<uint16_t>(); P.hist = c->hist.as<uint32_t>(); P.totals = c->totals.as<uint32_t>(); P.rbase = c->part_rbase.as<uint32_t>();
     P.tile_region = c->part_tile_region.as<uint32_t>(); P.n_tilesB = c->part_ntiles.as<uint32_t>(); P.histB = c->part_histB.as<uint32_t>();
@@ -676,7 +682,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->read_needed.ensure(n + 2ull));
     const uint32_t n_tiles = pg_tiles(Nn, direct);
     uint32_t ndig;
-    if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; }
+    if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; if (dense_direct(c, N)) HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4)); }
     else if (c->part_mode) {
         ndig = 1u << c->part_hi;
         const uint32_t tcap = pg_part_tiles_cap(Nn, c->part_hi);
@@ -751,7 +757,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         const bool fuse_plan = c->in_submit;
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
                                     c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
-                                    c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done));
+                                    c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
+                                    O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr));
         prof_end(c, c->st);
     } else if (c->part_mode) {
         // partitioned ranking, pass A and the counts of pass B (pg_place.hip): everything pg_count's result needs
@@ -901,7 +908,8 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         PgSortBufs S{};
         fill_sort(c, S, 0);
         prof_begin(c, "k_rank_emit", c->st);
-        HIP_TRY(c, pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K));
+        if (dense_direct(c, N)) HIP_TRY(c, pg_launch_rank_emit2(c->st, O.ev_slot, N, ns, S.hist, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K, c->part_Bp.as<uint32_t>()));
+        else HIP_TRY(c, pg_launch_rank_direct_emit(c->st, O.ev_slot, N, ns, S, c->keep.as<uint64_t>(), c->ev_off.as<uint64_t>(), totals, c->B, W, O, K));
         prof_end(c, c->st);
     } else if (c->part_mode) {
         PgPartBufs P{};
@@ -1081,6 +1089,11 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     for (auto &h : c->batches) { n_events += h.n_events; n_samples += h.n_samples; n_reads += h.n_reads; }
     if (c->batches.size() == 1) { // one batch: its arrays ARE the result (no per-event copy of up to GBs of samples)
         HostBatchResult &h = c->batches[0];
+        if (h.on_device) { // parked on the device for a merge that never came (a later batch was counted but not collected): fetch them now
+            h.samples.resize(h.n_samples);
+            HIP_TRY(c, hipMemcpy(h.samples.data(), h.dsamples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
+            h.dsamples.release(); h.on_device = false;
+        }
         c->r_counts.resize(ns);
         for (uint32_t sl = 0; sl < ns; sl++) c->r_counts[sl] = h.ev_off[sl + 1] - h.ev_off[sl];
         c->r_ev_off.swap(h.ev_off); c->r_samp_off.swap(h.samp_off); c->r_ev_len.swap(h.ev_len); c->r_ev_read.swap(h.ev_read);
@@ -1107,6 +1120,11 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     // the samples: merged on the device when every batch's are still there (the usual case: download_last), else on the host
     bool all_dev = true;
     for (auto &h : c->batches) if (h.n_samples && !h.on_device) all_dev = false;
+    if (all_dev && n_samples) { // room for the merged copy and the segment list? Else the host merge after all
+        size_t nseg = 0;
+        for (uint32_t sl = 0; sl < ns; sl++) for (auto &h : c->batches) nseg += h.ev_off[sl + 1] > h.ev_off[sl];
+        if (c->dseg.ensure(nseg * sizeof(PgSeg) + 16) != hipSuccess || c->dmerged.ensure(n_samples * 8ull) != hipSuccess) { (void)hipGetLastError(); c->dmerged.release(); all_dev = false; }
+    }
     if (!all_dev)
         for (auto &h : c->batches)
             if (h.on_device) { // mixed (a pg_finish between batches, or a batch that found no room): this one through the host after all

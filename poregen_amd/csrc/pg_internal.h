@@ -151,6 +151,9 @@ struct PgKeptOut; struct PgKeptRec;
 // part / n_kept_cap: the chunked gather's per-chunk sums of kept window lengths are accumulated by this launch (n_kept_cap = 0: not wanted)
 hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, const uint32_t *keep32, const uint64_t *ev_off, const PgWalkOut &O, const PgKeptOut &K,
                                   uint64_t *part, uint64_t n_kept_cap);
+// direct ranking with many useful tiles (large sample_limit): Bp = prefix of the block sums (pg_launch_rank_direct_count's extra workgroup)
+hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const uint32_t *hist, const uint64_t *keep, const uint64_t *ev_off,
+                                const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K, const uint32_t *Bp);
 // many kept events: sample offsets inside the gather's workgroups (part: >= 8192 entries of work space)
 hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
                                   bool sums_ready);
@@ -231,7 +234,8 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
                                  uint64_t *acc_copy /* device, may be null: second copy of acc_cnt (pg_count's output) */,
                                  // plan_keep != null (pg_submit: base = the context's running counts): the sample_limit cut rides in the same
                                  // launch (its last workgroup does pg_launch_slot_plan's work); *plan_done says whether it did
-                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done);
+                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done,
+                                 const uint32_t *btot /* PgWalkOut::btot */, uint32_t *Bp /* may be null: its prefix, for pg_launch_rank_emit2 */);
 hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);

@@ -501,6 +501,8 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
     const uint32_t tid = threadIdx.x, tile0 = blockIdx.x * 4u, k = W.k, tq = tid >> 8, lt = tid & 255u;
     const int lane = lane_id();
     const uint64_t N = B.n_ops;
+    // the op arrays are only read below NL: a caller's n_ops that is too large (reported by k_batch_init) is not followed behind them
+    const uint64_t NL = B.n_reads && B.op_off[B.n_reads] < N ? B.op_off[B.n_reads] : N;
     const uint64_t T0 = (uint64_t)(tile0 + tq) * PG_SORT_TILE, g0 = T0 + (uint64_t)lt * 16u;
     const bool tile_live = T0 < N; // wave-uniform
     if (COUNT) for (uint32_t i = tid; i < 4 * (PG_RANK_MAX_DIGITS + 32); i += 1024) (&cnt[0][0])[i] = 0;
@@ -513,12 +515,12 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
     }
     // the thread's own op_n: four 16-byte loads in flight in front of everything else
     uint32_t opn[16];
-    if (g0 + 16 <= N) {
+    if (g0 + 16 <= NL) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); opn[4 * v] = x.x; opn[4 * v + 1] = x.y; opn[4 * v + 2] = x.z; opn[4 * v + 3] = x.w; }
     } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) opn[j] = g0 + j < N ? B.op_n[g0 + j] : 0u;
+        for (int j = 0; j < 16; ++j) opn[j] = g0 + j < NL ? B.op_n[g0 + j] : 0u;
     }
     const uint64_t seq_total = B.seq_off[B.n_reads];
     const uint32_t *__restrict__ seq32 = reinterpret_cast<const uint32_t *>(B.seq); // 4-byte aligned (checked by the host)
@@ -642,7 +644,7 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
 #pragma unroll 1
         for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
             uint32_t rd;
-            const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, B.op_n[g0 + j], rd);
+            const uint32_t sl = event_slot_scalar(B, W, O, g0 + j, g0 + j < NL ? B.op_n[g0 + j] : 0u, rd);
             constexpr uint32_t UNK = COUNT == 2 ? PG_PART_REL_UNKNOWN : PG_REL_UNKNOWN, RSH = COUNT == 2 ? PG_PART_REL_SHIFT : PG_SLOT_BITS;
             const uint32_t rel = rd - rFirst < UNK ? rd - rFirst : UNK;
             O.ev_slot[g0 + j] = COUNT && sl != PG_INVALID_SLOT ? sl | (rel << RSH) : sl; // the read rides in the upper bits (PgWalkOut::tile_read)
@@ -687,8 +689,8 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
 #pragma unroll
             for (int v = 3; v >= 0; --v) {
                 uint32_t len[4] = {0, 0, 0, 0};
-                if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
-                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) len[u] = B.op_n[g0 + 4 * v + u]; }
+                if (g0 + 4 * v + 4 <= NL) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
+                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < NL) len[u] = B.op_n[g0 + 4 * v + u]; }
 #pragma unroll
                 for (int u = 3; u >= 0; --u) { dm = (dm << 1) | ((len[u] - W.min_dur <= range) ? 1u : 0u); orv |= len[u]; }
             }
@@ -781,8 +783,8 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
             }
             // the window lengths: the thread's own op_n again (they were summed long ago; registers are worth more than cache hits)
             uint32_t len[4] = {0, 0, 0, 0};
-            if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
-            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) len[u] = B.op_n[g0 + 4 * v + u]; }
+            if (g0 + 4 * v + 4 <= NL) { const uint4 x = *reinterpret_cast<const uint4 *>(B.op_n + g0 + 4 * v); len[0] = x.x; len[1] = x.y; len[2] = x.z; len[3] = x.w; }
+            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < NL) len[u] = B.op_n[g0 + 4 * v + u]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = 4 * v + u;
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__
     __syncthreads();               // ... before the one lane that signals for the workgroup adds to the counter
     if (threadIdx.x == 0) sh_ticket = __hip_atomic_fetch_add(plan.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (sh_ticket != gridDim.x - 1) return;
+    if (sh_ticket != gridDim.x - (bp_out ? 2u : 1u)) return; // (the block-sum workgroup, if any, takes no ticket)
     // ---- the last workgroup: keep = min(cnt, limit - running), offsets, totals (as k_slot_plan with base == running) ---------------
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     uint32_t carry = 0, full = 0; int tmax = -1;
@@ -2346,11 +2348,12 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *_
     if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
     // op-parallel part: 16 ops per thread; any op that is not a match (or not an op at all) sends its read to the generic walk
-    const uint64_t a = (uint64_t)i * 16u;
-    if (a < B.n_ops && n_reads) {
+    // (bounded by op_off[n_reads] as well: a caller's n_ops that is too large is reported above, not followed behind the op arrays)
+    const uint64_t a = (uint64_t)i * 16u, ops_end = n_reads ? (B.op_off[n_reads] < B.n_ops ? B.op_off[n_reads] : B.n_ops) : 0;
+    if (a < ops_end) {
         uint32_t w[4] = {0, 0, 0, 0};
-        if (op_t_aligned && a + 16 <= B.n_ops) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_t + a); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-        else for (uint64_t x = a; x < a + 16 && x < B.n_ops; ++x) w[(x - a) >> 2] |= (uint32_t)B.op_t[x] << (8 * ((x - a) & 3));
+        if (op_t_aligned && a + 16 <= ops_end) { const uint4 v = *reinterpret_cast<const uint4 *>(B.op_t + a); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+        else for (uint64_t x = a; x < a + 16 && x < ops_end; ++x) w[(x - a) >> 2] |= (uint32_t)B.op_t[x] << (8 * ((x - a) & 3));
         if (w[0] | w[1] | w[2] | w[3]) {
             uint32_t last = 0xffffffffu;
             for (uint32_t x = 0; x < 16; ++x)
@@ -2416,15 +2419,17 @@ static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 
 hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt, uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy,
-                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done) {
+                                 uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done,
+                                 const uint32_t *btot, uint32_t *Bp) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     *plan_done = false;
     if (n_tiles) { // the counts are in S.hist (k_events<true>)
         PgScanPlan P{};
         if (plan_keep) { P.keep = plan_keep; P.ev_off = plan_ev_off; P.plan_totals = plan_totals; P.running_out = running; P.ticket = plan_ticket; *plan_done = true; }
-        PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
-                  (const uint64_t *)running, limit, tile_last, acc_copy, P, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr);
+        // Bp (may be null): one extra workgroup leaves the prefix of k_events' block sums for k_rank_emit2's window starts
+        PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES + (Bp ? 1u : 0u)), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
+                  (const uint64_t *)running, limit, tile_last, acc_copy, P, btot, Bp ? (uint32_t)((n + 255) / 256) : 0u, Bp);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
         if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));

@@ -103,6 +103,22 @@ __device__ __forceinline__ PartLds part_lds(uint32_t ndig) {
 // row, lane). cnt zeroed and visible (barrier) on entry. On exit (behind a barrier): j[r] = place of the element among the tile's valid
 // elements in (digit, source order) order; ls as described above. One pass: the count and the rank inside the wave come from the
 // same ordered walk over the rows (ballots find the lanes of equal digit; the lowest of them advances the wave's counter).
+// the first half on its own: lrank[r] = elements of the same digit in front of the element inside its WAVE (rows in order, lanes in order);
+// the wave's counters hold its totals per digit afterwards
+__device__ __forceinline__ void wave_digit_ranks(const uint32_t (&dig)[PG_PART_ROWS], const bool (&valid)[PG_PART_ROWS], int nbits, uint32_t *mycnt, uint32_t (&lrank)[PG_PART_ROWS]) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < PG_PART_ROWS; ++r) {
+        const uint32_t d = dig[r], sh = (d & 1u) * 16u;
+        const uint64_t peers = match_digit(d, valid[r], nbits);
+        uint32_t b = 0;
+        if (valid[r]) b = (reinterpret_cast<volatile uint32_t *>(mycnt)[d >> 1] >> sh) & 0xffffu;
+        __builtin_amdgcn_wave_barrier();
+        if (valid[r] && lane == __ffsll((long long)peers) - 1) atomicAdd(&mycnt[d >> 1], (uint32_t)__popcll(peers) << sh);
+        __builtin_amdgcn_wave_barrier();
+        lrank[r] = b + (uint32_t)__popcll(peers & lanemask_lt());
+    }
+}
 __device__ __forceinline__ void tile_digit_order(const uint32_t (&dig)[PG_PART_ROWS], const bool (&valid)[PG_PART_ROWS], int nbits, uint32_t ndig,
                                                  const PartLds &L, uint32_t (&j)[PG_PART_ROWS]) {
     const uint32_t tid = threadIdx.x, w = tid >> 6, half = ndig / 2 ? ndig / 2 : 1;
@@ -221,11 +237,12 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         // every lane's own op_n: the window length of its event, and -- handed along the lanes -- the ops in front of it inside its group of
         // four, which is what the 4-op granularity of k_events' in-block sums leaves to add (a row starts at a multiple of 64 ops)
         const bool have_row = W.sig_move_offset == 0;
+        const uint64_t n_loads = B.n_reads && B.op_off[B.n_reads] < n ? B.op_off[B.n_reads] : n; // (a caller's n_ops that is too large is not followed behind the op arrays)
         uint32_t opn[PG_PART_ROWS];
 #pragma unroll
         for (int r = 0; r < PG_PART_ROWS; ++r) {
             const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
-            opn[r] = (have_row && g < n) ? B.op_n[g] : 0u;
+            opn[r] = (have_row && g < n_loads) ? B.op_n[g] : 0u;
         }
         uint4 el[PG_PART_ROWS];
 #pragma unroll
@@ -245,11 +262,20 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         __syncthreads();
         uint32_t j[PG_PART_ROWS];
         tile_digit_order(dig, valid, nbits, ndig, L, j);
+#ifdef PG_PART_DIRECT_STORE // experiment: every element straight from its registers to its place (the L2 merges a run's stores?)
+#pragma unroll
+        for (int r = 0; r < PG_PART_ROWS; ++r) if (valid[r]) {
+            const uint64_t dst = (uint64_t)L.aux[dig[r]] + (j[r] - L.ls[dig[r]]);
+            elemA[dst] = el[r]; loA[dst] = (uint16_t)(el[r].x & ((1u << shift) - 1u));
+        }
+        const uint32_t total = 0;
+#else
 #pragma unroll
         for (int r = 0; r < PG_PART_ROWS; ++r) if (valid[r]) L.stage[j[r]] = el[r];
         __syncthreads();
         // consecutive threads store consecutive elements of a digit's run
         const uint32_t total = L.ls[ndig];
+#endif
         for (uint32_t jj = tid; jj < total; jj += PG_PART_THREADS) {
             const uint4 e = L.stage[jj];
             const uint32_t d = (e.x >> shift) & (ndig - 1u);
@@ -385,6 +411,130 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
     if (part && tid < PG_PLACE_CSPAN && csum[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(part + c_lo + tid), (unsigned long long)csum[tid]); // integer sums: any order
+}
+
+// =====================================================================================================
+// direct ranking (<= 1024 slots), the placing kernel for MANY useful tiles (round 3)
+// =====================================================================================================
+// k_rank_emit (pg_kernels.hip) is built for the default limit, where a few dozen tiles place events: 16 waves per tile, 64 KB of per-wave
+// counters, the tile's column of the [slot][tile] table gathered line by line. With every tile useful (sample_limit 5000: 1588 tiles,
+// 2.1 M kept events) that cost 128 us = 6 % of the HBM roofline. Here: 8 waves per tile and 16 KB of packed 16-bit counters (three
+// workgroups per CU), count and rank in one ordered walk, FOUR consecutive tiles per workgroup so that a slot's four tile prefixes
+// are one 16-byte load, window starts from the block-sum prefix (two rounds of independent loads per kept event).
+#define PG_EMIT2_TILES 4
+#ifndef PG_EMIT2_INFLIGHT
+#define PG_EMIT2_INFLIGHT 2
+#endif
+__device__ __forceinline__ bool kept_window_bp(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const uint32_t *__restrict__ Bp, const KeptRead &kr,
+                                               uint64_t g, uint32_t &start, uint32_t &len) {
+    const uint64_t ge = g + W.sig_move_offset;
+    if (kr.generic) { start = O.m_start[ge]; len = O.m_len[ge]; return true; }
+    len = B.op_n[ge];
+    const uint64_t st = (uint64_t)kr.qs + (uint32_t)(op_prefix(B, O, Bp, ge) - op_prefix(B, O, Bp, kr.o0));
+    start = (uint32_t)st;
+    return st + len <= 0x7fffffffull;
+}
+__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_rank_emit2(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
+        const uint32_t *__restrict__ hist, const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ totals,
+        PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K, const uint32_t *__restrict__ Bp) {
+    __shared__ uint32_t cnt[PG_PART_WAVES * (PG_RANK_MAX_DIGITS / 2)];
+    __shared__ uint32_t s_hcol[PG_RANK_MAX_DIGITS], s_keep[PG_RANK_MAX_DIGITS], s_off[PG_RANK_MAX_DIGITS];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, ndig = 1u << nbits, half = ndig / 2 ? ndig / 2 : 1;
+    const int lane = lane_id();
+    const int64_t last_tile = (int64_t)totals[3];
+    const uint32_t n_groups = (n_tiles + PG_EMIT2_TILES - 1) / PG_EMIT2_TILES;
+    bool first = true;
+    for (uint32_t q = blockIdx.x; q < n_groups && (int64_t)q * PG_EMIT2_TILES <= last_tile; q += gridDim.x) {
+        const uint32_t tile0 = q * PG_EMIT2_TILES;
+        // slots tid and tid + 512: the four tile prefixes (one 16-byte load each: n_tiles is a multiple of 4), keep, offset
+        uint4 hc[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}; uint32_t kp[2] = {0, 0}, eo[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t d = tid + u * PG_PART_THREADS;
+            if (d < n_slots) { hc[u] = *reinterpret_cast<const uint4 *>(hist + (uint64_t)d * n_tiles + tile0); kp[u] = (uint32_t)keep[d]; eo[u] = (uint32_t)ev_off[d]; }
+        }
+        bool stop = false;
+        for (uint32_t k = 0; k < PG_EMIT2_TILES && !stop; ++k) {
+            const uint32_t tile = tile0 + k;
+            const uint64_t T0 = (uint64_t)tile * PG_SORT_TILE;
+            if (T0 >= n || (int64_t)tile > last_tile) break; // (block-uniform)
+            if (!first) __syncthreads(); // the previous tile's tables are read until its last thread is through
+            first = false;
+            const uint32_t tile_first = O.tile_read[tile];
+            uint32_t key[PG_PART_ROWS];
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) { const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane; key[r] = g < n ? keys[g] : PG_INVALID_SLOT; }
+            for (uint32_t i = tid; i < PG_PART_WAVES * half; i += PG_PART_THREADS) cnt[i] = 0;
+            int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t d = tid + u * PG_PART_THREADS;
+                if (d < ndig) {
+                    const uint32_t h = k == 0 ? hc[u].x : (k == 1 ? hc[u].y : (k == 2 ? hc[u].z : hc[u].w));
+                    s_hcol[d] = h; s_keep[d] = kp[u]; s_off[d] = eo[u];
+                    if (d < n_slots && h < kp[u]) any = 1;
+                }
+            }
+            if (!__syncthreads_or(any)) { stop = true; break; } // every k-mer this tile could feed is full (gmove.cpp:925-927), and so are the tiles behind it
+            bool valid[PG_PART_ROWS]; uint32_t dig[PG_PART_ROWS], lrank[PG_PART_ROWS];
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) { valid[r] = key[r] != PG_INVALID_SLOT; dig[r] = key[r] & (ndig - 1u); }
+            wave_digit_ranks(dig, valid, nbits, cnt + w * half, lrank);
+            __syncthreads();
+            if (tid < half) { // exclusive prefix over the waves, in place (both 16-bit halves of a word at once)
+                uint32_t run = 0;
+#pragma unroll
+                for (int ww = 0; ww < PG_PART_WAVES; ++ww) { const uint32_t word = cnt[ww * half + tid]; cnt[ww * half + tid] = run; run += word; }
+            }
+            __syncthreads();
+            // the kept events: rank < keep. Their windows in two rounds of independent loads: the read's record, then the op sums
+            uint32_t dst[PG_PART_ROWS];
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) {
+                const uint32_t d = dig[r], sh = (d & 1u) * 16u;
+                const uint32_t rank = s_hcol[d] + ((cnt[w * half + (d >> 1)] >> sh) & 0xffffu) + lrank[r];
+                dst[r] = (valid[r] && rank < s_keep[d]) ? s_off[d] + rank : 0xFFFFFFFFu;
+            }
+#ifdef PG_PROBE_EMIT2_NOWIN // timing probe only (results are garbage): no window work, one store per kept event
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) if (dst[r] != 0xFFFFFFFFu) K.rec[dst[r]] = PgKeptRec{0, 1, 0};
+            if (tile_first == 0xFFFFFFFFu)
+#endif
+#pragma unroll
+            for (int r0 = 0; r0 < PG_PART_ROWS; r0 += PG_EMIT2_INFLIGHT) { // a few rows' chains in flight
+                uint32_t rd[PG_EMIT2_INFLIGHT]; KeptRead kr[PG_EMIT2_INFLIGHT];
+#pragma unroll
+                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
+                    const int r = r0 + u;
+                    if (dst[r] == 0xFFFFFFFFu) continue;
+                    const uint32_t rel = key[r] >> PG_SLOT_BITS;
+                    rd[u] = rel != PG_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane);
+                    kr[u] = kept_read(O, rd[u]);
+                }
+                uint32_t ws[PG_EMIT2_INFLIGHT], wl[PG_EMIT2_INFLIGHT]; bool okr[PG_EMIT2_INFLIGHT];
+#pragma unroll
+                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
+                    const int r = r0 + u;
+                    ws[u] = 0; wl[u] = 0; okr[u] = true;
+                    if (dst[r] != 0xFFFFFFFFu) okr[u] = kept_window_bp(B, W, O, Bp, kr[u], T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ws[u], wl[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
+                    const int r = r0 + u;
+                    if (dst[r] == 0xFFFFFFFFu) continue;
+                    if (!okr[u]) { report_error(O, rd[u], PGR_ERR_RANGE); ws[u] = 0; wl[u] = 0; }
+                    uint32_t start = ws[u] - W.print_margin;
+                    const uint64_t we64 = (uint64_t)ws[u] + wl[u] + W.print_margin;
+                    uint32_t we = (uint32_t)(we64 > kr[u].L ? kr[u].L : we64);
+                    // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
+                    if (W.print_margin > ws[u] || we <= start) { report_error(O, rd[u], PGR_ERR_WINDOW); start = we = 0; }
+                    K.rec[dst[r]] = PgKeptRec{kr[u].sig0 + start, we - start, rd[u]};
+                    if (K.read_needed) K.read_needed[rd[u]] = 1;
+                }
+            }
+        }
+        if (stop) break;
+    }
 }
 
 // =====================================================================================================
@@ -536,6 +686,16 @@ hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t
     PG_LAUNCH(k_region_count, dim3(P.tilesB_cap), dim3(256), 0, st, (const uint16_t *)P.loA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
               (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, P.histB);
     PG_LAUNCH(k_region_scan, dim3(1u << P.hi_bits), dim3((1u << P.lo_bits) < 64u ? 64u : (1u << P.lo_bits)), 0, st, P.histB, (const uint32_t *)P.rbase, (int)P.lo_bits, n_slots, acc_cnt, acc_copy);
+    return hipSuccess;
+}
+
+hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const uint32_t *hist, const uint64_t *keep, const uint64_t *ev_off,
+                                const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K, const uint32_t *Bp) {
+    int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
+    const uint32_t n_tiles = pg_tiles(n, true);
+    if (!n_tiles) return hipSuccess;
+    const uint32_t groups = n_tiles / PG_EMIT2_TILES;
+    PG_LAUNCH(k_rank_emit2, dim3(groups < 1024u ? groups : 1024u), dim3(PG_PART_THREADS), 0, st, ev_slot, (uint32_t)n, nbits, n_slots, n_tiles, hist, keep, ev_off, totals, B, W, O, K, Bp);
     return hipSuccess;
 }
 

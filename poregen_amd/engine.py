@@ -418,10 +418,11 @@ class GmoveEngine:
         self._check(self._lib.pg_last_batch_device(self._h, C.byref(v)))
         return v
 
-    def kept_tensors(self, device=None):
+    def kept_tensors(self, device=None, with_reads=False):
         """The last collected batch as torch CUDA tensors that alias the library's device buffers (valid until the next
         submit/collect/reset): (kept events per slot int64[n_slots], window lengths int32[n_events] in slot-major
-        order, samples float64[n_samples]). What dist.gather_kept sends to the writing rank."""
+        order, samples float64[n_samples]; with_reads: also the kept events' read indices inside the batch, int32[n_events]). What
+        dist.gather_kept sends to the writing rank."""
         import torch
         v = self.device_view()
 
@@ -439,6 +440,8 @@ class GmoveEngine:
         counts = wrap(v.d_keep, self.n_slots, "<i8", torch.int64)
         ev_len = wrap(v.d_ev_len, v.n_events, "<i4", torch.int32)
         samples = wrap(v.d_samples, v.n_samples, "<f8", torch.float64)
+        if with_reads:
+            return counts, ev_len, samples, wrap(v.d_ev_read, v.n_events, "<i4", torch.int32)
         return counts, ev_len, samples
 
     def kernel_stats(self):

@@ -167,6 +167,54 @@ def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, 
     return b.validate_host()
 
 
+def add_indels_fast(b: Batch, del_rate=0.02, ins_rate=0.02, seed=1, rna=True) -> Batch:
+    """BASELINE configs[4]'s ss strings at throughput size: a matches-only batch (make_batch_fast) gets, vectorised, `del_rate` of its
+    matches a deletion op `nD` in front (n in 1..3: bases of the fetched sequence without samples -- they are inserted into the
+    sequence) and `ins_rate` of its matches (of 15 samples or more) an insertion op `nI` in front (n in 5..min(40, dwell - 5): samples
+    without a base, taken from the match's own dwell, so every read still covers exactly its signal). The signal is shared with `b`."""
+    rng = np.random.default_rng(seed)
+    n_ops = int(b.op_off[-1])
+    opn = b.op_n.astype(np.int64)
+    has_d = rng.random(n_ops) < del_rate
+    has_i = (rng.random(n_ops) < ins_rate) & (opn >= 15)
+    n_d = np.where(has_d, rng.integers(1, 4, n_ops), 0)
+    n_i = np.where(has_i, np.minimum(40, rng.integers(5, np.maximum(opn - 5, 6))), 0)
+    # ops: per original match [D?] [I?] M
+    cand_n = np.stack([n_d, n_i, opn - n_i], axis=1).reshape(-1)
+    cand_t = np.tile(np.array([2, 1, 0], np.uint8), n_ops)
+    keep = np.stack([has_d, has_i, np.ones(n_ops, bool)], axis=1).reshape(-1)
+    op_n = cand_n[keep].astype(np.uint32); op_t = cand_t[keep]
+    per_op = 1 + has_d.astype(np.int64) + has_i.astype(np.int64)
+    ob = b.op_off.astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(per_op)])
+    op_off = csum[ob].astype(np.uint64)
+    # bases in WALK order: the deleted bases in front of the match's own base
+    seq_off_old = b.seq_off.astype(np.int64)
+    nb_old = np.diff(seq_off_old)
+    read_of_op = np.repeat(np.arange(b.n_reads), np.diff(ob))
+    pos_in_read = np.arange(n_ops) - ob[read_of_op]
+    walk_old = b.seq[(seq_off_old[read_of_op] + (nb_old[read_of_op] - 1 - pos_in_read)) if rna else (seq_off_old[read_of_op] + pos_in_read)]
+    per_base = 1 + n_d
+    bsum = np.concatenate([[0], np.cumsum(per_base)])
+    walk = BASES[rng.integers(0, 4, int(bsum[-1]))]
+    walk[bsum[1:] - 1] = walk_old
+    seq_off = bsum[ob].astype(np.uint64)
+    nb = np.diff(seq_off.astype(np.int64))
+    if rna:  # fetched sequence = reverse of the walk order, per read
+        so = seq_off.astype(np.int64)
+        r_of_b = np.repeat(np.arange(b.n_reads), nb)
+        p = np.arange(int(bsum[-1])) - so[r_of_b]
+        seq = np.empty_like(walk)
+        seq[so[r_of_b] + (nb[r_of_b] - 1 - p)] = walk
+    else:
+        seq = walk
+    out = Batch(n_reads=b.n_reads, sig=b.sig, sig_off=b.sig_off, digitisation=b.digitisation, offset=b.offset, range=b.range,
+                query_start=b.query_start, target_start=(nb if rna else np.zeros(b.n_reads)).astype(np.int32),
+                target_end=(np.zeros(b.n_reads) if rna else nb).astype(np.int32), seq=np.ascontiguousarray(seq), seq_off=seq_off,
+                op_n=op_n, op_t=op_t, op_off=op_off)
+    return out.validate_host()
+
+
 OP_CHARS = ",ID"
 
 

@@ -149,6 +149,40 @@ def test_table_front_end_synthetic_equals_oracle(tmp_path, trim, extra):
 
 
 @pytest.mark.gpu
+def test_records_with_fewer_moves_than_k_have_no_events(tmp_path):
+    """A move-table / SAM record whose basecall is long enough (>= 10 bases) but whose move string holds a single '1' closes no
+    segment: k - 1 padding ops, fewer than k. The batch is then NOT one of whole-k matches only (PG_BATCH_ALL_MATCHES must not be
+    claimed): the read simply has no events, as on the reference's table path (gmove.cpp:616-700), and the run succeeds. A PAF
+    record whose ss string holds more matches than bases were fetched is undefined in the reference: both CLIs refuse it."""
+    b = synth.make_batch(40, kind="dna_r10", seed=83)
+    pre = str(tmp_path / "syn")
+    synth.write_table_files(b, pre)
+    rows = open(pre + ".table").read().split("\n")
+    c = rows[7].split("\t"); c[4] = "1" + "0" * (len(c[4]) - 1); rows[7] = "\t".join(c)
+    open(pre + ".table", "w").write("\n".join(rows))
+    sam = open(pre + ".sam").read().split("\n")
+    i7 = [i for i, ln in enumerate(sam) if ln.startswith("r7\t")][0]
+    c = sam[i7].split("\t"); mv = c[11].split(","); c[11] = ",".join(mv[:3] + ["1"] + ["0"] * (len(mv) - 4)); sam[i7] = "\t".join(c)
+    open(pre + ".sam", "w").write("\n".join(sam))
+    extra = ["-k", "5", "--file_limit", "1024", "--scaling", "1", "--sample_limit", "9", "-d"]
+    for ext in (".table", ".sam"):
+        r = cli([pre + ".slow5", pre + ext] + extra + [tmp_path / ("gpu" + ext)]); assert r.returncode == 0, r.stderr
+        o = oracle_cli([pre + ".slow5", pre + ext] + extra + [tmp_path / ("cpu" + ext)]); assert o.returncode == 0, o.stderr
+        assert_same_dirs(tmp_path / ("gpu" + ext), tmp_path / ("cpu" + ext))
+    # PAF: one match op more than fetched bases
+    synth.write_files(b, pre + "p")
+    lines = open(pre + "p.paf").read().split("\n")
+    cols = lines[5].split("\t")
+    ss = [i for i, x in enumerate(cols) if x.startswith("ss:Z:")][0]
+    cols[ss] = cols[ss] + "5,"
+    lines[5] = "\t".join(cols)
+    open(pre + "p.paf", "w").write("\n".join(lines))
+    pa = [pre + "p.slow5", pre + "p.paf", "--fastq", pre + "p.fastq", "-k", "5", "--file_limit", "1024", "--scaling", "1"]
+    assert cli(pa + [tmp_path / "gpu_p"]).returncode == 1
+    assert oracle_cli(pa + [tmp_path / "cpu_p"]).returncode != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kf", ["single_kmer_file.txt", "kmer_file.txt"])
 def test_sam_bam_front_end_fixture(tmp_path, kf):
     """SAM/BAM front-end (src/gmove.cpp:1061-1266): test_gmove.sh 1.3 / 2.3 -- BAM == table -- plus BAM == SAM == oracle(SAM)."""

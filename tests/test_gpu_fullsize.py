@@ -10,6 +10,15 @@ from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
 
 pytestmark = pytest.mark.gpu
 
+_BIG = {}
+
+
+def big_rna_batch():
+    """400 000 RNA004 reads x 4 000 samples (BASELINE configs[2] / configs[4]'s size), generated once per test session."""
+    if "b" not in _BIG:
+        _BIG["b"] = synth.make_batch_fast(400000, kind="rna004", seed=20251003 + 2)
+    return _BIG["b"]
+
 
 def check_invariants(res, sample_limit, n_reads):
     assert np.all(res.counts <= sample_limit)
@@ -177,7 +186,7 @@ def test_config2_full_size_8_rank_shards():
     import torch
     from poregen_amd.dist import shard_bounds
     limit, world = 5000, 8
-    b = synth.make_batch_fast(400000, kind="rna004", seed=20251003 + 2)
+    b = big_rna_batch()
     p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=limit)
     kmers = generate_kmers(5, rna=True)
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
@@ -240,3 +249,74 @@ def test_sample_limit_5000_at_oracle_size():
         eng.submit(b.slice_reads(lo, hi))
     assert_result_equals_oracle(eng.finish(), o, check_text_slots=0, sample_limit=5000)
     eng.close()
+
+
+def test_config4_full_size_8_rank_shards():
+    """BASELINE configs[4] AS STATED: 400 000 RNA reads x 4 000 samples whose ss strings carry 2 % deletions (nD, n in 1..3) and 2 %
+    insertions (nI, n in 5..40), a shuffled whitelist of 300 5-mers over ACGU of which the slice [51, 250] is dumped,
+    --kmer_pick_margin 2, sharded 8 contiguous ways. Nearly every read holds an I or a D op, so all of them take the generic walk
+    (src/gmove.cpp:204-211, 841-847). The eight 'ranks' are eight contexts on this one GPU around the calls of the 8-GPU job
+    (pg_count into a row of the all_gather buffer, pg_collect_gathered(world=8)); the same input also goes through pg_job with
+    devices [0] * 8 (what `poregen gmove --devices` runs). Checked: invariants, shard concatenation == the single run bit for bit,
+    the job layer == the single run, the oracle on a prefix for the k-mers it completes there (a slice never completes the WHOLE
+    list, so the reference reads every line and no prefix decides the whole output)."""
+    import torch
+    from poregen_amd.dist import shard_bounds
+    from poregen_amd.engine import GmoveJob
+    world = 8
+    b = synth.add_indels_fast(big_rna_batch(), del_rate=0.02, ins_rate=0.02, seed=20251003 + 4)
+    assert int((b.op_t == 1).sum()) > 500000 and int((b.op_t == 2).sum()) > 1000000
+    rng = np.random.default_rng(4)
+    full = generate_kmers(5, rna=True)
+    wl = [full[i] for i in rng.permutation(len(full))[:300]]
+    kmers = wl[50:250]
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, kmer_pick_margin=2, sample_limit=100)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 100, b.n_reads)
+    assert int(res.counts.min()) == 100
+    dev = torch.device("cuda:0")
+    gather_buf = torch.zeros(world * len(kmers), dtype=torch.int64, device=dev)
+    engs, keep_alive = [], []
+    for g in range(world):
+        lo, hi = shard_bounds(b.n_reads, world, g)
+        e = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=True, **p))
+        sh = b.slice_reads(lo, hi)
+        e.count(sh, out=gather_buf[g * len(kmers):(g + 1) * len(kmers)])
+        e.sync()
+        engs.append(e); keep_alive.append(sh)
+    parts = []
+    for g, e in enumerate(engs):
+        e.stats()
+        e.collect_gathered(gather_buf, world, g)
+        parts.append(e.finish())
+        tot, freq = (t.cpu().numpy() for t in e.job_totals())
+        assert np.array_equal(freq.astype(np.uint64), res.counts) and np.array_equal(np.minimum(tot, 100), freq)
+        e.close(); keep_alive[g] = None
+    lo_reads = [shard_bounds(b.n_reads, world, g)[0] for g in range(world)]
+    for s in range(len(kmers)):
+        vals = np.concatenate([r.slot_values(s) for r in parts])
+        assert np.array_equal(vals.view(np.uint64), res.slot_values(s).view(np.uint64)), s
+        a, e_ = int(res.ev_off[s]), int(res.ev_off[s + 1])
+        reads = np.concatenate([r.ev_read[int(r.ev_off[s]):int(r.ev_off[s + 1])].astype(np.int64) + lo_reads[g] for g, r in enumerate(parts)])
+        assert np.array_equal(reads, res.ev_read[a:e_].astype(np.int64)), s
+    assert sum(int(r.counts.sum()) for r in parts[1:]) == 0   # (the first shard's 50 000 reads fill the slice: the others place nothing)
+    del parts
+    # the same input through the job layer: eight shards on device 0, exchange through host memory
+    job = GmoveJob(GmoveParams(kmers=kmers, **p), [0] * world)
+    job.submit(b)
+    rj = job.finish()
+    for name in ("counts", "ev_off", "ev_len", "ev_read", "samp_off"):
+        assert np.array_equal(getattr(rj, name), getattr(res, name)), name
+    assert np.array_equal(rj.samples.view(np.uint64), res.samples.view(np.uint64))
+    job.close()
+    # the oracle on the first 4 000 reads: k-mers it completes there have their final content
+    o = oracle_for(wl, index_start=51, index_end=250, **p)
+    o.run_batch(b.slice_reads(0, 4000))
+    oc = o.counts()
+    done = np.flatnonzero(oc == 100)
+    assert done.size > 20
+    for s in done:
+        assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64)), int(s)
