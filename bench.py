@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0). Objects besides the contract's fields:
   config2_mode  (N>1) BASELINE configs[2]: the same N x 50 000 reads as ONE job at sample_limit 5000, same weak-scaling step
   job_layer     (N>1) the step through pg_job_* (one process, N host threads, ncclCommInitAll), the path `poregen gmove
                 --devices` uses; fed from host memory, so PCIe-inclusive and never `value`
-  hbm_not_mall, pcie_inclusive, end_to_end, lazy_statistics_mode, two_stream_mode, kmer_model_once_per_job, cpu_baseline (N=1)
+  hbm_not_mall, pcie_inclusive, end_to_end, lazy_statistics_mode, one_stream_mode, kmer_model_once_per_job, cpu_baseline (N=1)
 """
 import argparse
 import json
@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--lib", default=None, help="measurement builds: path of another libpgmove build to load instead of poregen_amd/libpgmove.so")
     ap.add_argument("--overlap-tail", action="store_true", help="statistics on a second stream next to the cut/emit/scan launches (PG_FLAG_OVERLAP_TAIL)")
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
-    ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP)")
+    ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP; the library's default since round 3 wherever it applies)")
+    ap.add_argument("--one-stream", action="store_true", help="every kernel of a batch on one stream (PG_FLAG_ONE_STREAM): round 2's default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +146,7 @@ def main():
         dist.init_process_group("nccl", init_method="file://" + tempfile.mktemp(prefix="pg_rdv_"), rank=0, world_size=1, device_id=dev)
 
     rna = args.kind == "rna004"
-    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=args.overlap, split_walk=args.split_walk, overlap_tail=args.overlap_tail)
+    p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit, device=local_rank, lazy_stats=args.lazy, overlap=True if args.overlap else (False if args.one_stream else None), split_walk=args.split_walk, overlap_tail=args.overlap_tail)
     if rna:
         p.update(min_dur=20, max_dur=40)
     kmers = generate_kmers(args.k, rna=rna)
@@ -313,17 +314,18 @@ def main():
                      "samples_touched": int(touched * args.read_len)}
         lz.close()
 
-    # the same job in two-stream mode (PG_FLAG_OVERLAP): statistics of batch i+1 next to the chain of batch i on a stream that
-    # may use three quarters of the CUs. Kernels then share the chip, so per-kernel timings are not clean: reported next to
-    # `value`, which stays the one-stream figure the roofline object describes.
-    two_stream = None
-    if world == 1 and not dist_step and not args.lazy and not args.overlap and not args.no_lazy_extra:
-        ts, tms, _, _ = timed(dict(p, overlap=True), args.steps, args.warmup)
+    # `value` is the library's default: two streams (PG_FLAG_OVERLAP) -- the statistics of batch i+1 next to the chain of batch i, on a
+    # stream that may use three quarters of every XCD's CUs. Kernels then share the chip, so the per-kernel times and the roofline
+    # object come from the profiled ONE-stream passes above; here the same job with every kernel on one stream (round 2's default).
+    one_stream = None
+    two_streams_on = world == 1 and not dist_step and not args.lazy and not args.one_stream
+    if two_streams_on and not args.no_lazy_extra:
+        ts, tms, _, _ = timed(dict(p, overlap=False), args.steps, args.warmup)
         tres = ts.finish()
         same = (np.array_equal(tres.samples, res.samples) and np.array_equal(tres.ev_read, res.ev_read)
                 and np.array_equal(tres.samp_off, res.samp_off))
-        two_stream = {"value": n_samples / (tms * 1e-3), "ms_per_step": tms, "whole_step_frac": balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "stats_stream_cus": "3/4 of every XCD (CU mask)", "results_equal_one_stream": bool(same)}
+        one_stream = {"value": n_samples / (tms * 1e-3), "ms_per_step": tms, "whole_step_frac": balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "results_equal_two_streams": bool(same)}
         ts.close()
 
     out = {
@@ -346,7 +348,8 @@ def main():
         "kernels_ms_per_step": kernels_ms,
         "host_enqueue_ms_per_step": enqueue_ms,
         "lazy_statistics_mode": lazy_info,
-        "two_stream_mode": two_stream,
+        "streams": ("two: statistics of the next batch on a stream of their own (3/4 of every XCD's CUs)" if two_streams_on else "one"),
+        "one_stream_mode": one_stream,
         "kmer_model_once_per_job": model_info,
         "gen_seconds": gen_s,
     }

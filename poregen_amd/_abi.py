@@ -25,6 +25,7 @@ PG_FLAG_STOP_WHEN_FULL = 64
 PG_FLAG_DEFER_STATS = 128
 PG_FLAG_DEBUG_SPLIT_WALK = 256
 PG_FLAG_OVERLAP_TAIL = 512
+PG_FLAG_ONE_STREAM = 1024
 PG_MODEL_KEEP_FIRST = 1
 PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 

@@ -280,7 +280,7 @@ int gmove_main(int argc, char **argv) {
     }
     prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
     const bool whole_list = slot_kmers.size() == kmers.size(); // only then can the reference's loop end early (gmove.cpp:733-735)
-    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = (whole_list ? PG_FLAG_STOP_WHEN_FULL : 0) | (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
+    prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = PG_FLAG_ONE_STREAM /* a job of a few batches: no second hardware queue (15-20 ms) */ | (whole_list ? PG_FLAG_STOP_WHEN_FULL : 0) | (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
     Backend dev;

@@ -303,6 +303,10 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     double tmark_ = timing_on() ? wall_now() : 0.0;
     pg_ctx *c = new pg_ctx();
     c->prm = *p;
+    // two-stream mode is the default wherever it applies (include/pgmove.h: PG_FLAG_ONE_STREAM)
+    if (!(p->flags & (PG_FLAG_ONE_STREAM | PG_FLAG_PROFILE | PG_FLAG_LAZY_STATS | PG_FLAG_SKIP_OUT_OF_RANGE | PG_FLAG_DEFER_STATS | PG_FLAG_OVERLAP_TAIL)) && p->scaling == 1 &&
+        !getenv("PGMOVE_ONE_STREAM"))
+        c->prm.flags |= PG_FLAG_OVERLAP;
     c->device = p->device;
     c->n_codes = 1u << (2 * p->kmer_size);
     c->key_bits = 1; while ((1ull << c->key_bits) < (uint64_t)p->n_slots) c->key_bits++;
@@ -319,7 +323,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high)); // "least" and "greatest" priority (numerically high / low)
     CTRY(hipStreamCreateWithPriority(&c->own_st, hipStreamNonBlocking, prio_high));
     c->st = c->own_st;
-    if (p->flags & (PG_FLAG_OVERLAP | PG_FLAG_OVERLAP_TAIL)) // the second stream only exists in the modes that use it: a hardware queue costs 15-20 ms to create
+    if (c->prm.flags & (PG_FLAG_OVERLAP | PG_FLAG_OVERLAP_TAIL)) // the second stream only exists in the modes that use it: a hardware queue costs 15-20 ms to create
     {
         // PG_FLAG_OVERLAP: the statistics stream may use three quarters of the compute units (the mask's bits go round the XCDs, so
         // every XCD keeps a quarter of its CUs free of it). Without the reservation the streaming kernel's one-wave workgroups refill
@@ -330,7 +334,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
         hipDeviceProp_t prop;
         CTRY(hipGetDeviceProperties(&prop, p->device));
         const int cus = prop.multiProcessorCount;
-        const int withheld = wh ? atoi(wh) : ((p->flags & PG_FLAG_OVERLAP) ? cus / 4 : 0);
+        const int withheld = wh ? atoi(wh) : ((c->prm.flags & PG_FLAG_OVERLAP) ? cus / 4 : 0);
         bool masked = false;
         if (withheld > 0 && withheld < cus) {
             std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);

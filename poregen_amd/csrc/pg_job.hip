@@ -195,7 +195,7 @@ pg_status pg_job_create(const pg_params *p, const int32_t *devices, uint32_t n, 
     pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
         pg_params q = *p;
         q.device = j->devices[g];
-        q.flags |= PG_FLAG_DEFER_STATS;
+        q.flags |= PG_FLAG_DEFER_STATS | PG_FLAG_ONE_STREAM;
         const pg_status st = pg_create(&q, &j->ctx[g]);
         if (st != PG_OK) { msg = pg_last_error(nullptr); return st; }
         hipError_t e = hipSetDevice(q.device);

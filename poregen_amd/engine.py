@@ -55,7 +55,7 @@ class GmoveParams:
     device: int = 0
     lazy_stats: bool = False
     profile: bool = False
-    overlap: bool = False
+    overlap: Optional[bool] = None       # None: the library's default (two streams when it computes eager statistics); True / False: PG_FLAG_OVERLAP / PG_FLAG_ONE_STREAM
     debug_narrow: bool = False
     overlap_tail: bool = False           # statistics on a second stream next to pg_collect's small launches (PG_FLAG_OVERLAP_TAIL)
     split_walk: bool = False             # measurement/tests: ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK)
@@ -224,7 +224,7 @@ def _fill_params(owner, lib, params: "GmoveParams"):
     p.kmer_pick_margin = params.kmer_pick_margin; p.scaling = params.scaling; p.allow_rna = int(params.rna)
     p.pa_min = params.pa_min; p.pa_max = params.pa_max; p.n_slots = n_slots
     p.flags = ((_abi.PG_FLAG_LAZY_STATS if params.lazy_stats else 0) | (_abi.PG_FLAG_PROFILE if params.profile else 0)
-               | (_abi.PG_FLAG_OVERLAP if params.overlap else 0) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
+               | (_abi.PG_FLAG_OVERLAP if params.overlap else (_abi.PG_FLAG_ONE_STREAM if params.overlap is False else 0)) | (_abi.PG_FLAG_DEBUG_NARROW if params.debug_narrow else 0)
                | (_abi.PG_FLAG_STOP_WHEN_FULL if params.stop_when_full else 0) | (_abi.PG_FLAG_DEFER_STATS if params.defer_stats else 0)
                | (_abi.PG_FLAG_DEBUG_SPLIT_WALK if params.split_walk else 0)
                | (_abi.PG_FLAG_OVERLAP_TAIL if params.overlap_tail else 0))
