@@ -104,38 +104,41 @@ __device__ __forceinline__ PartLds part_lds(uint32_t ndig) {
 // elements in (digit, source order) order; ls as described above. One pass: the count and the rank inside the wave come from the
 // same ordered walk over the rows (ballots find the lanes of equal digit; the lowest of them advances the wave's counter).
 // the first half on its own: lrank[r] = elements of the same digit in front of the element inside its WAVE (rows in order, lanes in order);
-// the wave's counters hold its totals per digit afterwards
+// the wave's counters hold its totals per digit afterwards. Per row: every valid lane reads its digit's running count, adds one to it
+// (LDS atomic, order-free), reads it again -- the difference is how many lanes of the row share the digit. Alone (the usual case:
+// 64 lanes over 512..1024 digits): done. Otherwise the lanes of each shared digit find their order with one ballot per such digit
+// (round 2's form paid nbits ballots and 64-bit selects for every row: these kernels are bound by instruction issue).
 __device__ __forceinline__ void wave_digit_ranks(const uint32_t (&dig)[PG_PART_ROWS], const bool (&valid)[PG_PART_ROWS], int nbits, uint32_t *mycnt, uint32_t (&lrank)[PG_PART_ROWS]) {
-    const int lane = lane_id();
+    (void)nbits;
+    volatile uint32_t *vc = reinterpret_cast<volatile uint32_t *>(mycnt);
 #pragma unroll
     for (int r = 0; r < PG_PART_ROWS; ++r) {
         const uint32_t d = dig[r], sh = (d & 1u) * 16u;
-        const uint64_t peers = match_digit(d, valid[r], nbits);
-        uint32_t b = 0;
-        if (valid[r]) b = (reinterpret_cast<volatile uint32_t *>(mycnt)[d >> 1] >> sh) & 0xffffu;
+        uint32_t b = 0, after = 0;
+        if (valid[r]) b = (vc[d >> 1] >> sh) & 0xffffu;
         __builtin_amdgcn_wave_barrier();
-        if (valid[r] && lane == __ffsll((long long)peers) - 1) atomicAdd(&mycnt[d >> 1], (uint32_t)__popcll(peers) << sh);
+        if (valid[r]) atomicAdd(&mycnt[d >> 1], 1u << sh);
         __builtin_amdgcn_wave_barrier();
-        lrank[r] = b + (uint32_t)__popcll(peers & lanemask_lt());
+        if (valid[r]) after = (vc[d >> 1] >> sh) & 0xffffu;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t below = 0;
+        uint64_t shared = __ballot(valid[r] && after - b > 1u); // lanes whose digit another lane of this row holds too
+        while (shared) {
+            const int l = __ffsll((long long)shared) - 1;
+            const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)d, l);
+            const uint64_t same = __ballot(valid[r] && d == dl);
+            if (d == dl) below = (uint32_t)__popcll(same & lanemask_lt());
+            shared &= ~same;
+        }
+        lrank[r] = b + below;
     }
 }
 __device__ __forceinline__ void tile_digit_order(const uint32_t (&dig)[PG_PART_ROWS], const bool (&valid)[PG_PART_ROWS], int nbits, uint32_t ndig,
                                                  const PartLds &L, uint32_t (&j)[PG_PART_ROWS]) {
     const uint32_t tid = threadIdx.x, w = tid >> 6, half = ndig / 2 ? ndig / 2 : 1;
     const int lane = lane_id();
-    uint32_t *mycnt = L.cnt + w * half;
     uint32_t lrank[PG_PART_ROWS];
-#pragma unroll
-    for (int r = 0; r < PG_PART_ROWS; ++r) {
-        const uint32_t d = dig[r], sh = (d & 1u) * 16u;
-        const uint64_t peers = match_digit(d, valid[r], nbits);
-        uint32_t b = 0;
-        if (valid[r]) b = (reinterpret_cast<volatile uint32_t *>(mycnt)[d >> 1] >> sh) & 0xffffu; // every peer reads the running count of its digit ...
-        __builtin_amdgcn_wave_barrier();
-        if (valid[r] && lane == __ffsll((long long)peers) - 1) atomicAdd(&mycnt[d >> 1], (uint32_t)__popcll(peers) << sh); // ... then the lowest advances it (the other half of the word may belong to another digit's leader: an atomic)
-        __builtin_amdgcn_wave_barrier();
-        lrank[r] = b + (uint32_t)__popcll(peers & lanemask_lt());
-    }
+    wave_digit_ranks(dig, valid, nbits, L.cnt + w * half, lrank);
     __syncthreads();
     // per digit: exclusive prefix over the waves (in place, both halves of a word at once: sums stay below 2^16), the tile's total
     uint32_t te = 0, to = 0;

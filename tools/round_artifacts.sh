@@ -3,7 +3,7 @@
 # trace of the same command and the HBM-traffic counters of the dominant kernel (separate --pmc passes).
 # usage (from the repo root, on the GPU box): bash tools/round_artifacts.sh <tag>   -> gpurun_out/<tag>/
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag; mkdir -p $out
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
 if [ "$2" != "nopytest" ]; then
