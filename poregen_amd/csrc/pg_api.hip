@@ -607,8 +607,10 @@ static int gather_lanes(const pg_ctx *c) {
 
 // direct ranking: will (nearly) every tile place events? Then the placing kernel built for that takes over (k_rank_emit2), and it wants
 // the prefix of the block sums. The bound is the same as the chunked gather's: more than 64 * 4096 events may be kept.
+// (PGMOVE_DENSE_MIN=n lowers the bound: tests and the fuzzers run small jobs through the kernels built for many kept events)
+static uint64_t dense_min() { const char *e = getenv("PGMOVE_DENSE_MIN"); return e ? strtoull(e, nullptr, 10) : 64ull * 4096; }
 static bool dense_direct(const pg_ctx *c, uint64_t n_ops) {
-    return c->prm.n_slots <= PG_DIRECT_MAX_SLOTS && std::min<uint64_t>(n_ops, (uint64_t)c->prm.n_slots * c->prm.sample_limit) > 64ull * 4096 && !getenv("PGMOVE_EMIT1");
+    return c->prm.n_slots <= PG_DIRECT_MAX_SLOTS && std::min<uint64_t>(n_ops, (uint64_t)c->prm.n_slots * c->prm.sample_limit) > dense_min() && !getenv("PGMOVE_EMIT1");
 }
 
 static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
@@ -905,7 +907,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
     // Many kept events (nearly every accepted event kept: large sample_limit, k = 9): the offset scan happens inside the gather's
     // workgroups (pg_place.hip). Few (the default limit: 10^5 events): the one-launch chained scan + the strided gather of round 2.
-    const bool chunked = ke_cap > 64ull * 4096 && (win_cap + 1) * 4096 < (1ull << 32);
+    const bool chunked = ke_cap > dense_min() && (win_cap + 1) * 4096 < (1ull << 32);
     bool sums_ready = false;
     if (chunked) HIP_TRY(c, c->chunk_part.ensure(8200 * 8));
     if (direct) {

@@ -47,6 +47,25 @@ def test_batch_matches_oracle(case):
     assert_result_equals_oracle(res, o, sample_limit=p.get("sample_limit", 100))
 
 
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_batch_matches_oracle_through_the_dense_kernels(case, monkeypatch):
+    """The same cases with PGMOVE_DENSE_MIN=0: however few events may be kept, the job takes the kernels built for MANY kept events
+    (k_rank_emit2: four tiles per workgroup, packed counters; the chunked gather with its offset scan inside), and -- PGMOVE_LSD_SORT=1
+    on the k = 9 case -- the round-1 LSD radix sort that stays for more than 2^20 slots."""
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    b = synth.make_batch(case["n"], kind=case["kind"], seed=20251003 + len(case["name"]), **case["gen"])
+    p = case["p"]
+    kmers = generate_kmers(p["kmer_size"], rna=p.get("rna", False))
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    res = run_engine([b.slice_reads(0, case["n"] // 3), b.slice_reads(case["n"] // 3, case["n"])], kmers=kmers, **p)
+    assert_result_equals_oracle(res, o, sample_limit=p.get("sample_limit", 100))
+    if p["kmer_size"] == 9:
+        monkeypatch.setenv("PGMOVE_LSD_SORT", "1")
+        res = run_engine([b], kmers=kmers, **p)
+        assert_result_equals_oracle(res, o, sample_limit=p.get("sample_limit", 100))
+
+
 def test_multi_batch_equals_single_batch_and_oracle():
     b = synth.make_batch(500, kind="rna004", seed=11)
     p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
