@@ -345,6 +345,8 @@ pg_status   pg_job_finish(pg_job *job, pg_result *out); /* merged view, owned by
 int32_t     pg_job_uses_rccl(const pg_job *job);
 /* The k-mer model of the whole job (see pg_model): the merged kept samples are reduced on the job's first device. */
 pg_status   pg_job_model(pg_job *job, uint32_t flags, pg_model_result *out);
+/* pg_kernel_stats of one shard's context (PG_FLAG_PROFILE in the job's params): what a rank-level early-out skipped shows up here */
+pg_status   pg_job_kernel_stats(pg_job *job, uint32_t shard, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out);
 
 /* profiling (PG_FLAG_PROFILE): per-kernel launch counts and HIP-event times since the last reset */
 pg_status pg_kernel_stats(pg_ctx *ctx, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out);

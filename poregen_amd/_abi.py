@@ -35,7 +35,7 @@ EXPORTS = [
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
     "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
-    "pg_job_uses_rccl", "pg_job_model", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
+    "pg_job_uses_rccl", "pg_job_model", "pg_job_kernel_stats", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
 ]
 PG_JOB_EXCHANGE_AUTO, PG_JOB_EXCHANGE_HOST, PG_JOB_EXCHANGE_RCCL = 0, 1, 2
 
@@ -167,5 +167,6 @@ def load():
     lib.pg_job_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish.restype = i32
     lib.pg_job_uses_rccl.argtypes = [vp]; lib.pg_job_uses_rccl.restype = i32
     lib.pg_job_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_job_model.restype = i32
+    lib.pg_job_kernel_stats.argtypes = [vp, u32, C.POINTER(PgKernelStat), u32, C.POINTER(u32)]; lib.pg_job_kernel_stats.restype = i32
     _lib = lib
     return lib

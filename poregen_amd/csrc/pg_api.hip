@@ -1041,6 +1041,14 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
 
 // pg_job.hip: the stream the chain runs on (events of the job's communication stream are ordered against it)
 void *pgi_stream(pg_ctx *c) { return c ? (void *)c->st : nullptr; }
+// pg_job.hip, rank-level early-out: the batch counted with PG_FLAG_DEFER_STATS will keep no event (every k-mer is complete below this
+// rank), so the collect that follows needs no statistics: none are queued (the gather reads a read's median / MAD for kept events only)
+pg_status pgi_skip_stats(pg_ctx *c) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_count) return fail(c, PG_ERR_STATE, "pgi_skip_stats without a preceding pg_count");
+    c->stats_deferred = false;
+    return PG_OK;
+}
 
 int32_t pg_all_slots_full(pg_ctx *c) {
     if (!c) return 0;

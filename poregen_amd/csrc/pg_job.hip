@@ -29,6 +29,7 @@
 #include <vector>
 
 extern "C" void *pgi_stream(pg_ctx *c); // pg_api.hip: the stream the context's chain currently runs on
+extern "C" pg_status pgi_skip_stats(pg_ctx *c); // pg_api.hip: a deferred-statistics batch that will keep nothing needs none
 
 static thread_local std::string g_job_create_error;
 
@@ -109,6 +110,7 @@ struct pg_job {
     std::vector<hipStream_t> comm_st;
     std::vector<hipEvent_t> ev_counted, ev_gathered;
     std::vector<uint64_t> host_rows;       // host exchange: uint64[n][n_slots]
+    std::vector<uint64_t> host_row0;       // host exchange: the job's accepted events per slot in front of the current batch (row 0 of the device tables)
     std::vector<std::vector<uint64_t>> cuts; // per batch: n + 1 read boundaries inside the batch
     std::vector<uint64_t> batch_reads;     // per batch
     std::string err;
@@ -219,7 +221,7 @@ pg_status pg_job_create(const pg_params *p, const int32_t *devices, uint32_t n, 
             j->use_rccl = false; j->err.clear();
         }
     }
-    if (!j->use_rccl) j->host_rows.assign((size_t)n * p->n_slots, 0);
+    if (!j->use_rccl) { j->host_rows.assign((size_t)n * p->n_slots, 0); j->host_row0.assign(p->n_slots, 0); }
     *out = j;
     return PG_OK;
 }
@@ -276,6 +278,10 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         return PG_OK;
     });
     if (s != PG_OK) return s;
+    // Nothing behind the completing read is touched by the reference (gmove.cpp:733-735). Was every k-mer complete before this batch?
+    // (the last shard's cut of the previous batch saw every accepted event of the job; phase 1 has settled it.) Then no rank computes
+    // statistics or gathers anything for this batch: its events only rank behind complete files.
+    const bool done_before = j->have_batch && pg_all_slots_full_settled(j->ctx[n - 1]);
     // phase 2: the exchange
     if (j->use_rccl) {
         for (uint32_t g = 0; g < n; ++g) { JHIP(j, hipSetDevice(j->devices[g])); JHIP(j, hipStreamWaitEvent(j->comm_st[g], j->ev_counted[g], 0)); }
@@ -295,7 +301,19 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
     s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
         pg_ctx *c = j->ctx[g];
         hipStream_t st = (hipStream_t)pgi_stream(c);
-        pg_status ps = pg_stats(c);
+        // rank-level early-out: complete before this batch, or -- the host exchange has the table at hand -- complete below this rank
+        // (the rows of the lower ranks fill every k-mer): this rank keeps nothing, so it needs no statistics. (With RCCL the table
+        // stays on the devices and the statistics are queued in front of the wait for it: there the rule of the previous batch alone.)
+        bool skip = done_before;
+        if (!skip && !j->use_rccl && j->sample_limit > 0) {
+            skip = true;
+            for (uint32_t sl = 0; sl < ns && skip; ++sl) {
+                uint64_t base = j->host_row0[sl];
+                for (uint32_t h = 0; h < g; ++h) base += j->host_rows[(size_t)h * ns + sl];
+                if (base < j->sample_limit) skip = false;
+            }
+        }
+        pg_status ps = skip ? pgi_skip_stats(c) : pg_stats(c);
         if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
         hipError_t e = hipSetDevice(j->devices[g]);
         if (j->use_rccl) { if (e == hipSuccess) e = hipStreamWaitEvent(st, j->ev_gathered[g], 0); }
@@ -312,6 +330,7 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         return PG_OK;
     });
     if (s != PG_OK) return s;
+    if (!j->use_rccl) for (uint32_t sl = 0; sl < ns; ++sl) for (uint32_t h = 0; h < n; ++h) j->host_row0[sl] += j->host_rows[(size_t)h * ns + sl];
     j->cuts.push_back(std::move(cut));
     j->batch_reads.push_back(nr);
     j->have_batch = true;
@@ -373,9 +392,18 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
     j->r_counts.assign(ns, 0); j->r_ev_off.assign(ns + 1, 0); j->r_samp_off.assign(n_events + 1, 0);
     j->r_ev_len.resize(n_events); j->r_ev_read.resize(n_events); j->r_samples.resize(n_samples);
     j->r_skipped.assign(bstart[nb], 0);
-    uint64_t e = 0, sp = 0;
-    std::vector<uint64_t> pos(n);
+    // where every slot's events and samples start in the merged arrays (cheap), then the copies -- hundreds of MB at large limits --
+    // slot ranges of about equal sample counts side by side on a few threads
+    std::vector<uint64_t> slot_e(ns + 1, 0), slot_s(ns + 1, 0);
     for (uint32_t sl = 0; sl < ns; ++sl) {
+        uint64_t ne = 0, nsm = 0;
+        for (uint32_t g = 0; g < n; ++g) { const uint64_t a = R[g].ev_off[sl], b2 = R[g].ev_off[sl + 1]; ne += b2 - a; if (b2 > a) nsm += R[g].samp_off[b2] - R[g].samp_off[a]; }
+        slot_e[sl + 1] = slot_e[sl] + ne; slot_s[sl + 1] = slot_s[sl] + nsm;
+    }
+    auto merge_slots = [&](uint32_t sl0, uint32_t sl1) {
+    uint64_t e = slot_e[sl0], sp = slot_s[sl0];
+    std::vector<uint64_t> pos(n);
+    for (uint32_t sl = sl0; sl < sl1; ++sl) {
         j->r_ev_off[sl] = e;
         for (uint32_t g = 0; g < n; ++g) pos[g] = R[g].ev_off[sl];
         for (size_t i = 0; i < nb; ++i)
@@ -397,7 +425,24 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
             }
         j->r_counts[sl] = e - j->r_ev_off[sl];
     }
-    j->r_ev_off[ns] = e; j->r_samp_off[n_events] = sp;
+    };
+    {
+        const unsigned nt = n_samples >= (8u << 20) ? 8u : 1u;
+        if (nt == 1) merge_slots(0, ns);
+        else {
+            std::vector<std::thread> pool;
+            uint32_t s0 = 0;
+            for (unsigned t = 0; t < nt; t++) {
+                uint32_t s1 = s0;
+                const uint64_t want = slot_s[ns] / nt * (t + 1);
+                while (s1 < ns && (t + 1 == nt || slot_s[s1 + 1] <= want)) s1++;
+                if (s1 > s0) pool.emplace_back(merge_slots, s0, s1);
+                s0 = s1;
+            }
+            for (auto &th : pool) th.join();
+        }
+    }
+    j->r_ev_off[ns] = slot_e[ns]; j->r_samp_off[n_events] = slot_s[ns];
     for (size_t i = 0; i < nb; ++i)
         for (uint32_t g = 0; g < n; ++g) {
             const uint64_t m = j->cuts[i][g + 1] - j->cuts[i][g];
@@ -410,6 +455,12 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
     j->merged = true;
     *out = v;
     return PG_OK;
+}
+
+pg_status pg_job_kernel_stats(pg_job *j, uint32_t shard, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out) {
+    if (!j || shard >= j->n) return PG_ERR_INVALID_ARG;
+    const pg_status st = pg_kernel_stats(j->ctx[shard], out, cap, n_out);
+    return st == PG_OK ? PG_OK : jfail(j, st, "shard %u: %s", shard, pg_last_error(j->ctx[shard]));
 }
 
 pg_status pg_job_model(pg_job *j, uint32_t flags, pg_model_result *out) {

@@ -500,6 +500,13 @@ class GmoveJob:
         self._check(self._lib.pg_job_model(self._h, _abi.PG_MODEL_KEEP_FIRST if keep_first else 0, C.byref(m)))
         return GmoveEngine._model_from(self, m)
 
+    def kernel_stats(self, shard: int):
+        """pg_kernel_stats of one shard's context (params.profile): {kernel: (launches, total ms)}."""
+        n = C.c_uint32(0)
+        buf = (_abi.PgKernelStat * 64)()
+        self._check(self._lib.pg_job_kernel_stats(self._h, shard, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(n.value, 64))}
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.pg_job_destroy(self._h)

@@ -60,6 +60,30 @@ def test_job_equals_single_context_and_stops_when_full():
     eng.close(); job.close()
 
 
+def test_rank_level_early_out_skips_statistics():
+    """Nothing behind the completing read is touched by the reference (src/gmove.cpp:733-735). Four shards on device 0 (host exchange):
+    all 64 3-mers are complete inside the first shards of batch 1, so the later shards -- whose base already fills every k-mer -- queue
+    no statistics kernel at all, and neither does ANY shard for a batch submitted after the job was complete. Same output as one context."""
+    b = synth.make_batch(600, kind="rna004", seed=605)
+    p = dict(kmer_size=3, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(3, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    job = GmoveJob(GmoveParams(kmers=kmers, profile=True, **p), [0, 0, 0, 0])
+    first, second = b.slice_reads(0, 400), b.slice_reads(400, 600)
+    eng.submit(first); job.submit(first); job.sync()
+    assert job.all_slots_full()
+    ks = [job.kernel_stats(g) for g in range(4)]
+    launches = [k.get("k_read_stats", (0, 0.0))[0] for k in ks]
+    assert launches[0] == 1 and launches[3] == 0 and launches[2] == 0, launches   # 100 reads fill 64 k-mers x 40 events
+    eng.submit(second); job.submit(second); job.sync()
+    assert [job.kernel_stats(g).get("k_read_stats", (0, 0.0))[0] for g in range(4)] == launches  # complete before the batch: no shard computes statistics
+    re, rj = eng.finish(), job.finish()
+    for name in ("counts", "ev_off", "ev_len", "ev_read", "samp_off", "read_skipped"):
+        assert np.array_equal(getattr(re, name), getattr(rj, name)), name
+    assert np.array_equal(re.samples.view(np.uint64), rj.samples.view(np.uint64))
+    eng.close(); job.close()
+
+
 def test_job_rccl_large_limit_many_batches():
     """The RCCL path (one-rank communicator) with the running total carried in row 0 of the receive buffer over five batches."""
     b = synth.make_batch_fast(2500, kind="rna004", seed=603)
