@@ -164,7 +164,10 @@ __device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub,
     auto conv = [&](int raw) {
         const double pA = ((double)raw + offset) * scale;             // TO_PICOAMPS, poregen.h:30
         double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;           // gmove.cpp:756-759
-        if (scaling) x = (x - md) / ma;                               // gmove.cpp:774
+        // gmove.cpp:774. (Round 3 tried the division's reciprocal refinement once per event -- it depends on the divisor alone while
+        // v_div_scale leaves the operands as they are -- and a multiplication + two FMAs per sample: bit-identical, 5 % SLOWER at k = 9
+        // (1027 vs 971 us): the gather is bound by the 64-byte sectors its windows pull over the fabric, not by FP64 issue.)
+        if (scaling) x = (x - md) / ma;
         return x;
     };
     auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1

@@ -80,6 +80,24 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(g_base, base.data(), base.size() * 8, hipMemcpyHostToDevice));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     std::vector<double> ref(n_out), got(n_out);
+    // A-local: mode A with every window's source folded into a small area of the signal (argv[5] MB, default 27): what the gather would cost if
+    // its random reads were served by the Infinity Cache / L2 instead of HBM (outputs differ from the reference run by construction)
+    {
+        const uint64_t area = (uint64_t)(argc > 5 ? atoi(argv[5]) : 27) * 1000000ull / 2; // samples
+        std::vector<uint32_t> loc(N);
+        for (uint32_t e = 0; e < N; ++e) loc[e] = (uint32_t)(d_src[e] % (area < total - 64 ? area : total - 64));
+        uint32_t *g_loc; CK(hipMalloc(&g_loc, N * 4ull)); CK(hipMemcpy(g_loc, loc.data(), N * 4ull, hipMemcpyHostToDevice));
+        for (int grid : {8192, 32768}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(k_move<0>, dim3(grid), dim3(256), 0, 0, g_sig, total, N, g_loc, g_dlen, g_dsoff, nullptr, nullptr, nullptr, g_out);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+            }
+            printf("mode A-local (sources inside %.0f MB)          grid %5d: %.3f ms\n", area * 2 / 1e6, grid, best);
+        }
+    }
     for (int mode = 0; mode < 3; ++mode) {
         for (int grid : {8192, 32768}) {
             float best = 1e9f;
