@@ -88,14 +88,15 @@ bool touch_dump_files(const std::string &out_dir, const std::vector<std::string>
     return true;
 }
 
-static void slot_text(const DumpInput &in, uint32_t s, bool delimit, uint32_t sample_limit, std::string &out) {
+// samples / first: the samples of (at least) this slot, the index of samples[0] in the job's sample stream
+static void slot_text(const DumpInput &in, uint32_t s, bool delimit, uint32_t sample_limit, std::string &out, const double *samples, uint64_t first) {
     char buf[400];
     const uint64_t a = in.ev_off[s], b = in.ev_off[s + 1];
     out.reserve((size_t)(in.samp_off[b] - in.samp_off[a]) * 13 + (delimit ? (size_t)in.n_reads : 0) + 64); // ~12 bytes per sample
     auto put_event = [&](uint64_t e) {
         const uint64_t so = in.samp_off[e], n = in.ev_len[e];
         for (uint64_t i = 0; i < n; i++) { // "%.8f," ... "%.8f;" (src/gmove.cpp:941-944)
-            size_t w = format_f8(in.samples[so + i], buf);
+            size_t w = format_f8(samples[so - first + i], buf);
             buf[w] = i + 1 == n ? ';' : ',';
             out.append(buf, w + 1);
         }
@@ -118,18 +119,44 @@ bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &
     std::atomic<uint32_t> next(0);
     std::atomic<bool> ok(true);
     std::string first_err;
+    // the writers take RANGES of slots. With the samples still on the device (in.samples == null) a range is fetched as one piece of
+    // about 8 MB -- one k-mer at a large sample_limit, thousands of them at k = 9 -- so that a copy over PCIe is never a few KB, and
+    // the next range travels while this one is formatted and written (the reference prints as it goes: src/gmove.cpp:938-944)
+    std::vector<uint32_t> range_end;
+    {
+        const uint64_t piece = 1u << 20; // samples
+        uint32_t s = 0;
+        while (s < in.n_slots) {
+            const uint64_t a = in.samp_off[in.ev_off[s]];
+            uint32_t e = s + 1;
+            while (e < in.n_slots && e - s < 4096 && in.samp_off[in.ev_off[e + 1]] - a <= piece) ++e;
+            range_end.push_back(e);
+            s = e;
+        }
+    }
     auto work = [&]() {
         std::string text;
+        std::vector<double> piece;
         for (;;) {
-            const uint32_t s = next.fetch_add(1);
-            if (s >= in.n_slots || !ok.load()) break;
-            text.clear();
-            slot_text(in, s, delimit, sample_limit, text);
-            if (text.empty()) continue; // the file already exists, empty (touch_dump_files)
-            const std::string path = out_dir + "/dump/" + slot_kmers[s];
-            FILE *f = fopen(path.c_str(), "w");
-            if (!f || fwrite(text.data(), 1, text.size(), f) != text.size()) { ok = false; if (f) fclose(f); break; }
-            fclose(f);
+            const uint32_t ri = next.fetch_add(1);
+            if (ri >= range_end.size() || !ok.load()) break;
+            const uint32_t s0 = ri ? range_end[ri - 1] : 0u, s1 = range_end[ri];
+            const uint64_t first = in.samp_off[in.ev_off[s0]], n = in.samp_off[in.ev_off[s1]] - first;
+            const double *samples = in.samples ? in.samples + first : nullptr;
+            if (!in.samples && n) {
+                piece.resize(n);
+                if (!in.fetch || !in.fetch(first, n, piece.data())) { ok = false; break; }
+                samples = piece.data();
+            }
+            for (uint32_t s = s0; s < s1 && ok.load(); ++s) {
+                text.clear();
+                slot_text(in, s, delimit, sample_limit, text, samples, first);
+                if (text.empty()) continue; // the file already exists, empty (touch_dump_files)
+                const std::string path = out_dir + "/dump/" + slot_kmers[s];
+                FILE *f = fopen(path.c_str(), "w");
+                if (!f || fwrite(text.data(), 1, text.size(), f) != text.size()) { ok = false; if (f) fclose(f); break; }
+                fclose(f);
+            }
         }
     };
     if (n_threads < 1) n_threads = 1;

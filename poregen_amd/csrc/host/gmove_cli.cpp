@@ -131,7 +131,9 @@ struct Backend {
     bool all_full() { return job ? pg_job_all_slots_full(job) != 0 : pg_all_slots_full(ctx) != 0; }            // waits for the device
     int32_t poll() { return job ? pg_job_poll(job) : pg_poll(ctx); } // 1: the device has finished the last batch (errors < 0), 0: not yet; no wait
     bool all_full_settled() const { return job ? pg_job_all_slots_full_settled(job) != 0 : pg_all_slots_full_settled(ctx) != 0; } // as of the batch already waited for
-    pg_status finish(pg_result *r) { return job ? pg_job_finish(job, r) : pg_finish(ctx, r); }
+    // one context: the kept samples stay on the device and the dump writers fetch them range by range (pg_fetch_samples)
+    pg_status finish(pg_result *r) { return job ? pg_job_finish(job, r) : pg_finish_deferred(ctx, r); }
+    bool fetch(uint64_t first, uint64_t n, double *dst) { return !job && pg_fetch_samples(ctx, first, n, dst) == PG_OK; }
     pg_status model(pg_model_result *m) { return job ? pg_job_model(job, 0, m) : pg_model(ctx, 0, m); }
     const char *error() const { return job ? pg_job_last_error(job) : pg_last_error(ctx); }
     void destroy() { if (job) pg_job_destroy(job); if (ctx) pg_destroy(ctx); job = nullptr; ctx = nullptr; }
@@ -615,7 +617,8 @@ int gmove_main(int argc, char **argv) {
         t_finish = secs(tq0, clk::now());
         if (fin != PG_OK) { if (dev.ok()) fprintf(stderr, "[gmove] %s\n", dev.error()); status = EXIT_FAILURE; }
         else {
-            pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads};
+            pgh::DumpInput in{res.n_slots, res.counts, res.ev_off, res.samp_off, res.ev_len, res.ev_read, res.samples, res.read_skipped, res.n_reads,
+                              [&](uint64_t first, uint64_t n, double *dst) { return dev.fetch(first, n, dst); }};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
             const clk::time_point td0 = clk::now();
             if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }

@@ -2,6 +2,7 @@
 // Everything here is I/O and bookkeeping; the computation is behind include/pgmove.h.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -108,9 +109,10 @@ struct DumpInput {
     uint32_t n_slots;
     const uint64_t *counts, *ev_off, *samp_off;
     const uint32_t *ev_len, *ev_read;
-    const double *samples;
+    const double *samples;   // the job's k-mer-major sample stream on the host, or null: then `fetch` brings ranges of it (pg_fetch_samples)
     const uint8_t *read_skipped;
     uint64_t n_reads;
+    std::function<bool(uint64_t first, uint64_t n, double *dst)> fetch; // callable from several threads at once
 };
 // writes dump/<kmer> for every slot and freq.txt; delimit = -d; returns false on I/O error
 bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const DumpInput &in, bool delimit,

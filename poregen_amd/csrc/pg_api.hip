@@ -57,6 +57,7 @@ struct HostBatchResult { // one collected batch, downloaded
     // more batches follow (or came before): the samples stay on the device, in a buffer of their own, until pg_finish merges the
     // batches there and downloads the result ONCE -- no per-batch download in front of the next submit, no second copy on the host
     DevBuf dsamples; bool on_device = false;
+    bool in_ctx = false; // on_device, and still in the context's own sample buffer (pg_finish_deferred of a one-batch job): no copy at all
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; bool bracket; };
@@ -116,6 +117,8 @@ struct pg_ctx {
 
     std::vector<HostBatchResult> batches;
     bool single_moved = false; // batches[0]'s arrays currently live in r_* (pg_finish of a one-batch job)
+    bool want_samples = true;       // false inside pg_finish_deferred: the kept samples stay on the device (pg_fetch_samples)
+    const double *fin_dev = nullptr; // the job's k-mer-major sample stream on the device, when the merged view does not hold it on the host
     bool merged_valid = false; // r_* hold the merged view of all downloaded batches (a repeated pg_finish / pg_model returns it as it is)
     uint64_t m_events = 0, m_samples = 0, m_reads = 0;
     // merged view
@@ -380,7 +383,7 @@ pg_status pg_reset(pg_ctx *c) {
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
     c->zero_running = true;
     for (auto &hb : c->batches) hb.dsamples.release();
-    c->batches.clear(); c->single_moved = false; c->have_job_totals = false; c->merged_valid = false;
+    c->batches.clear(); c->single_moved = false; c->have_job_totals = false; c->merged_valid = false; c->fin_dev = nullptr;
     c->have_count = c->have_batch_result = false; c->downloaded = true; c->totals_known = false;
     c->reads_before = 0; c->full_slots = 0; c->full_before_batch = false; c->cur_n_kept = c->cur_n_samples = 0;
     return PG_OK;
@@ -414,7 +417,10 @@ static pg_status download_last(pg_ctx *c, bool more_coming) {
     // (PGMOVE_HOST_MERGE=1: never -- A/B; PGMOVE_HOLD_MIN_BYTES=n: from n bytes on instead of 8 MB -- tests run small jobs through the device merge)
     const char *hm = getenv("PGMOVE_HOLD_MIN_BYTES");
     const uint64_t hold_min = hm ? strtoull(hm, nullptr, 10) : (8ull << 20);
-    if (h.n_samples && h.n_samples * 8ull >= hold_min && (more_coming || c->batches.size() > 1) && !getenv("PGMOVE_HOST_MERGE")) {
+    if (h.n_samples && !c->want_samples && !more_coming && c->batches.size() == 1) { // pg_finish_deferred of a one-batch job: they stay where they are
+        h.on_device = true; h.in_ctx = true;
+        h.samples.clear(); h.samples.shrink_to_fit();
+    } else if (h.n_samples && h.n_samples * 8ull >= hold_min && (more_coming || c->batches.size() > 1) && !getenv("PGMOVE_HOST_MERGE")) {
         if (h.dsamples.ensure(h.n_samples * 8ull) == hipSuccess &&
             hipMemcpyAsync(h.dsamples.p, c->samples.p, h.n_samples * 8ull, hipMemcpyDeviceToDevice, c->st) == hipSuccess) {
             h.on_device = true;
@@ -635,6 +641,12 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, hipSetDevice(c->device));
     pg_status s = download_last(c, true);
     if (s != PG_OK) return s;
+    for (auto &hb : c->batches)
+        if (hb.in_ctx) { // a deferred finish left this batch's samples in the buffer the next collect writes: park them first
+            HIP_TRY(c, hb.dsamples.ensure(hb.n_samples * 8ull));
+            HIP_TRY(c, hipMemcpyAsync(hb.dsamples.p, c->samples.p, hb.n_samples * 8ull, hipMemcpyDeviceToDevice, c->st));
+            hb.in_ctx = false; c->merged_valid = false; c->fin_dev = nullptr;
+        }
     if (c->have_batch_result) { c->reads_before += c->B.n_reads; c->have_batch_result = false; }
     c->have_count = false; c->rare_pending = false; c->plan_done = false;
     const uint32_t n = b->n_reads;
@@ -1085,10 +1097,16 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     pg_status s = download_last(c, false);
     if (s != PG_OK) return s;
     const uint32_t ns = c->prm.n_slots;
+    if (c->merged_valid && c->want_samples && c->fin_dev && c->m_samples) { // deferred before, wanted now: one download into the merged view
+        c->r_samples.resize(c->m_samples);
+        HIP_TRY(c, hipMemcpy(c->r_samples.data(), c->fin_dev, c->m_samples * 8ull, hipMemcpyDeviceToHost));
+        c->fin_dev = nullptr;
+        for (auto &hb : c->batches) if (hb.on_device && c->batches.size() == 1) { hb.on_device = false; hb.in_ctx = false; hb.dsamples.release(); }
+    }
     if (c->merged_valid) { // nothing was collected since the last call: the merged view is current
         out->n_slots = ns; out->reserved = 0; out->n_events = c->m_events; out->n_samples = c->m_samples; out->n_reads = c->m_reads;
         out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
-        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->fin_dev ? nullptr : c->r_samples.data();
         out->read_skipped = c->r_skipped.data();
         return PG_OK;
     }
@@ -1103,10 +1121,12 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     for (auto &h : c->batches) { n_events += h.n_events; n_samples += h.n_samples; n_reads += h.n_reads; }
     if (c->batches.size() == 1) { // one batch: its arrays ARE the result (no per-event copy of up to GBs of samples)
         HostBatchResult &h = c->batches[0];
-        if (h.on_device) { // parked on the device for a merge that never came (a later batch was counted but not collected): fetch them now
+        c->fin_dev = nullptr;
+        if (h.on_device && !c->want_samples) c->fin_dev = h.in_ctx ? c->samples.as<double>() : h.dsamples.as<double>(); // pg_fetch_samples reads them there
+        else if (h.on_device) { // parked on the device (for a merge that never came, or by an earlier deferred finish): fetch them now
             h.samples.resize(h.n_samples);
-            HIP_TRY(c, hipMemcpy(h.samples.data(), h.dsamples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
-            h.dsamples.release(); h.on_device = false;
+            HIP_TRY(c, hipMemcpy(h.samples.data(), h.in_ctx ? c->samples.p : h.dsamples.p, h.n_samples * 8ull, hipMemcpyDeviceToHost));
+            h.dsamples.release(); h.on_device = false; h.in_ctx = false;
         }
         c->r_counts.resize(ns);
         for (uint32_t sl = 0; sl < ns; sl++) c->r_counts[sl] = h.ev_off[sl + 1] - h.ev_off[sl];
@@ -1115,13 +1135,14 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         c->single_moved = true; // undone at the top of the next pg_finish (more batches may follow) and by pg_reset
         out->n_slots = ns; out->reserved = 0; out->n_events = n_events; out->n_samples = n_samples; out->n_reads = n_reads;
         out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
-        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+        out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->fin_dev ? nullptr : c->r_samples.data();
         out->read_skipped = c->r_skipped.data();
         c->merged_valid = true; c->m_events = n_events; c->m_samples = n_samples; c->m_reads = n_reads;
         return PG_OK;
     }
+    c->fin_dev = nullptr;
     c->r_counts.assign(ns, 0); c->r_ev_off.assign(ns + 1, 0); c->r_samp_off.resize(n_events + 1);
-    c->r_ev_len.resize(n_events); c->r_ev_read.resize(n_events); c->r_samples.resize(n_samples);
+    c->r_ev_len.resize(n_events); c->r_ev_read.resize(n_events);
     c->r_skipped.resize(n_reads);
     // pass 1 (cheap): where every slot's events and samples start in the merged arrays
     std::vector<uint64_t> slot_e(ns + 1, 0), slot_s(ns + 1, 0);
@@ -1139,6 +1160,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         for (uint32_t sl = 0; sl < ns; sl++) for (auto &h : c->batches) nseg += h.ev_off[sl + 1] > h.ev_off[sl];
         if (c->dseg.ensure(nseg * sizeof(PgSeg) + 16) != hipSuccess || c->dmerged.ensure(n_samples * 8ull) != hipSuccess) { (void)hipGetLastError(); c->dmerged.release(); all_dev = false; }
     }
+    if (!(all_dev && !c->want_samples)) c->r_samples.resize(n_samples); // (a deferred finish leaves the device merge's result on the device)
     if (!all_dev)
         for (auto &h : c->batches)
             if (h.on_device) { // mixed (a pg_finish between batches, or a batch that found no room): this one through the host after all
@@ -1198,8 +1220,9 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         HIP_TRY(c, hipMemcpyAsync(c->dseg.p, segs.data(), segs.size() * sizeof(PgSeg), hipMemcpyHostToDevice, c->st));
         HIP_TRY(c, pg_launch_merge_segments(c->st, c->dseg.as<PgSeg>(), (uint32_t)segs.size(), c->dmerged.as<double>()));
         HIP_TRY(c, hipStreamSynchronize(c->st));
+        if (!c->want_samples) c->fin_dev = c->dmerged.as<double>();
         // one download of the merged samples, slices side by side (pageable destination, first touch included)
-        const uint64_t bytes = n_samples * 8ull;
+        const uint64_t bytes = c->want_samples ? n_samples * 8ull : 0;
         const unsigned parts = bytes >= (64ull << 20) ? 8u : 1u;
         std::vector<hipError_t> rc(parts, hipSuccess);
         std::vector<std::thread> pool;
@@ -1207,7 +1230,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         for (unsigned t = 0; t < parts; t++)
             pool.emplace_back([&, t]() {
                 const uint64_t a2 = std::min<uint64_t>(n_samples, t * step), b2 = std::min<uint64_t>(n_samples, a2 + step);
-                if (b2 <= a2) return;
+                if (b2 <= a2 || !bytes) return;
                 rc[t] = hipSetDevice(c->device);
                 if (rc[t] == hipSuccess) rc[t] = hipMemcpy(c->r_samples.data() + a2, c->dmerged.as<double>() + a2, (b2 - a2) * 8ull, hipMemcpyDeviceToHost);
             });
@@ -1220,9 +1243,27 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
     for (auto &h : c->batches) { if (h.n_reads) memcpy(&c->r_skipped[rb], h.skipped.data(), h.n_reads); rb += h.n_reads; }
     out->n_slots = ns; out->reserved = 0; out->n_events = n_events; out->n_samples = n_samples; out->n_reads = n_reads;
     out->counts = c->r_counts.data(); out->ev_off = c->r_ev_off.data(); out->ev_len = c->r_ev_len.data();
-    out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->r_samples.data();
+    out->ev_read = c->r_ev_read.data(); out->samp_off = c->r_samp_off.data(); out->samples = c->fin_dev ? nullptr : c->r_samples.data();
     out->read_skipped = c->r_skipped.data();
     c->merged_valid = true; c->m_events = n_events; c->m_samples = n_samples; c->m_reads = n_reads;
+    return PG_OK;
+}
+
+pg_status pg_finish_deferred(pg_ctx *c, pg_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    c->want_samples = false;
+    const pg_status s = pg_finish(c, out);
+    c->want_samples = true;
+    return s;
+}
+
+pg_status pg_fetch_samples(pg_ctx *c, uint64_t first, uint64_t n, double *dst) {
+    if (!c || (!dst && n)) return PG_ERR_INVALID_ARG;
+    if (!c->merged_valid) return PG_ERR_STATE; // (no error text: several host threads may call this at once)
+    if (first > c->m_samples || n > c->m_samples - first) return PG_ERR_INVALID_ARG;
+    if (!n) return PG_OK;
+    if (!c->fin_dev) { memcpy(dst, c->r_samples.data() + first, n * sizeof(double)); return PG_OK; } // the merge went through the host
+    if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(dst, c->fin_dev + first, n * 8ull, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return PG_ERR_HIP; }
     return PG_OK;
 }
 
