@@ -18,7 +18,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_dev.h $(CSRC)/pg_selec
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_place.o build/pg_api.o build/pg_model.o build/pg_job.o
+poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_place.o build/pg_api.o build/pg_model.o build/pg_job.o build/pg_text.o
 	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lpthread
 
 poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
@@ -33,14 +33,14 @@ bin/poregen: $(CSRC)/pg_model.h $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/r
 # measurement build: counts the reads whose selection leaves the fast path (tools/count_fallbacks.py)
 fallback_probe:
 	@mkdir -p build/fb
-	for f in pg_kernels pg_place pg_api pg_model pg_job; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
-	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_place.o build/fb/pg_api.o build/fb/pg_model.o build/fb/pg_job.o -Wl,--allow-shlib-undefined
+	for f in pg_kernels pg_place pg_api pg_model pg_job pg_text; do $(HIPCC) $(HIPFLAGS) -DPG_COUNT_FALLBACKS -c -o build/fb/$$f.o $(CSRC)/$$f.hip || exit 1; done
+	$(CXX) -shared -o build/fb/libpgmove_fb.so build/fb/pg_kernels.o build/fb/pg_place.o build/fb/pg_api.o build/fb/pg_model.o build/fb/pg_job.o build/fb/pg_text.o -Wl,--allow-shlib-undefined
 
 # A/B builds: `make variant NAME=x EXTRA="-DPG_..."` -> build/x/libpgmove.so (bench.py --lib, tools/ab_lib.sh)
 variant:
 	@mkdir -p build/$(NAME)
-	for f in pg_kernels pg_place pg_api pg_model pg_job; do $(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o build/$(NAME)/$$f.o $(CSRC)/$$f.hip || exit 1; done
-	$(CXX) -shared -o build/$(NAME)/libpgmove.so build/$(NAME)/pg_kernels.o build/$(NAME)/pg_place.o build/$(NAME)/pg_api.o build/$(NAME)/pg_model.o build/$(NAME)/pg_job.o -Wl,--allow-shlib-undefined -ldl -lpthread
+	for f in pg_kernels pg_place pg_api pg_model pg_job pg_text; do $(HIPCC) $(HIPFLAGS) $(EXTRA) -c -o build/$(NAME)/$$f.o $(CSRC)/$$f.hip || exit 1; done
+	$(CXX) -shared -o build/$(NAME)/libpgmove.so build/$(NAME)/pg_kernels.o build/$(NAME)/pg_place.o build/$(NAME)/pg_api.o build/$(NAME)/pg_model.o build/$(NAME)/pg_job.o build/$(NAME)/pg_text.o -Wl,--allow-shlib-undefined -ldl -lpthread
 
 oracle_build:
 	$(MAKE) -C oracle

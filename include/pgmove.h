@@ -28,6 +28,9 @@
  *                                  per-k-mer counts between the two halves
  * pg_finish                        the bytes the fprintf calls would have produced, as binary
  *                                                                         src/gmove.cpp:938-950
+ * pg_finish_deferred /             the same with the samples left on the device, fetched range by range
+ * pg_fetch_samples
+ * pg_text / pg_fetch_text          those bytes themselves: fprintf(f, "%.8f,") ... "%.8f;" on the device   src/gmove.cpp:938-944
  * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
  * pg_model / pg_model_device /     the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
  * pg_model_format                  median / sstdev per k-mer, awk | datamash median of the dwell times
@@ -257,7 +260,22 @@ pg_status pg_finish(pg_ctx *ctx, pg_result *out);
  * way -- the reference prints as it goes (src/gmove.cpp:938-944); the CLI's dump writers do this. Valid until the next
  * pg_submit / pg_count / pg_reset. A later pg_finish still hands the samples out as a whole. */
 pg_status pg_finish_deferred(pg_ctx *ctx, pg_result *out);
-pg_status pg_fetch_samples(pg_ctx *ctx, uint64_t first, uint64_t n, double *dst);    /* sync, copy results to host, merge batches */
+pg_status pg_fetch_samples(pg_ctx *ctx, uint64_t first, uint64_t n, double *dst);
+
+/* The dump files' TEXT, produced on the device: for every slot the bytes the reference's fprintf calls write into dump/<KMER> --
+ * "%.8f," per sample, "%.8f;" for an event's last one (src/gmove.cpp:938-944) -- as one buffer in HBM, slot after slot; slot s is
+ * bytes [slot_off[s], slot_off[s+1]). Without -d only (the ':' of src/gmove.cpp:960-962 depend on the reads: a host job). The digits
+ * are printf's (correctly rounded, ties to even on the binary value). PG_ERR_UNSUPPORTED -- never a wrong digit -- if a kept sample is
+ * not finite or |sample| >= 4e7, or if the samples of several batches had to be merged on the host: format there (pg_finish).
+ * Calls pg_finish_deferred first; pg_fetch_text copies a byte range to the host and may be called from several threads at once.
+ * Valid until the next pg_submit / pg_count / pg_reset / pg_text. */
+typedef struct {
+    uint32_t n_slots, reserved;
+    uint64_t n_bytes;
+    const uint64_t *slot_off; /* [n_slots + 1], host memory owned by the context */
+} pg_text_result;
+pg_status pg_text(pg_ctx *ctx, pg_text_result *out);
+pg_status pg_fetch_text(pg_ctx *ctx, uint64_t first, uint64_t n, char *dst);    /* sync, copy results to host, merge batches */
 int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events (waits for the device) */
 /* The same as of the last batch the context has already waited for (pg_submit / pg_count wait for the PREVIOUS batch): no wait.
  * A host that parses batch i+1 while batch i is on the device asks this after submitting i+1 and learns about batch i. */

@@ -32,7 +32,7 @@ PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
-    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_finish_deferred", "pg_fetch_samples", "pg_all_slots_full",
+    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_finish_deferred", "pg_fetch_samples", "pg_text", "pg_fetch_text", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
     "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
     "pg_job_uses_rccl", "pg_job_model", "pg_job_kernel_stats", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
@@ -70,6 +70,10 @@ class PgResult(C.Structure):
         ("n_reads", C.c_uint64), ("counts", C.c_void_p), ("ev_off", C.c_void_p), ("ev_len", C.c_void_p),
         ("ev_read", C.c_void_p), ("samp_off", C.c_void_p), ("samples", C.c_void_p), ("read_skipped", C.c_void_p),
     ]
+
+
+class PgTextResult(C.Structure):
+    _fields_ = [("n_slots", C.c_uint32), ("reserved", C.c_uint32), ("n_bytes", C.c_uint64), ("slot_off", C.POINTER(C.c_uint64))]
 
 
 class PgDeviceView(C.Structure):
@@ -144,6 +148,8 @@ def load():
     lib.pg_collect_gathered.argtypes = [vp, u64p, C.c_uint32, C.c_uint32]; lib.pg_collect_gathered.restype = i32
     lib.pg_finish_deferred.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_finish_deferred.restype = i32
     lib.pg_fetch_samples.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_void_p]; lib.pg_fetch_samples.restype = i32
+    lib.pg_text.argtypes = [vp, C.POINTER(PgTextResult)]; lib.pg_text.restype = i32
+    lib.pg_fetch_text.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_void_p]; lib.pg_fetch_text.restype = i32
     lib.pg_job_totals_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]; lib.pg_job_totals_device.restype = i32
     lib.pg_sync.argtypes = [vp]; lib.pg_sync.restype = i32
     lib.pg_set_stream.argtypes = [vp, vp]; lib.pg_set_stream.restype = i32

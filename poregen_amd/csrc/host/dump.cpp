@@ -174,4 +174,48 @@ bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &
     return true;
 }
 
+bool write_dump_dir_text(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const TextInput &in, unsigned n_threads, std::string &err) {
+    std::vector<uint32_t> range_end; // ranges of slots of about 8 MB of text: one copy over PCIe each
+    for (uint32_t s = 0; s < in.n_slots;) {
+        uint32_t e = s + 1;
+        while (e < in.n_slots && e - s < 4096 && in.slot_off[e + 1] - in.slot_off[s] <= (8u << 20)) ++e;
+        range_end.push_back(e);
+        s = e;
+    }
+    std::atomic<uint32_t> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() {
+        std::vector<char> piece;
+        for (;;) {
+            const uint32_t ri = next.fetch_add(1);
+            if (ri >= range_end.size() || !ok.load()) break;
+            const uint32_t s0 = ri ? range_end[ri - 1] : 0u, s1 = range_end[ri];
+            const uint64_t first = in.slot_off[s0], n = in.slot_off[s1] - first;
+            if (!n) continue; // the files already exist, empty (touch_dump_files)
+            piece.resize(n);
+            if (!in.fetch(first, n, piece.data())) { ok = false; break; }
+            for (uint32_t s = s0; s < s1; ++s) {
+                const uint64_t a = in.slot_off[s] - first, b = in.slot_off[s + 1] - first;
+                if (b == a) continue;
+                const std::string path = out_dir + "/dump/" + slot_kmers[s];
+                FILE *f = fopen(path.c_str(), "w");
+                if (!f || fwrite(piece.data() + a, 1, b - a, f) != b - a) { ok = false; if (f) fclose(f); break; }
+                fclose(f);
+            }
+        }
+    };
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (!ok) { err = "error writing dump files under " + out_dir; return false; }
+    const std::string fp = out_dir + "/freq.txt"; // src/gmove.cpp:525-534
+    FILE *f = fopen(fp.c_str(), "w");
+    if (!f) { err = "Error in opening " + fp; return false; }
+    for (uint32_t s = 0; s < in.n_slots; s++) fprintf(f, "%s\t%llu\n", slot_kmers[s].c_str(), (unsigned long long)in.counts[s]);
+    fclose(f);
+    return true;
+}
+
 } // namespace pgh

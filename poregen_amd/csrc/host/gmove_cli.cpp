@@ -621,7 +621,16 @@ int gmove_main(int argc, char **argv) {
                               [&](uint64_t first, uint64_t n, double *dst) { return dev.fetch(first, n, dst); }};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
             const clk::time_point td0 = clk::now();
-            if (!pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
+            // the "%.8f" text itself comes from the device (pg_text) when it can: one context, no -d (the ':' of -d depend on the reads),
+            // every sample inside the fixed-point formatter's range. POREGEN_HOST_TEXT=1 keeps the host formatter (A/B, tests).
+            pg_text_result tx;
+            bool wrote = false;
+            if (dev.ctx && !opt.delimit_files && !getenv("POREGEN_HOST_TEXT") && pg_text(dev.ctx, &tx) == PG_OK) {
+                pgh::TextInput ti{tx.n_slots, tx.slot_off, res.counts, [&](uint64_t first, uint64_t n, char *dst) { return pg_fetch_text(dev.ctx, first, n, dst) == PG_OK; }};
+                if (!pgh::write_dump_dir_text(output_dir, slot_kmers, ti, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
+                wrote = true;
+            }
+            if (!wrote && !pgh::write_dump_dir(output_dir, slot_kmers, in, opt.delimit_files != 0, opt.sample_limit, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
             t_dump = secs(td0, clk::now());
             if (status == EXIT_SUCCESS && (raw_model_path || dwell_model_path)) { // scripts/poregen.sh:54-85, 33-52 without the text round trip
                 const clk::time_point tm0 = clk::now();

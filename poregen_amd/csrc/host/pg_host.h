@@ -117,6 +117,13 @@ struct DumpInput {
 // writes dump/<kmer> for every slot and freq.txt; delimit = -d; returns false on I/O error
 bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const DumpInput &in, bool delimit,
                     uint32_t sample_limit, unsigned n_threads, std::string &err);
+// the same from text the device has produced (pg_text): slot s is bytes [slot_off[s], slot_off[s + 1]) of one stream, fetched in pieces
+struct TextInput {
+    uint32_t n_slots;
+    const uint64_t *slot_off, *counts;
+    std::function<bool(uint64_t first, uint64_t n, char *dst)> fetch; // callable from several threads at once
+};
+bool write_dump_dir_text(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const TextInput &in, unsigned n_threads, std::string &err);
 bool touch_dump_files(const std::string &out_dir, const std::vector<std::string> &slot_kmers, std::string &err);
 
 } // namespace pgh

@@ -126,6 +126,8 @@ struct pg_ctx {
     std::vector<uint32_t> r_ev_len, r_ev_read;
     SampleVec r_samples;
     DevBuf dmerged, dseg; // pg_finish over device-held batches: merged samples, segment descriptors
+    DevBuf tx_samp_off, tx_ev_off, tx_len, tx_off, tx_text, tx_slot_off, tx_flag; // pg_text
+    std::vector<uint64_t> tx_slot_off_host; uint64_t tx_bytes = 0;
     std::vector<uint8_t> r_skipped;
     // pg_model
     std::vector<PgSlotModel> mo_raw;
@@ -252,6 +254,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec, &c->ev_len, &c->ev_read, &c->read_needed,
+                      &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
                       &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part,
                       &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
@@ -1264,6 +1267,56 @@ pg_status pg_fetch_samples(pg_ctx *c, uint64_t first, uint64_t n, double *dst) {
     if (!n) return PG_OK;
     if (!c->fin_dev) { memcpy(dst, c->r_samples.data() + first, n * sizeof(double)); return PG_OK; } // the merge went through the host
     if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(dst, c->fin_dev + first, n * 8ull, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return PG_ERR_HIP; }
+    return PG_OK;
+}
+
+pg_status pg_text(pg_ctx *c, pg_text_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    pg_result R;
+    pg_status s = pg_finish_deferred(c, &R);
+    if (s != PG_OK) return s;
+    if (R.n_samples && !c->fin_dev) return fail(c, PG_ERR_UNSUPPORTED, "pg_text: the job's samples were merged on the host; format them there");
+    const uint32_t ns = c->prm.n_slots;
+    const uint64_t ne = R.n_events;
+    const uint64_t *d_samp_off, *d_ev_off;
+    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == ne) { d_samp_off = c->samp_off.as<uint64_t>(); d_ev_off = c->ev_off.as<uint64_t>(); } // still there
+    else {
+        HIP_TRY(c, c->tx_samp_off.ensure((ne + 1) * 8ull)); HIP_TRY(c, c->tx_ev_off.ensure((ns + 1) * 8ull));
+        HIP_TRY(c, hipMemcpyAsync(c->tx_samp_off.p, R.samp_off, (ne + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        HIP_TRY(c, hipMemcpyAsync(c->tx_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
+        d_samp_off = c->tx_samp_off.as<uint64_t>(); d_ev_off = c->tx_ev_off.as<uint64_t>();
+    }
+    HIP_TRY(c, c->tx_len.ensure((ne + 1) * 4ull)); HIP_TRY(c, c->tx_off.ensure((ne + 2) * 8ull)); HIP_TRY(c, c->tx_flag.ensure(16));
+    HIP_TRY(c, c->tx_slot_off.ensure((ns + 2) * 8ull));
+    {
+        const size_t before = c->scan_scratch.cap;
+        HIP_TRY(c, c->scan_scratch.ensure((std::max<uint64_t>(ne, ns) / 4096 + 84) * 8));
+        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st));
+    }
+    prof_begin(c, "text", c->st, true);
+    HIP_TRY(c, pg_launch_text_lens(c->st, c->fin_dev, d_samp_off, ne, c->tx_len.as<uint32_t>(), c->tx_flag.as<uint32_t>()));
+    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->tx_len.as<uint32_t>(), 1, ne, nullptr, c->tx_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), nullptr, c->tx_flag.as<uint64_t>() + 1));
+    uint64_t head[2] = {0, 0}; // [0] flag, [1] total bytes
+    HIP_TRY(c, hipMemcpyAsync(head, c->tx_flag.p, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    if ((uint32_t)head[0]) { prof_end(c, c->st); return fail(c, PG_ERR_UNSUPPORTED, "pg_text: a kept sample is not finite or |sample| >= 4e7; format on the host"); }
+    c->tx_bytes = ne ? head[1] : 0;
+    HIP_TRY(c, c->tx_text.ensure(c->tx_bytes + 16));
+    HIP_TRY(c, pg_launch_text_write(c->st, c->fin_dev, d_samp_off, ne, c->tx_off.as<uint64_t>(), c->tx_text.as<char>(), d_ev_off, ns, c->tx_slot_off.as<uint64_t>()));
+    prof_end(c, c->st);
+    c->tx_slot_off_host.resize(ns + 1);
+    HIP_TRY(c, hipMemcpyAsync(c->tx_slot_off_host.data(), c->tx_slot_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    if (!ne) std::fill(c->tx_slot_off_host.begin(), c->tx_slot_off_host.end(), 0);
+    out->n_slots = ns; out->reserved = 0; out->n_bytes = c->tx_bytes; out->slot_off = c->tx_slot_off_host.data();
+    return PG_OK;
+}
+
+pg_status pg_fetch_text(pg_ctx *c, uint64_t first, uint64_t n, char *dst) {
+    if (!c || (!dst && n)) return PG_ERR_INVALID_ARG;
+    if (first > c->tx_bytes || n > c->tx_bytes - first) return PG_ERR_INVALID_ARG;
+    if (!n) return PG_OK;
+    if (hipSetDevice(c->device) != hipSuccess || hipMemcpy(dst, c->tx_text.as<char>() + first, n, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return PG_ERR_HIP; }
     return PG_OK;
 }
 

@@ -159,6 +159,10 @@ hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uin
                                   bool sums_ready);
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
                                    uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes);
+// pg_text.hip: the dump files' text on the device (flag[0] != 0 afterwards: a sample the fixed-point formatter does not take)
+hipError_t pg_launch_text_lens(hipStream_t st, const double *samples, const uint64_t *samp_off, uint64_t n_events, uint32_t *tlen, uint32_t *flag);
+hipError_t pg_launch_text_write(hipStream_t st, const double *samples, const uint64_t *samp_off, uint64_t n_events, const uint64_t *toff, char *text,
+                                const uint64_t *ev_off, uint32_t n_slots, uint64_t *slot_toff);
 hipError_t pg_launch_unpack_recs(hipStream_t st, const PgKeptRec *rec, uint64_t n, uint32_t *ev_len, uint32_t *ev_read);
 
 // ---- stats ---------------------------------------------------------------------------------------

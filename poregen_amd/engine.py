@@ -413,6 +413,17 @@ class GmoveEngine:
                      dwell_n=arr(m.dwell_n, np.uint64), dwell_median=arr(m.dwell_median, np.float64),
                      median_text=texts[0], sstdev_text=texts[1], dwell_text=texts[2])
 
+    def text(self):
+        """The dump files' text produced on the device (pg_text): list of bytes objects, one per slot -- what the reference's fprintf calls
+        write into dump/<KMER> without -d."""
+        t = _abi.PgTextResult()
+        self._check(self._lib.pg_text(self._h, C.byref(t)))
+        off = [int(t.slot_off[i]) for i in range(t.n_slots + 1)]
+        buf = C.create_string_buffer(int(t.n_bytes) + 1)
+        self._check(self._lib.pg_fetch_text(self._h, 0, int(t.n_bytes), buf))
+        raw = buf.raw
+        return [raw[off[i]:off[i + 1]] for i in range(t.n_slots)]
+
     def device_view(self):
         v = _abi.PgDeviceView()
         self._check(self._lib.pg_last_batch_device(self._h, C.byref(v)))

@@ -424,3 +424,26 @@ def test_wide_pa_windows_use_the_wider_histograms(pa):
     o.run_batch(b)
     res = run_engine([b], kmers=kmers, **p)
     assert_result_equals_oracle(res, o, sample_limit=8)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("rna_k5_medmad", "rna_k5_noscale_limit7", "dna_k9", "rna_pamin100", "dna_margin3")], ids=lambda c: c["name"])
+def test_device_text_equals_printf(case, monkeypatch):
+    """pg_text: the dump files' bytes produced on the device == '%.8f,' ... '%.8f;' of the oracle-checked doubles (src/gmove.cpp:938-944), for
+    one batch (samples still in the context's buffer) and for three (merged on the device first: PGMOVE_HOLD_MIN_BYTES=1 keeps even these
+    small batches there)."""
+    monkeypatch.setenv("PGMOVE_HOLD_MIN_BYTES", "1")
+    b = synth.make_batch(case["n"], kind=case["kind"], seed=20251003 + len(case["name"]), **case["gen"])
+    p = case["p"]
+    kmers = generate_kmers(p["kmer_size"], rna=p.get("rna", False))
+    for parts in ([b], [b.slice_reads(0, 40), b.slice_reads(40, 41), b.slice_reads(41, case["n"])]):
+        eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+        for part in parts:
+            eng.submit(part)
+        text = eng.text()
+        res = eng.finish()
+        nz = [s for s in range(len(kmers)) if res.counts[s]]
+        for s in nz[:300] + nz[-50:]:
+            assert text[s] == res.slot_text(s).encode(), s
+        assert sum(len(t) for t in text) == sum(len(res.slot_text(s)) for s in nz) if len(nz) <= 2000 else True
+        assert all(len(text[s]) == 0 for s in range(len(kmers)) if not res.counts[s])
+        eng.close()

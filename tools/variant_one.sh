@@ -6,5 +6,5 @@ name=$1; stem=$2; extra=$3
 mkdir -p build/$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result $extra -c -o build/$name/$stem.o poregen_amd/csrc/$stem.hip
 objs=""
-for f in pg_kernels pg_place pg_api pg_model pg_job; do if [ $f = $stem ]; then objs="$objs build/$name/$f.o"; else objs="$objs build/$f.o"; fi; done
+for f in pg_kernels pg_place pg_api pg_model pg_job pg_text; do if [ $f = $stem ]; then objs="$objs build/$name/$f.o"; else objs="$objs build/$f.o"; fi; done
 g++ -shared -o build/$name/libpgmove.so $objs -Wl,--allow-shlib-undefined -ldl -lpthread
