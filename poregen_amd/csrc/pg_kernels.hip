@@ -767,6 +767,65 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
             if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
             else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
         }
+    } else if (COUNT == 2 && tile_live && g0 < N) {
+        // ---- partitioned ranking (k = 9: global slot tables, 4 waves per SIMD, registers to spare): all 16 table look-ups of the thread are
+        // issued before the first one is used (the per-event form below waits for every look-up where it stands: 16 dependent L2 round
+        // trips per thread), the thread's own op_n stay in their registers, the slots go from registers to their four 16-byte stores
+        const uint32_t x0 = lt * 16u;
+        const int32_t iloA = t_ilo[tq][A.e], ihiA = t_ihi[tq][A.e];
+        int32_t iloB = 0, ihiB = -1;
+        if (jb < 16) { iloB = t_ilo[tq][Bs.e]; ihiB = t_ihi[tq][Bs.e]; }
+        const bool any_generic = (A.fl & 3u) == 2u || (jb < 16 && (Bs.fl & 3u) == 2u);
+        uint32_t tix[16], sl[16];
+        bool too_long = false;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            uint32_t wk[4] = {PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT, PG_INVALID_SLOT};
+            if (any_generic) { // events of generic reads come from k_walk
+                if (g0 + 4 * v + 4 <= N) { const uint4 x = *reinterpret_cast<const uint4 *>(O.ev_slot + g0 + 4 * v); wk[0] = x.x; wk[1] = x.y; wk[2] = x.z; wk[3] = x.w; }
+                else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) wk[u] = O.ev_slot[g0 + 4 * v + u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * v + u;
+                const bool inB = (uint32_t)j >= jb;
+                const int32_t o0r = inB ? Bs.o0 : A.o0, ilo = inB ? iloB : iloA, ihi = inB ? ihiB : ihiA;
+                const uint32_t fl = inB ? Bs.fl : A.fl, kind = fl & 3u;
+                const int32_t i = (int32_t)(x0 + j) - o0r;
+                tix[j] = 0xFFFFFFFFu; sl[j] = kind == 2u ? wk[u] : PG_INVALID_SLOT;
+                if (kind == 1u && i >= ilo && i <= ihi && g0 + j < N) {
+                    const uint32_t field = (uint32_t)(c64 >> (2 * j)) & ((1u << (2u * k)) - 1u), badf = (uint32_t)(((uint64_t)bad32 >> j) & ((1u << k) - 1u));
+                    const uint32_t xr = __builtin_bitreverse32(field);
+                    const uint32_t fwd = (((xr & 0xAAAAAAAAu) >> 1) | ((xr & 0x55555555u) << 1)) >> (32u - 2u * k);
+                    const bool rna = (fl >> 2) & 1u;
+                    const uint32_t dur = W.sig_move_offset == 0 ? opn[j] : B.op_n[g0 + j + W.sig_move_offset]; // gmove.cpp:916-921
+                    if (!badf && dur <= W.max_dur && dur >= W.min_dur) tix[j] = rna ? field + W.n_codes : fwd; // table_u sits behind table_t
+                }
+                if (kind == 1u && opn[j] >= PG_OP_N_LIMIT && g0 + j < N) too_long = true;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (tix[j] != 0xFFFFFFFFu) sl[j] = (uint32_t)W.table_t[tix[j]]; // -1 = not in the slice = PG_INVALID_SLOT
+        if (too_long) {
+            for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
+                const bool inB = j >= jb;
+                if (((inB ? Bs.fl : A.fl) & 3u) == 1u && B.op_n[g0 + j] >= PG_OP_N_LIMIT) report_error(O, rFirst + (inB ? Bs.e : A.e), PGR_ERR_RANGE);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            uint32_t o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = 4 * v + u;
+                const uint32_t x = sl[j];
+                if (x != PG_INVALID_SLOT && g0 + j < N) atomicAdd(&cnt[tq][cdig(x)], 1u);
+                const uint32_t rel = (uint32_t)j >= jb ? Bs.e : A.e; // the event's read rides in the upper bits (PgWalkOut::tile_read)
+                o4[u] = x == PG_INVALID_SLOT ? PG_INVALID_SLOT : x | (rel << PG_PART_REL_SHIFT);
+            }
+            if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
+        }
     } else if (tile_live && g0 < N) {
         const uint32_t x0 = lt * 16u;
         const int32_t iloA = t_ilo[tq][A.e], ihiA = t_ihi[tq][A.e];
