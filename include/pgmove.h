@@ -252,7 +252,7 @@ pg_status pg_sync(pg_ctx *ctx);                      /* wait for all device work
  * stream, so that collectives issued by the caller between pg_count and pg_collect are ordered without host
  * synchronisation. NULL restores the context's own stream. */
 pg_status pg_set_stream(pg_ctx *ctx, void *hip_stream);
-pg_status pg_finish(pg_ctx *ctx, pg_result *out);
+pg_status pg_finish(pg_ctx *ctx, pg_result *out);     /* sync, copy results to host, merge batches */
 /* pg_finish without the samples' trip to the host: every array of pg_result is filled except `samples` (NULL whenever the kept samples
  * are still on the device: one batch, or several merged there). pg_fetch_samples then copies any range [first, first + n) of the
  * job's k-mer-major sample stream (the indices samp_off counts in) into a host buffer of the caller's; after pg_finish_deferred it
@@ -275,7 +275,7 @@ typedef struct {
     const uint64_t *slot_off; /* [n_slots + 1], host memory owned by the context */
 } pg_text_result;
 pg_status pg_text(pg_ctx *ctx, pg_text_result *out);
-pg_status pg_fetch_text(pg_ctx *ctx, uint64_t first, uint64_t n, char *dst);    /* sync, copy results to host, merge batches */
+pg_status pg_fetch_text(pg_ctx *ctx, uint64_t first, uint64_t n, char *dst);
 int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events (waits for the device) */
 /* The same as of the last batch the context has already waited for (pg_submit / pg_count wait for the PREVIOUS batch): no wait.
  * A host that parses batch i+1 while batch i is on the device asks this after submitting i+1 and learns about batch i. */

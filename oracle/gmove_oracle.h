@@ -18,7 +18,7 @@
  *   (3) the reference tests' exit-status expectations (test_gmove.sh:50,58,66);
  *   (4) for the SAM/BAM path only the invariant BAM == table (test_gmove.sh:85-86,101-102): no known answers exist.
  * No reference-held golden output exists, so by the rules of this build: "parity unpinned" with
- * respect to reference-owned expected values; see DESIGN.md.
+ * respect to reference-owned expected values; see DESIGN.md 6.
  */
 #ifndef GMOVE_ORACLE_H
 #define GMOVE_ORACLE_H

@@ -2222,7 +2222,7 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 #define PG_STATS_SETPRIO 2 // 0 / 2 / 3 measured on one box: 86.4 / 83.8 / 83.5 us together with the late histogram clear (84.4 alone)
 #endif
 // ---- the main launch: one workgroup (= one wave) per read -------------------------------------------------------------
-// Measured alternatives (tools/probe/stream_probe.hip): a wave per 8 KB of signal with LDS-atomic binning
+// Measured alternatives (tools/probe/stream_probe.hip, HISTORY.md 3.1): a wave per 8 KB of signal with LDS-atomic binning
 // streams at 5.9 TB/s whether the waves are launched per read or kept persistent with a rolling register prefetch of the
 // next read; the persistent form only added bookkeeping and registers (fewer resident waves), so the hardware
 // dispatcher does the load balancing and the overlap comes from eight resident waves per SIMD.

@@ -1,4 +1,4 @@
-// scatter_probe.hip -- which side of the k-mer transposition should be the random one? (k = 9 gather)
+// scatter_probe.hip -- which side of the k-mer transposition should be the random one? (HISTORY.md 9.3)
 // N events with short windows (8..17 int16 samples, back to back in the source signal) go to n_slots buckets in stable order; the
 // output is double per sample, bucket-major. Three ways to move them:
 //   A  destination order: per kept event read {src, len, out offset} coalesced, the window at random (a 128-B line per ~25 bytes),
