@@ -1,6 +1,7 @@
 // dump.cpp -- k-mer list and the dump directory writer (exact "%.8f" text, -d delimiters, freq.txt).
 #include "pg_host.h"
 #include "../pg_model.h"
+#include <chrono>
 #include <cmath>
 
 #include <atomic>
@@ -9,6 +10,7 @@
 #include <cstring>
 #include <dirent.h>
 #include <fstream>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
 
@@ -136,7 +138,7 @@ bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &
     }
     auto work = [&]() {
         std::string text;
-        std::vector<double> piece;
+        HugeBuf piece;
         for (;;) {
             const uint32_t ri = next.fetch_add(1);
             if (ri >= range_end.size() || !ok.load()) break;
@@ -144,9 +146,8 @@ bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &
             const uint64_t first = in.samp_off[in.ev_off[s0]], n = in.samp_off[in.ev_off[s1]] - first;
             const double *samples = in.samples ? in.samples + first : nullptr;
             if (!in.samples && n) {
-                piece.resize(n);
-                if (!in.fetch || !in.fetch(first, n, piece.data())) { ok = false; break; }
-                samples = piece.data();
+                if (!piece.grow(n * sizeof(double), 0) || !in.fetch || !in.fetch(first, n, static_cast<double *>(piece.p))) { ok = false; break; }
+                samples = static_cast<const double *>(piece.p);
             }
             for (uint32_t s = s0; s < s1 && ok.load(); ++s) {
                 text.clear();
@@ -174,6 +175,21 @@ bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &
     return true;
 }
 
+void HugeBuf::release() { if (p) munmap(p, bytes); p = nullptr; bytes = 0; }
+bool HugeBuf::grow(size_t want, size_t keep) {
+    if (want <= bytes) return true;
+    const size_t huge = (size_t)2 << 20, nb = (want + huge - 1) & ~(huge - 1);
+    void *q = mmap(nullptr, nb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) return false;
+#ifdef MADV_HUGEPAGE
+    if (nb >= 2 * huge) (void)madvise(q, nb, MADV_HUGEPAGE);
+#endif
+    if (keep) memcpy(q, p, keep);
+    release();
+    p = q; bytes = nb;
+    return true;
+}
+
 bool write_dump_dir_text(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const TextInput &in, unsigned n_threads, std::string &err) {
     std::vector<uint32_t> range_end; // ranges of slots of about 8 MB of text: one copy over PCIe each
     for (uint32_t s = 0; s < in.n_slots;) {
@@ -184,22 +200,31 @@ bool write_dump_dir_text(const std::string &out_dir, const std::vector<std::stri
     }
     std::atomic<uint32_t> next(0);
     std::atomic<bool> ok(true);
+    const bool probe = getenv("POREGEN_DUMP_PROBE") != nullptr; // thread-seconds in the fetches and in the file writes, to stderr
+    std::atomic<uint64_t> ns_fetch(0), ns_write(0);
+    auto now = []() { return std::chrono::steady_clock::now(); };
     auto work = [&]() {
-        std::vector<char> piece;
+        HugeBuf hb;
         for (;;) {
             const uint32_t ri = next.fetch_add(1);
             if (ri >= range_end.size() || !ok.load()) break;
             const uint32_t s0 = ri ? range_end[ri - 1] : 0u, s1 = range_end[ri];
             const uint64_t first = in.slot_off[s0], n = in.slot_off[s1] - first;
             if (!n) continue; // the files already exist, empty (touch_dump_files)
-            piece.resize(n);
-            if (!in.fetch(first, n, piece.data())) { ok = false; break; }
+            if (!hb.grow(n, 0)) { ok = false; break; }
+            char *const piece = static_cast<char *>(hb.p);
+            const auto t0 = now();
+            if (!in.fetch(first, n, piece)) { ok = false; break; }
+            const auto t1 = now();
+            if (probe) ns_fetch += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            struct Stamp { std::atomic<uint64_t> &acc; std::chrono::steady_clock::time_point t; bool on;
+                           ~Stamp() { if (on) acc += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } stamp{ns_write, t1, probe};
             for (uint32_t s = s0; s < s1; ++s) {
                 const uint64_t a = in.slot_off[s] - first, b = in.slot_off[s + 1] - first;
                 if (b == a) continue;
                 const std::string path = out_dir + "/dump/" + slot_kmers[s];
                 FILE *f = fopen(path.c_str(), "w");
-                if (!f || fwrite(piece.data() + a, 1, b - a, f) != b - a) { ok = false; if (f) fclose(f); break; }
+                if (!f || fwrite(piece + a, 1, b - a, f) != b - a) { ok = false; if (f) fclose(f); break; }
                 fclose(f);
             }
         }
@@ -209,6 +234,7 @@ bool write_dump_dir_text(const std::string &out_dir, const std::vector<std::stri
     for (unsigned t = 1; t < n_threads; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
+    if (probe) fprintf(stderr, "[dump probe] %zu ranges on %u threads: %.3f thread-s in pg_fetch_text, %.3f thread-s in fopen/fwrite/fclose\n", range_end.size(), n_threads, ns_fetch.load() * 1e-9, ns_write.load() * 1e-9);
     if (!ok) { err = "error writing dump files under " + out_dir; return false; }
     const std::string fp = out_dir + "/freq.txt"; // src/gmove.cpp:525-534
     FILE *f = fopen(fp.c_str(), "w");

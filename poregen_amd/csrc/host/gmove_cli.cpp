@@ -86,24 +86,20 @@ void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
 }
 
 // The signal of a batch is hundreds of MB: a std::vector would zero every byte on resize (one thread, and the page faults
-// with it) before the pool threads overwrite it. Plain storage; the first touch of each page happens in the copying threads.
+// with it) before the pool threads overwrite it. Plain storage on huge pages (pgh::HugeBuf); the first touch happens in the copying threads.
 struct SampleBuf {
-    int16_t *p = nullptr; size_t n = 0, cap = 0;
-    SampleBuf() = default;
-    SampleBuf(const SampleBuf &) = delete; SampleBuf &operator=(const SampleBuf &) = delete;
-    ~SampleBuf() { free(p); }
-    int16_t *data() { return p; } const int16_t *data() const { return p; }
+    pgh::HugeBuf hb; size_t n = 0;
+    int16_t *data() { return static_cast<int16_t *>(hb.p); } const int16_t *data() const { return static_cast<const int16_t *>(hb.p); }
     size_t size() const { return n; }
     void clear() { n = 0; }
     void reserve(size_t want) {
+        const size_t cap = hb.bytes / sizeof(int16_t);
         if (want <= cap) return;
         size_t c = cap ? cap : 4096; while (c < want) c += c / 2 + 4096;
-        int16_t *q = (int16_t *)realloc(p, c * sizeof(int16_t));
-        if (!q) { fprintf(stderr, "[gmove] out of memory for %zu samples\n", c); exit(EXIT_FAILURE); }
-        p = q; cap = c;
+        if (!hb.grow(c * sizeof(int16_t), n * sizeof(int16_t))) { fprintf(stderr, "[gmove] out of memory for %zu samples\n", c); exit(EXIT_FAILURE); }
     }
     void resize(size_t want) { reserve(want); n = want; } // new elements are NOT initialised
-    void append(const int16_t *a, const int16_t *b) { const size_t k = (size_t)(b - a); reserve(n + k); if (k) memcpy(p + n, a, k * sizeof(int16_t)); n += k; }
+    void append(const int16_t *a, const int16_t *b) { const size_t k = (size_t)(b - a); reserve(n + k); if (k) memcpy(data() + n, a, k * sizeof(int16_t)); n += k; }
 };
 
 struct HostBatch {
@@ -626,6 +622,7 @@ int gmove_main(int argc, char **argv) {
             pg_text_result tx;
             bool wrote = false;
             if (dev.ctx && !opt.delimit_files && !getenv("POREGEN_HOST_TEXT") && pg_text(dev.ctx, &tx) == PG_OK) {
+                if (getenv("POREGEN_DUMP_PROBE")) fprintf(stderr, "[dump probe] pg_text: %.3f s for %.1f MB of text\n", secs(td0, clk::now()), tx.n_bytes / 1e6);
                 pgh::TextInput ti{tx.n_slots, tx.slot_off, res.counts, [&](uint64_t first, uint64_t n, char *dst) { return pg_fetch_text(dev.ctx, first, n, dst) == PG_OK; }};
                 if (!pgh::write_dump_dir_text(output_dir, slot_kmers, ti, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
                 wrote = true;

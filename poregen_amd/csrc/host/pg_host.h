@@ -1,6 +1,7 @@
 // pg_host.h -- host side of the `poregen gmove` drop-in: file parsers, k-mer list, dump writer.
 // Everything here is I/O and bookkeeping; the computation is behind include/pgmove.h.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -114,6 +115,19 @@ struct DumpInput {
     uint64_t n_reads;
     std::function<bool(uint64_t first, uint64_t n, double *dst)> fetch; // callable from several threads at once
 };
+// Plain storage for the big host buffers (a batch's signal, the pieces the dump writers fetch): a mapping of its own with transparent huge
+// pages asked for (the boxes run THP in "madvise" mode). 200 page faults instead of 100 000 per 400 MB at the first touch, the runtime pins
+// 200 pages instead of 100 000 when it copies from / into it (staging a 176 MB batch: 35 -> 14 ms; tools/probe/e2e_staging.sh), and as many
+// pages less to hand back when the process ends. Not initialised, not copyable.
+struct HugeBuf {
+    void *p = nullptr; size_t bytes = 0;
+    HugeBuf() = default;
+    HugeBuf(const HugeBuf &) = delete; HugeBuf &operator=(const HugeBuf &) = delete;
+    ~HugeBuf() { release(); }
+    void release();
+    bool grow(size_t want_bytes, size_t keep_bytes); // false: out of memory; the first keep_bytes survive
+};
+
 // writes dump/<kmer> for every slot and freq.txt; delimit = -d; returns false on I/O error
 bool write_dump_dir(const std::string &out_dir, const std::vector<std::string> &slot_kmers, const DumpInput &in, bool delimit,
                     uint32_t sample_limit, unsigned n_threads, std::string &err);
