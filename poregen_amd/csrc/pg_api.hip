@@ -3,6 +3,7 @@
 // without a usable HIP device pg_create fails.
 #include "../../include/pgmove.h"
 #include "pg_internal.h"
+#include "pg_hostmem.h"
 #include "pg_select.h"
 #include "pg_model.h"
 
@@ -38,20 +39,12 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-// vector<double> whose resize() leaves new elements uninitialised: the kept samples (hundreds of MB at large limits) are
-// overwritten by the download / merge right away, zero-filling them first costs as much as the copy
-template <class T> struct NoInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { using other = NoInitAlloc<U>; };
-    template <class U, class... A> void construct(U *p, A &&...a) {
-        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
-    }
-};
-using SampleVec = std::vector<double, NoInitAlloc<double>>;
 
 struct HostBatchResult { // one collected batch, downloaded
     uint64_t n_reads = 0, n_events = 0, n_samples = 0;
-    std::vector<uint64_t> keep, ev_off, samp_off;
-    std::vector<uint32_t> ev_len, ev_read;
+    std::vector<uint64_t> keep, ev_off;
+    BigVec64 samp_off;
+    BigVec32 ev_len, ev_read;
     SampleVec samples;
     std::vector<uint8_t> skipped;
     // more batches follow (or came before): the samples stay on the device, in a buffer of their own, until pg_finish merges the
@@ -122,8 +115,9 @@ struct pg_ctx {
     bool merged_valid = false; // r_* hold the merged view of all downloaded batches (a repeated pg_finish / pg_model returns it as it is)
     uint64_t m_events = 0, m_samples = 0, m_reads = 0;
     // merged view
-    std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
-    std::vector<uint32_t> r_ev_len, r_ev_read;
+    std::vector<uint64_t> r_counts, r_ev_off;
+    BigVec64 r_samp_off;
+    BigVec32 r_ev_len, r_ev_read;
     SampleVec r_samples;
     DevBuf dmerged, dseg; // pg_finish over device-held batches: merged samples, segment descriptors
     DevBuf tx_samp_off, tx_ev_off, tx_len, tx_off, tx_text, tx_slot_off, tx_flag; // pg_text

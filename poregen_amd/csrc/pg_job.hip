@@ -14,6 +14,7 @@
 // hold one copy: PyTorch's under Python, /opt/rocm's otherwise).
 #include "../../include/pgmove.h"
 #include "pg_internal.h"
+#include "pg_hostmem.h"
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -115,9 +116,10 @@ struct pg_job {
     std::vector<uint64_t> batch_reads;     // per batch
     std::string err;
     // merged view (pg_job_finish)
-    std::vector<uint64_t> r_counts, r_ev_off, r_samp_off;
-    std::vector<uint32_t> r_ev_len, r_ev_read;
-    std::vector<double> r_samples;
+    std::vector<uint64_t> r_counts, r_ev_off;
+    BigVec64 r_samp_off;
+    BigVec32 r_ev_len, r_ev_read;
+    SampleVec r_samples; // huge pages, not zero-filled: every element is written by the merge
     std::vector<uint8_t> r_skipped;
     bool merged = false; pg_result merged_view{};
     // pg_job_model
@@ -389,7 +391,7 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
     }
     uint64_t n_events = 0, n_samples = 0;
     for (uint32_t g = 0; g < n; ++g) { n_events += R[g].n_events; n_samples += R[g].n_samples; }
-    j->r_counts.assign(ns, 0); j->r_ev_off.assign(ns + 1, 0); j->r_samp_off.assign(n_events + 1, 0);
+    j->r_counts.assign(ns, 0); j->r_ev_off.assign(ns + 1, 0); j->r_samp_off.resize(n_events + 1);
     j->r_ev_len.resize(n_events); j->r_ev_read.resize(n_events); j->r_samples.resize(n_samples);
     j->r_skipped.assign(bstart[nb], 0);
     // where every slot's events and samples start in the merged arrays (cheap), then the copies -- hundreds of MB at large limits --
