@@ -704,6 +704,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         HIP_TRY(c, c->part_elem.ensure((size_t)tcap * PG_SORT_TILE * 16)); HIP_TRY(c, c->part_lodig.ensure((size_t)tcap * PG_SORT_TILE * 2)); HIP_TRY(c, c->part_rbase.ensure((ndig + 2) * 4ull));
         HIP_TRY(c, c->part_tile_region.ensure((tcap + 1) * 4ull)); HIP_TRY(c, c->part_ntiles.ensure(16));
         HIP_TRY(c, c->part_histB.ensure(((size_t)tcap << c->part_lo) * 4)); HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4));
+        HIP_TRY(c, c->chunk_part.ensure(PG_CHUNK_PART_N * 8));
     } else {
         const uint32_t passes = (c->key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
         ndig = 1u << ((c->key_bits + passes - 1) / passes);
@@ -781,7 +782,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         fill_part(c, P, Nn);
         if (N) {
             prof_begin(c, "part_tile_scan", c->st);
-            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot));
+            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot, c->chunk_part.as<uint64_t>()));
             prof_end(c, c->st);
             prof_begin(c, "k_part_bases", c->st);
             HIP_TRY(c, pg_launch_part_bases(c->st, P, c->B, O));
@@ -918,7 +919,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     // workgroups (pg_place.hip). Few (the default limit: 10^5 events): the one-launch chained scan + the strided gather of round 2.
     const bool chunked = ke_cap > dense_min() && (win_cap + 1) * 4096 < (1ull << 32);
     bool sums_ready = false;
-    if (chunked) HIP_TRY(c, c->chunk_part.ensure(8200 * 8));
+    if (chunked) HIP_TRY(c, c->chunk_part.ensure(PG_CHUNK_PART_N * 8)); // (partitioned ranking has it already, zeroed by its scan launch in pg_count)
     if (direct) {
         PgSortBufs S{};
         fill_sort(c, S, 0);

@@ -127,6 +127,7 @@ struct PgSortBufs {
 };
 
 // ---- partitioned ranking (PG_DIRECT_MAX_SLOTS < n_slots <= 2^PG_PART_MAX_KEY_BITS; pg_place.hip) ------------------------------
+#define PG_CHUNK_PART_N 8200u   // entries of the chunked gather's chunk sums (k_partials_scan holds 8192)
 #define PG_PART_MAX_KEY_BITS 20
 struct PgPartBufs {
     uint4 *elemA;          // [n_ops + (R + 1) * PG_SORT_TILE] accepted events {slot, window start, length | start's high bits, read}, partitioned by the
@@ -142,7 +143,7 @@ struct PgPartBufs {
     uint32_t hi_bits, lo_bits, tilesB_cap;
 };
 static inline uint32_t pg_part_tiles_cap(uint64_t n_ops, uint32_t hi_bits) { return (uint32_t)((n_ops + PG_SORT_TILE - 1) / PG_SORT_TILE) + (1u << hi_bits); }
-hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot);
+hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot, uint64_t *zero64 /* PG_CHUNK_PART_N chunk sums, zeroed by the extra workgroup */);
 hipError_t pg_launch_part_bases(hipStream_t st, const PgPartBufs &P, const PgDevBatch &B, const PgWalkOut &O);
 hipError_t pg_launch_part_scatter(hipStream_t st, const PgPartBufs &P, const uint32_t *ev_slot, uint64_t n, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // acc_cnt / acc_copy (may be null): accepted events per slot

@@ -971,7 +971,7 @@ struct PgScanPlan {
 __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__restrict__ hist, uint32_t n_tiles, uint32_t *__restrict__ totals,
                                                   uint64_t *__restrict__ acc_cnt, uint32_t n_slots, uint32_t n_digits, const uint64_t *running,
                                                   uint32_t limit, int32_t *__restrict__ tile_last, uint64_t *__restrict__ acc_copy, PgScanPlan plan,
-                                                  const uint32_t *__restrict__ bp_btot, uint32_t bp_nb, uint32_t *__restrict__ bp_out) {
+                                                  const uint32_t *__restrict__ bp_btot, uint32_t bp_nb, uint32_t *__restrict__ bp_out, uint64_t *__restrict__ zero64) {
     const uint32_t d = blockIdx.x * PG_SCAN_WAVES + (threadIdx.x >> 6); // one wave per digit
     const int lane = lane_id();
     if (bp_out && blockIdx.x == gridDim.x - 1) { // partitioned ranking: one extra workgroup turns k_events' 256-op block sums into their
@@ -979,6 +979,8 @@ __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__
         // thread, all 16 loads in flight, one workgroup-wide scan per 65 536 sums (k = 9, 50 000 reads: one trip)
         __shared__ uint32_t bsum[PG_SCAN_WAVES];
         uint32_t carry = 0;
+        // the chunk sums of the kept window lengths (k_region_place adds to them): zeroed here instead of by a fill launch
+        if (zero64) for (uint32_t i = threadIdx.x; i < PG_CHUNK_PART_N; i += PG_SCAN_WAVES * WAVE) zero64[i] = 0;
         for (uint32_t c = 0; c < bp_nb; c += PG_SCAN_WAVES * WAVE * 64) {
             const uint32_t i0 = c + threadIdx.x * 64;
             uint4 v[16];
@@ -2488,7 +2490,7 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
         if (plan_keep) { P.keep = plan_keep; P.ev_off = plan_ev_off; P.plan_totals = plan_totals; P.running_out = running; P.ticket = plan_ticket; *plan_done = true; }
         // Bp (may be null): one extra workgroup leaves the prefix of k_events' block sums for k_rank_emit2's window starts
         PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES + (Bp ? 1u : 0u)), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
-                  (const uint64_t *)running, limit, tile_last, acc_copy, P, btot, Bp ? (uint32_t)((n + 255) / 256) : 0u, Bp);
+                  (const uint64_t *)running, limit, tile_last, acc_copy, P, btot, Bp ? (uint32_t)((n + 255) / 256) : 0u, Bp, (uint64_t *)nullptr);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
         if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));
@@ -2498,11 +2500,11 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
 }
 
 // partitioned ranking: exclusive tile prefixes per high digit (in place), region sizes, and -- one extra workgroup -- the prefix of the block sums
-hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot) {
+hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_t n_ops, const uint32_t *btot, uint64_t *zero64) {
     const uint32_t n_tiles = pg_tiles(n_ops, true), R = 1u << P.hi_bits;
     if (!n_tiles) { PG_HIP(hipMemsetAsync(P.totals, 0, sizeof(uint32_t) * R, st)); return hipSuccess; }
     PG_LAUNCH(k_rank_scan, dim3((R + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES + 1), dim3(PG_SCAN_WAVES * WAVE), 0, st, P.hist, n_tiles, P.totals, (uint64_t *)nullptr, 0u, R,
-              (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, btot, (uint32_t)((n_ops + 255) / 256), P.Bp);
+              (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, btot, (uint32_t)((n_ops + 255) / 256), P.Bp, zero64);
     return hipSuccess;
 }
 
@@ -2531,7 +2533,7 @@ hipError_t pg_launch_sort_events(hipStream_t st, const uint32_t *ev_slot, uint64
         const uint32_t *n_ptr = p == 0 ? nullptr : S.count;
         PG_LAUNCH(k_rank_count, dim3(n_tiles), dim3(256), 0, st, kin, (uint32_t)n, n_ptr, shift, nbits, n_tiles, S.hist, S.wcnt);
         PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, (uint64_t *)nullptr, 0u, 1u << nbits,
-                  (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr);
+                  (const uint64_t *)nullptr, 0u, (int32_t *)nullptr, (uint64_t *)nullptr, PgScanPlan{}, (const uint32_t *)nullptr, 0u, (uint32_t *)nullptr, (uint64_t *)nullptr);
         PG_LAUNCH(k_sort_dbase, dim3(1), dim3(256), 0, st, (const uint32_t *)S.totals, 1u << nbits, S.dbase, S.count + 1);
         PG_LAUNCH(k_sort_scatter, dim3(n_tiles), dim3(256), 0, st, kin, vin, (uint32_t)n, n_ptr, shift, nbits, n_tiles,
                            (const uint32_t *)S.hist, (const uint32_t *)S.dbase, (const uint32_t *)S.wcnt, S.keys[out], S.vals[out]);

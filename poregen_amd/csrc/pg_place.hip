@@ -533,6 +533,8 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                     if (W.print_margin > ws[u] || we <= start) { report_error(O, rd[u], PGR_ERR_WINDOW); start = we = 0; }
                     K.rec[dst[r]] = PgKeptRec{kr[u].sig0 + start, we - start, rd[u]};
                     if (K.read_needed) K.read_needed[rd[u]] = 1;
+                    // (the chunked gather's chunk sums are NOT accumulated here as k_region_place does: a tile's kept events go to ~1000 different
+                    // k-mers, i.e. chunks -- nothing to combine in LDS first, and 2.1 M global 64-bit atomics took the kernel from 77 to 190 us)
                 }
             }
         }
@@ -692,6 +694,13 @@ hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t
     return hipSuccess;
 }
 
+static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk);
+static uint32_t pg_chunk_shift(uint64_t n_kept_cap) {
+    uint32_t m = 1, sh = 10;
+    if (n_kept_cap) (void)pg_gather_chunks(n_kept_cap, &m);
+    while ((1u << sh) < m * PG_G2_SUB) ++sh; // PG_G2_SUB * m, a power of two
+    return sh;
+}
 hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const uint32_t *hist, const uint64_t *keep, const uint64_t *ev_off,
                                 const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K, const uint32_t *Bp) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
@@ -702,15 +711,11 @@ hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_
     return hipSuccess;
 }
 
-static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk);
-// part (n_kept_cap != 0): the chunked gather's per-chunk sums of kept window lengths, accumulated here (zeroed first) -- k_len_partials' pass
-// over the records is not needed behind this launch
+// part (n_kept_cap != 0): the chunked gather's per-chunk sums of kept window lengths, accumulated here (zeroed by pg_launch_part_tile_scan) --
+// k_len_partials' pass over the records is not needed behind this launch
 hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, const uint32_t *keep32, const uint64_t *ev_off, const PgWalkOut &O, const PgKeptOut &K,
                                   uint64_t *part, uint64_t n_kept_cap) {
-    uint32_t m = 1, n_chunks = 1;
-    if (n_kept_cap) n_chunks = pg_gather_chunks(n_kept_cap, &m);
-    uint32_t chunk_shift = 10; while ((1u << chunk_shift) < m * PG_G2_SUB) ++chunk_shift; // PG_G2_SUB * m, a power of two
-    if (part) PG_HIP(hipMemsetAsync(part, 0, (size_t)(n_chunks + 1) * 8, st));
+    const uint32_t chunk_shift = pg_chunk_shift(n_kept_cap);
     const size_t lds = part_lds_bytes(1u << P.lo_bits);
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PG_RANK_MAX_DIGITS)));
     PG_LAUNCH(k_region_place, dim3(P.tilesB_cap), dim3(PG_PART_THREADS), lds, st, (const uint4 *)P.elemA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,

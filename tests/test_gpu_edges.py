@@ -232,6 +232,37 @@ def test_wrong_n_ops_of_a_device_batch_is_an_error_not_a_fault(delta):
     eng.close()
 
 
+def test_n_ops_too_large_with_the_ops_at_the_end_of_an_allocation():
+    """pgmove.h: "no kernel touches memory behind n_ops" must hold for the ARRAYS too when the caller's n_ops is too large: op_t and
+    op_n sit at the very end of allocations of their own (exactly one 2 MiB / 8 MiB segment each), so a kernel that trusted n_ops + 64
+    before verifying it would read past the mapping. Expected: PG_ERR_INVALID_ARG, and the context stays usable."""
+    import torch
+    from poregen_amd.engine import PgError
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=30)
+    kmers = generate_kmers(5, rna=True)
+    hb = synth.make_batch(150, kind="rna004", seed=505)
+    dev = torch.device("cuda:0")
+    db = hb.to_device(dev)
+    n = int(hb.op_off[-1])
+    seg_t = torch.empty(2 << 20, dtype=torch.uint8, device=dev)          # whole segments of the caching allocator
+    seg_n = torch.empty((8 << 20) // 4, dtype=torch.int32, device=dev)
+    pad = (n + 15) // 16 * 16                                            # the arrays keep their 16-byte alignment
+    t_view, n_view = seg_t[-pad:][:n], seg_n[-pad:][:n]
+    t_view.copy_(db.op_t[:n]); n_view.copy_(db.op_n[:n])
+    db.op_t, db.op_n = t_view, n_view
+    torch.cuda.synchronize()
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    db.n_ops = n + 64
+    with pytest.raises(PgError) as ei:
+        eng.submit(db); eng.finish()
+    assert ei.value.status == -2 and "n_ops" in ei.value.text
+    db.n_ops = n
+    o = oracle_for(kmers, **p); o.run_batch(hb)
+    eng.reset(); eng.submit(db)
+    assert_result_equals_oracle(eng.finish(), o, sample_limit=30)
+    eng.close()
+
+
 def test_sample_limit_zero_never_completes_a_kmer():
     """gmove.cpp:925-927 skips every event at limit 0 before 945-950 could count it: no k-mer ever completes, the loop never
     ends early, every read is looked at (and can fail the job), every read gets its ':' with -d."""
