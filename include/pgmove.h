@@ -30,7 +30,8 @@
  *                                                                         src/gmove.cpp:938-950
  * pg_finish_deferred /             the same with the samples left on the device, fetched range by range
  * pg_fetch_samples
- * pg_text / pg_fetch_text          those bytes themselves: fprintf(f, "%.8f,") ... "%.8f;" on the device   src/gmove.cpp:938-944
+ * pg_text / pg_fetch_text /        those bytes themselves: fprintf(f, "%.8f,") ... "%.8f;" on the device   src/gmove.cpp:938-944
+ * pg_text_device
  * pg_all_slots_full                the early loop exit                    src/gmove.cpp:733-735
  * pg_model / pg_model_device /     the step behind gmove in the reference's pipeline: dump files -> tr | tail | datamash
  * pg_model_format                  median / sstdev per k-mer, awk | datamash median of the dwell times
@@ -38,6 +39,9 @@
  * pg_job_create / _submit / _sync  a batch split over the node's GPUs from one process: the shape of the reference's only
  * / _finish / _all_slots_full /    parallel driver, work_db (a batch split over worker threads)   src/thread.c:119-132,
  * _model / _destroy                plugged in at the same seam as pg_submit                       src/gmove.cpp:515
+ * pg_job_finish_deferred /         the job's output side, as the pg_ctx calls of the same names: the shards' kept samples
+ * _fetch_samples / _text /         concatenated on the first device (peer copies over xGMI), text produced there
+ * _fetch_text                                                                                     src/gmove.cpp:938-950
  * pg_set_stream / pg_sync /        (no counterpart: the reference is synchronous and single-threaded)
  * pg_runtime_init / pg_poll / pg_all_slots_full_settled / pg_last_batch_device / pg_kernel_stats*
  */
@@ -276,6 +280,11 @@ typedef struct {
 } pg_text_result;
 pg_status pg_text(pg_ctx *ctx, pg_text_result *out);
 pg_status pg_fetch_text(pg_ctx *ctx, uint64_t first, uint64_t n, char *dst);
+/* The same from DEVICE arrays in pg_result layout (what pg_last_batch_device or poregen_amd.dist.gather_kept hand out; pg_job_text's
+ * merged view): n_events kept events, d_ev_off[n_slots + 1], d_samp_off[n_events + 1], d_samples on pg_params.device. The text is the
+ * context's (pg_fetch_text), the arrays stay the caller's. */
+pg_status pg_text_device(pg_ctx *ctx, uint32_t n_slots, uint64_t n_events, const uint64_t *d_ev_off, const uint64_t *d_samp_off,
+                         const double *d_samples, pg_text_result *out);
 int32_t   pg_all_slots_full(pg_ctx *ctx);            /* 1 when every slot holds sample_limit events (waits for the device) */
 /* The same as of the last batch the context has already waited for (pg_submit / pg_count wait for the PREVIOUS batch): no wait.
  * A host that parses batch i+1 while batch i is on the device asks this after submitting i+1 and learns about batch i. */
@@ -367,6 +376,17 @@ int32_t     pg_job_all_slots_full(pg_job *job);         /* src/gmove.cpp:733-735
 int32_t     pg_job_all_slots_full_settled(const pg_job *job); /* as pg_all_slots_full_settled */
 int32_t     pg_job_poll(pg_job *job);                    /* as pg_poll, for every device of the job */
 pg_status   pg_job_finish(pg_job *job, pg_result *out); /* merged view, owned by the job until the next submit / destroy */
+/* As pg_finish_deferred / pg_fetch_samples / pg_text / pg_fetch_text for the job. The shards' kept samples are concatenated ON THE
+ * JOB'S FIRST DEVICE -- one peer copy per shard that sits on another device (xGMI), one launch of (k-mer, batch, shard) segment copies:
+ * north_star's "concatenate the buffers over xGMI" -- and stay there: pg_job_finish_deferred returns everything but `samples` (NULL),
+ * pg_job_fetch_samples copies any range of the merged stream to the host (callable from several threads at once), pg_job_text
+ * produces the dump files' bytes from it on that device (PG_ERR_UNSUPPORTED as pg_text), pg_job_model reduces it there.
+ * pg_job_finish = the same merge + ONE download. (A shard whose own batches had to be merged on the host sends the job through the
+ * host merge instead; the results are the same.) */
+pg_status   pg_job_finish_deferred(pg_job *job, pg_result *out);
+pg_status   pg_job_fetch_samples(pg_job *job, uint64_t first, uint64_t n, double *dst);
+pg_status   pg_job_text(pg_job *job, pg_text_result *out);
+pg_status   pg_job_fetch_text(pg_job *job, uint64_t first, uint64_t n, char *dst);
 /* 1 when the last pg_job_create chose RCCL for this job's exchange, 0 = host memory */
 int32_t     pg_job_uses_rccl(const pg_job *job);
 /* The k-mer model of the whole job (see pg_model): the merged kept samples are reduced on the job's first device. */

@@ -32,9 +32,10 @@ PG_MODEL_TEXT_MEDIAN, PG_MODEL_TEXT_SSTDEV, PG_MODEL_TEXT_DWELL = 0, 1, 2
 # every symbol include/pgmove.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
-    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_finish_deferred", "pg_fetch_samples", "pg_text", "pg_fetch_text", "pg_all_slots_full",
+    "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_finish_deferred", "pg_fetch_samples", "pg_text", "pg_fetch_text", "pg_text_device", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
     "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
+    "pg_job_finish_deferred", "pg_job_fetch_samples", "pg_job_text", "pg_job_fetch_text",
     "pg_job_uses_rccl", "pg_job_model", "pg_job_kernel_stats", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
 ]
 PG_JOB_EXCHANGE_AUTO, PG_JOB_EXCHANGE_HOST, PG_JOB_EXCHANGE_RCCL = 0, 1, 2
@@ -173,6 +174,11 @@ def load():
     lib.pg_job_sync.argtypes = [vp]; lib.pg_job_sync.restype = i32
     lib.pg_job_all_slots_full.argtypes = [vp]; lib.pg_job_all_slots_full.restype = i32
     lib.pg_job_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish.restype = i32
+    lib.pg_job_finish_deferred.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish_deferred.restype = i32
+    lib.pg_job_fetch_samples.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_void_p]; lib.pg_job_fetch_samples.restype = i32
+    lib.pg_job_text.argtypes = [vp, C.POINTER(PgTextResult)]; lib.pg_job_text.restype = i32
+    lib.pg_job_fetch_text.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_void_p]; lib.pg_job_fetch_text.restype = i32
+    lib.pg_text_device.argtypes = [vp, u32, C.c_uint64, vp, vp, vp, C.POINTER(PgTextResult)]; lib.pg_text_device.restype = i32
     lib.pg_job_uses_rccl.argtypes = [vp]; lib.pg_job_uses_rccl.restype = i32
     lib.pg_job_model.argtypes = [vp, u32, C.POINTER(PgModelResult)]; lib.pg_job_model.restype = i32
     lib.pg_job_kernel_stats.argtypes = [vp, u32, C.POINTER(PgKernelStat), u32, C.POINTER(u32)]; lib.pg_job_kernel_stats.restype = i32

@@ -127,9 +127,12 @@ struct Backend {
     bool all_full() { return job ? pg_job_all_slots_full(job) != 0 : pg_all_slots_full(ctx) != 0; }            // waits for the device
     int32_t poll() { return job ? pg_job_poll(job) : pg_poll(ctx); } // 1: the device has finished the last batch (errors < 0), 0: not yet; no wait
     bool all_full_settled() const { return job ? pg_job_all_slots_full_settled(job) != 0 : pg_all_slots_full_settled(ctx) != 0; } // as of the batch already waited for
-    // one context: the kept samples stay on the device and the dump writers fetch them range by range (pg_fetch_samples)
-    pg_status finish(pg_result *r) { return job ? pg_job_finish(job, r) : pg_finish_deferred(ctx, r); }
-    bool fetch(uint64_t first, uint64_t n, double *dst) { return !job && pg_fetch_samples(ctx, first, n, dst) == PG_OK; }
+    // the kept samples stay on the device (a job: concatenated on its first device) and the dump writers fetch them range by range,
+    // or the files' text itself is produced there (pg_text / pg_job_text)
+    pg_status finish(pg_result *r) { return job ? pg_job_finish_deferred(job, r) : pg_finish_deferred(ctx, r); }
+    bool fetch(uint64_t first, uint64_t n, double *dst) { return (job ? pg_job_fetch_samples(job, first, n, dst) : pg_fetch_samples(ctx, first, n, dst)) == PG_OK; }
+    pg_status text(pg_text_result *t) { return job ? pg_job_text(job, t) : pg_text(ctx, t); }
+    bool fetch_text(uint64_t first, uint64_t n, char *dst) { return (job ? pg_job_fetch_text(job, first, n, dst) : pg_fetch_text(ctx, first, n, dst)) == PG_OK; }
     pg_status model(pg_model_result *m) { return job ? pg_job_model(job, 0, m) : pg_model(ctx, 0, m); }
     const char *error() const { return job ? pg_job_last_error(job) : pg_last_error(ctx); }
     void destroy() { if (job) pg_job_destroy(job); if (ctx) pg_destroy(ctx); job = nullptr; ctx = nullptr; }
@@ -617,13 +620,13 @@ int gmove_main(int argc, char **argv) {
                               [&](uint64_t first, uint64_t n, double *dst) { return dev.fetch(first, n, dst); }};
             unsigned nt = std::thread::hardware_concurrency(); if (nt > 16) nt = 16;
             const clk::time_point td0 = clk::now();
-            // the "%.8f" text itself comes from the device (pg_text) when it can: one context, no -d (the ':' of -d depend on the reads),
+            // the "%.8f" text itself comes from the device (pg_text / pg_job_text) when it can: no -d (the ':' of -d depend on the reads),
             // every sample inside the fixed-point formatter's range. POREGEN_HOST_TEXT=1 keeps the host formatter (A/B, tests).
             pg_text_result tx;
             bool wrote = false;
-            if (dev.ctx && !opt.delimit_files && !getenv("POREGEN_HOST_TEXT") && pg_text(dev.ctx, &tx) == PG_OK) {
+            if (!opt.delimit_files && !getenv("POREGEN_HOST_TEXT") && dev.text(&tx) == PG_OK) {
                 if (getenv("POREGEN_DUMP_PROBE")) fprintf(stderr, "[dump probe] pg_text: %.3f s for %.1f MB of text\n", secs(td0, clk::now()), tx.n_bytes / 1e6);
-                pgh::TextInput ti{tx.n_slots, tx.slot_off, res.counts, [&](uint64_t first, uint64_t n, char *dst) { return pg_fetch_text(dev.ctx, first, n, dst) == PG_OK; }};
+                pgh::TextInput ti{tx.n_slots, tx.slot_off, res.counts, [&](uint64_t first, uint64_t n, char *dst) { return dev.fetch_text(first, n, dst); }};
                 if (!pgh::write_dump_dir_text(output_dir, slot_kmers, ti, nt, err)) { fprintf(stderr, "%s\n", err.c_str()); status = EXIT_FAILURE; }
                 wrote = true;
             }

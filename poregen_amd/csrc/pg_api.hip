@@ -1051,6 +1051,8 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
 
 // pg_job.hip: the stream the chain runs on (events of the job's communication stream are ordered against it)
 void *pgi_stream(pg_ctx *c) { return c ? (void *)c->st : nullptr; }
+// the job's k-mer-major sample stream on the device after pg_finish_deferred (null: it is on the host, or there is none): pg_job's device-side merge
+const double *pgi_fin_dev(pg_ctx *c) { return c && c->merged_valid ? c->fin_dev : nullptr; }
 // pg_job.hip, rank-level early-out: the batch counted with PG_FLAG_DEFER_STATS will keep no event (every k-mer is complete below this
 // rank), so the collect that follows needs no statistics: none are queued (the gather reads a read's median / MAD for kept events only)
 pg_status pgi_skip_stats(pg_ctx *c) {
@@ -1216,7 +1218,7 @@ pg_status pg_finish(pg_ctx *c, pg_result *out) {
         }
         HIP_TRY(c, c->dseg.ensure(segs.size() * sizeof(PgSeg) + 16)); HIP_TRY(c, c->dmerged.ensure(n_samples * 8ull));
         HIP_TRY(c, hipMemcpyAsync(c->dseg.p, segs.data(), segs.size() * sizeof(PgSeg), hipMemcpyHostToDevice, c->st));
-        HIP_TRY(c, pg_launch_merge_segments(c->st, c->dseg.as<PgSeg>(), (uint32_t)segs.size(), c->dmerged.as<double>()));
+        HIP_TRY(c, pg_launch_merge_segments(c->st, c->dseg.as<PgSeg>(), (uint32_t)segs.size(), c->dmerged.as<double>(), n_samples));
         HIP_TRY(c, hipStreamSynchronize(c->st));
         if (!c->want_samples) c->fin_dev = c->dmerged.as<double>();
         // one download of the merged samples, slices side by side (pageable destination, first touch included)
@@ -1265,6 +1267,36 @@ pg_status pg_fetch_samples(pg_ctx *c, uint64_t first, uint64_t n, double *dst) {
     return PG_OK;
 }
 
+pg_status pg_text_device(pg_ctx *c, uint32_t ns, uint64_t ne, const uint64_t *d_ev_off, const uint64_t *d_samp_off, const double *d_samples, pg_text_result *out) {
+    if (!c || !out) return PG_ERR_INVALID_ARG;
+    if (ns && (!d_ev_off || !d_samp_off)) return fail(c, PG_ERR_INVALID_ARG, "pg_text_device: ev_off / samp_off missing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->tx_len.ensure((ne + 1) * 4ull)); HIP_TRY(c, c->tx_off.ensure((ne + 2) * 8ull)); HIP_TRY(c, c->tx_flag.ensure(16));
+    HIP_TRY(c, c->tx_slot_off.ensure((ns + 2) * 8ull));
+    {
+        const size_t before = c->scan_scratch.cap;
+        HIP_TRY(c, c->scan_scratch.ensure((std::max<uint64_t>(ne, ns) / 4096 + 84) * 8));
+        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st));
+    }
+    prof_begin(c, "text", c->st, true);
+    HIP_TRY(c, pg_launch_text_lens(c->st, d_samples, d_samp_off, ne, c->tx_len.as<uint32_t>(), c->tx_flag.as<uint32_t>()));
+    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->tx_len.as<uint32_t>(), 1, ne, nullptr, c->tx_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), nullptr, c->tx_flag.as<uint64_t>() + 1));
+    uint64_t head[2] = {0, 0}; // [0] flag, [1] total bytes
+    HIP_TRY(c, hipMemcpyAsync(head, c->tx_flag.p, 16, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    if ((uint32_t)head[0]) { prof_end(c, c->st); return fail(c, PG_ERR_UNSUPPORTED, "pg_text: a kept sample is not finite or |sample| >= 4e7; format on the host"); }
+    c->tx_bytes = ne ? head[1] : 0;
+    HIP_TRY(c, c->tx_text.ensure(c->tx_bytes + 16));
+    HIP_TRY(c, pg_launch_text_write(c->st, d_samples, d_samp_off, ne, c->tx_off.as<uint64_t>(), c->tx_text.as<char>(), d_ev_off, ns, c->tx_slot_off.as<uint64_t>()));
+    prof_end(c, c->st);
+    c->tx_slot_off_host.resize(ns + 1);
+    HIP_TRY(c, hipMemcpyAsync(c->tx_slot_off_host.data(), c->tx_slot_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost, c->st));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    if (!ne) std::fill(c->tx_slot_off_host.begin(), c->tx_slot_off_host.end(), 0);
+    out->n_slots = ns; out->reserved = 0; out->n_bytes = c->tx_bytes; out->slot_off = c->tx_slot_off_host.data();
+    return PG_OK;
+}
+
 pg_status pg_text(pg_ctx *c, pg_text_result *out) {
     if (!c || !out) return PG_ERR_INVALID_ARG;
     pg_result R;
@@ -1281,30 +1313,7 @@ pg_status pg_text(pg_ctx *c, pg_text_result *out) {
         HIP_TRY(c, hipMemcpyAsync(c->tx_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
         d_samp_off = c->tx_samp_off.as<uint64_t>(); d_ev_off = c->tx_ev_off.as<uint64_t>();
     }
-    HIP_TRY(c, c->tx_len.ensure((ne + 1) * 4ull)); HIP_TRY(c, c->tx_off.ensure((ne + 2) * 8ull)); HIP_TRY(c, c->tx_flag.ensure(16));
-    HIP_TRY(c, c->tx_slot_off.ensure((ns + 2) * 8ull));
-    {
-        const size_t before = c->scan_scratch.cap;
-        HIP_TRY(c, c->scan_scratch.ensure((std::max<uint64_t>(ne, ns) / 4096 + 84) * 8));
-        if (c->scan_scratch.cap != before) HIP_TRY(c, hipMemsetAsync(c->scan_scratch.p, 0, c->scan_scratch.cap, c->st));
-    }
-    prof_begin(c, "text", c->st, true);
-    HIP_TRY(c, pg_launch_text_lens(c->st, c->fin_dev, d_samp_off, ne, c->tx_len.as<uint32_t>(), c->tx_flag.as<uint32_t>()));
-    HIP_TRY(c, pg_launch_scan_u32_u64(c->st, c->tx_len.as<uint32_t>(), 1, ne, nullptr, c->tx_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(), nullptr, c->tx_flag.as<uint64_t>() + 1));
-    uint64_t head[2] = {0, 0}; // [0] flag, [1] total bytes
-    HIP_TRY(c, hipMemcpyAsync(head, c->tx_flag.p, 16, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    if ((uint32_t)head[0]) { prof_end(c, c->st); return fail(c, PG_ERR_UNSUPPORTED, "pg_text: a kept sample is not finite or |sample| >= 4e7; format on the host"); }
-    c->tx_bytes = ne ? head[1] : 0;
-    HIP_TRY(c, c->tx_text.ensure(c->tx_bytes + 16));
-    HIP_TRY(c, pg_launch_text_write(c->st, c->fin_dev, d_samp_off, ne, c->tx_off.as<uint64_t>(), c->tx_text.as<char>(), d_ev_off, ns, c->tx_slot_off.as<uint64_t>()));
-    prof_end(c, c->st);
-    c->tx_slot_off_host.resize(ns + 1);
-    HIP_TRY(c, hipMemcpyAsync(c->tx_slot_off_host.data(), c->tx_slot_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost, c->st));
-    HIP_TRY(c, hipStreamSynchronize(c->st));
-    if (!ne) std::fill(c->tx_slot_off_host.begin(), c->tx_slot_off_host.end(), 0);
-    out->n_slots = ns; out->reserved = 0; out->n_bytes = c->tx_bytes; out->slot_off = c->tx_slot_off_host.data();
-    return PG_OK;
+    return pg_text_device(c, ns, ne, d_ev_off, d_samp_off, c->fin_dev, out);
 }
 
 pg_status pg_fetch_text(pg_ctx *c, uint64_t first, uint64_t n, char *dst) {

@@ -298,7 +298,7 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
 // pg_finish over several batches: a batch's kept samples stay on the device until then; (k-mer, batch) segments are copied into the
 // job's k-mer-major order by one launch and leave the device once
 struct PgSeg { const double *src; uint64_t dst_off, n; };
-hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst);
+hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst, uint64_t n_total /* samples of all segments: picks the kernel's shape */);
 // n_kept_ptr: [0] kept events, [2] their samples (the offset scan's total_out)
 hipError_t pg_launch_gather(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec,
                       const uint64_t *samp_off, int scaling, double pa_min,

@@ -30,6 +30,7 @@
 #include <vector>
 
 extern "C" void *pgi_stream(pg_ctx *c); // pg_api.hip: the stream the context's chain currently runs on
+extern "C" const double *pgi_fin_dev(pg_ctx *c); // pg_api.hip: where pg_finish_deferred left the context's kept samples on its device (or null)
 extern "C" pg_status pgi_skip_stats(pg_ctx *c); // pg_api.hip: a deferred-statistics batch that will keep nothing needs none
 
 static thread_local std::string g_job_create_error;
@@ -122,6 +123,7 @@ struct pg_job {
     SampleVec r_samples; // huge pages, not zero-filled: every element is written by the merge
     std::vector<uint8_t> r_skipped;
     bool merged = false; pg_result merged_view{};
+    bool samples_on_host = false, samples_on_dev = false, small_on_dev = false; // where the merged view's arrays are (device = md[] on the first device)
     // pg_job_model
     void *md[4] = {nullptr, nullptr, nullptr, nullptr}; size_t md_cap[4] = {0, 0, 0, 0};
 };
@@ -369,19 +371,62 @@ int32_t pg_job_all_slots_full_settled(const pg_job *j) {
     return pg_all_slots_full_settled(j->ctx[j->n - 1]);
 }
 
-pg_status pg_job_finish(pg_job *j, pg_result *out) {
+// md[i] (device 0) grown to hold `bytes`
+static pg_status md_ensure(pg_job *j, int i, size_t bytes) {
+    if (bytes + 16 <= j->md_cap[i]) return PG_OK;
+    if (j->md[i]) JHIP(j, hipFree(j->md[i]));
+    j->md[i] = nullptr; j->md_cap[i] = 0;
+    JHIP(j, hipMalloc(&j->md[i], bytes + bytes / 8 + 64));
+    j->md_cap[i] = bytes + bytes / 8 + 64;
+    return PG_OK;
+}
+
+// The merged view of the job. Every rank finishes "deferred": its small arrays come to the host, its kept samples stay on its device.
+// The small arrays are merged here (reference order inside a k-mer: batch, then shard = PAF line order); the samples are concatenated ON
+// THE FIRST DEVICE -- north_star's "concatenate the buffers over xGMI": one peer copy per rank that sits on another device, one launch
+// of (slot, batch, rank) segment copies -- and come to the host only if the caller asks for them (pg_job_finish), as one download.
+// pg_job_finish_deferred leaves them there for pg_job_fetch_samples / pg_job_text / pg_job_model. A rank whose own batches had to be
+// merged on the host (no room on its device) sends the whole job through the host merge, as before.
+static pg_status job_finish(pg_job *j, pg_result *out, bool want_samples) {
     if (!j || !out) return PG_ERR_INVALID_ARG;
-    if (j->merged) { *out = j->merged_view; return PG_OK; }
     const uint32_t n = j->n, ns = j->n_slots;
+    if (j->merged) {
+        if (want_samples && !j->samples_on_host && j->merged_view.n_samples) { // deferred before, wanted now: one download
+            const uint64_t n_samples = j->merged_view.n_samples;
+            j->r_samples.resize(n_samples);
+            JHIP(j, hipSetDevice(j->devices[0]));
+            const unsigned parts = n_samples * 8ull >= (64ull << 20) ? 8u : 1u;
+            const uint64_t step = ((n_samples + parts - 1) / parts + 511) & ~511ull;
+            std::vector<hipError_t> rc(parts, hipSuccess);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < parts; t++)
+                pool.emplace_back([&, t]() {
+                    const uint64_t a = std::min<uint64_t>(n_samples, t * step), b2 = std::min<uint64_t>(n_samples, a + step);
+                    if (b2 <= a) return;
+                    rc[t] = hipSetDevice(j->devices[0]);
+                    if (rc[t] == hipSuccess) rc[t] = hipMemcpy(j->r_samples.data() + a, (const double *)j->md[3] + a, (b2 - a) * 8ull, hipMemcpyDeviceToHost);
+                });
+            for (auto &th : pool) th.join();
+            for (hipError_t e2 : rc) JHIP(j, e2);
+            j->samples_on_host = true;
+            j->merged_view.samples = j->r_samples.data();
+        }
+        *out = j->merged_view;
+        if (!want_samples && j->samples_on_dev) out->samples = nullptr; // pg_job_fetch_samples reads them on the device
+        return PG_OK;
+    }
     std::vector<pg_result> R(n);
     pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
-        const pg_status st = pg_finish(j->ctx[g], &R[g]);
+        const pg_status st = pg_finish_deferred(j->ctx[g], &R[g]);
         if (st != PG_OK) msg = pg_last_error(j->ctx[g]);
         return st;
     });
     if (s != PG_OK) return s;
-    // reference order inside a k-mer: batch, then shard (= PAF line order). A rank's own view is slot-major with its reads
-    // numbered over its shards of all batches, so the events of (slot, batch, rank) are a run of that rank's slot stream.
+    std::vector<const double *> dev_src(n, nullptr);
+    bool all_dev = !getenv("PGMOVE_JOB_HOST_MERGE");
+    for (uint32_t g = 0; g < n; ++g) { dev_src[g] = pgi_fin_dev(j->ctx[g]); if (R[g].n_samples && !dev_src[g]) all_dev = false; }
+    // a rank's own view is slot-major with its reads numbered over its shards of all batches, so the events of (slot, batch, rank)
+    // are a run of that rank's slot stream
     const size_t nb = j->cuts.size();
     std::vector<std::vector<uint64_t>> rb(n, std::vector<uint64_t>(nb + 1, 0)); // rank-local read index where batch i starts
     std::vector<uint64_t> bstart(nb + 1, 0);
@@ -391,8 +436,23 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
     }
     uint64_t n_events = 0, n_samples = 0;
     for (uint32_t g = 0; g < n; ++g) { n_events += R[g].n_events; n_samples += R[g].n_samples; }
+    // through the host after all: every rank's samples come down first (those still on a device in slices, side by side)
+    std::vector<SampleVec> host_src(all_dev ? 0 : n);
+    std::vector<const double *> hsrc(n, nullptr);
+    if (!all_dev) {
+        s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+            if (R[g].samples || !R[g].n_samples) { hsrc[g] = R[g].samples; return PG_OK; }
+            host_src[g].resize(R[g].n_samples);
+            const pg_status st = pg_fetch_samples(j->ctx[g], 0, R[g].n_samples, host_src[g].data());
+            if (st != PG_OK) msg = "pg_fetch_samples failed";
+            hsrc[g] = host_src[g].data();
+            return st;
+        });
+        if (s != PG_OK) return s;
+    }
     j->r_counts.assign(ns, 0); j->r_ev_off.assign(ns + 1, 0); j->r_samp_off.resize(n_events + 1);
-    j->r_ev_len.resize(n_events); j->r_ev_read.resize(n_events); j->r_samples.resize(n_samples);
+    j->r_ev_len.resize(n_events); j->r_ev_read.resize(n_events);
+    if (!all_dev) j->r_samples.resize(n_samples); else { SampleVec().swap(j->r_samples); }
     j->r_skipped.assign(bstart[nb], 0);
     // where every slot's events and samples start in the merged arrays (cheap), then the copies -- hundreds of MB at large limits --
     // slot ranges of about equal sample counts side by side on a few threads
@@ -402,7 +462,9 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
         for (uint32_t g = 0; g < n; ++g) { const uint64_t a = R[g].ev_off[sl], b2 = R[g].ev_off[sl + 1]; ne += b2 - a; if (b2 > a) nsm += R[g].samp_off[b2] - R[g].samp_off[a]; }
         slot_e[sl + 1] = slot_e[sl] + ne; slot_s[sl + 1] = slot_s[sl] + nsm;
     }
-    auto merge_slots = [&](uint32_t sl0, uint32_t sl1) {
+    const unsigned nt = n_samples >= (8u << 20) ? 8u : 1u;
+    std::vector<std::vector<PgSeg>> tsegs(nt); // device merge: (source, destination, length) per (slot, batch, rank) run, per thread
+    auto merge_slots = [&](uint32_t sl0, uint32_t sl1, unsigned tix) {
     uint64_t e = slot_e[sl0], sp = slot_s[sl0];
     std::vector<uint64_t> pos(n);
     for (uint32_t sl = sl0; sl < sl1; ++sl) {
@@ -417,7 +479,8 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
                 while (q < end && r.ev_read[q] < rb[g][i + 1]) ++q;
                 if (q == q0) continue;
                 const uint64_t s0 = r.samp_off[q0], s1 = r.samp_off[q];
-                memcpy(&j->r_samples[sp], r.samples + s0, (s1 - s0) * sizeof(double));
+                if (!all_dev) memcpy(&j->r_samples[sp], hsrc[g] + s0, (s1 - s0) * sizeof(double));
+                else if (s1 > s0) tsegs[tix].push_back(PgSeg{reinterpret_cast<const double *>((uintptr_t)((uint64_t)g << 48 | s0)), sp, s1 - s0}); // src = (rank, offset) until the sources' addresses on the first device are known
                 for (uint64_t t = q0; t < q; ++t, ++e) {
                     j->r_ev_len[e] = r.ev_len[t];
                     j->r_ev_read[e] = (uint32_t)(bstart[i] + j->cuts[i][g] + (r.ev_read[t] - rb[g][i]));
@@ -429,8 +492,7 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
     }
     };
     {
-        const unsigned nt = n_samples >= (8u << 20) ? 8u : 1u;
-        if (nt == 1) merge_slots(0, ns);
+        if (nt == 1) merge_slots(0, ns, 0);
         else {
             std::vector<std::thread> pool;
             uint32_t s0 = 0;
@@ -438,7 +500,7 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
                 uint32_t s1 = s0;
                 const uint64_t want = slot_s[ns] / nt * (t + 1);
                 while (s1 < ns && (t + 1 == nt || slot_s[s1 + 1] <= want)) s1++;
-                if (s1 > s0) pool.emplace_back(merge_slots, s0, s1);
+                if (s1 > s0) pool.emplace_back(merge_slots, s0, s1, t);
                 s0 = s1;
             }
             for (auto &th : pool) th.join();
@@ -450,14 +512,93 @@ pg_status pg_job_finish(pg_job *j, pg_result *out) {
             const uint64_t m = j->cuts[i][g + 1] - j->cuts[i][g];
             if (m) memcpy(&j->r_skipped[bstart[i] + j->cuts[i][g]], R[g].read_skipped + rb[g][i], m);
         }
+    j->samples_on_host = !all_dev; j->samples_on_dev = false;
+    if (all_dev && n_samples) { // the concatenation on the first device
+        const int dev0 = j->devices[0];
+        JHIP(j, hipSetDevice(dev0));
+        hipStream_t st0 = (hipStream_t)pgi_stream(j->ctx[0]);
+        { const pg_status se = md_ensure(j, 3, n_samples * 8ull); if (se != PG_OK) return se; }
+        std::vector<void *> staged(n, nullptr);
+        auto drop_staged = [&]() { for (void *p : staged) if (p) (void)hipFree(p); };
+        std::vector<const double *> base(n, nullptr);
+        for (uint32_t g = 0; g < n; ++g) {
+            if (!R[g].n_samples) continue;
+            if (j->devices[g] == dev0) { base[g] = dev_src[g]; continue; }
+            hipError_t e = hipMalloc(&staged[g], R[g].n_samples * 8ull); // this rank's stream over xGMI, whole
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(staged[g], dev0, dev_src[g], j->devices[g], R[g].n_samples * 8ull, st0);
+            if (e != hipSuccess) { drop_staged(); return jfail(j, PG_ERR_HIP, "peer copy of shard %u's samples (device %d -> %d): %s", g, j->devices[g], dev0, hipGetErrorString(e)); }
+            base[g] = static_cast<const double *>(staged[g]);
+        }
+        size_t nseg = 0;
+        for (auto &v : tsegs) nseg += v.size();
+        std::vector<PgSeg> segs; segs.reserve(nseg);
+        for (auto &v : tsegs) for (const PgSeg &sg : v) {
+            const uint64_t key = (uint64_t)(uintptr_t)sg.src;
+            segs.push_back(PgSeg{base[key >> 48] + (key & ((1ull << 48) - 1)), sg.dst_off, sg.n});
+        }
+        void *dseg = nullptr;
+        hipError_t e = hipMalloc(&dseg, segs.size() * sizeof(PgSeg) + 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(dseg, segs.data(), segs.size() * sizeof(PgSeg), hipMemcpyHostToDevice, st0);
+        if (e == hipSuccess) e = pg_launch_merge_segments(st0, static_cast<const PgSeg *>(dseg), (uint32_t)segs.size(), static_cast<double *>(j->md[3]), n_samples);
+        if (e == hipSuccess) e = hipStreamSynchronize(st0);
+        if (dseg) (void)hipFree(dseg);
+        drop_staged();
+        if (e != hipSuccess) return jfail(j, PG_ERR_HIP, "device merge of the shards' samples: %s", hipGetErrorString(e));
+        j->samples_on_dev = true;
+    }
     pg_result &v = j->merged_view;
     v.n_slots = ns; v.reserved = 0; v.n_events = n_events; v.n_samples = n_samples; v.n_reads = bstart[nb];
     v.counts = j->r_counts.data(); v.ev_off = j->r_ev_off.data(); v.ev_len = j->r_ev_len.data(); v.ev_read = j->r_ev_read.data();
-    v.samp_off = j->r_samp_off.data(); v.samples = j->r_samples.data(); v.read_skipped = j->r_skipped.data();
-    j->merged = true;
+    v.samp_off = j->r_samp_off.data(); v.samples = j->samples_on_host ? j->r_samples.data() : nullptr; v.read_skipped = j->r_skipped.data();
+    if (!n_samples) { j->samples_on_host = true; v.samples = j->r_samples.data(); }
+    j->merged = true; j->small_on_dev = false;
+    if (want_samples && !j->samples_on_host) return job_finish(j, out, true); // the one download
     *out = v;
     return PG_OK;
 }
+
+pg_status pg_job_finish(pg_job *j, pg_result *out) { return job_finish(j, out, true); }
+pg_status pg_job_finish_deferred(pg_job *j, pg_result *out) { return job_finish(j, out, false); }
+
+pg_status pg_job_fetch_samples(pg_job *j, uint64_t first, uint64_t n, double *dst) {
+    if (!j || (!dst && n)) return PG_ERR_INVALID_ARG;
+    if (!j->merged) return PG_ERR_STATE; // (no error text: several host threads may call this at once)
+    if (first > j->merged_view.n_samples || n > j->merged_view.n_samples - first) return PG_ERR_INVALID_ARG;
+    if (!n) return PG_OK;
+    if (j->samples_on_host) { memcpy(dst, j->r_samples.data() + first, n * sizeof(double)); return PG_OK; }
+    if (hipSetDevice(j->devices[0]) != hipSuccess || hipMemcpy(dst, (const double *)j->md[3] + first, n * 8ull, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return PG_ERR_HIP; }
+    return PG_OK;
+}
+
+// the merged view's arrays on the first device (md[0] ev_off, md[1] samp_off, md[2] ev_len, md[3] samples): what pg_text_device / pg_model_device read
+static pg_status job_device_view(pg_job *j, pg_result *R) {
+    pg_status s = job_finish(j, R, false);
+    if (s != PG_OK) return s;
+    JHIP(j, hipSetDevice(j->devices[0]));
+    const void *src[4] = {R->ev_off, R->samp_off, R->ev_len, j->samples_on_dev ? nullptr : j->r_samples.data()};
+    const size_t bytes[4] = {(R->n_slots + 1) * 8ull, (R->n_events + 1) * 8ull, R->n_events * 4ull, R->n_samples * 8ull};
+    for (int i = 0; i < 4; ++i) {
+        if (i < 3 && j->small_on_dev) continue;
+        if (i == 3 && (j->samples_on_dev || !bytes[3])) continue;
+        s = md_ensure(j, i, bytes[i]);
+        if (s != PG_OK) return s;
+        if (bytes[i]) JHIP(j, hipMemcpy(j->md[i], src[i], bytes[i], hipMemcpyHostToDevice));
+    }
+    j->small_on_dev = true;
+    if (bytes[3]) j->samples_on_dev = true; // (a host merge's samples are now there as well)
+    return PG_OK;
+}
+
+pg_status pg_job_text(pg_job *j, pg_text_result *out) {
+    if (!j || !out) return PG_ERR_INVALID_ARG;
+    pg_result R;
+    pg_status s = job_device_view(j, &R);
+    if (s != PG_OK) return s;
+    s = pg_text_device(j->ctx[0], R.n_slots, R.n_events, (const uint64_t *)j->md[0], (const uint64_t *)j->md[1], (const double *)j->md[3], out);
+    if (s != PG_OK) return jfail(j, s, "%s", pg_last_error(j->ctx[0]));
+    return PG_OK;
+}
+pg_status pg_job_fetch_text(pg_job *j, uint64_t first, uint64_t n, char *dst) { return j ? pg_fetch_text(j->ctx[0], first, n, dst) : PG_ERR_INVALID_ARG; }
 
 pg_status pg_job_kernel_stats(pg_job *j, uint32_t shard, pg_kernel_stat *out, uint32_t cap, uint32_t *n_out) {
     if (!j || shard >= j->n) return PG_ERR_INVALID_ARG;
@@ -468,20 +609,8 @@ pg_status pg_job_kernel_stats(pg_job *j, uint32_t shard, pg_kernel_stat *out, ui
 pg_status pg_job_model(pg_job *j, uint32_t flags, pg_model_result *out) {
     if (!j || !out) return PG_ERR_INVALID_ARG;
     pg_result R;
-    pg_status s = pg_job_finish(j, &R);
+    pg_status s = job_device_view(j, &R);
     if (s != PG_OK) return s;
-    JHIP(j, hipSetDevice(j->devices[0]));
-    const void *src[4] = {R.ev_off, R.samp_off, R.ev_len, R.samples};
-    const size_t bytes[4] = {(R.n_slots + 1) * 8ull, (R.n_events + 1) * 8ull, R.n_events * 4ull, R.n_samples * 8ull};
-    for (int i = 0; i < 4; ++i) {
-        if (bytes[i] + 16 > j->md_cap[i]) {
-            if (j->md[i]) JHIP(j, hipFree(j->md[i]));
-            j->md[i] = nullptr; j->md_cap[i] = 0;
-            JHIP(j, hipMalloc(&j->md[i], bytes[i] + bytes[i] / 8 + 64));
-            j->md_cap[i] = bytes[i] + bytes[i] / 8 + 64;
-        }
-        if (bytes[i]) JHIP(j, hipMemcpy(j->md[i], src[i], bytes[i], hipMemcpyHostToDevice));
-    }
     s = pg_model_device(j->ctx[0], R.n_slots, (const uint64_t *)j->md[0], (const uint64_t *)j->md[1], (const uint32_t *)j->md[2], (const double *)j->md[3], flags, out);
     if (s != PG_OK) return jfail(j, s, "%s", pg_last_error(j->ctx[0]));
     return PG_OK;

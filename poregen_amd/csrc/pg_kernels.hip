@@ -2628,16 +2628,21 @@ hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void 
     return hipSuccess;
 }
 
-// several batches' kept samples into the k-mer-major order of the whole job, on the device: one workgroup per (k-mer, batch) segment
-__global__ __launch_bounds__(256) void k_merge_segments(const PgSeg *__restrict__ seg, double *__restrict__ dst) {
-    const PgSeg sg = seg[blockIdx.x];
+// several batches' (or, for a pg_job, several ranks') kept samples into the k-mer-major order of the whole job, on the device: one
+// workgroup per (k-mer, batch) segment -- or one wave when the segments are short (k = 9 over 8 ranks: 2 M segments of ~90 samples)
+template <int PER_WG> __global__ __launch_bounds__(256) void k_merge_segments(const PgSeg *__restrict__ seg, uint32_t n_seg, double *__restrict__ dst) {
+    const uint32_t si = PER_WG == 1 ? blockIdx.x : blockIdx.x * PER_WG + (threadIdx.x >> 6);
+    if (si >= n_seg) return;
+    const PgSeg sg = seg[si];
     const double *__restrict__ src = sg.src;
     double *__restrict__ d = dst + sg.dst_off;
-    for (uint64_t i = threadIdx.x; i < sg.n; i += 256) d[i] = src[i];
+    const uint32_t t = PER_WG == 1 ? threadIdx.x : (uint32_t)lane_id(), step = PER_WG == 1 ? 256u : (uint32_t)WAVE;
+    for (uint64_t i = t; i < sg.n; i += step) d[i] = src[i];
 }
-hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst) {
+hipError_t pg_launch_merge_segments(hipStream_t st, const PgSeg *d_seg, uint32_t n_seg, double *dst, uint64_t n_total) {
     if (!n_seg) return hipSuccess;
-    PG_LAUNCH(k_merge_segments, dim3(n_seg), dim3(256), 0, st, d_seg, dst);
+    if (n_total / n_seg >= 1024) PG_LAUNCH(k_merge_segments<1>, dim3(n_seg), dim3(256), 0, st, d_seg, n_seg, dst);
+    else PG_LAUNCH(k_merge_segments<4>, dim3((n_seg + 3) / 4), dim3(256), 0, st, d_seg, n_seg, dst);
     return hipSuccess;
 }
 

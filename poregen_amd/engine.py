@@ -246,6 +246,25 @@ def _result_from(r) -> "Result":
                   read_skipped=arr(r.read_skipped, nr, np.uint8), n_reads=int(nr))
 
 
+def _text_slots(owner, t, fetch):
+    off = [int(t.slot_off[i]) for i in range(t.n_slots + 1)]
+    buf = C.create_string_buffer(int(t.n_bytes) + 1)
+    owner._check(fetch(owner._h, 0, int(t.n_bytes), buf))
+    raw = buf.raw
+    return [raw[off[i]:off[i + 1]] for i in range(t.n_slots)]
+
+
+def _deferred_result(owner, r, fetch, piece) -> "Result":
+    res = _result_from(r)
+    if r.n_samples and not r.samples:  # still on the device: range by range
+        smp = np.empty(int(r.n_samples), dtype=np.float64)
+        for a in range(0, int(r.n_samples), piece):
+            n = min(piece, int(r.n_samples) - a)
+            owner._check(fetch(owner._h, a, n, smp[a:a + n].ctypes.data_as(C.c_void_p)))
+        res.samples = smp
+    return res
+
+
 def _c_batch(b: "Batch"):
     cb = _abi.PgBatch()
     cb.struct_size = C.sizeof(_abi.PgBatch)
@@ -418,11 +437,13 @@ class GmoveEngine:
         write into dump/<KMER> without -d."""
         t = _abi.PgTextResult()
         self._check(self._lib.pg_text(self._h, C.byref(t)))
-        off = [int(t.slot_off[i]) for i in range(t.n_slots + 1)]
-        buf = C.create_string_buffer(int(t.n_bytes) + 1)
-        self._check(self._lib.pg_fetch_text(self._h, 0, int(t.n_bytes), buf))
-        raw = buf.raw
-        return [raw[off[i]:off[i + 1]] for i in range(t.n_slots)]
+        return _text_slots(self, t, self._lib.pg_fetch_text)
+
+    def finish_deferred(self, piece: int = 1 << 20) -> Result:
+        """pg_finish_deferred + pg_fetch_samples: the same Result as finish(), the samples fetched from the device `piece` at a time."""
+        r = _abi.PgResult()
+        self._check(self._lib.pg_finish_deferred(self._h, C.byref(r)))
+        return _deferred_result(self, r, self._lib.pg_fetch_samples, piece)
 
     def device_view(self):
         v = _abi.PgDeviceView()
@@ -505,6 +526,18 @@ class GmoveJob:
         r = _abi.PgResult()
         self._check(self._lib.pg_job_finish(self._h, C.byref(r)))
         return _result_from(r)
+
+    def finish_deferred(self, piece: int = 1 << 20) -> Result:
+        """pg_job_finish_deferred + pg_job_fetch_samples: the shards' samples concatenated on the job's first device, fetched in pieces."""
+        r = _abi.PgResult()
+        self._check(self._lib.pg_job_finish_deferred(self._h, C.byref(r)))
+        return _deferred_result(self, r, self._lib.pg_job_fetch_samples, piece)
+
+    def text(self):
+        """pg_job_text: the dump files' text of the whole job, produced on its first device; one bytes object per slot."""
+        t = _abi.PgTextResult()
+        self._check(self._lib.pg_job_text(self._h, C.byref(t)))
+        return _text_slots(self, t, self._lib.pg_job_fetch_text)
 
     def model(self, keep_first: bool = False) -> "Model":
         m = _abi.PgModelResult()

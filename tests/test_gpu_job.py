@@ -60,6 +60,39 @@ def test_job_equals_single_context_and_stops_when_full():
     eng.close(); job.close()
 
 
+@pytest.mark.parametrize("host_merge", [False, True], ids=["device_concat", "host_merge"])
+def test_job_output_side_on_the_first_device(host_merge, monkeypatch):
+    """pg_job_finish_deferred / _fetch_samples / _text / _model: the shards' kept samples concatenated on the job's first device (here
+    four shards of one GPU, three uneven batches; PGMOVE_HOLD_MIN_BYTES=1 keeps even these small batches on the device inside every
+    shard) against the oracle, against pg_job_finish, and against printf. PGMOVE_JOB_HOST_MERGE=1: the fallback through the host."""
+    monkeypatch.setenv("PGMOVE_HOLD_MIN_BYTES", "1")
+    if host_merge:
+        monkeypatch.setenv("PGMOVE_JOB_HOST_MERGE", "1")
+    wl, b, p = _whitelist_case()
+    p = dict(p, sample_limit=40)
+    o = oracle_for(wl, index_start=51, index_end=250, **p)
+    o.run_batch(b)
+    job = GmoveJob(GmoveParams(kmers=wl[50:250], **p), [0, 0, 0, 0])
+    for lo, hi in ((0, 150), (150, 151), (151, 420)):
+        job.submit(b.slice_reads(lo, hi))
+    res_d = job.finish_deferred(piece=1000)       # samples fetched in ranges from the device
+    assert_result_equals_oracle(res_d, o, sample_limit=40)
+    text = job.text()
+    for s in range(200):
+        assert text[s] == res_d.slot_text(s).encode(), s
+    m = job.model()
+    res = job.finish()                            # the same merged view, samples downloaded as a whole
+    assert np.array_equal(res.samples.view(np.uint64), res_d.samples.view(np.uint64))
+    for name in ("counts", "ev_off", "ev_len", "ev_read", "samp_off", "read_skipped"):
+        assert np.array_equal(getattr(res, name), getattr(res_d, name)), name
+    job.close()
+    eng = GmoveEngine(GmoveParams(kmers=wl[50:250], **p))
+    eng.submit(b)
+    me = eng.model()
+    assert me.median_text == m.median_text and me.sstdev_text == m.sstdev_text and me.dwell_text == m.dwell_text
+    eng.close()
+
+
 def test_rank_level_early_out_skips_statistics():
     """Nothing behind the completing read is touched by the reference (src/gmove.cpp:733-735). Four shards on device 0 (host exchange):
     all 64 3-mers are complete inside the first shards of batch 1, so the later shards -- whose base already fills every k-mer -- queue
