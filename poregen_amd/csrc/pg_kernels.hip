@@ -152,7 +152,6 @@ __device__ __forceinline__ void read_head_one(const PgDevBatch &B, const PgWalkP
 // k_walk: the generic walk (gmove.cpp:831-871) and event loop (891-927) of one read by one wave
 // ---------------------------------------------------------------------------------------------------------------------
 #define PG_EV_PER_THREAD 4 // four consecutive op indices per thread / lane
-#define PG_EV_TBL 128        // reads per tile (and its 16-op halo) k_events keeps in LDS
 // LDS window of a read's per-match values: what the event loop needs besides the window starts -- base code, window length, I/D ops
 // in front. A read of at most PG_WALK_LDS_OPS ss ops never writes them to global memory; a longer one re-fills the window per tile.
 #define PG_WALK_LDS_OPS 512

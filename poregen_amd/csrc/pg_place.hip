@@ -425,9 +425,6 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
 // workgroups per CU), count and rank in one ordered walk, FOUR consecutive tiles per workgroup so that a slot's four tile prefixes
 // are one 16-byte load, window starts from the block-sum prefix (two rounds of independent loads per kept event).
 #define PG_EMIT2_TILES 4
-#ifndef PG_EMIT2_INFLIGHT
-#define PG_EMIT2_INFLIGHT 2
-#endif
 __device__ __forceinline__ bool kept_window_bp(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const uint32_t *__restrict__ Bp, const KeptRead &kr,
                                                uint64_t g, uint32_t &start, uint32_t &len) {
     const uint64_t ge = g + W.sig_move_offset;
@@ -442,9 +439,15 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K, const uint32_t *__restrict__ Bp) {
     __shared__ uint32_t cnt[PG_PART_WAVES * (PG_RANK_MAX_DIGITS / 2)];
     __shared__ uint32_t s_hcol[PG_RANK_MAX_DIGITS], s_keep[PG_RANK_MAX_DIGITS], s_off[PG_RANK_MAX_DIGITS];
+    // the tile's reads (those k_events could name in an event's upper bits): what a kept event needs of its read, fetched ONCE per tile
+    // and read instead of five scattered record loads + the op sums in front of the read's first op per kept event
+    __shared__ uint64_t s_rsig0[PG_EV_TBL];
+    __shared__ uint32_t s_rqs[PG_EV_TBL], s_rL[PG_EV_TBL], s_rpre[PG_EV_TBL], s_rgen[PG_EV_TBL];
     const uint32_t tid = threadIdx.x, w = tid >> 6, ndig = 1u << nbits, half = ndig / 2 ? ndig / 2 : 1;
     const int lane = lane_id();
     const int64_t last_tile = (int64_t)totals[3];
+    const bool have_row = W.sig_move_offset == 0;
+    const uint64_t n_loads = B.n_reads && B.op_off[B.n_reads] < n ? B.op_off[B.n_reads] : n; // (a caller's n_ops that is too large is not followed behind the op arrays)
     const uint32_t n_groups = (n_tiles + PG_EMIT2_TILES - 1) / PG_EMIT2_TILES;
     bool first = true;
     for (uint32_t q = blockIdx.x; q < n_groups && (int64_t)q * PG_EMIT2_TILES <= last_tile; q += gridDim.x) {
@@ -467,6 +470,11 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
             uint32_t key[PG_PART_ROWS];
 #pragma unroll
             for (int r = 0; r < PG_PART_ROWS; ++r) { const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane; key[r] = g < n ? keys[g] : PG_INVALID_SLOT; }
+            // every lane's own op_n (sig_move_offset 0): the window length of its event and, handed along the lanes, the ops in front of it
+            // inside its group of four -- what the 4-op granularity of k_events' in-block sums leaves to add (k_part_scatter does the same)
+            uint32_t opn[PG_PART_ROWS];
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) { const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane; opn[r] = (have_row && g < n_loads) ? B.op_n[g] : 0u; }
             for (uint32_t i = tid; i < PG_PART_WAVES * half; i += PG_PART_THREADS) cnt[i] = 0;
             int any = 0; // does any slot still have room at this tile's position in the (read, event) order?
 #pragma unroll
@@ -476,6 +484,14 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                     const uint32_t h = k == 0 ? hc[u].x : (k == 1 ? hc[u].y : (k == 2 ? hc[u].z : hc[u].w));
                     s_hcol[d] = h; s_keep[d] = kp[u]; s_off[d] = eo[u];
                     if (d < n_slots && h < kp[u]) any = 1;
+                }
+            }
+            if (tid >= PG_PART_THREADS - PG_EV_TBL) { // (the last two waves: the first ones carry the slot columns above)
+                const uint32_t t = tid - (PG_PART_THREADS - PG_EV_TBL), r = tile_first + t;
+                if (r < B.n_reads) {
+                    const KeptRead kr = kept_read(O, r);
+                    s_rsig0[t] = kr.sig0; s_rqs[t] = kr.qs; s_rL[t] = kr.L; s_rgen[t] = kr.generic ? 1u : 0u;
+                    s_rpre[t] = kr.generic ? 0u : op_prefix(B, O, Bp, kr.o0);
                 }
             }
             if (!__syncthreads_or(any)) { stop = true; break; } // every k-mer this tile could feed is full (gmove.cpp:925-927), and so are the tiles behind it
@@ -504,38 +520,38 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
             if (tile_first == 0xFFFFFFFFu)
 #endif
 #pragma unroll
-            for (int r0 = 0; r0 < PG_PART_ROWS; r0 += PG_EMIT2_INFLIGHT) { // a few rows' chains in flight
-                uint32_t rd[PG_EMIT2_INFLIGHT]; KeptRead kr[PG_EMIT2_INFLIGHT];
-#pragma unroll
-                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
-                    const int r = r0 + u;
-                    if (dst[r] == 0xFFFFFFFFu) continue;
-                    const uint32_t rel = key[r] >> PG_SLOT_BITS;
-                    rd[u] = rel != PG_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane);
-                    kr[u] = kept_read(O, rd[u]);
+            for (int r = 0; r < PG_PART_ROWS; ++r) {
+                const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3 (all lanes take part)
+                const uint32_t m4 = (uint32_t)lane & 3u, partial = (m4 > 0 ? v1 : 0u) + (m4 > 1 ? v2 : 0u) + (m4 > 2 ? v3 : 0u);
+                if (dst[r] == 0xFFFFFFFFu) continue;
+                const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ge = g + W.sig_move_offset;
+                const uint32_t rel = key[r] >> PG_SLOT_BITS;
+                uint32_t rd, ws, wl, qs, L, pre0; uint64_t sig0; bool gen;
+                if (rel != PG_REL_UNKNOWN) { rd = tile_first + rel; sig0 = s_rsig0[rel]; qs = s_rqs[rel]; L = s_rL[rel]; pre0 = s_rpre[rel]; gen = s_rgen[rel] != 0; }
+                else { // a tile that more than PG_EV_TBL reads touch
+                    rd = owner_of(B, O, g);
+                    const KeptRead kr = kept_read(O, rd);
+                    sig0 = kr.sig0; qs = kr.qs; L = kr.L; gen = kr.generic; pre0 = gen ? 0u : op_prefix(B, O, Bp, kr.o0);
                 }
-                uint32_t ws[PG_EMIT2_INFLIGHT], wl[PG_EMIT2_INFLIGHT]; bool okr[PG_EMIT2_INFLIGHT];
-#pragma unroll
-                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
-                    const int r = r0 + u;
-                    ws[u] = 0; wl[u] = 0; okr[u] = true;
-                    if (dst[r] != 0xFFFFFFFFu) okr[u] = kept_window_bp(B, W, O, Bp, kr[u], T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ws[u], wl[u]);
+                bool ok = true;
+                if (gen) { ws = O.m_start[ge]; wl = O.m_len[ge]; }
+                else {
+                    wl = have_row ? opn[r] : B.op_n[ge];
+                    const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + partial : op_prefix(B, O, Bp, ge);
+                    const uint64_t st = (uint64_t)qs + (uint32_t)(pre - pre0);
+                    ws = (uint32_t)st;
+                    ok = st + wl <= 0x7fffffffull;
                 }
-#pragma unroll
-                for (int u = 0; u < PG_EMIT2_INFLIGHT; ++u) {
-                    const int r = r0 + u;
-                    if (dst[r] == 0xFFFFFFFFu) continue;
-                    if (!okr[u]) { report_error(O, rd[u], PGR_ERR_RANGE); ws[u] = 0; wl[u] = 0; }
-                    uint32_t start = ws[u] - W.print_margin;
-                    const uint64_t we64 = (uint64_t)ws[u] + wl[u] + W.print_margin;
-                    uint32_t we = (uint32_t)(we64 > kr[u].L ? kr[u].L : we64);
-                    // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
-                    if (W.print_margin > ws[u] || we <= start) { report_error(O, rd[u], PGR_ERR_WINDOW); start = we = 0; }
-                    K.rec[dst[r]] = PgKeptRec{kr[u].sig0 + start, we - start, rd[u]};
-                    if (K.read_needed) K.read_needed[rd[u]] = 1;
-                    // (the chunked gather's chunk sums are NOT accumulated here as k_region_place does: a tile's kept events go to ~1000 different
-                    // k-mers, i.e. chunks -- nothing to combine in LDS first, and 2.1 M global 64-bit atomics took the kernel from 77 to 190 us)
-                }
+                if (!ok) { report_error(O, rd, PGR_ERR_RANGE); ws = 0; wl = 0; }
+                uint32_t start = ws - W.print_margin;
+                const uint64_t we64 = (uint64_t)ws + wl + W.print_margin;
+                uint32_t we = (uint32_t)(we64 > L ? L : we64);
+                // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
+                if (W.print_margin > ws || we <= start) { report_error(O, rd, PGR_ERR_WINDOW); start = we = 0; }
+                K.rec[dst[r]] = PgKeptRec{sig0 + start, we - start, rd};
+                if (K.read_needed) K.read_needed[rd] = 1;
+                // (the chunked gather's chunk sums are NOT accumulated here as k_region_place does: a tile's kept events go to ~1000 different
+                // k-mers, i.e. chunks -- nothing to combine in LDS first, and 2.1 M global 64-bit atomics took the kernel from 77 to 190 us)
             }
         }
         if (stop) break;
