@@ -11,9 +11,9 @@ out=gpurun_out/$tag; mkdir -p $out
 R=$PWD; cd /tmp && export TMPDIR=/tmp && cd $R
 common="--no-cpu-baseline --no-lazy-extra --no-extras"
 python3 bench.py --steps 20 --warmup 3 $common "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
-rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 $common "$@" > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out/trace -o trace -- python3 bench.py --steps 10 --warmup 2 --one-stream $common "$@" > $out/trace_bench.json 2> $out/trace.err || { tail -5 $out/trace.err; exit 1; }
 for pass in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$pass -- python3 bench.py --steps 2 --warmup 1 $common "$@" > /dev/null 2> $out/pmc_$pass.err || { tail -5 $out/pmc_$pass.err; exit 1; }
+  rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$pass -- python3 bench.py --steps 2 --warmup 1 --one-stream $common "$@" > /dev/null 2> $out/pmc_$pass.err || { tail -5 $out/pmc_$pass.err; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, collections, json, sqlite3, sys
