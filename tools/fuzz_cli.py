@@ -54,7 +54,12 @@ for case in range(n_cases):
             continue
         gargs = [a[:-4] + ".bam" if (front == "sam" and use_bam and a.endswith(".sam")) else a for a in args] if front != "paf" else \
                 [a[:-6] + ".blow5" if (blow5 and a.endswith(".slow5")) else a for a in args]
-        g = subprocess.run([BIN, "gmove"] + gargs + [os.path.join(d, "gpu"), "--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))], capture_output=True, text=True)
+        extra = ["--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))]
+        if rng.random() < 0.25:  # the job layer: several shards on the one GPU of the box (host exchange), or one rank over RCCL
+            extra += ["--devices", str(rng.choice(["0,0", "0,0,0,0", "0"]))]
+        env = dict(os.environ)
+        if rng.random() < 0.3: env["PGMOVE_HOLD_MIN_BYTES"] = "1"  # small batches' samples stay on the device too (device merge, device text)
+        g = subprocess.run([BIN, "gmove"] + gargs + [os.path.join(d, "gpu")] + extra, capture_output=True, text=True, env=env)
         ok = (o.returncode == 0) == (g.returncode == 0)
         if ok and o.returncode == 0:
             ok = open(os.path.join(d, "gpu", "freq.txt")).read() == open(os.path.join(d, "cpu", "freq.txt")).read()
@@ -67,7 +72,7 @@ for case in range(n_cases):
             bad += 1
             keep = os.path.join(ROOT, "gpurun_out", f"fuzz_cli_case{case}")
             os.makedirs(os.path.dirname(keep), exist_ok=True); shutil.copytree(d, keep, dirs_exist_ok=True)
-            print("CASE", case, "DIFFERS:", front, " ".join(args), "| oracle rc", o.returncode, "gpu rc", g.returncode, g.stderr[-300:].replace("\n", " | "), flush=True)
+            print("CASE", case, "DIFFERS:", front, " ".join(args + extra), "| oracle rc", o.returncode, "gpu rc", g.returncode, g.stderr[-300:].replace("\n", " | "), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     if case % 20 == 19:
