@@ -98,7 +98,7 @@ struct PgWalkOut {
     uint32_t *tile_read; // [n_tiles + 1]
 };
 #define PG_SLOT_BITS 10
-#define PG_EV_TBL 128        // reads per tile (and its 16-op halo) k_events keeps in LDS (an event's read relative to its tile's first read is < this, or unknown)
+#define PG_EV_TBL 128        // reads per tile (and its 16-op halo) k_events keeps in LDS (an event names its read relative to the first read of its tile: an entry of this table, a larger number from the scalar path, or "unknown")
 #define PG_SLOT_MASK ((1u << PG_SLOT_BITS) - 1u)
 #define PG_REL_UNKNOWN ((1u << (32 - PG_SLOT_BITS)) - 2u) // not all ones: slot 1023 with an unknown read must not read as PG_INVALID_SLOT
 

@@ -527,9 +527,9 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ge = g + W.sig_move_offset;
                 const uint32_t rel = key[r] >> PG_SLOT_BITS;
                 uint32_t rd, ws, wl, qs, L, pre0; uint64_t sig0; bool gen;
-                if (rel != PG_REL_UNKNOWN) { rd = tile_first + rel; sig0 = s_rsig0[rel]; qs = s_rqs[rel]; L = s_rL[rel]; pre0 = s_rpre[rel]; gen = s_rgen[rel] != 0; }
-                else { // a tile that more than PG_EV_TBL reads touch
-                    rd = owner_of(B, O, g);
+                if (rel < PG_EV_TBL) { rd = tile_first + rel; sig0 = s_rsig0[rel]; qs = s_rqs[rel]; L = s_rL[rel]; pre0 = s_rpre[rel]; gen = s_rgen[rel] != 0; }
+                else { // a tile that more than PG_EV_TBL reads touch: the read is named beyond the table, or not at all
+                    rd = rel != PG_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, g);
                     const KeptRead kr = kept_read(O, rd);
                     sig0 = kr.sig0; qs = kr.qs; L = kr.L; gen = kr.generic; pre0 = gen ? 0u : op_prefix(B, O, Bp, kr.o0);
                 }

@@ -314,12 +314,25 @@ def _tiny_reads_batch(n_reads, seed, k, rna, max_ops=6, op_len=(18, 45), indel_e
 
 @pytest.mark.parametrize("k,rna,max_ops,indel_every", [(1, False, 3, 0), (2, True, 4, 0), (3, False, 6, 0), (2, False, 5, 7), (1, True, 2, 0)])
 def test_tiny_reads_many_per_group_and_per_tile(k, rna, max_ops, indel_every):
+    _tiny_reads_case(k, rna, max_ops, indel_every, 0)
+
+
+@pytest.mark.parametrize("k,rna,max_ops,indel_every,move_offset", [(2, True, 4, 0, 1), (3, False, 6, 0, 0), (2, False, 5, 7, 2), (6, False, 9, 0, 1), (6, True, 8, 5, 0)])
+def test_tiny_reads_through_the_dense_kernels(k, rna, max_ops, indel_every, move_offset, monkeypatch):
+    """The same with PGMOVE_DENSE_MIN=0: k_rank_emit2 (its LDS table of a tile's first 128 reads, events that name a read beyond it or none
+    at all) and, for k = 6, the partitioned ranking, with a window that is the one of match i + sig_move_offset (found by the fuzzer:
+    an event naming read 129 of its tile read the table out of bounds)."""
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    _tiny_reads_case(k, rna, max_ops, indel_every, move_offset)
+
+
+def _tiny_reads_case(k, rna, max_ops, indel_every, move_offset):
     """Reads far shorter than a 256-op block: three or four reads inside one thread's group of four ops, > 1024 reads inside one
     tile of 4096 ops. Direct path, the forced generic path and the oracle agree bit for bit."""
     import torch
     b = _tiny_reads_batch(9000, 700 + k, k, rna, max_ops=max_ops, indel_every=indel_every)
     limit = 1000000  # no k-mer ever completes: every read of the batch reaches the output
-    p = dict(kmer_size=k, rna=rna, scaling=1, sample_limit=limit, kmer_pick_margin=0, min_dur=5, max_dur=70)
+    p = dict(kmer_size=k, rna=rna, scaling=1, sample_limit=limit, kmer_pick_margin=0, min_dur=5, max_dur=70, sig_move_offset=move_offset)
     kmers = generate_kmers(k, rna=rna)
     o = oracle_for(kmers, **p)
     rcs = o.run_batch(b)
