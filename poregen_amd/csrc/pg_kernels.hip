@@ -481,10 +481,13 @@ __device__ __forceinline__ uint32_t event_slot_scalar(const PgDevBatch &B, const
 //   3. an event is k consecutive codes starting at its op (its own thread's and the next one's) -> slot table -> duration and
 //      position tests. COUNT (direct ranking): the accepted events are counted per (tile, slot) into hist[slot][tile..tile+3].
 // A tile touched by more than PG_EV_TBL reads, and a thread whose 16 ops span more than two reads, take event_slot_scalar.
+#ifndef PG_EV2_WAVES
+#define PG_EV2_WAVES 4 // waves per SIMD the partitioned variant is compiled for (8 = two workgroups per CU, if it fits 64 registers)
+#endif
 // LT: both slot tables (<= 1024 codes each: k <= 5; <= 1024 slots: COUNT) as 16-bit entries in LDS -- 16 look-ups per thread at LDS latency
 // COUNT: 0 = slots only; 1 = direct ranking: counts per (tile, slot), the event's read in the upper bits of its slot word; 2 = partitioned
 // ranking (pg_place.hip): counts per (tile, high digit of the slot = slot >> cshift), plain slot words
-template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT == 1 ? 8 : 4, 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist, uint32_t cshift) {
+template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(COUNT == 1 ? 8 : (COUNT == 2 ? PG_EV2_WAVES : 4), 8))) void k_events(PgDevBatch B, PgWalkParams W, PgWalkOut O, int nbits, uint32_t n_tiles, uint32_t *__restrict__ hist, uint32_t cshift) {
     constexpr int TBL = PG_EV_TBL;
     __shared__ uint16_t ltab[LT ? 2048 + 2 : 2]; // [2048]: 0xFFFF, where a position that is no candidate looks itself up
     __shared__ uint32_t cnt[COUNT ? 4 : 1][COUNT ? PG_RANK_MAX_DIGITS + 32 : 1]; // + 32 dummy bins: positions that are no event
