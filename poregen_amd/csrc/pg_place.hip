@@ -603,6 +603,9 @@ __global__ __launch_bounds__(1024) void k_partials_scan(uint64_t *__restrict__ p
 #ifndef PG_GC_EVENTS
 #define PG_GC_EVENTS 2
 #endif
+#ifndef PG_GC_WAVES
+#define PG_GC_WAVES 4 // waves per SIMD the chunked gather is compiled for
+#endif
 // The sub-chunk's records sit in LDS (they came in with one coalesced pass, which also feeds the scan of their lengths): an event's
 // chain is then LDS -> window + calibration (one memory round) -> stores, not record -> window -> stores (two)
 template <int G, int P>
@@ -630,7 +633,7 @@ __device__ __forceinline__ void gather_chunk(const PgDevBatch &B, uint64_t total
         }
     }
 }
-template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_gather_chunks(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ part,
+template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GC_WAVES, PG_GC_WAVES))) void k_gather_chunks(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ part,
                                                        uint32_t sub_per_chunk, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
                                                        double *__restrict__ samples, const double *__restrict__ gcal) {
     __shared__ uint4 s_rec[PG_G2_SUB];
