@@ -98,6 +98,33 @@ int main(int argc, char **argv) {
             printf("mode A-local (sources inside %.0f MB)          grid %5d: %.3f ms\n", area * 2 / 1e6, grid, best);
         }
     }
+    // A-banded: mode A walking the destination events band by band -- ranks [64 b, 64 b + 64) of EVERY slot, then the next band -- instead of
+    // slot by slot. A slot's events are in source order, so a band of ranks is a band of the source: the windows the chip has in flight then
+    // come from a narrow range of the signal (cache lines are used by their ~2.3 windows while they are resident) while a slot's 64 events
+    // still leave as one run of ~14 KB. argv[6] = band width in ranks (default 64)
+    {
+        const uint32_t band = argc > 6 ? atoi(argv[6]) : 64;
+        std::vector<uint32_t> bsrc, blen; std::vector<uint64_t> bsoff;
+        bsrc.reserve(N); blen.reserve(N); bsoff.reserve(N);
+        uint32_t maxc = 0; for (uint32_t sl = 0; sl < n_slots; ++sl) maxc = std::max(maxc, start[sl + 1] - start[sl]);
+        for (uint32_t b0 = 0; b0 < maxc; b0 += band)
+            for (uint32_t sl = 0; sl < n_slots; ++sl)
+                for (uint32_t e = start[sl] + b0; e < start[sl + 1] && e < start[sl] + b0 + band; ++e) { bsrc.push_back(d_src[e]); blen.push_back(d_len[e]); bsoff.push_back(d_soff[e]); }
+        uint32_t *g_bsrc, *g_blen; uint64_t *g_bsoff;
+        CK(hipMalloc(&g_bsrc, N * 4ull)); CK(hipMalloc(&g_blen, N * 4ull)); CK(hipMalloc(&g_bsoff, N * 8ull));
+        CK(hipMemcpy(g_bsrc, bsrc.data(), N * 4ull, hipMemcpyHostToDevice)); CK(hipMemcpy(g_blen, blen.data(), N * 4ull, hipMemcpyHostToDevice)); CK(hipMemcpy(g_bsoff, bsoff.data(), N * 8ull, hipMemcpyHostToDevice));
+        for (int grid : {8192, 32768}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipMemset(g_out, 0, n_out * 8));
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(k_move<0>, dim3(grid), dim3(256), 0, 0, g_sig, total, N, g_bsrc, g_blen, g_bsoff, nullptr, nullptr, nullptr, g_out);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+            }
+            printf("mode A-banded (bands of %u ranks across all slots) grid %5d: %.3f ms\n", band, grid, best);
+        }
+    }
     for (int mode = 0; mode < 3; ++mode) {
         for (int grid : {8192, 32768}) {
             float best = 1e9f;
