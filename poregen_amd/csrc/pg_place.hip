@@ -423,17 +423,11 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
 // counters, the tile's column of the [slot][tile] table gathered line by line. With every tile useful (sample_limit 5000: 1588 tiles,
 // 2.1 M kept events) that cost 128 us = 6 % of the HBM roofline. Here: 8 waves per tile and 16 KB of packed 16-bit counters (three
 // workgroups per CU), count and rank in one ordered walk, FOUR consecutive tiles per workgroup so that a slot's four tile prefixes
-// are one 16-byte load, window starts from the block-sum prefix (two rounds of independent loads per kept event).
+// are one 16-byte load. A kept event's window: what it needs of its read (signal offset, query start, length, the op sums in front of the
+// read's first op) comes from a table of the tile's first PG_EV_TBL reads that is filled once per tile in LDS; its own op_n is the lane's
+// row value, the ops in front of it inside its group of four come along the lanes (DPP); the block-sum prefix adds the rest. 128 us ->
+// 77 (ranking as above) -> 61 (the table and the row). The ranking alone takes 35 us (PG_PROBE_EMIT2_NOWIN).
 #define PG_EMIT2_TILES 4
-__device__ __forceinline__ bool kept_window_bp(const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const uint32_t *__restrict__ Bp, const KeptRead &kr,
-                                               uint64_t g, uint32_t &start, uint32_t &len) {
-    const uint64_t ge = g + W.sig_move_offset;
-    if (kr.generic) { start = O.m_start[ge]; len = O.m_len[ge]; return true; }
-    len = B.op_n[ge];
-    const uint64_t st = (uint64_t)kr.qs + (uint32_t)(op_prefix(B, O, Bp, ge) - op_prefix(B, O, Bp, kr.o0));
-    start = (uint32_t)st;
-    return st + len <= 0x7fffffffull;
-}
 __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_rank_emit2(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
         const uint32_t *__restrict__ hist, const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ totals,
         PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K, const uint32_t *__restrict__ Bp) {
