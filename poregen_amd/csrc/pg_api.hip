@@ -1413,8 +1413,7 @@ size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, c
             const unsigned __int128 s2 = ((unsigned __int128)m->sum2_hi[slot] << 64) | m->sum2_lo[slot];
             const __int128 s1 = r.s1;
             const unsigned __int128 num = (unsigned __int128)r.n * s2 - (unsigned __int128)(s1 * s1);
-            const long double sd = sqrtl((long double)num / ((long double)r.n * (long double)(r.n - 1))) / 1e8L;
-            w = snprintf(buf, cap, "%.14Lg", sd);
+            w = pg_model_sstdev_text(r.n, num, buf, cap); // "%.14Lg" of the standard deviation, its 14 digits decided in exact arithmetic
         }
     } else return 0;
     return (w < 0 || (size_t)w >= cap) ? 0 : (size_t)w;

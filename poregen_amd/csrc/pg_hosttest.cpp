@@ -130,5 +130,17 @@ extern "C" void pgt_model_texts(const long long *units, size_t n, char *med, cha
     med[0] = sd[0] = 0;
     if (!n) return;
     snprintf(med, cap, "%.14Lg", pg_model_median(m));
-    if (n < 2) snprintf(sd, cap, "nan"); else snprintf(sd, cap, "%.14Lg", pg_model_sstdev_units(m) / 1e8L);
+    if (n < 2) snprintf(sd, cap, "nan");
+    else {
+        const unsigned __int128 s2 = ((unsigned __int128)m.s2_hh << 40) + ((unsigned __int128)m.s2_hl << 21) + m.s2_ll;
+        const __int128 s1 = m.s1;
+        pg_model_sstdev_text(n, (unsigned __int128)n * s2 - (unsigned __int128)(s1 * s1), sd, cap);
+    }
+}
+// the sstdev text of n values whose n * sum d^2 - (sum d)^2 is num (given as two 64-bit halves), and -- for comparison -- the plain
+// "%.14Lg" of the long double square root
+extern "C" void pgt_sstdev_text(unsigned long long n, unsigned long long num_hi, unsigned long long num_lo, char *exact, char *plain, size_t cap) {
+    const unsigned __int128 num = ((unsigned __int128)num_hi << 64) | num_lo;
+    pg_model_sstdev_text(n, num, exact, cap);
+    snprintf(plain, cap, "%.14Lg", sqrtl((long double)num / ((long double)n * (long double)(n - 1))) / 1e8L);
 }

@@ -521,9 +521,10 @@ static pg_status job_finish(pg_job *j, pg_result *out, bool want_samples) {
         std::vector<void *> staged(n, nullptr);
         auto drop_staged = [&]() { for (void *p : staged) if (p) (void)hipFree(p); };
         std::vector<const double *> base(n, nullptr);
+        const bool force_peer = getenv("PGMOVE_JOB_FORCE_PEER") != nullptr; // tests on a one-GPU box: the staging + peer-copy branch for shards of the SAME device too
         for (uint32_t g = 0; g < n; ++g) {
             if (!R[g].n_samples) continue;
-            if (j->devices[g] == dev0) { base[g] = dev_src[g]; continue; }
+            if (j->devices[g] == dev0 && !force_peer) { base[g] = dev_src[g]; continue; }
             hipError_t e = hipMalloc(&staged[g], R[g].n_samples * 8ull); // this rank's stream over xGMI, whole
             if (e == hipSuccess) e = hipMemcpyPeerAsync(staged[g], dev0, dev_src[g], j->devices[g], R[g].n_samples * 8ull, st0);
             if (e != hipSuccess) { drop_staged(); return jfail(j, PG_ERR_HIP, "peer copy of shard %u's samples (device %d -> %d): %s", g, j->devices[g], dev0, hipGetErrorString(e)); }

@@ -8,6 +8,8 @@
 #pragma once
 #include <stdint.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #if defined(__HIPCC__)
 #define PGM_HD __host__ __device__ __forceinline__
@@ -65,6 +67,52 @@ inline long double pg_model_sstdev_units(const PgSlotModel &m) {
     const unsigned __int128 num = (unsigned __int128)m.n * s2 - (unsigned __int128)(s1 * s1);
     const long double den = (long double)m.n * (long double)(m.n - 1);
     return sqrtl((long double)num / den);
+}
+// The sstdev text, "%.14Lg" of the sample standard deviation, as the CORRECTLY ROUNDED 14 digits of the exact value. The long double above
+// is within half a unit of its 64-bit mantissa (19 digits), so its 14 digits are right unless the exact value sits within ~1e-19 (relative)
+// of a rounding boundary -- seen once in ~1600 fuzzed model files: exact 2.89847887318104999994..., long double just above the boundary,
+// text ...811 instead of ...81. The verdict at the two boundaries next to the printed digits is therefore taken in exact integer arithmetic:
+// sd < (2D +- 1)/2 * 10^e  <=>  4 * num * 10^16... against (2D +- 1)^2 * n (n - 1), numbers of up to ~220 bits.
+struct PgBig512 { uint64_t w[8]; };
+inline void pg_big_set(PgBig512 &b, unsigned __int128 x) { for (int i = 0; i < 8; ++i) b.w[i] = 0; b.w[0] = (uint64_t)x; b.w[1] = (uint64_t)(x >> 64); }
+inline void pg_big_mul(PgBig512 &b, uint64_t m) { unsigned __int128 c = 0; for (int i = 0; i < 8; ++i) { const unsigned __int128 t = (unsigned __int128)b.w[i] * m + c; b.w[i] = (uint64_t)t; c = t >> 64; } }
+inline void pg_big_mul_pow10(PgBig512 &b, int k) { while (k >= 19) { pg_big_mul(b, 10000000000000000000ull); k -= 19; } uint64_t p = 1; while (k-- > 0) p *= 10; pg_big_mul(b, p); }
+inline int pg_big_cmp(const PgBig512 &a, const PgBig512 &b) { for (int i = 7; i >= 0; --i) if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1; return 0; }
+// sign of  sqrt(num / (den * 10^16)) - (d2 / 2) * 10^e   (the standard deviation in sample units against a decimal boundary)
+inline int pg_sstdev_cmp(unsigned __int128 num, uint64_t den, uint64_t d2, int e) {
+    PgBig512 L, R;
+    pg_big_set(L, num); pg_big_mul(L, 4);
+    pg_big_set(R, (unsigned __int128)d2 * d2); pg_big_mul(R, den);
+    const int f = 2 * e + 16;
+    if (f >= 0) pg_big_mul_pow10(R, f); else pg_big_mul_pow10(L, -f);
+    return pg_big_cmp(L, R);
+}
+// n >= 2 values, num = n * sum d^2 - (sum d)^2 in (1e-8 unit)^2. Returns snprintf's count.
+inline int pg_model_sstdev_text(uint64_t n, unsigned __int128 num, char *buf, size_t cap) {
+    const uint64_t den = n * (n - 1);
+    long double sd = sqrtl((long double)num / ((long double)n * (long double)(n - 1))) / 1e8L;
+    char t[64];
+    snprintf(t, sizeof t, "%.13Le", sd); // d.ddddddddddddde+XX: the 14 digits "%.14Lg" prints
+    if (num != 0 && t[1] == '.') {
+        uint64_t D = (uint64_t)(t[0] - '0');
+        int i = 2;
+        for (; t[i] >= '0' && t[i] <= '9'; ++i) D = D * 10 + (uint64_t)(t[i] - '0');
+        if (i == 15 && t[i] == 'e') {
+            const int e = atoi(t + i + 1) - 13; // sd ~ D * 10^e
+            if (e >= -40 && e <= 8) { // (in range of the 512-bit products)
+                uint64_t D1 = D;
+                const int up = pg_sstdev_cmp(num, den, 2 * D + 1, e);
+                if (up > 0 || (up == 0 && (D & 1))) D1 = D + 1;                         // at or above the upper boundary (ties to even)
+                else { const int lo = pg_sstdev_cmp(num, den, 2 * D - 1, e); if (lo < 0 || (lo == 0 && (D & 1))) D1 = D - 1; }
+                if (D1 != D && D1 >= 10000000000000ull && D1 <= 100000000000000ull) {
+                    char dec[64];
+                    snprintf(dec, sizeof dec, "%llue%d", (unsigned long long)D1, e);
+                    sd = strtold(dec, nullptr); // 14 digits: a long double holds them (19), "%.14Lg" prints them back
+                }
+            }
+        }
+    }
+    return snprintf(buf, cap, "%.14Lg", sd);
 }
 // datamash median of the decimal texts: each text becomes the long double nearest to units/10^8 (strtold), the two
 // middle ones are averaged in long double.

@@ -60,13 +60,15 @@ def test_job_equals_single_context_and_stops_when_full():
     eng.close(); job.close()
 
 
-@pytest.mark.parametrize("host_merge", [False, True], ids=["device_concat", "host_merge"])
+@pytest.mark.parametrize("host_merge", [False, True, "peer"], ids=["device_concat", "host_merge", "peer_copies"])
 def test_job_output_side_on_the_first_device(host_merge, monkeypatch):
     """pg_job_finish_deferred / _fetch_samples / _text / _model: the shards' kept samples concatenated on the job's first device (here
     four shards of one GPU, three uneven batches; PGMOVE_HOLD_MIN_BYTES=1 keeps even these small batches on the device inside every
     shard) against the oracle, against pg_job_finish, and against printf. PGMOVE_JOB_HOST_MERGE=1: the fallback through the host."""
     monkeypatch.setenv("PGMOVE_HOLD_MIN_BYTES", "1")
-    if host_merge:
+    if host_merge == "peer":  # the branch a multi-GPU job takes for shards on other devices: staging buffer on the first device + hipMemcpyPeerAsync
+        monkeypatch.setenv("PGMOVE_JOB_FORCE_PEER", "1")
+    elif host_merge:
         monkeypatch.setenv("PGMOVE_JOB_HOST_MERGE", "1")
     wl, b, p = _whitelist_case()
     p = dict(p, sample_limit=40)

@@ -21,6 +21,7 @@ def host():
     L = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
     L.pgt_fixed8.argtypes = [C.c_double, C.POINTER(C.c_int)]; L.pgt_fixed8.restype = C.c_longlong
     L.pgt_model_texts.argtypes = [C.POINTER(C.c_longlong), C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.pgt_sstdev_text.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_char_p, C.c_char_p, C.c_size_t]
     return L
 
 
@@ -103,6 +104,36 @@ def test_library_arithmetic_is_exact(host):
         else:
             want = sqrt_text14(evar)
             assert close14(sd.value.decode(), want, ulps=0), (sd.value, want)   # exact moments: correctly rounded text
+
+
+def test_sstdev_text_next_to_a_rounding_boundary(host):
+    """The 14 digits of the sstdev text are decided in exact integer arithmetic (pg_model_sstdev_text): moments whose standard deviation
+    sits one part in 10^29 below / above / exactly on the boundary between two 14-digit decimals -- far inside the long double's own
+    rounding error, where the plain "%.14Lg" of the square root gets about half of them wrong (the fuzzer met one such file in ~1600)."""
+    rng = random.Random(5)
+    plain_wrong = 0
+    for trial in range(400):
+        n = rng.choice([2, 3, 10, 1000])
+        den = n * (n - 1)
+        D = rng.randrange(10**13, 10**14 - 1)
+        e = rng.choice([-9, -8, -7])                       # sd = D * 10^e: 1e4 .. 1e7 sample units
+        # boundary b = (2D + 1) / 2 * 10^e; sd = b  <=>  num = b^2 * den * 10^16 = (2D + 1)^2 * den * 10^(2e + 16) / 4
+        tie_num = Fraction((2 * D + 1) ** 2 * den * 10 ** (2 * e + 18), 400)
+        base = tie_num.numerator // tie_num.denominator
+        for num in (base - 1, base, base + 1, base + 2):
+            if num >= 1 << 128:
+                continue
+            exact, plain = C.create_string_buffer(64), C.create_string_buffer(64)
+            host.pgt_sstdev_text(n, num >> 64, num & ((1 << 64) - 1), exact, plain, 64)
+            var = Fraction(num, den) / 10**16
+            want = sqrt_text14(var)
+            on_tie = Fraction(num) == tie_num
+            if on_tie:                                     # exactly half way: ties to even on the 14th digit
+                assert Decimal(exact.value.decode()) == Decimal(D + (D & 1)).scaleb(e), (n, D, e, exact.value)
+            else:
+                assert close14(exact.value.decode(), want, ulps=0), (n, D, e, num - base, exact.value, want)
+                plain_wrong += not close14(plain.value.decode(), want, ulps=0)
+    assert plain_wrong > 50                                # the test does exercise what the long double cannot decide
 
 
 def write_dir(tmp_path, files):
