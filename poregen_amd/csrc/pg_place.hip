@@ -428,7 +428,10 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
 // row value, the ops in front of it inside its group of four come along the lanes (DPP); the block-sum prefix adds the rest. 128 us ->
 // 77 (ranking as above) -> 61 (the table and the row). The ranking alone takes 35 us (PG_PROBE_EMIT2_NOWIN).
 #define PG_EMIT2_TILES 4
-__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(4, 6))) void k_rank_emit2(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
+#ifndef PG_EMIT2_WAVES
+#define PG_EMIT2_WAVES 4 // waves per SIMD the kernel is compiled for (6 = three workgroups per CU, if it fits 80 registers)
+#endif
+__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(PG_EMIT2_WAVES, 6))) void k_rank_emit2(const uint32_t *__restrict__ keys, uint32_t n, int nbits, uint32_t n_slots, uint32_t n_tiles,
         const uint32_t *__restrict__ hist, const uint64_t *__restrict__ keep, const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ totals,
         PgDevBatch B, PgWalkParams W, PgWalkOut O, PgKeptOut K, const uint32_t *__restrict__ Bp) {
     __shared__ uint32_t cnt[PG_PART_WAVES * (PG_RANK_MAX_DIGITS / 2)];
