@@ -103,7 +103,10 @@ def main():
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
     ap.add_argument("--overlap", action="store_true", help="statistics of a batch on a second stream (PG_FLAG_OVERLAP; the library's default since round 3 wherever it applies)")
     ap.add_argument("--one-stream", action="store_true", help="every kernel of a batch on one stream (PG_FLAG_ONE_STREAM): round 2's default")
+    ap.add_argument("--job-layer-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: run the pg_job_* step over this many devices and print its JSON object
     args = ap.parse_args()
+    if args.job_layer_child:
+        return job_layer_child(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -375,7 +378,7 @@ def main():
         out["config2_mode"] = {"workload": workload_label(args.kind, args.reads, args.read_len, args.k, 5000, world), "ms_per_step": ms2,
                                "value": world * n_samples / (ms2 * 1e-3), "unit": "samples/s", "useful": u2}
         e2.close()
-        out["job_layer"] = job_layer(host, kmers, p, world, rank, dist)
+        out["job_layer"] = job_layer(args, world, rank, dist)
     if extras and rank == 0 and world == 1:
         t0 = time.time()
         out["all_kept_mode"] = mode_run(shard, host, kmers, dict(p, sample_limit=5000),
@@ -443,35 +446,68 @@ def config3_mode(dev):
     return r
 
 
-def job_layer(host, kmers, p, world, rank, dist):
-    """The step through pg_job_* on rank 0: ONE process, `world` devices, a host thread and a context per device, the exchange over
-    ncclCommInitAll -- what `poregen gmove --devices 0,1,...` runs. The other ranks' processes idle at the barrier meanwhile. The job
-    layer stages its batch from host memory (rank 0's shard, cut `world` ways), so this is a PCIe-inclusive figure."""
-    import torch
-    from poregen_amd import _abi
-    from poregen_amd.engine import GmoveJob, GmoveParams
+def job_layer(args, world, rank, dist):
+    """The step through pg_job_* : ONE process, `world` devices, a host thread and a context per device, the exchange over
+    ncclCommInitAll, the shards' kept samples concatenated on the first device -- what `poregen gmove --devices 0,1,...` runs. It runs in
+    a CHILD process of rank 0 (this file with --job-layer-child) under a time limit, while the ranks idle at the barrier: the path has
+    never seen more than one GPU before the driver's first multi-GPU run, and a fault or a hang in it must not take the headline line
+    with it. The job layer stages its batch from host memory (rank 0's shard, cut `world` ways): a PCIe-inclusive figure."""
+    import subprocess
     info = None
     if rank == 0:
+        cmd = [sys.executable, os.path.abspath(__file__), "--job-layer-child", str(world), "--reads", str(args.reads), "--read-len", str(args.read_len),
+               "--kind", args.kind, "--k", str(args.k), "--sample-limit", str(args.sample_limit)]
+        if args.lib:
+            cmd += ["--lib", args.lib]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
         try:
-            q = {k: v for k, v in p.items() if k not in ("device",)}
-            job = GmoveJob(GmoveParams(kmers=kmers, **q), list(range(world)), _abi.PG_JOB_EXCHANGE_AUTO)
-            job.submit(host); job.sync()      # contexts, communicators, first buffers
-            t0 = time.perf_counter()
-            n = 3
-            for _ in range(n):
-                job.submit(host)
-            job.sync()
-            ms = (time.perf_counter() - t0) / n * 1e3
-            r = job.finish()
-            info = {"devices": world, "exchange": "rccl" if job.uses_rccl else "host", "rccl_ranks_seen": world if job.uses_rccl else 0,
-                    "ms_per_step_pcie_inclusive": ms, "reads_per_step": host.n_reads, "samples_per_step": int(host.n_samples),
-                    "kept_events": int(r.counts.sum()), "all_kmers_complete": job.all_slots_full()}
-            job.close()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            info = json.loads(line[-1]) if line else {"error": "child exited %d: %s" % (r.returncode, r.stderr[-300:])}
+        except subprocess.TimeoutExpired:
+            info = {"error": "the pg_job child did not finish within 240 s (killed)"}
         except Exception as ex:  # the headline must not die with the extra
             info = {"error": repr(ex)[:300]}
-    torch.cuda.synchronize()
     dist.barrier()
     return info
+
+
+def job_layer_child(args):
+    """see job_layer: one process, args.job_layer_child devices; prints ONE JSON object"""
+    world = args.job_layer_child
+    try:
+        if args.lib:
+            from poregen_amd import _abi as abi0
+            abi0.LIB_PATH = os.path.abspath(args.lib)
+        from poregen_amd import _abi, synth
+        from poregen_amd.engine import GmoveJob, GmoveParams, generate_kmers
+        rna = args.kind == "rna004"
+        p = dict(kmer_size=args.k, rna=rna, scaling=1, sample_limit=args.sample_limit)
+        if rna:
+            p.update(min_dur=20, max_dur=40)
+        kmers = generate_kmers(args.k, rna=rna)
+        host = synth.make_batch_fast(args.reads, read_len=args.read_len, kind=args.kind, seed=20251003 + 1)
+        job = GmoveJob(GmoveParams(kmers=kmers, **p), list(range(world)), _abi.PG_JOB_EXCHANGE_AUTO)
+        job.submit(host); job.sync()      # contexts, communicators, first buffers
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            job.submit(host)
+        job.sync()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        t1 = time.perf_counter()
+        r = job.finish_deferred()         # small arrays merged on the host, samples concatenated on the first device (peer copies) and fetched
+        fin_ms = (time.perf_counter() - t1) * 1e3
+        info = {"devices": world, "exchange": "rccl" if job.uses_rccl else "host", "rccl_ranks_seen": world if job.uses_rccl else 0,
+                "ms_per_step_pcie_inclusive": ms, "reads_per_step": host.n_reads, "samples_per_step": int(host.n_samples),
+                "kept_events": int(r.counts.sum()), "kept_samples": int(r.samples.size), "finish_deferred_and_fetch_ms": fin_ms,
+                "all_kmers_complete": job.all_slots_full(), "process": "child of rank 0"}
+        job.close()
+    except Exception as ex:
+        info = {"error": repr(ex)[:300]}
+    sys.stdout.flush()
+    print(json.dumps(info), flush=True)
+    return 0
 
 
 def hbm_not_mall(shard, kmers, p, dev, copies=8):
