@@ -620,7 +620,11 @@ __device__ __forceinline__ void gather_chunk(const PgDevBatch &B, uint64_t total
             const uint32_t i = i0 + u * STEP;
             const uint4 r = s_rec[i < cnt ? i : 0u]; // every lane of the group reads the same 16 bytes: a broadcast
             so[u] = s_off[i < cnt ? i : 0u];
+#ifdef PG_PROBE_GC_CLAMP16 // timing probe only (results are garbage): the first 16 samples of every window -- what a sweep without the long windows' passes costs
+            len[u] = i < cnt ? (r.z < 16u ? r.z : 16u) : 0u; src[u] = (uint64_t)r.x | ((uint64_t)r.y << 32);
+#else
             len[u] = i < cnt ? r.z : 0u; src[u] = (uint64_t)r.x | ((uint64_t)r.y << 32);
+#endif
             if (i < cnt) gather_load<G, P>(B, sub, r.w, len[u], src[u], total, scaling, nullptr, nullptr, gcal, R[u]);
         }
 #pragma unroll
