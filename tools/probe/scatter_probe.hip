@@ -48,6 +48,32 @@ template <int MODE> __global__ __launch_bounds__(256) void k_move(const int16_t 
     }
 }
 
+// mode A with XCD affinity: block b belongs to XCD b % 8 (workgroups go round the XCDs) and walks only that XCD's list of events
+// [xstart[x], xstart[x + 1]) of arrays that are grouped by XCD: the events of the regions (= 1 / 256 of the slots each) r with r % 8 == x
+__global__ __launch_bounds__(256) void k_move_xcd(const int16_t *__restrict__ sig, uint64_t total, const uint32_t *__restrict__ xstart,
+        const uint32_t *__restrict__ src, const uint32_t *__restrict__ len, const uint64_t *__restrict__ soff, double *__restrict__ out) {
+    const uint32_t sub = threadIdx.x & 7u, x = blockIdx.x & 7u, j = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const uint32_t *sig32 = reinterpret_cast<const uint32_t *>(sig);
+    const uint32_t a = xstart[x], b = xstart[x + 1];
+    for (uint64_t i = (uint64_t)a + (uint64_t)j * 32 + (threadIdx.x >> 3); i < b; i += (uint64_t)per * 32) {
+        const uint32_t s = src[i], l = len[i];
+        const uint64_t o = soff[i];
+        const uint32_t odd = s & 1u; const uint64_t d0 = s >> 1;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const uint32_t t = 2 * sub + 16 * ps;
+            if (t < l) {
+                uint2 q = make_uint2(0, 0);
+                if (2 * (d0 + (t >> 1)) + 3 < total) q = *reinterpret_cast<const uint2 *>(sig32 + d0 + (t >> 1));
+                const int s0 = odd ? (int)q.x >> 16 : (int)(short)(q.x & 0xffffu);
+                const int s1 = odd ? (int)(short)(q.y & 0xffffu) : (int)q.x >> 16;
+                if (t + 1 < l) *reinterpret_cast<double2 *>(out + o + t) = make_double2(conv(s0), conv(s1));
+                else out[o + t] = conv(s0);
+            }
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     const uint32_t N = (argc > 1 ? atoi(argv[1]) : 16) * 1000000u, n_slots = argc > 2 ? atoi(argv[2]) : 262144;
     const uint32_t lmin = argc > 3 ? atoi(argv[3]) : 8, lspan = argc > 4 ? atoi(argv[4]) : 10;
@@ -123,6 +149,56 @@ int main(int argc, char **argv) {
                 float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
             }
             printf("mode A-banded (bands of %u ranks across all slots) grid %5d: %.3f ms\n", band, grid, best);
+        }
+    }
+    // A-bucket: what the gather would see if pass A of the partition carried every event's int16 window into its region's bucket (region =
+    // 1 / 256 of the slots, ~1.5 MB of windows at the K9 shape, laid out in source order inside the bucket): sources compact per region.
+    // (a) walked as mode A (workgroups round the XCDs: every XCD's L2 sees every region), (b) with XCD affinity (k_move_xcd): a region's
+    // windows are read by ONE XCD, whose 4 MB L2 holds them
+    {
+        const uint32_t R = 256, per_r = (n_slots + R - 1) / R;
+        std::vector<uint64_t> rbytes(R + 1, 0);          // bucket sizes in samples, then bases
+        for (uint32_t i = 0; i < N; ++i) rbytes[slot[i] / per_r + 1] += len[i] + (len[i] & 1); // (even lengths keep the 4-byte alignment)
+        for (uint32_t r = 0; r < R; ++r) rbytes[r + 1] += rbytes[r];
+        std::vector<uint64_t> fill(rbytes.begin(), rbytes.end() - 1);
+        std::vector<uint32_t> bsrc_of(N);                // bucket position of source event i (source order inside the bucket)
+        for (uint32_t i = 0; i < N; ++i) { const uint32_t r = slot[i] / per_r; bsrc_of[i] = (uint32_t)fill[r]; fill[r] += len[i] + (len[i] & 1); }
+        std::vector<uint32_t> inv(N); for (uint32_t i = 0; i < N; ++i) inv[dst[i]] = i;   // destination event e came from source event inv[e]
+        std::vector<uint32_t> asrc(N); for (uint32_t e = 0; e < N; ++e) asrc[e] = bsrc_of[inv[e]];
+        uint32_t *g_asrc; CK(hipMalloc(&g_asrc, N * 4ull)); CK(hipMemcpy(g_asrc, asrc.data(), N * 4ull, hipMemcpyHostToDevice));
+        for (int grid : {8192, 32768}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(k_move<0>, dim3(grid), dim3(256), 0, 0, g_sig, total, N, g_asrc, g_dlen, g_dsoff, nullptr, nullptr, nullptr, g_out);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+            }
+            printf("mode A-bucket (windows in 256 region buckets), workgroups round the XCDs   grid %5d: %.3f ms\n", grid, best);
+        }
+        // grouped by XCD: regions r with r % 8 == x, in region order, destination order inside
+        std::vector<uint32_t> xsrc, xlen; std::vector<uint64_t> xsoff; std::vector<uint32_t> xstart(9, 0);
+        xsrc.reserve(N); xlen.reserve(N); xsoff.reserve(N);
+        for (uint32_t x = 0; x < 8; ++x) {
+            for (uint32_t r = x; r < R; r += 8) {
+                const uint32_t s0 = r * per_r, s1 = std::min(n_slots, (r + 1) * per_r);
+                for (uint32_t e = start[s0]; e < start[s1]; ++e) { xsrc.push_back(asrc[e]); xlen.push_back(d_len[e]); xsoff.push_back(d_soff[e]); }
+            }
+            xstart[x + 1] = (uint32_t)xsrc.size();
+        }
+        uint32_t *g_xsrc, *g_xlen, *g_xstart; uint64_t *g_xsoff;
+        CK(hipMalloc(&g_xsrc, N * 4ull)); CK(hipMalloc(&g_xlen, N * 4ull)); CK(hipMalloc(&g_xsoff, N * 8ull)); CK(hipMalloc(&g_xstart, 9 * 4));
+        CK(hipMemcpy(g_xsrc, xsrc.data(), N * 4ull, hipMemcpyHostToDevice)); CK(hipMemcpy(g_xlen, xlen.data(), N * 4ull, hipMemcpyHostToDevice));
+        CK(hipMemcpy(g_xsoff, xsoff.data(), N * 8ull, hipMemcpyHostToDevice)); CK(hipMemcpy(g_xstart, xstart.data(), 9 * 4, hipMemcpyHostToDevice));
+        for (int grid : {2048, 8192, 32768}) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(k_move_xcd, dim3(grid), dim3(256), 0, 0, g_sig, total, g_xstart, g_xsrc, g_xlen, g_xsoff, g_out);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+                float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best;
+            }
+            printf("mode A-bucket with XCD affinity (a region's windows are read by one XCD)    grid %5d: %.3f ms\n", grid, best);
         }
     }
     for (int mode = 0; mode < 3; ++mode) {
