@@ -21,7 +21,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_dev.h $(CSRC)/pg_selec
 poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_place.o build/pg_api.o build/pg_model.o build/pg_job.o build/pg_text.o
 	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lpthread
 
-poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
+poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_hostmem.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread
 
 HOST = $(CSRC)/host

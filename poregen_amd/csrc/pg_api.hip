@@ -604,6 +604,7 @@ static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
 static int gather_lanes(const pg_ctx *c) {
     static const char *ov = getenv("PGMOVE_GATHER_LANES");
     if (ov) return atoi(ov);
+    return 0; // k_gather_wave (round 4): a lane per pair of output samples, a wave per 64 events. What follows chose the lane groups of k_gather_chunks.
     const uint32_t mw = c->win_hint ? c->win_hint : c->prm.min_dur + (c->prm.max_dur > c->prm.min_dur ? (c->prm.max_dur - c->prm.min_dur) / 4 : 0) + 2 * c->prm.signal_print_margin;
     return mw <= 6 ? 4 : (mw <= 36 ? 8 : 16); // (k = 9, mean window 12.4: 8 lanes 0.91-0.97 ms, 4 lanes 1.07-1.10 ms)
 }

@@ -22,8 +22,8 @@ template <class T> struct NoInitAlloc {
         if (const size_t m = mapped(n)) {
             void *q = mmap(nullptr, m, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (q == MAP_FAILED) throw std::bad_alloc();
-#ifdef MADV_kHugePagePAGE
-            (void)madvise(q, m, MADV_kHugePagePAGE);
+#ifdef MADV_HUGEPAGE
+            (void)madvise(q, m, MADV_HUGEPAGE);
 #endif
             return static_cast<T *>(q);
         }

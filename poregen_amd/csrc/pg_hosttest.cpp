@@ -144,3 +144,28 @@ extern "C" void pgt_sstdev_text(unsigned long long n, unsigned long long num_hi,
     pg_model_sstdev_text(n, num, exact, cap);
     snprintf(plain, cap, "%.14Lg", sqrtl((long double)num / ((long double)n * (long double)(n - 1))) / 1e8L);
 }
+
+// ---- pg_hostmem.h: does a big SampleVec really ask for transparent huge pages? -------------------------------------------------
+#include "pg_hostmem.h"
+#include <fstream>
+#include <sstream>
+// 1 = the mapping that holds a SampleVec of n doubles carries the "hg" VmFlag (madvise(MADV_HUGEPAGE) took effect), 0 = it does not,
+// -1 = /proc/self/smaps could not be read. anon_huge_kb (may be null): the mapping's AnonHugePages after a first touch.
+extern "C" int pgt_samplevec_hugepage(size_t n, long *anon_huge_kb) {
+    SampleVec v;
+    v.resize(n);
+    for (size_t i = 0; i < n; i += 512) v[i] = 1.0; // first touch
+    const uintptr_t p = reinterpret_cast<uintptr_t>(v.data());
+    std::ifstream f("/proc/self/smaps");
+    if (!f) return -1;
+    std::string line; bool inside = false; int hg = 0; long ahp = 0;
+    while (std::getline(f, line)) {
+        unsigned long a = 0, b = 0;
+        if (sscanf(line.c_str(), "%lx-%lx ", &a, &b) == 2) { inside = p >= a && p < b; continue; } /* a mapping's header line */
+        if (!inside) continue;
+        if (line.rfind("AnonHugePages:", 0) == 0) ahp = atol(line.c_str() + 14);
+        if (line.rfind("VmFlags:", 0) == 0) { std::istringstream is(line.substr(8)); std::string t; while (is >> t) if (t == "hg") hg = 1; }
+    }
+    if (anon_huge_kb) *anon_huge_kb = ahp;
+    return hg;
+}

@@ -681,6 +681,220 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
     }
 }
 
+// ---- the wave form (round 4): one lane per PAIR OF OUTPUT SAMPLES instead of a lane group per event -------------------------------------
+// k_gather_chunks gives an event G lanes and walks its window in passes of 2 * G samples: at k = 9 (mean window 12.4, a third of the
+// windows longer than 16) 35 % of the lane-slots it issues carry a sample, and its stores are ragged 16-byte pieces. Here the OUTPUT range
+// is the index space: lane j of a trip owns the 16-byte aligned pair of output samples 2j, 2j + 1, finds the event(s) they belong to,
+// loads their int16 samples, converts and writes one 16-byte store -- every lane busy, every store instruction 1 KB of consecutive
+// doubles. The event of an output sample comes from a bit map of the window starts over the group's sample range, kept in LDS with the
+// running count of set bits per word: event = prefix + popcount(word & mask) - 1, one 8-byte LDS read. Per event the stage holds
+// (source - offset) -- a sample's source index is that plus its output index --, the read's calibration and the reciprocal of its MAD.
+// A WAVE owns 64 consecutive events at a time and a 4 KB slice of the LDS: one 16-byte record per lane, offsets by DPP scan, bit map +
+// per-word prefix by the wave alone (LDS operations of one wave execute in order), then its trips over the group's output pairs; records
+// and calibrations are requested one group ahead. The only workgroup barrier is the one behind the group sums of a chunk segment (2048
+// events). (A first form with a workgroup per 512 events and seven barriers per sub-chunk was 10 % SLOWER than k_gather_chunks.)
+// What bounds it, measured: profiles/r04_gather_bound.txt. k = 9: 984 -> 875 us, sample_limit 5000: 247 -> 218 us on one box.
+#define PG_GW_SPAN 4096        // output samples per bit map (128 words)
+#define PG_GW_SEG 2048         // events per segment of a chunk (32 groups of 64)
+#ifndef PG_GW_TRIPS
+#define PG_GW_TRIPS 4
+#endif
+#ifndef PG_GW_WAVES
+#define PG_GW_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES, 8))) void k_gather_wave(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
+        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+        double *__restrict__ samples, const double *__restrict__ gcal) {
+    __shared__ uint32_t gsum[PG_GW_SEG / 64];
+    __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - offset inside the group (64 bits), read, -
+    __shared__ double s_cal_all[4][64 * 4];           // its read's offset, scale, median, MAD
+    __shared__ uint2 s_bits_all[4][PG_GW_SPAN / 32];  // x: window starts over this tile of the group's output samples, y: non-empty events in front of the word
+    const uint64_t n_kept = n_kept_ptr[0];
+    const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
+    if (c0 >= n_kept) return;
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const int lane = lane_id();
+    uint4 *s_ev = s_ev_all[w]; double *s_cal = s_cal_all[w]; uint2 *s_bits = s_bits_all[w];
+    const uint64_t c1 = c0 + (uint64_t)sub_per_chunk * PG_G2_SUB < n_kept ? c0 + (uint64_t)sub_per_chunk * PG_G2_SUB : n_kept;
+    const int16_t *__restrict__ sig = B.sig;
+    uint64_t run = part[blockIdx.x];
+    for (uint64_t seg = c0; seg < c1; seg += PG_GW_SEG) {
+        const uint32_t nseg = c1 - seg < PG_GW_SEG ? (uint32_t)(c1 - seg) : PG_GW_SEG;
+        // ---- sums of the window lengths per group of 64 events (8 threads x 8 events each)
+        if (seg != c0) __syncthreads(); // the previous segment's sums are read until its last wave has scanned them
+        {
+            const uint32_t *__restrict__ lens = reinterpret_cast<const uint32_t *>(rec + seg) + 2;
+            uint32_t sm = 0;
+#pragma unroll
+            for (int i = 0; i < PG_GW_SEG / 256; ++i) { const uint32_t x = tid * (PG_GW_SEG / 256) + i; sm += x < nseg ? lens[4u * x] : 0u; }
+            sm += (uint32_t)__shfl_xor((int)sm, 1, WAVE); sm += (uint32_t)__shfl_xor((int)sm, 2, WAVE); sm += (uint32_t)__shfl_xor((int)sm, 4, WAVE);
+            if ((tid & 7u) == 0u) gsum[tid >> 3] = sm;
+        }
+        __syncthreads();
+        const uint32_t gv = lane < PG_GW_SEG / 64 ? gsum[lane] : 0u, ginc = wave_incl_scan_u32(gv);
+        const uint32_t segtot = (uint32_t)__builtin_amdgcn_readlane((int)ginc, WAVE - 1);
+        // the records and calibrations of a group are requested one group ahead (records: two), so that the two dependent memory rounds
+        // in front of a group's trips (record -> calibration of its read) run beside the previous group's trips
+        auto load_rec = [&](uint32_t g) {
+            const uint32_t gn = g * 64u < nseg ? (nseg - g * 64u < 64u ? nseg - g * 64u : 64u) : 0u;
+            return (uint32_t)lane < gn ? reinterpret_cast<const uint4 *>(rec + seg + g * 64u)[lane] : make_uint4(0, 0, 0, 0);
+        };
+        // lanes 2i and 2i + 1 fetch the two halves of event i's (then event 32 + i's) 32-byte calibration record: one request per record
+        auto load_cal = [&](const uint4 &qq, double2 (&c)[2]) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int evl = hh * 32 + (lane >> 1);
+                const uint32_t rd = (uint32_t)__shfl((int)qq.w, evl, WAVE), ok = (uint32_t)__shfl((int)qq.z, evl, WAVE);
+                c[hh] = make_double2(0.0, 0.0);
+                if (ok) {
+#ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event uses one of eight reads' calibrations
+                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * (rd & 7u) + 2u * (lane & 1));
+#else
+                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1)); // {offset, range / digitisation as the statistics used it}, {median, MAD}
+#endif
+                    else c[hh] = (lane & 1) ? make_double2(0.0, 1.0) : make_double2(B.off[rd], B.range[rd] / B.dig[rd]);
+                }
+            }
+        };
+        uint4 q_cur = load_rec(w), q_nxt = load_rec(w + 4);
+        double2 c_cur[2];
+        load_cal(q_cur, c_cur);
+        for (uint32_t g = w; g * 64u < nseg; g += 4) {
+            const uint64_t e0 = seg + g * 64u, gbase = run + (uint32_t)__shfl((int)(ginc - gv), (int)g, WAVE);
+            const uint32_t n = nseg - g * 64u < 64u ? nseg - g * 64u : 64u;
+            // ---- this group: a record per lane
+            const uint4 q = q_cur;
+            const double2 c0 = c_cur[0], c1 = c_cur[1];
+            q_cur = q_nxt; load_cal(q_cur, c_cur); q_nxt = load_rec(g + 8);
+            const uint32_t len = q.z, nzf = len != 0u;
+            const uint32_t inc = wave_incl_scan_u32(len), off = inc - len, tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+            const uint32_t idx = wave_incl_scan_u32(nzf) - nzf;
+#ifndef PG_PROBE_NO_SOFF
+            if ((uint32_t)lane < n) samp_off[e0 + lane] = gbase + off;
+#endif
+            __builtin_amdgcn_wave_barrier(); // (the previous group's trips have read the stage)
+            if (nzf) {
+                const uint64_t srcbase = ((uint64_t)q.x | ((uint64_t)q.y << 32)) - off;
+                *reinterpret_cast<uint2 *>(&s_ev[idx]) = make_uint2((uint32_t)srcbase, (uint32_t)(srcbase >> 32)); // (.z, .w: the reciprocal of the MAD, below)
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int evl = hh * 32 + (lane >> 1);
+                const uint32_t ok = (uint32_t)__shfl((int)nzf, evl, WAVE), ix = (uint32_t)__shfl((int)idx, evl, WAVE);
+                if (ok) {
+                    const double2 cc = hh ? c1 : c0;
+                    *reinterpret_cast<double2 *>(s_cal + 4u * ix + 2u * (lane & 1)) = cc;
+                    // the reciprocal of the read's MAD, once per event (conv below): the odd lane holds {median, MAD}
+                    if (lane & 1) *reinterpret_cast<double *>(&s_ev[ix].z) = 1.0 / cc.y;
+                }
+            }
+            uint32_t before = 0; // non-empty events that start in front of the tile
+            for (uint32_t tb = 0; tb < tot; tb += PG_GW_SPAN) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < PG_GW_SPAN / 32 / 64; ++i) s_bits[lane + 64 * i].x = 0u;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rel = off - tb; // (wraps for events in front of the tile)
+                if (nzf && rel < PG_GW_SPAN) atomicOr(&s_bits[rel >> 5].x, 1u << (rel & 31u));
+                __builtin_amdgcn_wave_barrier();
+                constexpr int WT = PG_GW_SPAN / 32 / 64;
+                uint32_t wd[WT], pc = 0;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) { wd[i] = s_bits[lane * WT + i].x; pc += (uint32_t)__popc(wd[i]); }
+                const uint32_t ipc = wave_incl_scan_u32(pc);
+                uint32_t pre = before + ipc - pc;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) { s_bits[lane * WT + i].y = pre; pre += (uint32_t)__popc(wd[i]); }
+                before += (uint32_t)__builtin_amdgcn_readlane((int)ipc, WAVE - 1);
+                __builtin_amdgcn_wave_barrier();
+                // ---- the pairs: global output samples 2 * gp, 2 * gp + 1; the tile's first and last pair may hold one sample of a neighbour
+                const uint32_t tn = tot - tb < PG_GW_SPAN ? tot - tb : PG_GW_SPAN;
+                const uint32_t a = (uint32_t)((gbase + tb) & 1ull);
+                const uint32_t npairs = (tn + a + 1u) >> 1;
+                double *__restrict__ out = samples + gbase + tb - a; // 16-byte aligned
+                // (x - median) / MAD of gmove.cpp:774 as the hardware's own division sequence computes it -- q0 = a * y, r = a - b * q0 (exact, FMA),
+                // q = q0 + r * y -- with y = the correctly rounded 1 / MAD computed once per event instead of the refined v_rcp_f64 per sample.
+                // With y correctly rounded and q0 within an ulp this last step is Markstein's: q is the correctly rounded a / b (MAD >= 1, nothing
+                // under- or overflows here). tools/div_check.c: 1.4e10 random and near-tie cases without a difference; every parity test and the
+                // fuzzers compare the doubles bit for bit against the oracle's plain division. -DPG_GATHER_DIV_INSN restores the instruction
+                // sequence (FP64 is half rate here and the division is 2/3 of a sample's arithmetic: 948 -> 8xx us at k = 9).
+                auto conv = [&](int raw, const double4 &c, double y) {
+#ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
+                    return (double)raw;
+#endif
+                    const double pA = ((double)raw + c.x) * c.y;                 // TO_PICOAMPS, poregen.h:30
+                    double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;          // gmove.cpp:756-759
+                    if (scaling) {
+                        const double num = x - c.z;
+#if defined(PG_PROBE_GC_NODIV)
+                        x = num * c.w;
+#elif defined(PG_GATHER_DIV_INSN)
+                        x = num / c.w;
+#else
+                        const double q0 = num * y, r = __builtin_fma(-c.w, q0, num);
+                        x = __builtin_fma(r, y, q0);
+#endif
+                    }
+                    return x;
+                };
+                // A trip's body is branch-free up to its store, so that the compiler requests the LDS reads and the window samples of all
+                // PG_GW_TRIPS trips together (the first form of this loop had five dependent waits per trip and was bound by exactly that
+                // chain at five waves per SIMD): out-of-range lanes work on a clamped position of the tile and drop the result.
+                for (uint32_t j0 = lane; j0 < npairs; j0 += 64 * PG_GW_TRIPS) {
+                    uint32_t qp[PG_GW_TRIPS][2]; bool v[PG_GW_TRIPS][2]; uint2 bw[PG_GW_TRIPS][2];
+#pragma unroll
+                    for (int u = 0; u < PG_GW_TRIPS; ++u) {
+                        const uint32_t j = j0 + u * 64;
+                        const uint32_t p1 = 2u * j + 1u - a, p0 = p1 - 1u; // positions inside the tile (p0 wraps for the first pair when a = 1)
+                        v[u][0] = j < npairs && p0 < tn; v[u][1] = j < npairs && p1 < tn;
+                        qp[u][0] = v[u][0] ? p0 : (v[u][1] ? p1 : 0u);
+                        qp[u][1] = v[u][1] ? p1 : qp[u][0];
+                        bw[u][0] = s_bits[qp[u][0] >> 5]; bw[u][1] = s_bits[qp[u][1] >> 5];
+                    }
+                    uint32_t ev[PG_GW_TRIPS][2]; uint4 ee[PG_GW_TRIPS][2];
+#pragma unroll
+                    for (int u = 0; u < PG_GW_TRIPS; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ev[u][h] = bw[u][h].y + (uint32_t)__popc(bw[u][h].x & ((2u << (qp[u][h] & 31u)) - 1u)) - 1u;
+                            ee[u][h] = s_ev[ev[u][h]];
+                        }
+                    int raw[PG_GW_TRIPS][2];
+#pragma unroll
+                    for (int u = 0; u < PG_GW_TRIPS; ++u)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+#ifdef PG_PROBE_GC_NOREAD
+                            raw[u][h] = (int)(ee[u][h].x + qp[u][h]);
+#else
+                            raw[u][h] = sig[((uint64_t)ee[u][h].x | ((uint64_t)ee[u][h].y << 32)) + tb + qp[u][h]];
+#endif
+                        }
+#pragma unroll
+                    for (int u = 0; u < PG_GW_TRIPS; ++u) {
+                        const uint32_t j = j0 + u * 64;
+                        const double x0 = conv(raw[u][0], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][0]), __hiloint2double((int)ee[u][0].w, (int)ee[u][0].z));
+                        const double x1 = conv(raw[u][1], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][1]), __hiloint2double((int)ee[u][1].w, (int)ee[u][1].z));
+#ifdef PG_PROBE_GC_NOSTORE
+                        if (x0 + x1 == 1.2345e300) out[2u * j] = x0;
+#else
+#ifndef PG_GW_PLAIN_STORE // streaming ("nt") stores: 974 -> 911 us at k = 9 (the calibration table and the records stay in the L2 longer)
+                        typedef double pg_d2 __attribute__((ext_vector_type(2)));
+                        if (v[u][0] && v[u][1]) { pg_d2 xx; xx.x = x0; xx.y = x1; __builtin_nontemporal_store(xx, reinterpret_cast<pg_d2 *>(out + 2u * j)); }
+#else
+                        if (v[u][0] && v[u][1]) *reinterpret_cast<double2 *>(out + 2u * j) = make_double2(x0, x1);
+#endif
+                        else if (v[u][0]) out[2u * j] = x0;
+                        else if (v[u][1]) out[2u * j + 1u] = x1;
+#endif
+                    }
+                }
+            }
+        }
+        run += segtot;
+    }
+}
+
 // the kept events' lengths and reads as arrays of their own (pg_result / pg_device_view; off the step's path)
 __global__ __launch_bounds__(256) void k_unpack_recs(const PgKeptRec *__restrict__ rec, uint64_t n, uint32_t *__restrict__ ev_len, uint32_t *__restrict__ ev_read) {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -759,11 +973,15 @@ hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uin
     PG_LAUNCH(k_partials_scan, dim3(1), dim3(1024), 0, st, part, n_chunks, n_kept_ptr, samp_off, total_out);
     return hipSuccess;
 }
-// lanes: lanes per kept event (4, 8 or 16): any value is correct for any window length; the caller picks by the mean window it expects
+// lanes: 0 = k_gather_wave (the default); else lanes per kept event (4, 8 or 16) of k_gather_chunks: any value is correct for any window length
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
                                    uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes) {
     if (n_kept_cap == 0) return hipSuccess;
     uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
+        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+        return hipSuccess;
+    }
     if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
     else if (lanes <= 8) PG_LAUNCH((k_gather_chunks<8, 3>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
     else PG_LAUNCH((k_gather_chunks<16, 2>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);

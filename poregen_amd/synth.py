@@ -108,9 +108,11 @@ def make_batch(n_reads=1000, read_len=4000, kind="rna004", seed=20251003, indel_
     return b.validate_host()
 
 
-def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, spike_rate=0.005, chunk_reads=5000):
+def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, spike_rate=0.005, chunk_reads=5000, homopolymer_frac=0.0):
     """Vectorised generator for throughput-sized batches (matches only, no indels): same distributions as
-    make_batch but without the per-read Python loop."""
+    make_batch but without the per-read Python loop. homopolymer_frac: that share of the reads carries one 40-base run of a single
+    base (SURVEY 8d cfg 3's "10 % homopolymer-rich reads": a handful of low-complexity k-mers far above sample_limit); 0 draws
+    nothing extra, so the other workloads keep their streams."""
     rng = np.random.default_rng(seed)
     rna = kind == "rna004"
     mean_extra = 5.2 if rna else 1.5
@@ -133,6 +135,12 @@ def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, 
         dw = np.where(last, (read_len - prev)[:, None], dw)
         dw = np.where(valid, dw, 0)
         bases = rng.integers(0, 4, size=(nr, cand))
+        if homopolymer_frac > 0:
+            hp = np.flatnonzero(rng.random(nr) < homopolymer_frac)
+            a = (rng.random(hp.size) * np.maximum(1, nb[hp] - 40)).astype(np.int64)
+            run = rng.integers(0, 4, hp.size)
+            cols = a[:, None] + np.arange(40)[None, :]
+            bases[hp[:, None], np.minimum(cols, cand - 1)] = run[:, None]
         code = np.zeros((nr, cand), np.uint64)
         for t in range(5):
             sh = np.roll(bases, t, axis=1).astype(np.uint64); sh[:, :t] = 0

@@ -56,3 +56,19 @@ def test_slot_text_delimiters():
     assert res.slot_text(0) == "1.00000000;2.50000000,-0.12500000;"
     assert res.slot_text(0, delimit=True, sample_limit=2) == "1.00000000;:2.50000000,-0.12500000;"
     assert res.slot_text(1, delimit=True, sample_limit=2) == ":100.12345679;:"
+
+
+def test_big_host_vectors_ask_for_huge_pages():
+    """pg_hostmem.h: a SampleVec of 4 MB or more is a mapping of its own with MADV_HUGEPAGE (the "hg" VmFlag in /proc/self/smaps);
+    small ones come from the heap. (A typo once compiled the madvise call out: results are identical, only this shows it.)"""
+    import ctypes as C
+    import os
+    h = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "poregen_amd", "_pg_hosttest.so"))
+    h.pgt_samplevec_hugepage.argtypes = [C.c_size_t, C.POINTER(C.c_long)]
+    kb = C.c_long(0)
+    big = h.pgt_samplevec_hugepage(1 << 20, C.byref(kb))   # 8 MB
+    if big < 0:
+        import pytest
+        pytest.skip("/proc/self/smaps not readable")
+    assert big == 1
+    assert h.pgt_samplevec_hugepage(1000, C.byref(kb)) == 0
