@@ -60,7 +60,7 @@ struct ProfEntry { const char *name; hipEvent_t a, b; bool bracket; };
 struct pg_ctx {
     pg_params prm{};
     int device = 0;
-    hipStream_t st = nullptr, st2 = nullptr, own_st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr, own_st = nullptr; // st3: the gather of a two-stream context (created at its first use)
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}; // per statistics slot
     bool slot_used[2] = {false, false};
@@ -75,13 +75,14 @@ struct pg_ctx {
     // per-batch work buffers
     DevBuf m_start, m_len, m_base, m_tix, ev_slot, status, errflag;
     DevBuf sk[2], sv[2], hist, wcnt, totals, dbase, scount;
-    DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals, base_stage, tile_last;
-    DevBuf ev_rec, ev_len, ev_read, read_needed, samp_off, scan_scratch, samples; // ev_len / ev_read: unpacked from the records on demand (ensure_unpacked)
+    DevBuf slot_start, slot_end, acc_cnt, running, keep, keep32, ev_off, plan_totals[2], base_stage, tile_last; // plan_totals, chunk_part: per statistics slot (the gather of batch i may run beside the chain of batch i + 1)
+    DevBuf ev_rec[2], ev_len, ev_read, read_needed, samp_off[2], scan_scratch, samples; // ev_rec, samp_off: per statistics slot, like plan_totals // ev_len / ev_read: unpacked from the records on demand (ensure_unpacked)
     bool unpacked = false;
     uint32_t win_hint = 0; // mean kept window of the last settled batch (samples): picks the gather's lanes per event
     // partitioned ranking (1024 < slots <= 2^20; pg_place.hip)
     bool part_mode = false; uint32_t part_hi = 0, part_lo = 0;
-    DevBuf part_elem, part_lodig, part_rbase, part_tile_region, part_ntiles, part_histB, part_Bp, chunk_part;
+    DevBuf part_elem, part_lodig, part_rbase, part_tile_region, part_ntiles, part_histB, part_Bp, chunk_part[2];
+    bool gather_side = false; int gather_side_slot = 0; bool side_used[2] = {false, false}; // the last chunked gather was queued on the second stream (two-stream mode) and nothing on `st` has waited for it yet
     DevBuf med[2], mad[2], gcal[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
     DevBuf meta, huge_scratch, oor;
@@ -243,14 +244,15 @@ void pg_destroy(pg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
+    if (c->st3) (void)hipStreamSynchronize(c->st3);
     DevBuf *bufs[] = {&c->table_t, &c->table_u, &c->s_sig, &c->s_sig_off, &c->s_dig, &c->s_off, &c->s_range, &c->s_qs, &c->s_ts,
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
-                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals, &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec, &c->ev_len, &c->ev_read, &c->read_needed,
+                      &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals[0], &c->plan_totals[1], &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec[0], &c->ev_rec[1], &c->ev_len, &c->ev_read, &c->read_needed,
                       &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
-                      &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part,
-                      &c->samp_off, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1],
+                      &c->samp_off[0], &c->samp_off[1], &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
@@ -262,6 +264,7 @@ void pg_destroy(pg_ctx *c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     if (c->st2) (void)hipStreamDestroy(c->st2);
+    if (c->st3) (void)hipStreamDestroy(c->st3);
     delete c;
 }
 
@@ -357,7 +360,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     const uint32_t ns = p->n_slots;
     CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
     CTRY(c->acc_cnt.ensure(ns * 8ull)); CTRY(c->running.ensure(ns * 8ull)); CTRY(c->keep.ensure(ns * 8ull)); CTRY(c->tile_last.ensure(ns * 4ull));
-    CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals.ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
+    CTRY(c->ev_off.ensure((ns + 1) * 8ull)); CTRY(c->plan_totals[0].ensure(64)); CTRY(c->plan_totals[1].ensure(64)); CTRY(c->base_stage.ensure(ns * 8ull));
     CTRY(c->job_total.ensure(ns * 8ull)); CTRY(c->job_freq.ensure(ns * 8ull)); // allocated once: callers may cache the pointers
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(32));
     CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut), [24] u32 ticket (k_rank_scan)
@@ -375,6 +378,7 @@ pg_status pg_reset(pg_ctx *c) {
     if (c->prm.flags & PG_FLAG_PROFILE) {
         HIP_TRY(c, hipStreamSynchronize(c->st));
         if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
         prof_drain(c);
     }
     // the running per-slot counts are zeroed by the next batch's init kernel (stream order is enough)
@@ -406,7 +410,7 @@ static pg_status download_last(pg_ctx *c, bool more_coming) {
     HIP_TRY(c, hipMemcpy(h.ev_off.data(), c->ev_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost));
     if (h.n_events) {
         { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
-        HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off.p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off[c->slot].p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
     } else h.samp_off[0] = 0;
@@ -502,7 +506,7 @@ static pg_status check_read_errors(pg_ctx *c) {
         // would the reference have read this line at all? It stops once every k-mer is complete (gmove.cpp:733-735)
         if (c->full_before_batch) return PG_OK; // complete before this batch: none of its reads is looked at
         uint64_t tot[2] = {0, 0};
-        HIP_TRY(c, hipMemcpy(tot, c->plan_totals.p, 16, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(tot, c->plan_totals[c->slot].p, 16, hipMemcpyDeviceToHost));
         // every slot full and nothing kept here: the bases alone (earlier batches / lower ranks) had completed the job
         if (tot[1] == c->prm.n_slots && tot[0] == 0) return PG_OK;
         if (tot[1] == c->prm.n_slots && tot[0] > 0) { // complete inside this batch: at the read of its last kept event
@@ -627,7 +631,7 @@ static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
 static pg_status ensure_unpacked(pg_ctx *c) {
     if (c->unpacked) return PG_OK;
     HIP_TRY(c, c->ev_len.ensure((c->cur_n_kept + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((c->cur_n_kept + 1) * 4));
-    HIP_TRY(c, pg_launch_unpack_recs(c->st, c->ev_rec.as<PgKeptRec>(), c->cur_n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>()));
+    HIP_TRY(c, pg_launch_unpack_recs(c->st, c->ev_rec[c->slot].as<PgKeptRec>(), c->cur_n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>()));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->unpacked = true;
     return PG_OK;
@@ -653,6 +657,10 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     c->batch_is_host = b->location == PG_LOC_HOST;
     c->batch_all_matches = (b->flags & PG_BATCH_ALL_MATCHES) != 0 && !(c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK);
     if (b->location == PG_LOC_HOST) {
+        if (c->gather_side) { // the staging buffers still hold the batch whose gather runs on the second stream
+            HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_gathered[c->gather_side_slot], 0));
+            c->gather_side = false;
+        }
         s = stage_host_batch(c, b);
         if (s != PG_OK) return s;
         PG_TMARK("count: staging copies queued");
@@ -705,7 +713,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         HIP_TRY(c, c->part_elem.ensure((size_t)tcap * PG_SORT_TILE * 16)); HIP_TRY(c, c->part_lodig.ensure((size_t)tcap * PG_SORT_TILE * 2)); HIP_TRY(c, c->part_rbase.ensure((ndig + 2) * 4ull));
         HIP_TRY(c, c->part_tile_region.ensure((tcap + 1) * 4ull)); HIP_TRY(c, c->part_ntiles.ensure(16));
         HIP_TRY(c, c->part_histB.ensure(((size_t)tcap << c->part_lo) * 4)); HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4));
-        HIP_TRY(c, c->chunk_part.ensure(PG_CHUNK_PART_N * 8));
+        HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8));
     } else {
         const uint32_t passes = (c->key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
         ndig = 1u << ((c->key_bits + passes - 1) / passes);
@@ -774,7 +782,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         const bool fuse_plan = c->in_submit;
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
                                     c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
-                                    c->plan_totals.as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
+                                    c->plan_totals[c->slot].as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
                                     O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr));
         prof_end(c, c->st);
     } else if (c->part_mode) {
@@ -783,7 +791,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         fill_part(c, P, Nn);
         if (N) {
             prof_begin(c, "part_tile_scan", c->st);
-            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot, c->chunk_part.as<uint64_t>()));
+            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot, c->chunk_part[c->slot].as<uint64_t>()));
             prof_end(c, c->st);
             prof_begin(c, "k_part_bases", c->st);
             HIP_TRY(c, pg_launch_part_bases(c->st, P, c->B, O));
@@ -883,7 +891,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
                                   base_location == PG_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
         d_base = c->base_stage.as<uint64_t>();
     }
-    uint64_t *totals = c->plan_totals.as<uint64_t>();
+    uint64_t *totals = c->plan_totals[c->slot].as<uint64_t>();
     // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
     // actual counts from device memory, so the batch needs no host round trip
     const uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
@@ -906,21 +914,57 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
-    HIP_TRY(c, c->ev_rec.ensure((ke_cap + 1) * sizeof(PgKeptRec)));
-    HIP_TRY(c, c->samp_off.ensure((ke_cap + 2) * 8));
+    HIP_TRY(c, c->ev_rec[c->slot].ensure((ke_cap + 1) * sizeof(PgKeptRec)));
+    HIP_TRY(c, c->samp_off[c->slot].ensure((ke_cap + 2) * 8));
     c->unpacked = false;
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     PgKeptOut K{};
-    K.rec = c->ev_rec.as<PgKeptRec>();
+    K.rec = c->ev_rec[c->slot].as<PgKeptRec>();
     // the per-read "owns a kept event" flags are only consumed by the lazy statistics: no scattered byte stores otherwise
     K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
     // Many kept events (nearly every accepted event kept: large sample_limit, k = 9): the offset scan happens inside the gather's
     // workgroups (pg_place.hip). Few (the default limit: 10^5 events): the one-launch chained scan + the strided gather of round 2.
     const bool chunked = ke_cap > dense_min() && (win_cap + 1) * 4096 < (1ull << 32);
     bool sums_ready = false;
-    if (chunked) HIP_TRY(c, c->chunk_part.ensure(PG_CHUNK_PART_N * 8)); // (partitioned ranking has it already, zeroed by its scan launch in pg_count)
+    // Two-stream mode, many kept events: the gather of this batch goes to a THIRD stream, behind the batch's statistics (second stream)
+    // and its placing kernel, and the main stream goes on with the next batch's init / events / ranking / placing -- chains of dependent
+    // round trips that leave the memory system idle (VALU 0.2-0.3 busy, 0.15-0.4 of the HBM rate) -- beside it. What the next batch's
+    // chain writes and this gather reads exists per statistics slot (records, sample offsets, kept-event total, chunk sums); the sample
+    // buffer exists once: gathers follow each other on their stream.
+    // Measured (profiles/r04_side_gather.txt): 0-5 % at sample_limit 5000, nothing at k = 9, whatever share of the CUs the gather's stream
+    // is given -- the chain's kernels wait inside occupied wave slots, they do not leave CUs free, and the gather needs its CUs (half of them:
+    // +14 %). So it is opt-in (PGMOVE_GATHER_SIDE=1), and tests/test_gpu_parity.py runs the suite's cases through it once.
+    static const bool gather_side_on = getenv("PGMOVE_GATHER_SIDE") != nullptr;
+    const bool side = chunked && c->stats_in_flight && c->st2 && !c->user_stream && gather_side_on && (c->prm.flags & PG_FLAG_OVERLAP);
+    if (side && !c->st3) { // like the statistics stream: a quarter of every XCD's CUs stays free of it, or the chain's 16-wave workgroups never find room
+        const char *wh = getenv("PGMOVE_GATHER_CU_WITHHELD");
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        const int cus = prop.multiProcessorCount, withheld = wh ? atoi(wh) : cus / 4;
+        bool masked = false;
+        if (withheld > 0 && withheld < cus) {
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int i = 0; i < cus - withheld; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+            masked = hipExtStreamCreateWithCUMask(&c->st3, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) (void)hipGetLastError();
+        }
+        if (!masked) {
+            int prio_low = 0, prio_high = 0;
+            HIP_TRY(c, hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->st3, hipStreamNonBlocking, prio_low));
+        }
+    }
+    if (c->side_used[c->slot]) { // the gather that read this slot's records two batches ago
+        HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_gathered[c->slot], 0));
+        c->side_used[c->slot] = false;
+    }
+    if (!side && c->gather_side) { // this batch's gather runs on the main stream and writes the sample buffer the previous one is still filling
+        HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_gathered[c->gather_side_slot], 0));
+        c->gather_side = false;
+    }
+    if (chunked) HIP_TRY(c, c->chunk_part[c->slot].ensure(PG_CHUNK_PART_N * 8)); // (partitioned ranking has it already, zeroed by its scan launch in pg_count)
     if (direct) {
         PgSortBufs S{};
         fill_sort(c, S, 0);
@@ -933,7 +977,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         fill_part(c, P, N ? N : 1);
         if (N) {
             prof_begin(c, "k_region_place", c->st);
-            HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part.as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
+            HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part[c->slot].as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
             prof_end(c, c->st);
             sums_ready = chunked;
         }
@@ -958,11 +1002,11 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
             c->rare_pending = false;
         }
         prof_begin(c, "len_partials", c->st, true);
-        HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec.as<PgKeptRec>(), c->chunk_part.as<uint64_t>(), c->samp_off.as<uint64_t>(), totals + 2, sums_ready));
+        HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), totals + 2, sums_ready));
         prof_end(c, c->st);
     } else {
         prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
-        HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec.p) + 2, 4, ke_cap, totals, c->samp_off.as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
+        HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec[c->slot].p) + 2, 4, ke_cap, totals, c->samp_off[c->slot].as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
                                           c->rare_pending ? &c->rare : nullptr, totals + 2));
         c->rare_pending = false;
         prof_end(c, c->st);
@@ -970,7 +1014,12 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     if (samp_cap * 8 > c->samples.cap) {
         // grow once to the worst case if that is moderate; otherwise size exactly from the device total (one sync)
-        if (samp_cap * 8 <= (4ull << 30)) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));
+        // (moderate: an eighth of the device's memory -- k = 9 with the default max_dur has a 9 GB worst case for 1.5 GB of samples, and
+        // sizing it exactly costs a host round trip per batch, which is what kept k = 9 batches from overlapping each other)
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_total = 0; }
+        const uint64_t moderate = std::max<uint64_t>(4ull << 30, std::min<uint64_t>(mem_total / 8, mem_free / 2));
+        if (samp_cap * 8 <= moderate) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));
         else {
             uint64_t tot[3] = {0, 0, 0};
             HIP_TRY(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, c->st));
@@ -979,17 +1028,25 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
             gather_cap = tot[0];
         }
     }
+    hipStream_t gst = c->st;
+    if (side) { // behind this batch's statistics (second stream) and behind the placing kernel + chunk sums of the main one
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
+        HIP_TRY(c, hipStreamWaitEvent(c->st3, c->ev_fork, 0));
+        HIP_TRY(c, hipStreamWaitEvent(c->st3, c->ev_join[c->slot], 0));
+        gst = c->st3; c->stats_in_flight = false;
+    }
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
-    prof_begin(c, "k_gather", c->st);
+    prof_begin(c, "k_gather", gst);
     if (chunked)
-        HIP_TRY(c, pg_launch_gather_chunks(c->st, c->B, ke_cap, totals, c->ev_rec.as<PgKeptRec>(), c->chunk_part.as<uint64_t>(), c->samp_off.as<uint64_t>(), c->prm.scaling,
+        HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling,
                                            c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c)));
     else
-        HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec.as<PgKeptRec>(),
-                     c->samp_off.as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
+        HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(),
+                     c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr));
-    prof_end(c, c->st);
-    HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], c->st));
+    prof_end(c, gst);
+    HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], gst));
+    if (side) { c->gather_side = true; c->gather_side_slot = c->slot; c->side_used[c->slot] = true; }
     PG_TMARK("collect: buffers + kernels queued");
     if (timing_on()) { HIP_TRY(c, hipStreamSynchronize(c->st)); PG_TMARK("collect: kernels done (sync)"); }
     c->slot_used[c->slot] = true;
@@ -1002,13 +1059,14 @@ static pg_status settle_batch(pg_ctx *c) {
     if (!c->have_batch_result || c->totals_known) return PG_OK;
     HIP_TRY(c, hipStreamSynchronize(c->st));
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     pg_status s = check_read_errors(c);
     if (s != PG_OK) { c->have_batch_result = false; c->downloaded = true; return s; }
     uint64_t tot[2] = {0, 0};
-    HIP_TRY(c, hipMemcpy(tot, c->plan_totals.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(tot, c->plan_totals[c->slot].p, 16, hipMemcpyDeviceToHost));
     c->cur_n_kept = tot[0]; c->full_slots = tot[1];
     uint64_t n_samples = 0;
-    HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off.as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off[c->slot].as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
     c->cur_n_samples = n_samples;
     if (tot[0]) c->win_hint = (uint32_t)((n_samples + tot[0] - 1) / tot[0]);
     c->totals_known = true;
@@ -1037,6 +1095,7 @@ pg_status pg_sync(pg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     return settle_batch(c);
 }
 
@@ -1045,6 +1104,7 @@ pg_status pg_set_stream(pg_ctx *c, void *hip_stream) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
     c->user_stream = hip_stream != nullptr;
     return PG_OK;
@@ -1073,7 +1133,7 @@ int32_t pg_poll(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     if (!c->have_batch_result || c->totals_known) return 1;
     if (hipSetDevice(c->device) != hipSuccess) return PG_ERR_HIP;
-    if (hipStreamQuery(c->st) != hipSuccess || (c->st2 && hipStreamQuery(c->st2) != hipSuccess)) { (void)hipGetLastError(); return 0; } // hipErrorNotReady
+    if (hipStreamQuery(c->st) != hipSuccess || (c->st2 && hipStreamQuery(c->st2) != hipSuccess) || (c->st3 && hipStreamQuery(c->st3) != hipSuccess)) { (void)hipGetLastError(); return 0; } // hipErrorNotReady
     const pg_status s = settle_batch(c);
     return s == PG_OK ? 1 : s;
 }
@@ -1087,7 +1147,7 @@ pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
     v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
     v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
-    v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off.as<uint64_t>(); v->d_samples = c->samples.as<double>();
+    v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off[c->slot].as<uint64_t>(); v->d_samples = c->samples.as<double>();
     v->d_med = c->prm.scaling == 1 ? c->med[c->slot].as<double>() : nullptr; v->d_mad = c->prm.scaling == 1 ? c->mad[c->slot].as<double>() : nullptr;
     return PG_OK;
 }
@@ -1307,7 +1367,7 @@ pg_status pg_text(pg_ctx *c, pg_text_result *out) {
     const uint32_t ns = c->prm.n_slots;
     const uint64_t ne = R.n_events;
     const uint64_t *d_samp_off, *d_ev_off;
-    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == ne) { d_samp_off = c->samp_off.as<uint64_t>(); d_ev_off = c->ev_off.as<uint64_t>(); } // still there
+    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == ne) { d_samp_off = c->samp_off[c->slot].as<uint64_t>(); d_ev_off = c->ev_off.as<uint64_t>(); } // still there
     else {
         HIP_TRY(c, c->tx_samp_off.ensure((ne + 1) * 8ull)); HIP_TRY(c, c->tx_ev_off.ensure((ns + 1) * 8ull));
         HIP_TRY(c, hipMemcpyAsync(c->tx_samp_off.p, R.samp_off, (ne + 1) * 8ull, hipMemcpyHostToDevice, c->st));
@@ -1369,7 +1429,7 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
     if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
         // one batch: its kept events are still on the device, in the same order
         { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
-        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off.as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
+        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off[c->slot].as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
     } else { // several batches were merged on the host (slot-major): hand the merged arrays back
         HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
         HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4)); HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
@@ -1425,6 +1485,7 @@ pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     prof_drain(c);
     uint32_t n = 0;
     for (auto &name : c->prof_names) {
@@ -1439,6 +1500,7 @@ pg_status pg_kernel_stats_reset(pg_ctx *c) {
     if (!c) return PG_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->st));
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
+    if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     prof_drain(c);
     c->prof_acc.clear(); c->prof_names.clear();
     return PG_OK;
