@@ -100,6 +100,7 @@ struct pg_ctx {
     uint32_t wide_blocks = 0;    // wide-list length of the last settled batch (sizes the next rare launch)
     bool plan_in_init = false;   // this batch's statistics records were written by its k_batch_init
     bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
+    DevBuf cancel_flag; bool cancel_pending = false; uint64_t stats_cancelled = 0; // pgi_stats_gathered: the device's own rank-level early-out
 
     PgDevBatch B{};       // current batch (device view)
     bool have_count = false, have_batch_result = false, downloaded = true;
@@ -252,7 +253,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals[0], &c->plan_totals[1], &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec[0], &c->ev_rec[1], &c->ev_len, &c->ev_read, &c->read_needed,
                       &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
                       &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1],
-                      &c->samp_off[0], &c->samp_off[1], &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
@@ -859,6 +860,25 @@ pg_status pg_stats(pg_ctx *c) {
     return launch_stats(c, c->st, nullptr, false, c->plan_in_init, true);
 }
 
+// pg_job.hip, RCCL exchange: pg_stats for a rank whose base is only known on the device. all_counts / world / rank as pg_collect_gathered
+// takes them, the table complete on the context's stream. If every k-mer is complete below this rank (gmove.cpp:733-735: the reference
+// would not have read this shard), the statistics launches that are queued here touch no sample: the decision is a flag on the device.
+pg_status pgi_stats_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
+    if (!c) return PG_ERR_INVALID_ARG;
+    if (!c->have_count) return fail(c, PG_ERR_STATE, "pgi_stats_gathered without a preceding pg_count");
+    if (!all_counts || rank >= world) return fail(c, PG_ERR_INVALID_ARG, "pgi_stats_gathered: all_counts / world / rank");
+    if (!c->stats_deferred) return PG_OK;
+    if (rank == 0 || c->prm.sample_limit == 0 || !c->plan_in_init) return pg_stats(c); // nothing below this rank / nothing is ever complete / no records yet
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->stats_deferred = false;
+    { pg_status se = ensure_stats_buffers(c); if (se != PG_OK) return se; }
+    HIP_TRY(c, c->cancel_flag.ensure(16));
+    HIP_TRY(c, pg_launch_stats_cancel_if_full(c->st, all_counts, rank, c->prm.n_slots, c->prm.sample_limit, c->cancel_flag.as<uint32_t>(),
+                                              c->read_plan[c->slot].p, c->B.n_reads));
+    c->cancel_pending = true;
+    return launch_stats(c, c->st, nullptr, false, true, true);
+}
+
 pg_status pg_collect(pg_ctx *c, const uint64_t *base, int32_t base_location) { return collect_impl(c, base, base_location, nullptr, 0, 0); }
 
 pg_status pg_collect_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank) {
@@ -936,7 +956,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     // Measured (profiles/r04_side_gather.txt): 0-5 % at sample_limit 5000, nothing at k = 9, whatever share of the CUs the gather's stream
     // is given -- the chain's kernels wait inside occupied wave slots, they do not leave CUs free, and the gather needs its CUs (half of them:
     // +14 %). So it is opt-in (PGMOVE_GATHER_SIDE=1), and tests/test_gpu_parity.py runs the suite's cases through it once.
-    static const bool gather_side_on = getenv("PGMOVE_GATHER_SIDE") != nullptr;
+    const bool gather_side_on = getenv("PGMOVE_GATHER_SIDE") != nullptr;
     const bool side = chunked && c->stats_in_flight && c->st2 && !c->user_stream && gather_side_on && (c->prm.flags & PG_FLAG_OVERLAP);
     if (side && !c->st3) { // like the statistics stream: a quarter of every XCD's CUs stays free of it, or the chain's 16-wave workgroups never find room
         const char *wh = getenv("PGMOVE_GATHER_CU_WITHHELD");
@@ -1068,6 +1088,12 @@ static pg_status settle_batch(pg_ctx *c) {
     uint64_t n_samples = 0;
     HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off[c->slot].as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
     c->cur_n_samples = n_samples;
+    if (c->cancel_pending) {
+        uint32_t fl[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(fl, c->cancel_flag.p, 8, hipMemcpyDeviceToHost));
+        if (fl[1]) c->stats_cancelled++;
+        c->cancel_pending = false;
+    }
     if (tot[0]) c->win_hint = (uint32_t)((n_samples + tot[0] - 1) / tot[0]);
     c->totals_known = true;
     return PG_OK;
@@ -1492,6 +1518,10 @@ pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t
         if (out && n < cap) { auto &a = c->prof_acc[name]; out[n].name = name.c_str(); out[n].launches = a.first; out[n].total_ms = a.second; }
         n++;
     }
+    if (c->stats_cancelled) { // batches whose statistics the device's rank-level early-out cancelled (pgi_stats_gathered): launched, but no sample read
+        if (out && n < cap) { out[n].name = "stats_cancelled_on_device"; out[n].launches = c->stats_cancelled; out[n].total_ms = 0.0; }
+        n++;
+    }
     *n_out = n;
     return PG_OK;
 }
@@ -1502,7 +1532,7 @@ pg_status pg_kernel_stats_reset(pg_ctx *c) {
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     prof_drain(c);
-    c->prof_acc.clear(); c->prof_names.clear();
+    c->prof_acc.clear(); c->prof_names.clear(); c->stats_cancelled = 0;
     return PG_OK;
 }
 

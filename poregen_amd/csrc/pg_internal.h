@@ -287,6 +287,9 @@ struct PgRareArgs {
 hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t stride, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
                                   const PgRareArgs *rare, uint64_t *total_out);
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
+// flag[0] = some slot still open below this rank (sum of rows_below rows of all_counts < limit), flag[1] = statistics cancelled; if none
+// is open, the reads' statistics records (plan_buf) are set to "skip"
+hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_counts, uint32_t rows_below, uint32_t n_slots, uint64_t limit, uint32_t *flag, void *plan_buf, uint32_t n_reads);
 // plan_buf: one PgStatRec (64 bytes) per read: everything k_read_stats needs of a read, in one scalar load
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0

@@ -32,6 +32,7 @@
 extern "C" void *pgi_stream(pg_ctx *c); // pg_api.hip: the stream the context's chain currently runs on
 extern "C" const double *pgi_fin_dev(pg_ctx *c); // pg_api.hip: where pg_finish_deferred left the context's kept samples on its device (or null)
 extern "C" pg_status pgi_skip_stats(pg_ctx *c); // pg_api.hip: a deferred-statistics batch that will keep nothing needs none
+extern "C" pg_status pgi_stats_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank); // pg_api.hip: pg_stats, cancelled on the device when the rows below `rank` complete every k-mer
 
 static thread_local std::string g_job_create_error;
 
@@ -305,11 +306,15 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
     s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
         pg_ctx *c = j->ctx[g];
         hipStream_t st = (hipStream_t)pgi_stream(c);
-        // rank-level early-out: complete before this batch, or -- the host exchange has the table at hand -- complete below this rank
-        // (the rows of the lower ranks fill every k-mer): this rank keeps nothing, so it needs no statistics. (With RCCL the table
-        // stays on the devices and the statistics are queued in front of the wait for it: there the rule of the previous batch alone.)
+        // rank-level early-out (gmove.cpp:733-735): complete before this batch, or complete below this rank INSIDE the batch (the rows of
+        // the lower ranks fill every k-mer): this rank keeps nothing, so it needs no statistics. The host exchange has the table at hand
+        // and decides here; with RCCL the table stays on the devices, and a rank that has rows below it queues its statistics BEHIND the
+        // wait for the table, cancelled there if the table says so (pgi_stats_gathered). Rank 0 (nothing below it but the earlier
+        // batches, which `done_before` covers) keeps its statistics in front of the wait, where they hide the collective.
+        // PGMOVE_JOB_DEVICE_RULE=1: the host exchange takes the device's rule too (tests on one GPU).
+        const bool dev_rule = !done_before && g > 0 && j->sample_limit > 0 && (j->use_rccl || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr);
         bool skip = done_before;
-        if (!skip && !j->use_rccl && j->sample_limit > 0) {
+        if (!skip && !dev_rule && !j->use_rccl && j->sample_limit > 0) {
             skip = true;
             for (uint32_t sl = 0; sl < ns && skip; ++sl) {
                 uint64_t base = j->host_row0[sl];
@@ -317,13 +322,15 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
                 if (base < j->sample_limit) skip = false;
             }
         }
-        pg_status ps = skip ? pgi_skip_stats(c) : pg_stats(c);
+        pg_status ps = PG_OK;
+        if (!dev_rule) ps = skip ? pgi_skip_stats(c) : pg_stats(c);
         if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
         hipError_t e = hipSetDevice(j->devices[g]);
         if (j->use_rccl) { if (e == hipSuccess) e = hipStreamWaitEvent(st, j->ev_gathered[g], 0); }
         else if (e == hipSuccess) // the table assembled on the host in phase 2
             e = hipMemcpyAsync(j->gbuf[g] + ns, j->host_rows.data(), (size_t)n * ns * sizeof(uint64_t), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        if (dev_rule) { ps = pgi_stats_gathered(c, j->gbuf[g], n + 1, g + 1); if (ps != PG_OK) { msg = pg_last_error(c); return ps; } }
         ps = pg_collect_gathered(c, j->gbuf[g], n + 1, g + 1);
         if (ps != PG_OK) { msg = pg_last_error(c); return ps; }
         const uint64_t *d_total = nullptr;

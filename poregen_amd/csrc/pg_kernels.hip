@@ -2601,6 +2601,34 @@ hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t s
     return hipSuccess;
 }
 
+// ---- rank-level early-out decided ON THE DEVICE (pg_job's RCCL exchange: the table of accepted events never comes to the host) ----------
+// Nothing behind the completing read is touched by the reference (gmove.cpp:733-735). all_counts: uint64[rows][n_slots], rows_below of
+// them precede this rank in PAF order. flag[0] ends up non-zero iff some k-mer is still open below this rank (the caller zeroes it).
+__global__ __launch_bounds__(256) void k_base_open(const uint64_t *__restrict__ all_counts, uint32_t rows_below, uint32_t n_slots, uint64_t limit, uint32_t *__restrict__ flag) {
+    bool open = false;
+    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < n_slots; s += gridDim.x * 256) {
+        uint64_t base = 0;
+        for (uint32_t h = 0; h < rows_below; ++h) base += all_counts[(uint64_t)h * n_slots + s];
+        open |= base < limit;
+    }
+    if (__ballot(open) && lane_id() == 0) atomicOr(flag, 1u);
+}
+// ... and acted upon: every k-mer is complete below this rank, so its reads' statistics records say "skip" and the statistics launches
+// that follow on the stream return at once, read by read (k_read_stats reads the record first: no sample is touched)
+__global__ __launch_bounds__(256) void k_stats_cancel(uint32_t *__restrict__ flag, PgStatRec *__restrict__ rec, uint32_t n_reads) {
+    if (flag[0] != 0) return;
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads && rec[r].mode == PG_STAT_RUN) rec[r].mode = PG_STAT_SKIP;
+    if (r == 0) flag[1] = 1u; // told to the host when the batch settles (pg_kernel_stats: "stats_cancelled_on_device")
+}
+hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_counts, uint32_t rows_below, uint32_t n_slots, uint64_t limit, uint32_t *flag, void *plan_buf, uint32_t n_reads) {
+    PG_HIP(hipMemsetAsync(flag, 0, 8, st));
+    const uint32_t nb = (n_slots + 255) / 256;
+    PG_LAUNCH(k_base_open, dim3(nb < 512u ? nb : 512u), dim3(256), 0, st, all_counts, rows_below, n_slots, limit, flag);
+    if (n_reads) PG_LAUNCH(k_stats_cancel, dim3((n_reads + 255) / 256), dim3(256), 0, st, flag, reinterpret_cast<PgStatRec *>(plan_buf), n_reads);
+    return hipSuccess;
+}
+
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
     if (A.B.n_reads == 0) return hipSuccess;
     // the workers stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)

@@ -119,6 +119,34 @@ def test_rank_level_early_out_skips_statistics():
     eng.close(); job.close()
 
 
+def test_rank_level_early_out_decided_on_the_device(monkeypatch):
+    """The same rule where the table of accepted events never comes to the host (the RCCL exchange; here the host exchange is told to take
+    the device's rule, PGMOVE_JOB_DEVICE_RULE=1, because an RCCL communicator wants distinct devices): a shard with rows below it queues
+    its statistics behind the table, and a flag computed there cancels them INSIDE the batch that completes the job -- the launches happen,
+    every read's record says "skip", no sample is read (gmove.cpp:733-735). Same output as one context."""
+    monkeypatch.setenv("PGMOVE_JOB_DEVICE_RULE", "1")
+    b = synth.make_batch(600, kind="rna004", seed=605)
+    p = dict(kmer_size=3, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=40)
+    kmers = generate_kmers(3, rna=True)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    job = GmoveJob(GmoveParams(kmers=kmers, profile=True, **p), [0, 0, 0, 0])
+    first, second = b.slice_reads(0, 400), b.slice_reads(400, 600)
+    eng.submit(first); job.submit(first); job.sync()
+    assert job.all_slots_full()
+    ks = [job.kernel_stats(g) for g in range(4)]
+    cancelled = [k.get("stats_cancelled_on_device", (0, 0.0))[0] for k in ks]
+    assert cancelled[0] == 0 and cancelled[2] == 1 and cancelled[3] == 1, cancelled   # 100 reads fill 64 k-mers x 40 events: shards 2, 3 lie behind them
+    t_run, t_cancelled = ks[0]["k_read_stats"][1], ks[3]["k_read_stats"][1]
+    assert t_cancelled < t_run, (t_run, t_cancelled)    # a cancelled launch reads 64-byte records, not 100 reads' signal
+    eng.submit(second); job.submit(second); job.sync()  # complete before the batch: the host knows, nothing is queued at all
+    assert [job.kernel_stats(g).get("k_read_stats", (0, 0.0))[0] for g in range(4)] == [k["k_read_stats"][0] for k in ks]
+    re, rj = eng.finish(), job.finish()
+    for name in ("counts", "ev_off", "ev_len", "ev_read", "samp_off", "read_skipped"):
+        assert np.array_equal(getattr(re, name), getattr(rj, name)), name
+    assert np.array_equal(re.samples.view(np.uint64), rj.samples.view(np.uint64))
+    eng.close(); job.close()
+
+
 def test_job_rccl_large_limit_many_batches():
     """The RCCL path (one-rank communicator) with the running total carried in row 0 of the receive buffer over five batches."""
     b = synth.make_batch_fast(2500, kind="rna004", seed=603)

@@ -249,6 +249,34 @@ def test_overlap_mode_same_bits(mode):
         assert_result_equals_oracle(res, o, check_text_slots=2, sample_limit=60)
 
 
+@pytest.mark.parametrize("k", [5, 9])
+def test_gather_beside_the_next_batch_same_bits(k, monkeypatch):
+    """PGMOVE_GATHER_SIDE=1: the chunked gather of a batch on a third stream while the main stream already runs the next batch's chain
+    (records, sample offsets, totals and chunk sums per statistics slot). Different device-resident batches back to back without a
+    synchronisation in between, as bench.py's steps are: each job's result equals its own oracle run, whatever was in flight beside it."""
+    import torch
+    monkeypatch.setenv("PGMOVE_GATHER_SIDE", "1")
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    kind = "rna004" if k == 5 else "dna_r10"
+    p = dict(kmer_size=k, rna=k == 5, scaling=1, sample_limit=40 if k == 5 else 3)
+    if k == 5:
+        p.update(min_dur=20, max_dur=40)
+    kmers = generate_kmers(k, rna=k == 5)
+    dev = torch.device("cuda:0")
+    hosts = [synth.make_batch(n, kind=kind, seed=77 + i) for i, n in enumerate((260, 90, 200))]
+    shards = [h.to_device(dev) for h in hosts]
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    for last in (2, 0, 1):
+        for i in (0, 1, 2, 0, 1, 2):       # a train of jobs, none of them waited for
+            eng.reset(); eng.submit(shards[i])
+        eng.reset(); eng.submit(shards[last])
+        res = eng.finish()
+        o = oracle_for(kmers, **p)
+        o.run_batch(hosts[last])
+        assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
+    eng.close()
+
+
 def test_split_walk_same_bits():
     """PG_FLAG_DEBUG_SPLIT_WALK: the ss walk and the event filter as two launches (k_walk<false> + k_events) instead of the
     fused kernel every other test runs. Indels, pick margin, move offset, DNA and RNA orientation, skipped reads."""
