@@ -72,7 +72,7 @@ void print_help(FILE *fp, const Opt &o) { // src/gmove.cpp:80-104
     fprintf(fp, "   --verbose INT              verbosity level [%d]\n", 3);
     fprintf(fp, "   --version                  print version\n");
     fprintf(fp, "\nMI355X implementation options:\n");
-    fprintf(fp, "   --batch_reads INT          reads per GPU batch [20000]\n");
+    fprintf(fp, "   --batch_reads INT          reads per batch [20000 per device: a batch is cut into one shard per device]\n");
     fprintf(fp, "   --device INT               HIP device [0]\n");
     fprintf(fp, "   --devices LIST             several GPUs of this node, e.g. 0,1,2,3,4,5,6,7: every batch is cut into contiguous shards,\n");
     fprintf(fp, "                              one per listed device, with one RCCL all-gather of per-k-mer counts per batch (pg_job_*);\n");
@@ -146,7 +146,7 @@ int gmove_main(int argc, char **argv) {
     int longindex = 0, c, signal_scale = 0;
     const char *input_kmer_file = nullptr, *input_fastq_file = nullptr;
     FILE *fp_help = stderr;
-    uint32_t batch_reads = 20000; int device = 0; bool lazy = false;
+    uint32_t batch_reads = 20000; bool batch_reads_set = false; int device = 0; bool lazy = false;
     std::vector<int32_t> devices; uint32_t exchange = PG_JOB_EXCHANGE_AUTO;
     const char *raw_model_path = nullptr, *dwell_model_path = nullptr, *stdv_limit = "3.1";
     optind = 1;
@@ -172,7 +172,7 @@ int gmove_main(int argc, char **argv) {
         else if (c == 0 && longindex == 15) opt.pa_max = atof(optarg);
         else if (c == 0 && longindex == 16) opt.kmer_pick_margin = atoi(optarg);
         else if (c == 0 && longindex == 17) opt.flag_rna = 1;
-        else if (c == 0 && longindex == 22) batch_reads = (uint32_t)std::max(1, atoi(optarg));
+        else if (c == 0 && longindex == 22) { batch_reads = (uint32_t)std::max(1, atoi(optarg)); batch_reads_set = true; }
         else if (c == 0 && longindex == 23) device = atoi(optarg);
         else if (c == 0 && longindex == 24) lazy = true;
         else if (c == 0 && longindex == 25) raw_model_path = optarg;
@@ -196,6 +196,12 @@ int gmove_main(int argc, char **argv) {
         return fp_help == stdout ? EXIT_SUCCESS : EXIT_FAILURE;
     }
     const char *slow5file = argv[optind], *move_table = argv[optind + 1], *output_dir = argv[optind + 2];
+    // --devices cuts every batch into one contiguous shard per device: the default batch grows with the device count, so that a shard
+    // stays at the 20 000 reads (160 MB of signal) the one-device pipeline is tuned for instead of shrinking to a latency-bound sliver
+    const size_t n_shards = devices.empty() ? 1 : devices.size();
+    if (!batch_reads_set) batch_reads = (uint32_t)std::min<uint64_t>(20000ull * n_shards, 0x7fffffffull);
+    const size_t batch_samples_cap = ((size_t)1 << 29) * n_shards; // and so does the byte budget of a batch (1 GB of samples per device)
+    if (getenv("POREGEN_BATCH_PROBE")) fprintf(stderr, "[batch probe] batch_reads %u (%zu device%s x %u)\n", batch_reads, n_shards, n_shards == 1 ? "" : "s", (unsigned)(batch_reads / n_shards));
     // the HIP runtime takes 0.1-0.2 s to come up: it starts NOW, on a thread of its own, next to the directory set-up, the k-mer list,
     // the file indices and the parsing of the first batch; the context is created behind it
     const int first_device = devices.empty() ? device : devices[0];
@@ -499,7 +505,7 @@ int gmove_main(int argc, char **argv) {
                 return k;
             };
             unsigned n_runs = kept_runs();
-            if (placing && tot > ((uint64_t)1 << 29)) { placing = false; on_threads(pass1); n_runs = kept_runs(); } // several device batches: the runs keep their own samples
+            if (placing && tot > batch_samples_cap) { placing = false; on_threads(pass1); n_runs = kept_runs(); } // several device batches: the runs keep their own samples
             if (placing) { // pass 2: every run's samples to their place, then the rest of its lines
                 hbs[cur].sig.resize(tot);
                 std::vector<uint64_t> base(nt + 1, 0);
@@ -523,7 +529,7 @@ int gmove_main(int argc, char **argv) {
             if (job_complete()) { if (status == EXIT_SUCCESS) stop = true; break; }
             unsigned t0 = 0;
             while (t0 < n_runs && !stop && status == EXIT_SUCCESS) {
-                const unsigned t1 = tot > ((uint64_t)1 << 29) ? t0 + 1 : n_runs; // too big for one batch: run by run
+                const unsigned t1 = tot > batch_samples_cap ? t0 + 1 : n_runs; // too big for one batch: run by run
                 uint64_t ns = 0, nq = 0, no = 0, nb = 0;
                 for (unsigned t = t0; t < t1; t++) { ns += runs[t].b.sig_off.back(); nq += runs[t].b.seq_off.back(); no += runs[t].b.op_off.back(); nb += runs[t].b.n(); }
                 const clk::time_point tc0 = clk::now();
@@ -598,7 +604,7 @@ int gmove_main(int argc, char **argv) {
         hbs[cur].seq.insert(hbs[cur].seq.end(), seq.begin(), seq.end()); hbs[cur].seq_off.push_back(hbs[cur].seq.size());
         hbs[cur].op_off.push_back(hbs[cur].op_n.size());
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
-        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= (size_t)1 << 29) { if (!flush()) { status = EXIT_FAILURE; break; } }
+        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= batch_samples_cap) { if (!flush()) { status = EXIT_FAILURE; break; } }
     }
     if (status == EXIT_FAILURE && !is_paf && whole_list && dev.ok()) {
         // a record the reference may never have read: it stops once every k-mer of the whole list is complete (gmove.cpp:733-735), and the

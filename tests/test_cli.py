@@ -318,6 +318,21 @@ def test_sample_limit_zero_reads_every_line(tmp_path):
     assert oracle_cli(args + [tmp_path / "cpu2"]).returncode != 0
 
 
+def test_devices_scale_the_default_batch(tmp_path):
+    """`--devices` cuts a batch into one shard per device: the default batch is 20 000 reads PER DEVICE (a shard stays as large as the
+    one-device batch), an explicit --batch_reads is taken as given. (Option handling only: the run then fails on the missing files.)"""
+    env = dict(os.environ, POREGEN_BATCH_PROBE="1")
+    def probe(extra):
+        r = subprocess.run([BIN, "gmove", "nope.blow5", "nope.paf", str(tmp_path / "o"), "--fastq", "nope.fastq"] + extra, capture_output=True, text=True, env=env)
+        line = [x for x in r.stderr.splitlines() if x.startswith("[batch probe]")]
+        assert line, r.stderr
+        return line[0]
+    assert "batch_reads 20000 (1 device x 20000)" in probe([])
+    assert "batch_reads 160000 (8 devices x 20000)" in probe(["--devices", "0,1,2,3,4,5,6,7"])
+    assert "batch_reads 60000 (3 devices x 20000)" in probe(["--devices", "0,0,0"])
+    assert "batch_reads 100 (3 devices x 33)" in probe(["--devices", "0,0,0", "--batch_reads", "100"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("devopts", [["--devices", "0,0,0"], ["--devices", "0", "--exchange", "rccl"]], ids=["three_shards_host_exchange", "rccl_one_rank"])
 def test_devices_option_equals_oracle(tmp_path, devopts):

@@ -97,3 +97,65 @@ def test_two_rank_gloo_equals_sequential_oracle(tmp_path):
     assert np.array_equal(g["counts"].astype(np.uint64), o.counts())
     assert np.array_equal(g["ev_len"], np.concatenate([o.event_lens(s) for s in range(len(kmers))]).astype(np.int32))
     assert np.array_equal(g["samples"].view(np.uint64), np.concatenate([o.values(s) for s in range(len(kmers))]).view(np.uint64))
+
+
+# ---- the same with the REAL engine: two gloo ranks share cuda:0 (what tools/rehearse_two_ranks.sh did by hand in round 3) -------------
+def _gpu_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from poregen_amd import dist as pgdist
+    from poregen_amd import synth
+    from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
+    tdist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    b = synth.make_batch(240, kind="rna004", seed=23, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=9)
+    kmers = generate_kmers(5, rna=True)
+    lo, hi = pgdist.shard_bounds(b.n_reads, world, rank)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=True, **p))  # the statistics placed by sharded_step, as bench.py --gpus N does
+    shard = b.slice_reads(lo, hi).to_device(dev)
+    total = pgdist.sharded_step(eng, shard)
+    eng.sync()
+    freq = pgdist.merged_freq(total, p["sample_limit"], engine=eng).cpu().numpy()
+    counts, ev_len, samples = eng.kept_tensors(device=dev)
+    sizes = torch.zeros(len(kmers), dtype=torch.int64)
+    starts = torch.cumsum(counts, 0) - counts
+    cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(ev_len.to(torch.int64), 0)])
+    sizes = (cs[(starts + counts)] - cs[starts]).cpu().numpy()          # kept samples per slot of this rank
+    np.savez(os.path.join(out_dir, f"grank{rank}.npz"), freq=freq, sizes=sizes, flat=samples.cpu().numpy())
+    # the single-writer end on CPU tensors (gloo has no device point-to-point)
+    g = pgdist.gather_kept(counts.cpu(), ev_len.cpu(), samples.cpu())
+    assert (g is None) == (rank != 0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "ggathered.npz"), counts=g[0].numpy(), ev_len=g[1].numpy(), samples=g[2].numpy())
+    tdist.barrier()
+    eng.close()
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_gloo_real_engine(tmp_path):
+    """Two PROCESSES, one rank each, both on cuda:0, through dist.sharded_step with the real GmoveEngine (libpgmove): pg_count ->
+    exchange of u64[n_slots] (gloo) -> pg_stats -> pg_collect with the lower rank's base. The rank-ordered concatenation of the ranks'
+    streams equals ONE sequential oracle run bit for bit, and so does dist.gather_kept on the writing rank."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from helpers import oracle_for
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    b = synth.make_batch(240, kind="rna004", seed=23, indel_rate=0.02)
+    p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=9)
+    kmers = generate_kmers(5, rna=True)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    r = [np.load(tmp_path / f"grank{i}.npz") for i in range(2)]
+    assert np.array_equal(r[0]["freq"], r[1]["freq"])
+    assert np.array_equal(r[0]["freq"].astype(np.uint64), o.counts())
+    offs = [np.concatenate([[0], np.cumsum(x["sizes"])]) for x in r]
+    for sl in range(len(kmers)):
+        cat = np.concatenate([r[i]["flat"][offs[i][sl]:offs[i][sl + 1]] for i in range(2)])
+        assert np.array_equal(cat.view(np.uint64), o.values(sl).view(np.uint64)), sl
+    g = np.load(tmp_path / "ggathered.npz")
+    assert np.array_equal(g["counts"].astype(np.uint64), o.counts())
+    assert np.array_equal(g["ev_len"], np.concatenate([o.event_lens(sl) for sl in range(len(kmers))]).astype(np.int32))
+    assert np.array_equal(g["samples"].view(np.uint64), np.concatenate([o.values(sl) for sl in range(len(kmers))]).view(np.uint64))
