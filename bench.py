@@ -469,7 +469,15 @@ def job_layer(args, world, rank, dist):
     never seen more than one GPU before the driver's first multi-GPU run, and a fault or a hang in it must not take the headline line
     with it. The job layer stages its batch from host memory (rank 0's shard, cut `world` ways): a PCIe-inclusive figure."""
     import subprocess
+    import torch
     info = None
+    # The other ranks wait on the HOST (a gloo group: no RCCL kernel spins on their GPUs while the child times its steps on the same
+    # devices), with their GPU work drained first.
+    torch.cuda.synchronize()
+    try:
+        cpu_group = dist.new_group(backend="gloo")
+    except Exception:
+        cpu_group = None
     if rank == 0:
         cmd = [sys.executable, os.path.abspath(__file__), "--job-layer-child", str(world), "--reads", str(args.reads), "--read-len", str(args.read_len),
                "--kind", args.kind, "--k", str(args.k), "--sample-limit", str(args.sample_limit)]
@@ -484,7 +492,12 @@ def job_layer(args, world, rank, dist):
             info = {"error": "the pg_job child did not finish within 240 s (killed)"}
         except Exception as ex:  # the headline must not die with the extra
             info = {"error": repr(ex)[:300]}
-    dist.barrier()
+        if isinstance(info, dict):
+            info["other_ranks_during_the_child"] = "idle on a host-side (gloo) barrier, GPU work drained" if cpu_group is not None else "inside an RCCL barrier"
+    if cpu_group is not None:
+        dist.barrier(group=cpu_group)
+    else:
+        dist.barrier()
     return info
 
 

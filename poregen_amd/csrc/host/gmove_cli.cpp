@@ -340,6 +340,7 @@ int gmove_main(int argc, char **argv) {
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     double t_device = 0, t_finish = 0, t_dump = 0, t_lines = 0, t_decode = 0, t_concat = 0;
     const clk::time_point t_loop0 = clk::now();
+    bool flush_failed = false; // the move-table / SAM / BAM loop: a submit failed (as opposed to a bad record)
     auto flush = [&]() -> bool {
         if (hbs[cur].n() == 0) return true;
         const clk::time_point tf0 = clk::now();
@@ -604,12 +605,18 @@ int gmove_main(int argc, char **argv) {
         hbs[cur].seq.insert(hbs[cur].seq.end(), seq.begin(), seq.end()); hbs[cur].seq_off.push_back(hbs[cur].seq.size());
         hbs[cur].op_off.push_back(hbs[cur].op_n.size());
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
-        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= batch_samples_cap) { if (!flush()) { status = EXIT_FAILURE; break; } }
+        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= batch_samples_cap) { if (!flush()) { status = EXIT_FAILURE; flush_failed = true; break; } }
     }
-    if (status == EXIT_FAILURE && !is_paf && whole_list && dev.ok()) {
-        // a record the reference may never have read: it stops once every k-mer of the whole list is complete (gmove.cpp:733-735), and the
-        // batches in flight may have done that. Wait for them and look before failing (the PAF loop does the same above).
-        if (dev.sync() == PG_OK && dev.all_full()) { status = EXIT_SUCCESS; stop = true; }
+    if (status == EXIT_FAILURE && !is_paf && !flush_failed && whole_list) {
+        // A RECORD error (a failed submit / device error is never rescued): the reference may never have read that record -- it stops once
+        // every k-mer of the whole list is complete (gmove.cpp:733-735), and the reads in front of the bad record, queued or still in
+        // the unflushed batch, may do that. As the PAF loop above: drop what the bad record left half-appended, submit the valid reads in
+        // front of it, wait for the batches in flight, and look before failing.
+        HostBatch &h = hbs[cur];
+        h.sig.resize((size_t)h.sig_off.back()); h.seq.resize((size_t)h.seq_off.back());
+        h.op_n.resize((size_t)h.op_off.back()); h.op_t.resize((size_t)h.op_off.back());
+        h.qs.resize(h.n()); h.ts.resize(h.n()); h.te.resize(h.n());
+        if (flush() && dev.ok() && dev.sync() == PG_OK && dev.all_full()) { status = EXIT_SUCCESS; stop = true; }
     }
     if (status == EXIT_SUCCESS && !stop && !flush()) status = EXIT_FAILURE;
     free(line); fclose(paf_fp);

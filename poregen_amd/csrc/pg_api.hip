@@ -1448,7 +1448,9 @@ static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[3], const 
 pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
     if (!c || !out) return PG_ERR_INVALID_ARG;
     pg_result R;
-    pg_status s = pg_finish(c, &R);
+    // deferred: the small arrays come to the host, the kept samples stay where they are on the device (after pg_finish_deferred + pg_text
+    // of the CLI a plain pg_finish here would download the whole k-mer-major stream and, for several batches, upload it again)
+    pg_status s = pg_finish_deferred(c, &R);
     if (s != PG_OK) return s;
     const uint32_t ns = c->prm.n_slots;
     const uint64_t *d_ev_off, *d_samp_off; const uint32_t *d_ev_len; const double *d_samples;
@@ -1458,12 +1460,17 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
         d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off[c->slot].as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
     } else { // several batches were merged on the host (slot-major): hand the merged arrays back
         HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
-        HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4)); HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
+        HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4));
         HIP_TRY(c, hipMemcpyAsync(c->md_ev_off.p, R.ev_off, (ns + 1) * 8ull, hipMemcpyHostToDevice, c->st));
         HIP_TRY(c, hipMemcpyAsync(c->md_samp_off.p, R.samp_off, (R.n_events + 1) * 8ull, hipMemcpyHostToDevice, c->st));
         if (R.n_events) HIP_TRY(c, hipMemcpyAsync(c->md_ev_len.p, R.ev_len, R.n_events * 4ull, hipMemcpyHostToDevice, c->st));
-        if (R.n_samples) HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
-        d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>(); d_samples = c->md_samples.as<double>();
+        if (c->fin_dev || !R.n_samples) d_samples = c->fin_dev; // the batches were merged on the device: the stream is there already
+        else { // the merge went through the host (no room on the device at the time)
+            HIP_TRY(c, c->md_samples.ensure(R.n_samples * 8ull + 8));
+            HIP_TRY(c, hipMemcpyAsync(c->md_samples.p, R.samples, R.n_samples * 8ull, hipMemcpyHostToDevice, c->st));
+            d_samples = c->md_samples.as<double>();
+        }
+        d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>();
     }
     int any_kind[3] = {0, 0, 0}; // which of the three kernels have work (the host holds the offsets since pg_finish)
     const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;

@@ -366,7 +366,9 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
     uint32_t r, nv; uint64_t first;
     if (!region_tile(blockIdx.x, n_tilesB, tile_region, rbase, totals, r, first, nv)) return;
     const PartLds L = part_lds(ndig);
-    __shared__ uint32_t csum[PG_PLACE_CSPAN]; // window lengths of this tile's kept events per chunk of the gather (k_gather_chunks)
+    // window lengths of this tile's kept events per chunk of the gather. 32 bits are enough: `part` is only passed when the caller's
+    // "chunked" condition holds -- (longest window + 1) * 4096 < 2^32 (pg_api.hip collect_impl) -- and a tile holds 4096 events
+    __shared__ uint32_t csum[PG_PLACE_CSPAN];
     if (tid < PG_PLACE_CSPAN) csum[tid] = 0;
     const uint64_t c_lo = ev_off[(uint64_t)r << lo_bits] >> chunk_shift; // first chunk the region's kept events can fall into
     for (uint32_t i = tid; i < PG_PART_WAVES * (ndig / 2 ? ndig / 2 : 1); i += PG_PART_THREADS) L.cnt[i] = 0;
@@ -543,8 +545,10 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 uint32_t start = ws - W.print_margin;
                 const uint64_t we64 = (uint64_t)ws + wl + W.print_margin;
                 uint32_t we = (uint32_t)(we64 > L ? L : we64);
-                // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window)
-                if (W.print_margin > ws || we <= start) { report_error(O, rd, PGR_ERR_WINDOW); start = we = 0; }
+                // a kept event's window must be printable (gmove.cpp:928-944 is undefined for margin > start or an empty window); ONE verdict
+                // per event, as event_element leaves it for the partitioned path: a window that failed the range check is not judged again
+                if (!ok) start = we = 0;
+                else if (W.print_margin > ws || we <= start) { report_error(O, rd, PGR_ERR_WINDOW); start = we = 0; }
                 K.rec[dst[r]] = PgKeptRec{sig0 + start, we - start, rd};
                 if (K.read_needed) K.read_needed[rd] = 1;
                 // (the chunked gather's chunk sums are NOT accumulated here as k_region_place does: a tile's kept events go to ~1000 different

@@ -300,6 +300,37 @@ def test_malformed_line_behind_the_completing_read(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bad_move_record_behind_the_completing_read(tmp_path):
+    """The same on the move-table front-end (gmove.cpp:539-706): a malformed record behind the read that completes the whole list goes
+    unnoticed by the reference. The completing read may sit in a batch that is already queued (--batch_reads 40) or in the LAST, still
+    unflushed one (--batch_reads 1000: the valid reads in front of the bad record are submitted before the verdict); what the bad record
+    left half-appended is dropped. With a slice of the list both CLIs fail."""
+    b = synth.make_batch(150, kind="dna_r10", seed=97)
+    pre = str(tmp_path / "syn")
+    synth.write_table_files(b, pre)
+    lines = open(pre + ".table").read().split("\n")
+    cols = lines[120].split("\t")
+    lines[120] = "\t".join(cols[:5])                                # fewer than 7 columns: exit in the reference
+    open(pre + ".table", "w").write("\n".join(lines))
+    whole = [pre + ".slow5", pre + ".table", "-k", "3", "--scaling", "1", "--file_limit", "64", "--sample_limit", "5"]
+    o = oracle_cli(whole + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    for name, br in (("gpu", "40"), ("gpu1", "1000"), ("gpu2", "119")):
+        r = cli(whole + [tmp_path / name, "--batch_reads", br]); assert r.returncode == 0, (br, r.stderr)
+        assert_same_dirs(tmp_path / name, tmp_path / "cpu")
+    sl = [x if x != "64" else "10" for x in whole]
+    assert cli(sl + [tmp_path / "gpu3"]).returncode == 1
+    assert oracle_cli(sl + [tmp_path / "cpu3"]).returncode != 0
+    # a record that fails half-way through (moves shorter than -m asks for) leaves samples behind in the batch: they must not be submitted
+    lines[120] = "\t".join(cols[:4] + ["1"] + cols[5:])
+    open(pre + ".table", "w").write("\n".join(lines))
+    r = cli(whole + ["-m", "1", tmp_path / "gpu4", "--batch_reads", "1000"])
+    o = oracle_cli(whole + ["-m", "1", tmp_path / "cpu4"])
+    assert (r.returncode == 0) == (o.returncode == 0), (r.stderr, o.stderr)
+    if o.returncode == 0:
+        assert_same_dirs(tmp_path / "gpu4", tmp_path / "cpu4")
+
+
+@pytest.mark.gpu
 def test_sample_limit_zero_reads_every_line(tmp_path):
     """--sample_limit 0: no k-mer ever completes (gmove.cpp:925-927 skips in front of 945-950), so the reference reads every
     line, writes ':' per read with -d, and still exits on an RNA-oriented record without --rna behind the first batch."""
