@@ -139,6 +139,27 @@ class Oracle:
         p = self.L.orc_slot_values(self.h, s)
         return np.frombuffer((C.c_char * (8 * n)).from_address(p), dtype=np.float64).copy()
 
+    def all_values(self):
+        """Every slot's kept samples back to back in slot order (the k-mer-major stream the product returns), one memmove per slot."""
+        ns = [self.L.orc_slot_n_values(self.h, s) for s in range(self.n_slots)]
+        out = np.empty(int(sum(ns)), dtype=np.float64)
+        pos = 0
+        for s, n in enumerate(ns):
+            if n:
+                C.memmove(out.ctypes.data + 8 * pos, self.L.orc_slot_values(self.h, s), 8 * n)
+                pos += n
+        return out
+
+    def all_event_lens(self):
+        cnt = self.counts()
+        out = np.empty(int(cnt.sum()), dtype=np.uint32)
+        pos = 0
+        for s in np.flatnonzero(cnt):
+            n = int(cnt[s])
+            C.memmove(out.ctypes.data + 4 * pos, self.L.orc_slot_event_lens(self.h, int(s)), 4 * n)
+            pos += n
+        return out
+
     def event_lens(self, s):
         n = self.count(s)
         if n == 0:

@@ -75,20 +75,66 @@ def test_config3_dna_k9_all_slots():
     check_invariants(res, 1000, b.n_reads)
     oc = o.counts()
     assert np.array_equal(res.counts, oc)
-    hot = np.argsort(oc)[-40:]
-    for s in list(hot) + list(np.flatnonzero(oc)[:200]):
-        assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64))
+    assert int((oc == 1000).sum()) >= 1          # the homopolymer k-mers reach the cap: the cut runs
+    # EVERY slot's values and window lengths (the product's stream is k-mer-major: one comparison each)
+    assert np.array_equal(res.ev_len, o.all_event_lens())
+    assert np.array_equal(res.samples.view(np.uint64), o.all_values().view(np.uint64))
+
+
+@pytest.mark.parametrize("dense", [False, True], ids=["sparse_gather", "chunked_gather"])
+def test_k9_one_region_holds_most_events(dense, monkeypatch):
+    """k = 9 with reads that are 70 % one long homopolymer: AAAAAAAAA alone accepts most events (cut at the cap in the middle of a tile),
+    and its REGION of the two-level partition (high digit 0: the k-mers AAAAA....) holds more than half of all accepted events --
+    region skew in k_part_bases / k_part_scatter / k_region_place, where the uniform workloads have 1/512 per region. All slots against
+    the oracle (gmove.cpp:922-950)."""
+    if dense:
+        monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    b = synth.make_batch(400, kind="dna_r10", seed=20251003 + 33)
+    seq = b.seq.copy()
+    for r in range(b.n_reads):
+        a, e = int(b.seq_off[r]), int(b.seq_off[r + 1])
+        seq[a + (e - a) // 10: a + (e - a) // 10 + (7 * (e - a)) // 10] = ord("A")
+    b.seq = seq
+    p = dict(kmer_size=9, scaling=1, sample_limit=1000)
+    kmers = generate_kmers(9)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    big = dict(p); big["sample_limit"] = 2 ** 31 - 1
+    ou = oracle_for(kmers, **big)
+    ou.run_batch(b)
+    acc = ou.counts().astype(np.int64)
+    assert acc[:512].sum() > acc.sum() // 2 and acc[0] > 20 * 1000     # region 0 holds most accepted events, slot 0 is far above the cap
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b.slice_reads(0, 150)); eng.submit(b.slice_reads(150, 400))
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 1000, b.n_reads)
+    assert np.array_equal(res.counts, o.counts()) and int(res.counts[0]) == 1000
+    assert np.array_equal(res.ev_len, o.all_event_lens())
+    assert np.array_equal(res.samples.view(np.uint64), o.all_values().view(np.uint64))
 
 
 def test_config3_full_size_properties():
     """50 000 DNA reads, k=9: properties only at full size (counts vs limit, ordering, batch-split invariance)."""
-    b = synth.make_batch_fast(50000, kind="dna_r10", seed=20251003 + 3)
+    b = synth.make_batch_fast(50000, kind="dna_r10", seed=20251003 + 3, homopolymer_frac=0.1)   # SURVEY 8(d) cfg 3: 10 % homopolymer-rich reads
     p = dict(kmer_size=9, scaling=1, sample_limit=1000)
     kmers = generate_kmers(9)
     eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
     eng.submit(b)
     res = eng.finish()
     check_invariants(res, 1000, b.n_reads)
+    assert int((res.counts == 1000).sum()) >= 4      # the four homopolymer 9-mers (5 000 reads x 32 events each) sit at the cap
+    # the oracle on the prefix that completes them (the slots that reach the cap inside 6 000 reads are final there)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b.slice_reads(0, 6000))
+    oc = o.counts()
+    full = np.flatnonzero(oc == 1000)
+    assert full.size >= 4
+    for sl in full:
+        assert np.array_equal(res.slot_values(int(sl)).view(np.uint64), o.values(int(sl)).view(np.uint64)), int(sl)
+    for sl in np.flatnonzero(oc)[:: 997]:            # and a sample of the open ones: the oracle's values are a prefix of the job's
+        ov = o.values(int(sl))
+        assert np.array_equal(res.slot_values(int(sl))[:ov.size].view(np.uint64), ov.view(np.uint64)), int(sl)
     eng.reset()
     eng.submit(b.slice_reads(0, 20000)); eng.submit(b.slice_reads(20000, 50000))
     res2 = eng.finish()
