@@ -281,18 +281,19 @@ def main():
     stats_bytes = 2 * n_samples + (24 + 16 + 16) * host.n_reads
     # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes, FETCH_SIZE doubled per the gfx950
     # note of MI355X_MICROARCH.md): measured offline on the headline workload and committed under profiles/
-    traffic = None; trace_ms = None
+    traffic = None; trace_ms = None; traffic_source = None
     headline = args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004" and args.k == 5
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if headline:
                 traffic = pmc["traffic_bytes_per_launch"]
+                traffic_source = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes of this command; a committed constant, NOT measured in this run)"
             break
         except Exception:
             pass
     # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison
-    for name in ("r03_kernel_stats.csv", "r02_kernel_stats.csv"):
+    for name in ("r04_kernel_stats.csv", "r03_kernel_stats.csv", "r02_kernel_stats.csv"):
         try:
             import csv
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
@@ -304,14 +305,14 @@ def main():
     trace2_ms = None  # the same kernel in the committed trace of the DEFAULT command (two streams: it shares the chip there by design)
     try:
         import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_kernel_stats_two_streams.csv"))):
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats_two_streams.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r04_kernel_stats_two_streams.csv")) else "r03_kernel_stats_two_streams.csv"))):
             if row["Name"].startswith("k_read_stats(") and headline:
                 trace2_ms = float(row["AverageNs"]) * 1e-6
     except Exception:
         pass
     roofline = {
         "bound": "hbm", "kernel": "k_read_stats", "achieved": stats_bytes / (stats_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+        "unit": "GB/s", "frac": stats_bytes / (stats_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
         "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
         "committed_trace_avg_launch_ms": trace_ms, "committed_trace_frac": (stats_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if trace_ms else None,
         "measured": "dispatch time stamps (HIP events attached to the launches) in a profile-mode pass of this run, kernels on one stream; "

@@ -80,11 +80,14 @@ enum {
                                      _LAZY_STATS / _SKIP_OUT_OF_RANGE / _DEFER_STATS / _OVERLAP_TAIL is set: batches that follow each other
                                      run 14-17 % faster (0.161 -> 0.139 ms per 50 000-read batch). This flag keeps the one-stream form:
                                      short jobs (a hardware queue takes 15-20 ms to create: the CLI sets it), clean per-kernel timings. */
-    PG_FLAG_OVERLAP = 1u << 2,    /* two-stream mode: the statistics kernels of batch i+1 run on a second stream next to the event /
-                                     rank / emit chain of batches i and i+1; that stream is created with a quarter of the compute
-                                     units (of every XCD) withheld, so that the chain's workgroups find room. Pays when batches
-                                     follow each other (measured on configs[1]: 0.181 -> 0.157 ms per batch); every kernel then
-                                     shares the chip, so the default stays one stream with clean per-kernel timings. */
+    PG_FLAG_OVERLAP = 1u << 2,    /* two-stream mode, THE DEFAULT since round 3 (see PG_FLAG_ONE_STREAM for when it applies): the statistics
+                                     kernels of batch i+1 run on a second stream next to the event / rank / emit chain of batches i and
+                                     i+1; that stream is created with a quarter of the compute units (of every XCD) withheld, so that the
+                                     chain's workgroups find room. Pays when batches follow each other (configs[1]: 0.162 -> 0.141 ms per
+                                     batch). Every kernel then shares the chip: per-kernel timings (PG_FLAG_PROFILE, bench.py's roofline
+                                     object) are taken on one stream. Setting the flag explicitly asks for the mode where it is not the
+                                     default; PGMOVE_GATHER_SIDE=1 additionally puts the gather of batch i beside the chain of batch i+1
+                                     (measured: 0-5 %, profiles/r04_side_gather.txt). */
     PG_FLAG_SHORT_READS_OK = 1u << 4, /* a read with fewer than k matched bases simply has no events (move-table front-end,
                                         where that is well defined); default: PG_ERR_INPUT, because the PAF path of the
                                         reference has undefined behaviour there (src/gmove.cpp:891) */
@@ -343,7 +346,12 @@ pg_status pg_model(pg_ctx *ctx, uint32_t flags, pg_model_result *out);
 pg_status pg_model_device(pg_ctx *ctx, uint32_t n_slots, const uint64_t *d_ev_off, const uint64_t *d_samp_off,
                           const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out);
 /* The number as datamash prints it ("%.14Lg" of its long double; "nan" for sstdev of one value; empty string when the
- * slot has no value at all, like datamash on empty input). Returns the length written (excluding the NUL), 0 on error. */
+ * slot has no value at all, like datamash on empty input). Returns the length written (excluding the NUL), 0 on error.
+ * Caveat (parity of this call is UNPINNED: datamash is not in the image): the 14 digits of the sample standard deviation are
+ * decided here in exact integer arithmetic on the "%.8f" values. datamash rounds a long double that it computed with rounded
+ * intermediate sums; on a file whose exact sstdev lies within a few 1e-19 (relative) of a 14th-digit rounding boundary -- the
+ * fuzzer found one 5e-9 of a 14th-digit unit below it -- the real pipeline (scripts/poregen.sh:54-85) may print the neighbouring
+ * digit. Undecidable without datamash; the exact value is what this returns. */
 size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, char *buf, size_t cap);
 
 /* ---- one job over several GPUs of one node, driven from ONE host process ---------------------------------------------
