@@ -67,6 +67,24 @@ __device__ __forceinline__ uint4 event_element(const PgDevBatch &B, const PgWalk
     return make_uint4(slot, (uint32_t)src, wl | ((uint32_t)(src >> 32) << 24), rd);
 }
 
+// the arithmetic of event_element for a direct read whose loads have been made by the caller (k_part_scatter requests the loads of all
+// its rows together): lq = {L, qs}, fs = {flags, opsum0, sig0 lo, sig0 hi} of the read's record, pre = op sum in front of the event's op
+__device__ __forceinline__ uint4 element_finish(const PgWalkParams &W, uint32_t slot, uint32_t rd, const uint2 &lq, const uint4 &fs, uint32_t len, uint32_t pre) {
+    const uint64_t sig0 = (uint64_t)fs.z | ((uint64_t)fs.w << 32);
+    const uint64_t st = (uint64_t)lq.y + (uint32_t)(pre - fs.y);
+    const uint32_t start = (uint32_t)st;
+    const bool ok = st + len <= 0x7fffffffull;
+    int code = ok ? 0 : PGR_ERR_RANGE;
+    const uint64_t we64 = (uint64_t)start + len + W.print_margin;
+    const uint32_t we = (uint32_t)(we64 > lq.x ? lq.x : we64), ws = start - W.print_margin;
+    if (ok && (W.print_margin > start || we <= ws)) code = PGR_ERR_WINDOW;
+    const uint64_t src = sig0 + ws;
+    const uint32_t wl = we - ws;
+    if (!code && (wl >= (1u << 24) || (src >> 40))) code = PGR_ERR_RANGE;
+    if (code) return make_uint4(slot, (uint32_t)code, 0u, rd);
+    return make_uint4(slot, (uint32_t)src, wl | ((uint32_t)(src >> 32) << 24), rd);
+}
+
 // =====================================================================================================
 // a tile of 4096 elements in stable digit order (512 threads: 8 waves x 8 rows of 64)
 // =====================================================================================================
@@ -204,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_part_bases(const uint32_t *__restrict_
 }
 
 // pass A proper: the elements of PG_PART_TILES_PER_WG consecutive tiles of op indices go to their regions
-__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_part_scatter(const uint32_t *__restrict__ ev_slot, uint32_t n, uint32_t shift, int nbits, uint32_t n_tiles_pad,
+__global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_part_scatter(const uint32_t *__restrict__ ev_slot, uint32_t n, uint32_t shift, int nbits, uint32_t n_tiles_pad,
                                                                    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ rbase,
                                                                    PgDevBatch B, PgWalkParams W, PgWalkOut O, const uint32_t *__restrict__ Bp, uint4 *__restrict__ elemA,
                                                                    uint16_t *__restrict__ loA) {
@@ -247,38 +265,67 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
             const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
             opn[r] = (have_row && g < n_loads) ? B.op_n[g] : 0u;
         }
-        uint4 el[PG_PART_ROWS];
 #pragma unroll
-        for (int r = 0; r < PG_PART_ROWS; ++r) {
-            const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
-            const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3
-            const uint32_t m = (uint32_t)lane & 3u, partial = (m > 0 ? v1 : 0u) + (m > 1 ? v2 : 0u) + (m > 2 ? v3 : 0u);
-            valid[r] = key[r] != PG_INVALID_SLOT;
-            dig[r] = (key[r] >> shift) & (ndig - 1u);
-            el[r] = make_uint4(0, 0, 0, 0);
-            if (valid[r]) { // the read: its entry in the tile's table rides in the slot word's upper bits (k_events<2>), else a look-up
-                const uint32_t rel = key[r] >> PG_PART_REL_SHIFT;
-                const uint32_t rd = rel != PG_PART_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, g);
-                el[r] = event_element(B, W, O, Bp, key[r] & ((1u << PG_PART_REL_SHIFT) - 1u), g, rd, have_row, opn[r], partial);
-            }
-        }
+        for (int r = 0; r < PG_PART_ROWS; ++r) { valid[r] = key[r] != PG_INVALID_SLOT; dig[r] = (key[r] >> shift) & (ndig - 1u); }
         __syncthreads();
         uint32_t j[PG_PART_ROWS];
         tile_digit_order(dig, valid, nbits, ndig, L, j);
-#ifdef PG_PART_DIRECT_STORE // experiment: every element straight from its registers to its place (the L2 merges a run's stores?)
+        // The elements, straight into the stage at their place. The loads an element needs -- two of its read's record, two of the op-sum
+        // tables -- are requested for FOUR rows together with no branch in between (the first form asked for them row by row inside
+        // `if (valid)`: sixteen to twenty-four dependent round trips per tile, most of the 26 us a tile took); four, not eight, and behind
+        // the ranking rather than in front of it, so that the kernel stays within 128 registers (two workgroups per CU).
+        // the read of row r's event: its entry in the tile's table rides in the slot word's upper bits (k_events<2>), else a look-up
+        // (rare: a loop of loads); a lane without an event reads the tile's first record and drops the result
+        auto read_of = [&](int r) {
+            const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+            const uint32_t rel = key[r] >> PG_PART_REL_SHIFT;
+            if (!valid[r]) return tile_first < B.n_reads ? tile_first : 0u;
+            return rel != PG_PART_REL_UNKNOWN ? tile_first + rel : owner_of(B, O, g);
+        };
+        // the ops in front of row r's op inside its group of four, handed along the lanes (all lanes take part: DPP)
+        auto partial_of = [&](int r) {
+            const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3
+            const uint32_t m = (uint32_t)lane & 3u;
+            return (m > 0 ? v1 : 0u) + (m > 1 ? v2 : 0u) + (m > 2 ? v3 : 0u);
+        };
+        if (have_row) {
+            constexpr int HB = PG_PART_ROWS / 2;
 #pragma unroll
-        for (int r = 0; r < PG_PART_ROWS; ++r) if (valid[r]) {
-            const uint64_t dst = (uint64_t)L.aux[dig[r]] + (j[r] - L.ls[dig[r]]);
-            elemA[dst] = el[r]; loA[dst] = (uint16_t)(el[r].x & ((1u << shift) - 1u));
+            for (int r0 = 0; r0 < PG_PART_ROWS; r0 += HB) {
+                uint2 lq[HB]; uint4 fs[HB]; uint32_t pre[HB], rd[HB];
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    const int r = r0 + i;
+                    const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, gs = g < n ? g : (uint64_t)n - 1u; // (n >= 1: the tile exists)
+                    rd[i] = read_of(r);
+                    const PgReadMeta *mt = O.meta + rd[i];
+                    lq[i] = *reinterpret_cast<const uint2 *>(&mt->L);     // L, qs
+                    fs[i] = *reinterpret_cast<const uint4 *>(&mt->flags); // flags, opsum0, sig0
+                    pre[i] = Bp[gs >> 8] + O.cum[gs >> 2] + partial_of(r);
+                }
+#pragma unroll
+                for (int i = 0; i < HB; ++i) {
+                    const int r = r0 + i;
+                    const uint32_t part_r = partial_of(r); // (DPP: in front of the branch)
+                    if (!valid[r]) continue;
+                    const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+                    const uint32_t slot = key[r] & ((1u << PG_PART_REL_SHIFT) - 1u);
+                    if (fs[i].x & PG_RM_GENERIC) L.stage[j[r]] = event_element(B, W, O, Bp, slot, g, rd[i], true, opn[r], part_r); // window from the generic walk's arrays
+                    else L.stage[j[r]] = element_finish(W, slot, rd[i], lq[i], fs[i], opn[r], pre[i]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PG_PART_ROWS; ++r) {
+                const uint32_t part_r = partial_of(r);
+                if (!valid[r]) continue;
+                const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane;
+                L.stage[j[r]] = event_element(B, W, O, Bp, key[r] & ((1u << PG_PART_REL_SHIFT) - 1u), g, read_of(r), false, opn[r], part_r);
+            }
         }
-        const uint32_t total = 0;
-#else
-#pragma unroll
-        for (int r = 0; r < PG_PART_ROWS; ++r) if (valid[r]) L.stage[j[r]] = el[r];
         __syncthreads();
         // consecutive threads store consecutive elements of a digit's run
         const uint32_t total = L.ls[ndig];
-#endif
         for (uint32_t jj = tid; jj < total; jj += PG_PART_THREADS) {
             const uint4 e = L.stage[jj];
             const uint32_t d = (e.x >> shift) & (ndig - 1u);
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (gen) { ws = O.m_start[ge]; wl = O.m_len[ge]; }
                 else {
                     wl = have_row ? opn[r] : B.op_n[ge];
-                    const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + partial : op_prefix(B, O, Bp, ge);
+                    const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + partial : op_prefix(B, O, Bp, ge); // (all rows' table loads in front of the branches, as k_part_scatter does: 63 -> 64 us here, one register spill)
                     const uint64_t st = (uint64_t)qs + (uint32_t)(pre - pre0);
                     ws = (uint32_t)st;
                     ok = st + wl <= 0x7fffffffull;
