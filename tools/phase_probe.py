@@ -11,9 +11,13 @@ from poregen_amd.engine import GmoveEngine, GmoveParams, generate_kmers
 
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 limit = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-host = synth.make_batch_fast(reads, read_len=4000, kind="rna004", seed=20251003 + 1)
-p = dict(kmer_size=5, rna=True, scaling=1, sample_limit=limit, min_dur=20, max_dur=40)
-eng = GmoveEngine(GmoveParams(kmers=generate_kmers(5, rna=True), **p))
+kind = sys.argv[3] if len(sys.argv) > 3 else "rna004"   # e.g. `50000 1000 dna_r10 9` = BASELINE configs[3]
+k = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+rna = kind == "rna004"
+host = synth.make_batch_fast(reads, read_len=4000, kind=kind, seed=20251003 + 1, homopolymer_frac=0.0 if rna else 0.1)
+p = dict(kmer_size=k, rna=rna, scaling=1, sample_limit=limit)
+if rna: p.update(min_dur=20, max_dur=40)
+eng = GmoveEngine(GmoveParams(kmers=generate_kmers(k, rna=rna), **p))
 lib = eng._lib
 import numpy as np
 W = 65536
