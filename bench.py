@@ -408,13 +408,13 @@ def main():
         dist.destroy_process_group()
 
 
-def mode_run(shard, host, kmers, q, what, steps=10):
-    """One more workload on a device-resident batch: ms per step (one stream, plain pg_submit), the whole step against the HBM
-    roofline, per-kernel times from a separate profiled pass."""
+def mode_run(shard, host, kmers, q, what, steps=20):
+    """One more workload on a device-resident batch: ms per step (plain pg_submit: the library's default, two streams), the whole step
+    against the HBM roofline, per-kernel times from a separate profiled (one-stream) pass."""
     import torch
     from poregen_amd.engine import GmoveEngine, GmoveParams
     e = GmoveEngine(GmoveParams(kmers=kmers, **q))
-    for _ in range(3):
+    for _ in range(5):
         e.reset(); e.submit(shard)
     e.sync()
     t0 = time.perf_counter()
