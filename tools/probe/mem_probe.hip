@@ -54,6 +54,29 @@ __global__ __launch_bounds__(256) void k_meta(const int16_t *__restrict__ src, c
         *reinterpret_cast<double2 *>(out + s0) = make_double2(x0, x1);
     }
 }
+// how does the cost of the random window reads scale: with the number of LANE loads or with the bytes? S samples per lane, read as ONE
+// load of 2 * S bytes (windows start at multiples of S samples here, so every load is aligned and inside one window), nothing stored
+// (STORE false) or the S doubles stored as S / 2 16-byte stores (lane stride 8 * S bytes)
+template <int S, bool STORE>
+__global__ __launch_bounds__(256) void k_wide(const int16_t *__restrict__ src, const uint32_t *__restrict__ starts, uint32_t len, double *out, uint64_t nitems, uint32_t per, double *sink) {
+    const uint64_t p0 = (uint64_t)blockIdx.x * per;
+    double acc = 0;
+    for (uint32_t i = threadIdx.x; i < per && p0 + i < nitems; i += 256) {
+        const uint64_t s0 = (uint64_t)S * (p0 + i), e0 = s0 / len;
+        const uint64_t idx = ((uint64_t)starts[e0] / S) * S + (s0 - e0 * len); // (len is a multiple of S in this mode)
+        int v[S];
+        if (S == 1) v[0] = src[idx];
+        else if (S == 2) { const uint32_t x = *reinterpret_cast<const uint32_t *>(src + idx); v[0] = (short)x; v[1] = (int)x >> 16; }
+        else if (S == 4) { const uint2 x = *reinterpret_cast<const uint2 *>(src + idx); v[0] = (short)x.x; v[1] = (int)x.x >> 16; v[2] = (short)x.y; v[3] = (int)x.y >> 16; }
+        else { const uint4 x = *reinterpret_cast<const uint4 *>(src + idx); const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+               for (int q = 0; q < 4; ++q) { v[2 * q] = (short)w[q]; v[2 * q + 1] = (int)w[q] >> 16; } }
+        double x[S];
+        for (int q = 0; q < S; ++q) x[q] = ((double)v[q] + 3.0) * 0.137;
+        if (STORE) { if (S == 1) out[s0] = x[0]; else for (int q = 0; q < S; q += 2) *reinterpret_cast<double2 *>(out + s0 + q) = make_double2(x[q], x[q + 1]); }
+        else for (int q = 0; q < S; ++q) acc += x[q];
+    }
+    if (!STORE && acc == 1.2345e300) *sink = acc;
+}
 template <class F> static float timeit(F f, int reps = 5) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -89,6 +112,14 @@ int main(int argc, char **argv) {
     printf("R  random windows only         %.3f ms  %.1f G windows/s\n", t, E / t / 1e6);
     t = timeit([&] { hipLaunchKernelGGL((k_rw<true, true>), dim3(grid), dim3(256), 0, 0, src, starts, len, out, npairs, per, sink); });
     printf("RW random windows + stores     %.3f ms  %.2f TB/s of output\n", t, D * 8 / t / 1e9);
+    if (len % 8 == 0) { // lane-load width sweep (needs windows of a multiple of 8 samples): mem_probe 11600000 16
+        const uint64_t ns = D;
+        #define WIDE(SS) { const uint32_t perw = per * 2 / SS; const uint32_t gridw = (uint32_t)((ns / SS + perw - 1) / perw); \
+            float tr = timeit([&] { hipLaunchKernelGGL((k_wide<SS, false>), dim3(gridw), dim3(256), 0, 0, src, starts, len, out, ns / SS, perw, sink); }); \
+            float tw = timeit([&] { hipLaunchKernelGGL((k_wide<SS, true>), dim3(gridw), dim3(256), 0, 0, src, starts, len, out, ns / SS, perw, sink); }); \
+            printf("lane loads of %2d bytes (%d samples per lane): reads only %.3f ms, reads + stores %.3f ms\n", 2 * SS, SS, tr, tw); }
+        WIDE(1) WIDE(2) WIDE(4) WIDE(8)
+    }
     // metadata variants
     const uint32_t nreads = 50000;
     uint4 *rec; double *cal; uint64_t *soff;
