@@ -70,6 +70,7 @@ struct pg_ctx {
     uint32_t n_codes = 0, key_bits = 1;
 
     DevBuf table_t, table_u;
+    int32_t tab_ok[2] = {0, 0}; uint32_t tab_lo[2] = {1, 1}, tab_hi[2] = {0, 0}; int32_t tab_delta[2] = {0, 0}; // PgWalkParams::aff_*
     // staged copy of a host batch
     DevBuf s_sig, s_sig_off, s_dig, s_off, s_range, s_qs, s_ts, s_te, s_seq, s_seq_off, s_op_n, s_op_t, s_op_off;
     // per-batch work buffers
@@ -357,6 +358,21 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->table_t.ensure(2 * tb));
     CTRY(hipMemcpy(c->table_t.p, p->table_t, tb, hipMemcpyHostToDevice));
     CTRY(hipMemcpy(c->table_t.as<char>() + tb, p->table_u, tb, hipMemcpyHostToDevice));
+    { // is a table affine (PgWalkParams::aff_ok)?
+        const int32_t *tabs[2] = {p->table_t, p->table_u};
+        for (int x = 0; x < 2; x++) {
+            const int32_t *t = tabs[x];
+            size_t lo = 0, hi = c->n_codes;
+            while (lo < c->n_codes && t[lo] < 0) ++lo;
+            while (hi > lo && t[hi - 1] < 0) --hi; // [lo, hi)
+            c->tab_ok[x] = 1; c->tab_lo[x] = 1; c->tab_hi[x] = 0; c->tab_delta[x] = 0;
+            if (lo < hi) {
+                c->tab_lo[x] = (uint32_t)lo; c->tab_hi[x] = (uint32_t)(hi - 1); c->tab_delta[x] = t[lo] - (int32_t)lo;
+                for (size_t i = lo; i < hi; i++) if (t[i] != (int32_t)i + c->tab_delta[x]) { c->tab_ok[x] = 0; break; }
+            }
+            if (getenv("PGMOVE_NO_AFFINE")) c->tab_ok[x] = 0; // (tests, A/B: always look the slot up)
+        }
+    }
     c->prm.table_t = nullptr; c->prm.table_u = nullptr;
     const uint32_t ns = p->n_slots;
     CTRY(c->slot_start.ensure(ns * 4ull)); CTRY(c->slot_end.ensure(ns * 4ull));
@@ -587,6 +603,7 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     W.short_ok = (c->prm.flags & PG_FLAG_SHORT_READS_OK) ? 1 : 0;
     W.no_generic = c->batch_all_matches ? 1 : 0;
     W.n_codes = c->n_codes; W.table_t = c->table_t.as<int32_t>(); W.table_u = c->table_t.as<int32_t>() + c->n_codes;
+    for (int x = 0; x < 2; x++) { W.aff_ok[x] = c->tab_ok[x]; W.aff_lo[x] = c->tab_lo[x]; W.aff_hi[x] = c->tab_hi[x]; W.aff_delta[x] = c->tab_delta[x]; }
     O.m_start = c->m_start.as<uint32_t>(); O.m_len = c->m_len.as<uint32_t>(); O.m_base = c->m_base.as<uint8_t>();
     O.m_tix = c->m_tix.as<uint32_t>() + PG_TIX_FRONT(c->prm.kmer_pick_margin); O.ev_slot = c->ev_slot.as<uint32_t>();
     O.meta = c->meta.as<PgReadMeta>();

@@ -24,6 +24,12 @@ struct PgWalkParams {
     int32_t no_generic; // PG_BATCH_ALL_MATCHES: k_walk is not launched, a read that needs it has no events and fails the batch
     uint32_t n_codes; // 4^k
     const int32_t *table_t, *table_u; // table_u == table_t + n_codes (one allocation)
+    // Table x (0: T-spelled, 1: U-spelled) is "affine" when aff_ok[x]: slot = code + aff_delta[x] for aff_lo[x] <= code <= aff_hi[x], -1
+    // elsewhere (pg_create looks; an empty table has lo > hi). True for the table a generated k-mer list is spelled in and for every
+    // contiguous slice of it -- the reference's default --, false for a --kmer_file in another order (and for the OTHER spelling's table,
+    // which holds the T / U-free k-mers only). k_events' partitioned variant then computes the slot instead of looking it up: a scattered
+    // 4-byte load costs the texture addresser a cycle per LANE (profiles/r04_gather_bound.txt 5), 16 K of them per workgroup.
+    int32_t aff_ok[2]; uint32_t aff_lo[2], aff_hi[2]; int32_t aff_delta[2];
 };
 
 // per-read status codes written by k_walk_events (negative = error, reported through the C ABI)

@@ -609,8 +609,19 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
         const int64_t a = rna ? (int64_t)(s0 + t_slen[tq][sg.e]) - NB - (int64_t)i : (int64_t)(s0 + i);
         const int64_t adw = a >> 2;
         uint32_t d[NW + 1];
+        if (adw >= 0 && adw + NW <= seq_last_dw) {
+            // the window's NW + 1 dwords as 16- and 8-byte loads (4-byte aligned): a load costs the texture addresser per LANE, whatever
+            // its width (profiles/r04_gather_bound.txt 5) -- two lane loads instead of six or eight
+            typedef uint32_t pg_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef uint32_t pg_a2 __attribute__((ext_vector_type(2), aligned(4)));
+            const pg_a4 v0 = *reinterpret_cast<const pg_a4 *>(seq32 + adw);
+            d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
+            if (NW + 1 == 6) { const pg_a2 v1 = *reinterpret_cast<const pg_a2 *>(seq32 + adw + 4); d[4] = v1.x; d[5] = v1.y; }
+            else { const pg_a4 v1 = *reinterpret_cast<const pg_a4 *>(seq32 + adw + 4); d[4] = v1.x; d[5] = v1.y; d[NW + 1 > 6 ? 6 : 0] = v1.z; d[NW + 1 > 7 ? 7 : 0] = v1.w; }
+        } else { // at the ends of the sequence buffer: dword by dword, clamped
 #pragma unroll
-        for (int q = 0; q < NW + 1; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
+            for (int q = 0; q < NW + 1; ++q) { int64_t x = adw + q; x = x < 0 ? 0 : (x > seq_last_dw ? seq_last_dw : x); d[q] = seq32[x]; }
+        }
         const uint32_t sh = (uint32_t)(a & 3) * 8u;
         uint32_t w[NW];
 #pragma unroll
@@ -806,8 +817,20 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
                 if (kind == 1u && opn[j] >= PG_OP_N_LIMIT && g0 + j < N) too_long = true;
             }
         }
+        PG_MARK(1, 5); // partitioned variant: position / base / duration tests, table indices
+        // a table that is code + constant inside a range (PgWalkParams::aff_ok) is computed; only the other indices are looked up
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (tix[j] != 0xFFFFFFFFu) {
+            const uint32_t x = tix[j] >= W.n_codes ? 1u : 0u;
+            if (W.aff_ok[x]) {
+                const uint32_t code = tix[j] - (x ? W.n_codes : 0u);
+                sl[j] = (code >= W.aff_lo[x] && code <= W.aff_hi[x]) ? (uint32_t)((int32_t)code + W.aff_delta[x]) : PG_INVALID_SLOT;
+                tix[j] = 0xFFFFFFFFu;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 16; ++j) if (tix[j] != 0xFFFFFFFFu) sl[j] = (uint32_t)W.table_t[tix[j]]; // -1 = not in the slice = PG_INVALID_SLOT
+        PG_MARK(1, 6); // partitioned variant: the 16 slot look-ups
         if (too_long) {
             for (uint32_t j = 0; j < 16 && g0 + j < N; ++j) {
                 const bool inB = j >= jb;

@@ -31,7 +31,7 @@ lib.pg_debug_phases(buf.ctypes.data, 0, 1)
 eng.reset(); eng.submit(shard); eng.sync()
 names = {0: ("k_read_stats", ["record load", "samples arrive", "binning", "prefix scan", "selection + stores"]),
          1: ("k_events<true> (per wave, 4 tiles)", ["first reads of the tiles + op_n", "table entry + block sums", "the two barriers", "reads of the group + base codes",
-                                                   "stores (or events, other forms)", "masks (op_n arrives)", "look-ups + counts"])}
+                                                   "stores (straight-line form) / counts + stores (partitioned) / the whole of the events (other forms)", "masks (straight-line) / tests + table indices (partitioned)", "look-ups + counts (straight-line) / look-ups (partitioned)"])}
 # k_events: the last barrier and the histogram rows are the rest of the lifetime
 names[2] = ("k_rank_emit (waves of the tiles that place events)", ["last useful tile known", "keys + column + keep + offsets arrive", "any-room test, counts, wave bases",
                                                                     "ordered rows (+ read records)", "windows", "stores"])
