@@ -621,14 +621,16 @@ static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
     S.dbase = c->dbase.as<uint32_t>(); S.count = c->scount.as<uint32_t>(); S.n_tiles = n_tiles;
 }
 
-// lanes per kept event of the chunked gather: by the mean kept window of the last settled batch, else by a guess from the duration
-// filter (dwells lean towards min_dur). Every choice is correct for every window; PGMOVE_GATHER_LANES overrides (measurements).
+// which gather for many kept events: by the mean kept window of the last settled batch, else by a guess from the duration filter (dwells
+// lean towards min_dur). 0 = k_gather_wave (a lane per pair of OUTPUT samples: short windows, k = 9's mean of 12), 1 = k_gather_evpair (a
+// lane per pair of samples of ONE window: one load per lane, but a lane-slot lost per odd window -- pays from ~16 samples up: sample_limit
+// 5000's mean of 28: 218 -> 197 us; k = 9: 837 -> 904). Every choice is correct for every window; PGMOVE_GATHER_LANES overrides
+// (measurements: 4 / 8 / 16 = round 3's k_gather_chunks with that many lanes per event).
 static int gather_lanes(const pg_ctx *c) {
     static const char *ov = getenv("PGMOVE_GATHER_LANES");
     if (ov) return atoi(ov);
-    return 0; // k_gather_wave (round 4): a lane per pair of output samples, a wave per 64 events. What follows chose the lane groups of k_gather_chunks.
-    const uint32_t mw = c->win_hint ? c->win_hint : c->prm.min_dur + (c->prm.max_dur > c->prm.min_dur ? (c->prm.max_dur - c->prm.min_dur) / 4 : 0) + 2 * c->prm.signal_print_margin;
-    return mw <= 6 ? 4 : (mw <= 36 ? 8 : 16); // (k = 9, mean window 12.4: 8 lanes 0.91-0.97 ms, 4 lanes 1.07-1.10 ms)
+    const uint32_t mw = c->win_hint ? c->win_hint : c->prm.min_dur + (c->prm.max_dur > c->prm.min_dur ? (c->prm.max_dur - c->prm.min_dur) / 8 : 0) + 2 * c->prm.signal_print_margin;
+    return mw > 16 ? 1 : 0;
 }
 
 // direct ranking: will (nearly) every tile place events? Then the placing kernel built for that takes over (k_rank_emit2), and it wants

@@ -946,6 +946,208 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
     }
 }
 
+#ifndef PG_GE_TRIPS
+#define PG_GE_TRIPS 4
+#endif
+#ifndef PG_GE_WAVES
+#define PG_GE_WAVES 4
+#endif
+// ---- the event-pair form: k_gather_wave with the lanes' pairs taken inside ONE window (pair slots), so that a lane needs one event
+// look-up, one calibration and ONE 8-byte load (profiles/r04_gather_bound.txt 5, 6: scattered loads cost a cycle per lane, and a second,
+// masked load inside a trip costs more than it saves). Stores are 16 bytes at 8-byte alignment, 8 bytes for the odd tail of a window.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES, 8))) void k_gather_evpair(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
+        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+        double *__restrict__ samples, const double *__restrict__ gcal) {
+    __shared__ uint32_t gsum[PG_GW_SEG / 64];
+    __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - 2 * first pair slot (64 bits), output offset - 2 * first pair slot, 2 * first pair slot + length
+    __shared__ double s_cal_all[4][64 * 6];           // its read's offset, scale, median, MAD; 1 / MAD; -
+    __shared__ uint2 s_bits_all[4][PG_GW_SPAN / 64];  // x: first pair slots of the events over this tile of the group's pair slots, y: non-empty events in front of the word
+    const uint64_t n_kept = n_kept_ptr[0];
+    const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
+    if (c0 >= n_kept) return;
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const int lane = lane_id();
+    uint4 *s_ev = s_ev_all[w]; double *s_cal = s_cal_all[w]; uint2 *s_bits = s_bits_all[w];
+    const uint64_t c1 = c0 + (uint64_t)sub_per_chunk * PG_G2_SUB < n_kept ? c0 + (uint64_t)sub_per_chunk * PG_G2_SUB : n_kept;
+    const int16_t *__restrict__ sig = B.sig;
+    const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
+    const uint64_t total = B.sig_off[B.n_reads];
+    uint64_t run = part[blockIdx.x];
+    for (uint64_t seg = c0; seg < c1; seg += PG_GW_SEG) {
+        const uint32_t nseg = c1 - seg < PG_GW_SEG ? (uint32_t)(c1 - seg) : PG_GW_SEG;
+        // ---- sums of the window lengths per group of 64 events (8 threads x 8 events each)
+        if (seg != c0) __syncthreads(); // the previous segment's sums are read until its last wave has scanned them
+        {
+            const uint32_t *__restrict__ lens = reinterpret_cast<const uint32_t *>(rec + seg) + 2;
+            uint32_t sm = 0;
+#pragma unroll
+            for (int i = 0; i < PG_GW_SEG / 256; ++i) { const uint32_t x = tid * (PG_GW_SEG / 256) + i; sm += x < nseg ? lens[4u * x] : 0u; }
+            sm += (uint32_t)__shfl_xor((int)sm, 1, WAVE); sm += (uint32_t)__shfl_xor((int)sm, 2, WAVE); sm += (uint32_t)__shfl_xor((int)sm, 4, WAVE);
+            if ((tid & 7u) == 0u) gsum[tid >> 3] = sm;
+        }
+        __syncthreads();
+        const uint32_t gv = lane < PG_GW_SEG / 64 ? gsum[lane] : 0u, ginc = wave_incl_scan_u32(gv);
+        const uint32_t segtot = (uint32_t)__builtin_amdgcn_readlane((int)ginc, WAVE - 1);
+        // the records and calibrations of a group are requested one group ahead (records: two), so that the two dependent memory rounds
+        // in front of a group's trips (record -> calibration of its read) run beside the previous group's trips
+        auto load_rec = [&](uint32_t g) {
+            const uint32_t gn = g * 64u < nseg ? (nseg - g * 64u < 64u ? nseg - g * 64u : 64u) : 0u;
+            return (uint32_t)lane < gn ? reinterpret_cast<const uint4 *>(rec + seg + g * 64u)[lane] : make_uint4(0, 0, 0, 0);
+        };
+        // lanes 2i and 2i + 1 fetch the two halves of event i's (then event 32 + i's) 32-byte calibration record: one request per record
+        auto load_cal = [&](const uint4 &qq, double2 (&c)[2]) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int evl = hh * 32 + (lane >> 1);
+                const uint32_t rd = (uint32_t)__shfl((int)qq.w, evl, WAVE), ok = (uint32_t)__shfl((int)qq.z, evl, WAVE);
+                c[hh] = make_double2(0.0, 0.0);
+                if (ok) {
+#ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event uses one of eight reads' calibrations
+                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * (rd & 7u) + 2u * (lane & 1));
+#else
+                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1)); // {offset, range / digitisation as the statistics used it}, {median, MAD}
+#endif
+                    else c[hh] = (lane & 1) ? make_double2(0.0, 1.0) : make_double2(B.off[rd], B.range[rd] / B.dig[rd]);
+                }
+            }
+        };
+        uint4 q_cur = load_rec(w), q_nxt = load_rec(w + 4);
+        double2 c_cur[2];
+        load_cal(q_cur, c_cur);
+        for (uint32_t g = w; g * 64u < nseg; g += 4) {
+            const uint64_t e0 = seg + g * 64u, gbase = run + (uint32_t)__shfl((int)(ginc - gv), (int)g, WAVE);
+            const uint32_t n = nseg - g * 64u < 64u ? nseg - g * 64u : 64u;
+            // ---- this group: a record per lane
+            const uint4 q = q_cur;
+            const double2 c0 = c_cur[0], c1 = c_cur[1];
+            q_cur = q_nxt; load_cal(q_cur, c_cur); q_nxt = load_rec(g + 8);
+            const uint32_t len = q.z, nzf = len != 0u;
+            const uint32_t inc = wave_incl_scan_u32(len), off = inc - len;
+            const uint32_t idx = wave_incl_scan_u32(nzf) - nzf;
+            const uint32_t len2 = (len + 1u) >> 1, inc2 = wave_incl_scan_u32(len2), off2 = inc2 - len2, tot2 = (uint32_t)__builtin_amdgcn_readlane((int)inc2, WAVE - 1); // pair slots: lanes own samples (2k, 2k + 1) of ONE window
+#ifndef PG_PROBE_NO_SOFF
+            if ((uint32_t)lane < n) samp_off[e0 + lane] = gbase + off;
+#endif
+            __builtin_amdgcn_wave_barrier(); // (the previous group's trips have read the stage)
+            if (nzf) {
+                const uint64_t srcbase = ((uint64_t)q.x | ((uint64_t)q.y << 32)) - 2ull * off2;
+                s_ev[idx] = make_uint4((uint32_t)srcbase, (uint32_t)(srcbase >> 32), off - 2u * off2, 2u * off2 + len);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int evl = hh * 32 + (lane >> 1);
+                const uint32_t ok = (uint32_t)__shfl((int)nzf, evl, WAVE), ix = (uint32_t)__shfl((int)idx, evl, WAVE);
+                if (ok) {
+                    const double2 cc = hh ? c1 : c0;
+                    *reinterpret_cast<double2 *>(s_cal + 6u * ix + 2u * (lane & 1)) = cc;
+                    // the reciprocal of the read's MAD, once per event (conv below): the odd lane holds {median, MAD}
+                    if (lane & 1) s_cal[6u * ix + 4u] = 1.0 / cc.y;
+                }
+            }
+            uint32_t before = 0; // non-empty events that start in front of the tile
+            constexpr uint32_t SPAN2 = PG_GW_SPAN / 2; // pair slots per bit map: one word per lane
+            for (uint32_t tb = 0; tb < tot2; tb += SPAN2) {
+                __builtin_amdgcn_wave_barrier();
+                s_bits[lane].x = 0u;
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t rel = off2 - tb; // (wraps for events in front of the tile)
+                if (nzf && rel < SPAN2) atomicOr(&s_bits[rel >> 5].x, 1u << (rel & 31u));
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t wd = s_bits[lane].x, pc = (uint32_t)__popc(wd);
+                const uint32_t ipc = wave_incl_scan_u32(pc);
+                s_bits[lane].y = before + ipc - pc;
+                before += (uint32_t)__builtin_amdgcn_readlane((int)ipc, WAVE - 1);
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t tn = tot2 - tb < SPAN2 ? tot2 - tb : SPAN2; // pair slots of this tile
+                double *__restrict__ out = samples + gbase;
+                // (x - median) / MAD of gmove.cpp:774 as the hardware's own division sequence computes it -- q0 = a * y, r = a - b * q0 (exact, FMA),
+                // q = q0 + r * y -- with y = the correctly rounded 1 / MAD computed once per event instead of the refined v_rcp_f64 per sample.
+                // With y correctly rounded and q0 within an ulp this last step is Markstein's: q is the correctly rounded a / b (MAD >= 1, nothing
+                // under- or overflows here). tools/div_check.c: 1.4e10 random and near-tie cases without a difference; every parity test and the
+                // fuzzers compare the doubles bit for bit against the oracle's plain division. -DPG_GATHER_DIV_INSN restores the instruction
+                // sequence (FP64 is half rate here and the division is 2/3 of a sample's arithmetic: 948 -> 8xx us at k = 9).
+                auto conv = [&](int raw, const double4 &c, double y) {
+#ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
+                    return (double)raw;
+#endif
+                    const double pA = ((double)raw + c.x) * c.y;                 // TO_PICOAMPS, poregen.h:30
+                    double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;          // gmove.cpp:756-759
+                    if (scaling) {
+                        const double num = x - c.z;
+#if defined(PG_PROBE_GC_NODIV)
+                        x = num * c.w;
+#elif defined(PG_GATHER_DIV_INSN)
+                        x = num / c.w;
+#else
+                        const double q0 = num * y, r = __builtin_fma(-c.w, q0, num);
+                        x = __builtin_fma(r, y, q0);
+#endif
+                    }
+                    return x;
+                };
+                // A trip: lane j owns pair slot tb + j = samples (2k, 2k + 1) of ONE window: one event look-up, one 8-byte load (the two dwords
+                // that hold both samples whatever the parity of the source index), two conversions, one 16-byte store at 8-byte alignment
+                // (8 bytes for the odd tail of a window). No pair straddles two events, so nothing in a trip branches but the store width.
+                for (uint32_t j0 = lane; j0 < tn; j0 += 64 * PG_GE_TRIPS) {
+                    uint32_t qp[PG_GE_TRIPS]; bool v[PG_GE_TRIPS]; uint2 bw[PG_GE_TRIPS];
+#pragma unroll
+                    for (int u = 0; u < PG_GE_TRIPS; ++u) {
+                        const uint32_t j = j0 + u * 64;
+                        v[u] = j < tn; qp[u] = v[u] ? j : tn - 1u;
+                        bw[u] = s_bits[qp[u] >> 5];
+                    }
+                    uint32_t ev[PG_GE_TRIPS]; uint4 ee[PG_GE_TRIPS];
+#pragma unroll
+                    for (int u = 0; u < PG_GE_TRIPS; ++u) {
+                        ev[u] = bw[u].y + (uint32_t)__popc(bw[u].x & ((2u << (qp[u] & 31u)) - 1u)) - 1u;
+                        ee[u] = s_ev[ev[u]];
+                    }
+                    uint64_t i0[PG_GE_TRIPS]; bool tail = false;
+#pragma unroll
+                    for (int u = 0; u < PG_GE_TRIPS; ++u) {
+                        i0[u] = ((uint64_t)ee[u].x | ((uint64_t)ee[u].y << 32)) + 2ull * (tb + qp[u]);
+                        tail |= (i0[u] | 1ull) + 2ull >= total; // the dwords of samples i, i + 1 end behind the batch's signal
+                    }
+                    int raw[PG_GE_TRIPS][2];
+                    if (!__ballot(tail)) { // (wave-uniform; only the wave that holds the batch's last samples takes the other side)
+#pragma unroll
+                        for (int u = 0; u < PG_GE_TRIPS; ++u) {
+#ifdef PG_PROBE_GC_NOREAD
+                            raw[u][0] = (int)(ee[u].x + qp[u]); raw[u][1] = raw[u][0] + 1;
+#else
+                            typedef uint32_t pg_a2 __attribute__((ext_vector_type(2), aligned(4)));
+                            const pg_a2 qq = *reinterpret_cast<const pg_a2 *>(sig32 + (i0[u] >> 1));
+                            const uint64_t v64 = ((uint64_t)qq.y << 32) | qq.x;
+                            const uint32_t sh = (uint32_t)(i0[u] & 1u) * 16u;
+                            raw[u][0] = (int)(short)(uint16_t)(v64 >> sh); raw[u][1] = (int)(short)(uint16_t)(v64 >> (sh + 16u));
+#endif
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PG_GE_TRIPS; ++u) { raw[u][0] = sig[i0[u]]; raw[u][1] = i0[u] + 1 < total ? sig[i0[u] + 1] : 0; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < PG_GE_TRIPS; ++u) {
+                        const double4 cc = *reinterpret_cast<const double4 *>(s_cal + 6u * ev[u]);
+                        const double y = s_cal[6u * ev[u] + 4u];
+                        const double x0 = conv(raw[u][0], cc, y), x1 = conv(raw[u][1], cc, y);
+                        const uint32_t s2 = 2u * (tb + qp[u]);                 // the pair's first sample, counted in pair slots x 2
+                        double *dst = out + (uint32_t)(ee[u].z + s2);          // + (offset of the window in the group - 2 x its first pair slot)
+#ifdef PG_PROBE_GC_NOSTORE
+                        if (x0 + x1 == 1.2345e300) *dst = x0;
+#else
+                        typedef double pg_d2 __attribute__((ext_vector_type(2), aligned(8)));
+                        if (v[u] && s2 + 1u < ee[u].w) { pg_d2 xx; xx.x = x0; xx.y = x1; __builtin_nontemporal_store(xx, reinterpret_cast<pg_d2 *>(dst)); }
+                        else if (v[u]) *dst = x0; // the odd tail of a window
+#endif
+                    }
+                }
+            }
+        }
+        run += segtot;
+    }
+}
+
 // the kept events' lengths and reads as arrays of their own (pg_result / pg_device_view; off the step's path)
 __global__ __launch_bounds__(256) void k_unpack_recs(const PgKeptRec *__restrict__ rec, uint64_t n, uint32_t *__restrict__ ev_len, uint32_t *__restrict__ ev_read) {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1029,6 +1231,10 @@ hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t
                                    uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes) {
     if (n_kept_cap == 0) return hipSuccess;
     uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    if (lanes == 1) { // the event-pair form (a lane per pair of samples of ONE window)
+        PG_LAUNCH(k_gather_evpair, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+        return hipSuccess;
+    }
     if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
         PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
         return hipSuccess;
