@@ -888,6 +888,10 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
                     const uint32_t dur = W.sig_move_offset == 0 ? len[u] : B.op_n[g0 + j + W.sig_move_offset];
                     if (!badf && dur <= W.max_dur && dur >= W.min_dur) {
                         if (LT) { const uint32_t t16 = ltab[rna ? 1024u + field : fwd]; sl = t16 == 0xFFFFu ? PG_INVALID_SLOT : t16; }
+                        else if (W.aff_ok[rna ? 1 : 0]) { // the table in use is code + constant inside a range: computed (see the partitioned variant)
+                            const uint32_t x = rna ? 1u : 0u, code = rna ? field : fwd;
+                            sl = (code >= W.aff_lo[x] && code <= W.aff_hi[x]) ? (uint32_t)((int32_t)code + W.aff_delta[x]) : PG_INVALID_SLOT;
+                        }
                         else sl = (uint32_t)W.table_t[rna ? field + W.n_codes : fwd]; // table_u sits behind table_t; -1 = not in the slice = PG_INVALID_SLOT
                     }
                 }
