@@ -1,5 +1,5 @@
 #!/bin/bash
-# the three gather forms on one box, three workloads: bash tools/ab_gather.sh <tag> [build dir names...]
+# the gather forms (k_gather_wave, round 3's k_gather_chunks<8>, k_gather_evpair) on one box, three workloads: bash tools/ab_gather.sh <tag> [build dir names...]
 set -o pipefail
 tag=$1; shift
 out=gpurun_out/$tag; mkdir -p $out
@@ -12,9 +12,9 @@ run() { # name, env, lib
 }
 run wave "X=1" ""
 run chunks8 "PGMOVE_GATHER_LANES=8" ""
-run flat "PGMOVE_GATHER_LANES=1" ""
+run evpair "PGMOVE_GATHER_LANES=1" ""
 for v in "$@"; do run $v "X=1" "--lib build/$v/libpgmove.so"; done
-python3 - $out wave chunks8 flat "$@" > $out/summary.txt <<'PY'
+python3 - $out wave chunks8 evpair "$@" > $out/summary.txt <<'PY'
 import json, sys
 for v in sys.argv[2:]:
     for n in ("k9", "l5000"):
