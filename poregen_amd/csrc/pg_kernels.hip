@@ -851,7 +851,7 @@ template <int COUNT, bool LT> __global__ __launch_bounds__(1024) __attribute__((
             if (g0 + 4 * v + 4 <= N) *reinterpret_cast<uint4 *>(O.ev_slot + g0 + 4 * v) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
             else { for (int u = 0; u < 4; ++u) if (g0 + 4 * v + u < N) O.ev_slot[g0 + 4 * v + u] = o4[u]; }
         }
-    } else if (tile_live && g0 < N) {
+    } else if (COUNT != 2 && tile_live && g0 < N) { // (the partitioned variant has taken its own branch above: not compiled into it)
         const uint32_t x0 = lt * 16u;
         const int32_t iloA = t_ilo[tq][A.e], ihiA = t_ihi[tq][A.e];
         int32_t iloB = 0, ihiB = -1;

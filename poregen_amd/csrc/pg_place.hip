@@ -330,11 +330,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
             const uint4 e = L.stage[jj];
             const uint32_t d = (e.x >> shift) & (ndig - 1u);
             const uint64_t dst = (uint64_t)L.aux[d] + (jj - L.ls[d]);
-#ifdef PG_PART_NT_STORE // probe: streaming stores for the elements
-            { typedef uint32_t pg_v4 __attribute__((ext_vector_type(4))); pg_v4 x; x.x = e.x; x.y = e.y; x.z = e.z; x.w = e.w; __builtin_nontemporal_store(x, reinterpret_cast<pg_v4 *>(elemA + dst)); }
-#else
-            elemA[dst] = e;
-#endif
+            elemA[dst] = e; // (streaming "nt" stores here: 164 -> 229 us, and 168 -> 248 us for pass B's records: profiles/r04_probes.txt)
             loA[dst] = (uint16_t)(e.x & ((1u << shift) - 1u)); // the low digits once more, 2 bytes each: all that pass B's count kernel reads
         }
     }
@@ -458,11 +454,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         if (jj >= L.aux[d]) continue; // its k-mer is full (gmove.cpp:925-927)
         const uint32_t dst = jj + L.aux[ndig + d], len = e.z & 0xffffffu;
         if (len == 0) { report_error(O, e.w, (int)e.y); K.rec[dst] = PgKeptRec{0, 0, e.w}; } // the verdict event_element left
-#ifdef PG_PLACE_NT_STORE // probe: streaming stores for the records
-        else { typedef uint32_t pg_v4 __attribute__((ext_vector_type(4))); pg_v4 x; x.x = e.y; x.y = e.z >> 24; x.z = len; x.w = e.w; __builtin_nontemporal_store(x, reinterpret_cast<pg_v4 *>(K.rec + dst)); }
-#else
         else K.rec[dst] = PgKeptRec{(uint64_t)e.y | ((uint64_t)(e.z >> 24) << 32), len, e.w};
-#endif
         if (K.read_needed) K.read_needed[e.w] = 1;
         if (!part) continue;
         const uint64_t ch = ((uint64_t)dst >> chunk_shift) - c_lo;
