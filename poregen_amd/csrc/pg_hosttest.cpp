@@ -4,6 +4,7 @@
 #include "pg_select.h"
 #include <vector>
 #include <cstdint>
+#include <cstring>
 
 extern "C" int pgt_plan(double dig, double off, double range, double pa_min, double pa_max, int32_t *out4) {
     PgReadPlan p = pg_make_plan(dig, off, range, pa_min, pa_max);
@@ -43,6 +44,15 @@ extern "C" int pgt_medmad_sym(const int16_t *raw, uint64_t n, double dig, double
     *med = mm.med; *mad = mm.mad; *mad_raw = mm.mad_raw;
     return 1;
 }
+
+// the dense gathers' division (pg_select.h: pg_div_by_recip) next to the plain one: 1 = the two agree bit for bit
+extern "C" int pgt_div_by_recip(double a, double b, double *q_recip, double *q_div) {
+    const double y = 1.0 / b;
+    *q_recip = pg_div_by_recip(a, b, y); *q_div = a / b;
+    uint64_t x, z; memcpy(&x, q_recip, 8); memcpy(&z, q_div, 8);
+    return x == z;
+}
+extern "C" int pgt_div_domain_ok(double offset, double scale) { return pg_div_domain_ok(offset, scale) ? 1 : 0; }
 
 // ---- host parsers / writer of the CLI (poregen_amd/csrc/host) ------------------------------------------
 #include "host/pg_host.h"

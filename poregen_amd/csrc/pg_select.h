@@ -32,6 +32,24 @@ struct PgReadPlan {
 
 PG_HD double pg_pa(int code, double offset, double scale) { return ((double)code + offset) * scale; }
 
+// (x - median) / MAD of src/gmove.cpp:774 with the reciprocal y = 1.0 / b taken ONCE per event (b = the read's MAD >= 1.0) instead of a
+// division per sample: q0 = a * y, r = a - b * q0 (one FMA), q = q0 + r * y (one FMA). q is the correctly rounded a / b -- the
+// argument is DESIGN.md section 6 ("the gather's division"), the constructed cases tools/div_check.c and tests/test_select_host.py --
+// for operands inside pg_div_domain_ok() below; outside it the dense gathers use the division itself.
+PG_HD double pg_div_by_recip(double a, double b, double y) {
+    const double q0 = a * y, r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, y, q0);
+}
+// The proof needs normal numbers end to end: no subnormal quotient, no inexact residual. With a read's scale = range / digitisation and
+// |offset| inside [2^-200, 2^200] (or offset == 0): raw + offset is 0 or a multiple of 2^-252 below 2^201, so every non-zero pA of the
+// read has magnitude 2^-452 .. 2^401, every non-zero difference x - median is >= 2^-504 (a multiple of the smaller operand's ulp), the
+// MAD is < 2^403, a quotient is >= 2^-907 and the residual a - b * q0 is 0 or >= 2^-1012: normal numbers throughout. Every real
+// calibration is inside (scale ~ 0.1 .. 1, offset ~ -300 .. 30); a read outside is still computed exactly, with the division itself.
+PG_HD bool pg_div_domain_ok(double offset, double scale) {
+    const double lo = 0x1p-200, hi = 0x1p200, ao = offset < 0.0 ? -offset : offset;
+    return scale >= lo && scale <= hi && (ao == 0.0 || (ao >= lo && ao <= hi));
+}
+
 // first code in [-32768, 32768] (32768 = none) for which pred(code) holds; pred must be monotone
 template <class Pred> PG_HD int pg_first_code(Pred pred) {
     int lo = -32768, hi = 32768;

@@ -146,3 +146,66 @@ def test_plan_boundaries_match_brute_force(shim):
         c_z = int(codes[ge0[0]]) if ge0.size else 32768
         span = max(c_gt - c_lo, 0)
         assert (out[0], out[1], out[2]) == (c_lo, span, min(max(c_z - c_lo, 0), span)), (dig, off, rg, pmin, pmax)
+
+
+# ---- the dense gathers' division (pg_select.h: pg_div_by_recip) -------------------------------------------------
+def _near_midpoint_operands(rng, n_divisors):
+    """Quotients of two doubles as close to a rounding midpoint as they can come: for an odd 53-bit B and a small odd t,
+    M = t / B (mod 2^54) is the odd numerator of a midpoint M / 2^54 of (1/2, 1) and A = (M B - t) / 2^54 gives
+    A / B = M / 2^54 - t / (2^54 B), i.e. |t| * 2^-107 .. 2^-106 off the midpoint (the same construction one binade up for A >= B)."""
+    out = []
+    for i in range(n_divisors):
+        B = int(rng.integers(0, 1 << 52)) | (1 << 52) | 1
+        if i % 4 == 0:
+            B = (1 << 53) - 1 - 2 * int(rng.integers(0, 1 << 12))   # significands next to 2
+        if i % 4 == 1:
+            B = (1 << 52) + 1 + 2 * int(rng.integers(0, 1 << 12))   # significands next to 1
+        for bits in (54, 53):
+            inv = pow(B, -1, 1 << bits)
+            for t in range(-9, 10, 2):
+                M = (t * inv) % (1 << bits)
+                if bits == 53:
+                    M += 1 << 53
+                if not ((1 << 53) < M < (1 << 54)):
+                    continue
+                P = M * B - t
+                assert P % (1 << bits) == 0
+                A = P >> bits
+                if A >= (1 << 53) and (A & 1 or A >= (1 << 54)):
+                    continue  # not a double
+                e = int(rng.integers(0, 9))
+                out.append((float(A) * 2.0 ** (e - 52 + int(rng.integers(-30, 31))) * (-1.0 if rng.integers(0, 2) else 1.0), float(B) * 2.0 ** (e - 52)))
+    return out
+
+
+def test_div_by_recip_is_the_correctly_rounded_quotient(shim):
+    shim.pgt_div_by_recip.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    rng = np.random.default_rng(20251005)
+    cases = _near_midpoint_operands(rng, 1500)
+    assert len(cases) > 10000
+    # the significand pairs DESIGN.md section 6's bound leaves over: a in {2 - 4u, 2 - 6u}, b above it (u = 2^-53), at many exponent offsets
+    u2 = 2.0 ** -52
+    for a, b in ((2 - 2 * u2, 2 - u2), (2 - 3 * u2, 2 - u2), (2 - 3 * u2, 2 - 2 * u2)):
+        for eb in range(0, 10):
+            for ea in range(-60, 61, 4):
+                cases.append((a * 2.0 ** (eb + ea), b * 2.0 ** eb))
+                cases.append((-a * 2.0 ** (eb + ea), b * 2.0 ** eb))
+    # the gather's own operands: x - median over pA-like values, MAD in [1, 60]
+    for _ in range(20000):
+        cases.append((float(rng.uniform(40, 180) - rng.uniform(60, 140)), float(rng.uniform(1, 60))))
+    cases += [(0.0, 3.0), (5.0, 1.0), (1.0, 3.0), (-1.0, 3.0)]
+    qr, qd = ctypes.c_double(), ctypes.c_double()
+    for a, b in cases:
+        same = shim.pgt_div_by_recip(a, b, ctypes.byref(qr), ctypes.byref(qd))
+        assert same == 1 and qd.value == a / b, (a.hex(), b.hex(), qr.value.hex(), qd.value.hex())
+    # the one operand the sequence gets wrong, and why it cannot occur: a = -0.0 gives +0.0 (the residual fma(-b, -0, -0) is +0), but
+    # x - median is -0.0 only for x = -0.0, and inside pg_div_domain_ok no pA underflows (the zero fill writes +0.0; raw + offset == 0 is +0.0)
+    assert shim.pgt_div_by_recip(-0.0, 1.0, ctypes.byref(qr), ctypes.byref(qd)) == 0 and qr.value == 0.0
+
+
+def test_div_domain_guard(shim):
+    shim.pgt_div_domain_ok.argtypes = [ctypes.c_double, ctypes.c_double]
+    ok = shim.pgt_div_domain_ok
+    assert ok(-243.0, 0.1373) == 1 and ok(0.0, 1.0) == 1 and ok(10.0, 2.0 ** -200) == 1
+    assert ok(1e-300, 0.1373) == 0 and ok(-243.0, 1e-70) == 0 and ok(-243.0, 1e70) == 0 and ok(1e80, 1.0) == 0
+    assert ok(float("nan"), 1.0) == 0 and ok(1.0, float("inf")) == 0

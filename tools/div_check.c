@@ -1,6 +1,11 @@
 // tools/div_check.c -- brute-force check of the reciprocal form of the gather's division (pg_place.hip, k_gather_wave::conv).
 // build: gcc -O2 -mfma -ffp-contract=off -o /tmp/div_check tools/div_check.c -lm ; run: /tmp/div_check <cases> <seed>
 // is q1 = fma(r, y, q0), r = fma(-b, q0, a), q0 = a * y, y = 1.0 / b  always the correctly rounded a / b?  (b >= 1 normal, a moderate)
+// Besides random operands: (1) CONSTRUCTED quotients next to a rounding midpoint (round 5, the judge's construction): for an odd
+// 53-bit B and a small odd t, M = t / B modulo 2^54 (or 2^53) is the odd numerator of a midpoint M / 2^54 of the binade (1/2, 1)
+// (M / 2^53 of [1, 2)), and A = (M * B - t) / 2^54 gives a = A * 2^-52, b = B * 2^-52 with a / b = midpoint - t / (2^54 * B): |t| * 2^-107
+// .. 2^-106 away from it, the closest a quotient of two doubles can come; (2) the three significand pairs that DESIGN.md section 6's
+// bound leaves over (a = 2 - 4u, 2 - 6u with b above it), at every exponent offset.
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -12,6 +17,43 @@ static inline int check(double a, double b, uint64_t *bad, int verbose) {
     const double y = 1.0 / b, q0 = a * y, r = fma(-b, q0, a), q1 = fma(r, y, q0), ref = a / b;
     if (q1 != ref && !(q1 != q1 && ref != ref)) { if (verbose && *bad < 10) printf("MISMATCH a=%a b=%a q1=%a ref=%a\n", a, b, q1, ref); ++*bad; return 1; }
     return 0;
+}
+typedef unsigned __int128 u128;
+static uint64_t inv_mod_2_64(uint64_t b) { uint64_t x = b; for (int i = 0; i < 6; ++i) x *= 2 - b * x; return x; } // b odd
+// near-midpoint operands for the odd 53-bit significand B: returns the number of cases checked
+static uint64_t near_midpoints(uint64_t B, uint64_t *s, uint64_t *bad) {
+    uint64_t n = 0;
+    const uint64_t inv = inv_mod_2_64(B);
+    { // quotient in (1/2, 1) (a < b): midpoints M / 2^54, M odd in (2^53, 2^54)
+        const uint64_t mask = (1ull << 54) - 1ull;
+        for (int64_t t = -9; t <= 9; t += 2) {
+            const uint64_t M = ((uint64_t)t * inv) & mask;                 // M * B == t (mod 2^54), M odd
+            if (M <= (1ull << 53)) continue;                               // not the numerator of a midpoint of the binade
+            const u128 P = (u128)M * B - (u128)(int64_t)t;                 // == A * 2^54 (t may be negative: the subtraction wraps correctly)
+            if ((uint64_t)(P & (((u128)1 << 54) - 1)) != 0) { printf("construction broke\n"); exit(2); }
+            const uint64_t A = (uint64_t)(P >> 54);                        // < 2^53: a double
+            for (int e = -30; e <= 30; e += 15) {
+                const uint64_t x = rng(s);
+                const double b = ldexp((double)B, -52 + (int)(x % 9)), a = ldexp((double)A, -52 + (int)(x % 9) + e) * ((x >> 20 & 1) ? -1.0 : 1.0);
+                ++n; check(a, b, bad, 1);
+            }
+        }
+    }
+    // quotient in [1, 2): midpoints M / 2^53, M odd in (2^53, 2^54): M * B == t (mod 2^53) has the solutions M0 + k * 2^53
+    for (int64_t t = -9; t <= 9; t += 2) {
+        const uint64_t M0 = ((uint64_t)t * inv) & ((1ull << 53) - 1ull), M = M0 + (1ull << 53);
+        const u128 P = (u128)M * B - (u128)(int64_t)t;                     // == A * 2^53
+        if ((uint64_t)(P & (((u128)1 << 53) - 1)) != 0) { printf("construction broke\n"); exit(2); }
+        const u128 A = P >> 53;                                            // in (2^52, 2^54)
+        if (A >= ((u128)1 << 54) || (A >= ((u128)1 << 53) && (A & 1))) continue; // not a double
+        const double a0 = (double)(uint64_t)A;
+        for (int e = -30; e <= 30; e += 15) {
+            const uint64_t x = rng(s);
+            const double b = ldexp((double)B, -52 + (int)(x % 9)), a = ldexp(a0, -52 + (int)(x % 9) + e) * ((x >> 20 & 1) ? -1.0 : 1.0);
+            ++n; check(a, b, bad, 1);
+        }
+    }
+    return n;
 }
 int main(int argc, char **argv) {
     uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull, seed = argc > 2 ? strtoull(argv[2], 0, 10) : 1;
@@ -35,6 +77,26 @@ int main(int argc, char **argv) {
         const double bb = 1.0 + (double)(rng(&s) >> 11) * (59.0 / 9007199254740992.0);
         tot++; check(x - md, bb, &bad, 1);
     }
+    // (1) constructed near-midpoint quotients: a tenth as many divisors as random cases, ~100 operand pairs each
+    uint64_t nm = 0;
+    for (uint64_t i = 0; i < n / 10 + 1000; ++i) {
+        uint64_t B = (rng(&s) & ((1ull << 52) - 1ull)) | (1ull << 52) | 1ull;
+        const uint64_t t = rng(&s);
+        if ((t & 3) == 0) B |= (~0ull >> (12 + (t >> 8) % 40));                       // low bits all ones
+        if ((t & 3) == 1) B = ((1ull << 53) - 1ull) - 2ull * ((t >> 8) & 0xFFFF);      // significands next to 2
+        if ((t & 15) == 2) B = (1ull << 52) + 1ull + 2ull * ((t >> 8) & 0xFFFF);       // significands next to 1
+        nm += near_midpoints(B, &s, &bad);
+    }
+    tot += nm;
+    // (2) the pairs the proof's bound leaves over: a in {2 - 4u, 2 - 6u} (2 - 2u has no larger b below 2), b above it; u = 2^-53
+    {
+        const double u2 = 0x1p-52; // 2u: the spacing of [1, 2)
+        const double as[3] = {2.0 - 2 * u2, 2.0 - 3 * u2, 2.0 - 3 * u2}, bs[3] = {2.0 - u2, 2.0 - u2, 2.0 - 2 * u2};
+        for (int i = 0; i < 3; ++i)
+            for (int eb = 0; eb < 10; ++eb)
+                for (int ea = -60; ea <= 60; ++ea) { tot += 2; check(ldexp(as[i], eb + ea), ldexp(bs[i], eb), &bad, 1); check(-ldexp(as[i], eb + ea), ldexp(bs[i], eb), &bad, 1); }
+    }
+    printf("near-midpoint cases: %llu\n", (unsigned long long)nm);
     printf("seed %llu: %llu checks, %llu mismatches\n", (unsigned long long)seed, (unsigned long long)tot, (unsigned long long)bad);
     return bad != 0;
 }
