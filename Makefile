@@ -5,6 +5,7 @@
 #   oracle/                       the CPU oracle (test infrastructure)
 HIPCC ?= /opt/rocm/bin/hipcc
 CXX ?= g++
+CC ?= gcc
 ARCH ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-result
 CSRC = poregen_amd/csrc
@@ -45,8 +46,27 @@ variant:
 oracle_build:
 	$(MAKE) -C oracle
 
+# Sanitizer builds of everything that runs on the HOST (the reference has `make asan=1`, /root/reference/Makefile:28-31, and a valgrind
+# mode, test/test.sh:31-37): the shared host/device arithmetic + the file readers (build/asan/_pg_hosttest.so), the CPU oracle
+# (build/asan/libgmove_oracle.so, gmove_oracle, model_oracle) and `poregen reform` alone (build/asan/poregen_reform: the reform subtool
+# needs no device code). CPU box only -- there is no GPU AddressSanitizer on this pool. Run the CPU suite under them with
+#     make asan && make asan_test
+# (= LD_PRELOAD of libasan + PG_HOSTTEST_SO / PG_ORACLE_DIR / PG_REFORM_BIN pointing at build/asan, python's own leaks not reported).
+SAN = -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -g -O1
+asan:
+	@mkdir -p build/asan
+	$(CXX) $(SAN) -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o build/asan/_pg_hosttest.so $(CSRC)/pg_hosttest.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread
+	$(CC) $(SAN) -std=gnu99 -fPIC -ffp-contract=off -shared -o build/asan/libgmove_oracle.so oracle/gmove_oracle.c -lm
+	$(CC) $(SAN) -std=gnu99 -ffp-contract=off -o build/asan/gmove_oracle oracle/gmove_oracle_cli.c oracle/gmove_oracle.c -lm
+	$(CC) $(SAN) -std=gnu99 -ffp-contract=off -o build/asan/model_oracle oracle/model_oracle.c -lm
+	$(CXX) $(SAN) -std=c++17 -DPG_REFORM_ONLY -o build/asan/poregen_reform $(HOST)/main.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread
+asan_test: asan
+	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$$($(CC) -print-file-name=libasan.so):$$($(CC) -print-file-name=libubsan.so) \
+	    PG_HOSTTEST_SO=$(CURDIR)/build/asan/_pg_hosttest.so PG_ORACLE_DIR=$(CURDIR)/build/asan PG_REFORM_BIN=$(CURDIR)/build/asan/poregen_reform POREGEN_CLEAN_EXIT=1 \
+	    python3 -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
+
 clean:
 	rm -f poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all clean oracle_build fallback_probe variant
+.PHONY: all clean oracle_build fallback_probe variant asan asan_test

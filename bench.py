@@ -20,6 +20,9 @@ Prints ONE JSON line (rank 0). Objects besides the contract's fields:
   config3_mode  (N=1) BASELINE configs[3]: 50 000 DNA reads, k = 9 (262 144 k-mers), sample_limit 1000: ms/step, whole-step
                 fraction of the HBM roofline, per-kernel times
   all_kept_mode (N=1) the headline reads at sample_limit 5000 (configs[2]'s limit: every accepted event is kept)
+  ragged_mode   (N=1) DNA reads of lognormal length 2 000 .. 200 000 samples + 0.1 % of 10^6, the same 2 x 10^8 samples, k = 9 and k = 5:
+                k_read_stats' share of the roofline with the long reads split across waves, and with one wave per read
+  ms_per_step_blocks  three timed blocks (min / median / max) for value, one_stream_mode, config3_mode, all_kept_mode
   config2_mode  (N>1) BASELINE configs[2]: the same N x 50 000 reads as ONE job at sample_limit 5000, same weak-scaling step
   job_layer     (N>1) the step through pg_job_* (one process, N host threads, ncclCommInitAll), the path `poregen gmove
                 --devices` uses; fed from host memory, so PCIe-inclusive and never `value`
@@ -172,7 +175,7 @@ def main():
     # multi-GPU step: the statistics are queued between the issue of the all_gather and the wait for it (dist.sharded_step)
     defer = dist_step and not args.no_defer and not args.lazy and not args.overlap
 
-    def timed(params, steps, warmup):
+    def timed(params, steps, warmup, extra_blocks=0):
         """warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both sides, MAX over ranks."""
         eng = GmoveEngine(GmoveParams(kmers=kmers, defer_stats=defer, **params))
         if stream_ordered:
@@ -209,6 +212,21 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # two more blocks of the same K steps, reported beside the contract's block (`value` stays the first block: EXACTLY K timed steps):
+        # boxes, and minutes on one box, differ by several per cent
+        extra = []
+        for _ in range(extra_blocks):
+            tb = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            d2 = time.perf_counter() - tb
+            if world > 1:
+                t = torch.tensor([d2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d2 = float(t.item())
+            extra.append(d2 / steps * 1e3)
+        state["extra_blocks_ms"] = extra
         return eng, dt / steps * 1e3, enqueue_ms, state
 
     def useful_of(eng, state, limit):
@@ -243,8 +261,9 @@ def main():
         tot, use = sum(x["samples"] for x in per_rank), sum(x["useful_samples"] for x in per_rank)
         return {"all_kmers_complete": full, "samples": tot, "useful_samples": use, "useful_fraction": use / tot if tot else None, "per_rank": per_rank}
 
-    eng, ms_per_step, enqueue_ms, state = timed(p, args.steps, args.warmup)
+    eng, ms_per_step, enqueue_ms, state = timed(p, args.steps, args.warmup, extra_blocks=2)
     value = world * n_samples / (ms_per_step * 1e-3)
+    all_blocks = sorted([ms_per_step] + state["extra_blocks_ms"])
     useful = useful_of(eng, state, args.sample_limit)
 
     # ---- per-kernel times: the dispatches' own time stamps (PG_FLAG_PROFILE), separate untimed passes ----------
@@ -283,7 +302,7 @@ def main():
     # note of MI355X_MICROARCH.md): measured offline on the headline workload and committed under profiles/
     traffic = None; trace_ms = None; traffic_source = None
     headline = args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004" and args.k == 5
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if headline:
@@ -293,19 +312,22 @@ def main():
         except Exception:
             pass
     # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison
-    for name in ("r04_kernel_stats.csv", "r03_kernel_stats.csv", "r02_kernel_stats.csv"):
+    trace_name = None
+    for name in ("r05_kernel_stats.csv", "r04_kernel_stats.csv", "r03_kernel_stats.csv", "r02_kernel_stats.csv"):
         try:
             import csv
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
                 if row["Name"].startswith("k_read_stats(") and headline:
                     trace_ms = float(row["AverageNs"]) * 1e-6
+            trace_name = "profiles/" + name
             break
         except Exception:
             pass
     trace2_ms = None  # the same kernel in the committed trace of the DEFAULT command (two streams: it shares the chip there by design)
     try:
         import csv
-        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r04_kernel_stats_two_streams.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r04_kernel_stats_two_streams.csv")) else "r03_kernel_stats_two_streams.csv"))):
+        two = next(n for n in ("r05_kernel_stats_two_streams.csv", "r04_kernel_stats_two_streams.csv", "r03_kernel_stats_two_streams.csv") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        for row in csv.DictReader(open(os.path.join(ROOT, "profiles", two))):
             if row["Name"].startswith("k_read_stats(") and headline:
                 trace2_ms = float(row["AverageNs"]) * 1e-6
     except Exception:
@@ -316,7 +338,7 @@ def main():
         "bytes_per_launch": stats_bytes, "avg_launch_ms": stats_ms,
         "committed_trace_avg_launch_ms": trace_ms, "committed_trace_frac": (stats_bytes / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if trace_ms else None,
         "measured": "dispatch time stamps (HIP events attached to the launches) in a profile-mode pass of this run, kernels on one stream; "
-                    "the committed trace (profiles/r03_kernel_stats.csv) is `bench.py --one-stream` for the same reason: in the default two-stream "
+                    f"the committed trace ({trace_name}) is `bench.py --one-stream` for the same reason: in the default two-stream "
                     "step the statistics share the chip with the ranking kernels by design",
         "committed_trace_two_streams_avg_launch_ms": trace2_ms,
     }
@@ -343,11 +365,13 @@ def main():
     one_stream = None
     two_streams_on = world == 1 and not dist_step and not args.lazy and not args.one_stream
     if two_streams_on and not args.no_lazy_extra:
-        ts, tms, _, _ = timed(dict(p, overlap=False), args.steps, args.warmup)
+        ts, tms, _, tst = timed(dict(p, overlap=False), args.steps, args.warmup, extra_blocks=2)
+        tblocks = sorted([tms] + tst["extra_blocks_ms"]); tms = tblocks[1]
         tres = ts.finish()
         same = (np.array_equal(tres.samples, res.samples) and np.array_equal(tres.ev_read, res.ev_read)
                 and np.array_equal(tres.samp_off, res.samp_off))
-        one_stream = {"value": n_samples / (tms * 1e-3), "ms_per_step": tms, "whole_step_frac": balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        one_stream = {"value": n_samples / (tms * 1e-3), "ms_per_step": tms, "ms_per_step_blocks": {"min": tblocks[0], "median": tms, "max": tblocks[-1]},
+                      "whole_step_frac": balg / (tms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "results_equal_two_streams": bool(same)}
         ts.close()
 
@@ -364,6 +388,8 @@ def main():
             "statistics_placement": ("behind the issue of the all_gather (pg_stats)" if defer else "inside pg_count") if dist_step else None,
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples, "homopolymer_frac": hp_frac,
         },
+        "ms_per_step_blocks": {"contract_block": ms_per_step, "min": all_blocks[0], "median": all_blocks[len(all_blocks) // 2], "max": all_blocks[-1], "steps_per_block": args.steps,
+                               "note": "value / ms_per_step are the first block (exactly --steps timed steps); two more blocks of the same length follow it"},
         "roofline": roofline,
         "whole_step": whole_step,
         "whole_step_frac": whole_step["frac"],
@@ -396,6 +422,7 @@ def main():
         del shard
         torch.cuda.empty_cache()
         out["config3_mode"] = config3_mode(dev)
+        out["ragged_mode"] = ragged_mode(dev)
         out["end_to_end"] = end_to_end(host, args)
         out["extras_seconds"] = time.time() - t0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -408,7 +435,7 @@ def main():
         dist.destroy_process_group()
 
 
-def mode_run(shard, host, kmers, q, what, steps=20):
+def mode_run(shard, host, kmers, q, what, steps=10):
     """One more workload on a device-resident batch: ms per step (plain pg_submit: the library's default, two streams), the whole step
     against the HBM roofline, per-kernel times from a separate profiled (one-stream) pass."""
     import torch
@@ -417,11 +444,14 @@ def mode_run(shard, host, kmers, q, what, steps=20):
     for _ in range(5):
         e.reset(); e.submit(shard)
     e.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e.reset(); e.submit(shard)
-    e.sync(); torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    blocks = []  # three timed blocks: boxes (and minutes) differ by several per cent, one number says little
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.reset(); e.submit(shard)
+        e.sync(); torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / steps * 1e3)
+    ms = sorted(blocks)[1]
     v = e.device_view()
     ke, ksm = int(v.n_events), int(v.n_samples)
     e.close()
@@ -432,13 +462,17 @@ def mode_run(shard, host, kmers, q, what, steps=20):
     for _ in range(5):
         pe.reset(); pe.submit(shard)
     pe.sync()
-    ks = {k: v2[1] / 5 for k, v2 in pe.kernel_stats().items()}
+    raw = pe.kernel_stats()
+    counters = {k: v2[0] for k, v2 in raw.items() if v2[1] == 0.0 and k in ("long_reads_split", "long_helpers_short_batches", "stats_cancelled_on_device")}
+    ks = {k: v2[1] / 5 for k, v2 in raw.items() if k not in counters}
     pe.close()
     n_ops, n_bases = int(host.op_off[-1]), int(host.seq_off[-1])
     balg = b_alg(host.n_samples, host.n_reads, n_ops, n_bases, ksm, ke, len(kmers))
-    return {"workload": what, "sample_limit": q["sample_limit"], "ms_per_step": ms, "value": host.n_samples / (ms * 1e-3), "unit": "samples/s",
+    return {"workload": what, "sample_limit": q["sample_limit"], "ms_per_step": ms, "ms_per_step_blocks": {"min": min(blocks), "median": ms, "max": max(blocks), "steps_per_block": steps},
+            "value": host.n_samples / (ms * 1e-3), "unit": "samples/s",
             "kept_events": ke, "kept_samples": ksm, "algorithmic_bytes": balg, "whole_step_frac": balg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "kernels_ms_per_step": ks}
+            "whole_step_frac_blocks": {"min": balg / (max(blocks) * 1e-3) / 1e9 / HBM_PEAK_GBS, "max": balg / (min(blocks) * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernels_ms_per_step": ks, "counters": counters}
 
 
 def config3_mode(dev):
@@ -461,6 +495,39 @@ def config3_mode(dev):
     r["skew"] = {"accepted_events": int(acc.sum()), "slots_at_cap": int((acc >= 1000).sum()), "events_cut_by_cap": int(np.maximum(acc - 1000, 0).sum()),
                  "largest_slot": int(acc.max()), "largest_region_share_of_512": float(reg.max() / max(1, reg.sum())), "mean_region_share": 1.0 / 512}
     return r
+
+
+def ragged_mode(dev):
+    """The regime no fixed-length workload shows (SURVEY section 5 "long-context", section 7 "hard parts"): DNA reads of lognormal length
+    2 000 .. 200 000 samples plus 0.1 % reads of 10^6 samples, 2 x 10^8 samples in all -- the headline's total -- at k = 9 (configs[3]'s
+    flags) and k = 5. A read above 32 768 samples has its statistics cut into slices for several waves (pg_internal.h: PgLongState);
+    `one_wave_per_read` is the same step with that switched off (PGMOVE_NO_LONG_SPLIT=1): one wave then streams a 2 MB read alone."""
+    import numpy as np
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    L = synth.ragged_lengths(total_samples=200_000_000, seed=20251005)
+    host = synth.make_ragged_fast(L, kind="dna_r10", seed=20251005 + 7)
+    shard = host.to_device(dev)
+    out = {"reads": int(host.n_reads), "samples": int(host.n_samples), "ss_ops": int(host.op_off[-1]),
+           "read_length": {"min": int(L.min()), "median": int(np.median(L)), "mean": float(L.mean()), "max": int(L.max()), "reads_of_1e6": int((L == 1_000_000).sum()),
+                           "reads_above_split_threshold_32768": int((L > 32768).sum()), "share_of_samples_in_them": float(L[L > 32768].sum() / L.sum())}}
+    stats_bytes = 2 * host.n_samples + 56 * host.n_reads
+    for k, limit in ((9, 1000), (5, 100)):
+        kmers = generate_kmers(k, rna=False)
+        q = dict(kmer_size=k, rna=False, scaling=1, sample_limit=limit, device=dev.index or 0)
+        r = mode_run(shard, host, kmers, q, f"ragged DNA reads, k={k}, scaling med-MAD, sample_limit={limit}", steps=5)
+        ms = r["kernels_ms_per_step"].get("k_read_stats")
+        r["k_read_stats"] = {"avg_launch_ms": ms, "bytes_per_launch": stats_bytes, "GB/s": stats_bytes / (ms * 1e-3) / 1e9, "frac": stats_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        os.environ["PGMOVE_NO_LONG_SPLIT"] = "1"
+        try:
+            r1 = mode_run(shard, host, kmers, q, "the same, one wave per read", steps=3)
+        finally:
+            del os.environ["PGMOVE_NO_LONG_SPLIT"]
+        ms1 = r1["kernels_ms_per_step"].get("k_read_stats")
+        r["one_wave_per_read"] = {"ms_per_step": r1["ms_per_step"], "whole_step_frac": r1["whole_step_frac"], "k_read_stats_ms": ms1,
+                                  "k_read_stats_frac": stats_bytes / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        out[f"k{k}"] = r
+    return out
 
 
 def job_layer(args, world, rank, dist):

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+_HERE = os.environ.get("PG_ORACLE_DIR") or os.path.dirname(os.path.abspath(__file__))  # PG_ORACLE_DIR: the sanitizer builds (make asan)
 LIB = os.path.join(_HERE, "libgmove_oracle.so")
 CLI = os.path.join(_HERE, "gmove_oracle")
 

@@ -86,18 +86,23 @@ bool Slow5File::index_blow5(std::string &err) {
     if (sig_press_ > 1) { err = "BLOW5 signal compression other than none/svb-zd is not supported"; return false; }
     uint32_t hlen; memcpy(&hlen, d + 64, 4);
     uint64_t pos = 68 + (uint64_t)hlen;
+    if (pos > f_.size) { err = "truncated BLOW5 header"; return false; }
+    bool eof_marker = false;
     z_stream zs; bool zs_ready = false; // one inflate state for all record heads (inflateReset is far cheaper than inflateInit)
     struct ZEnd { z_stream *z; bool *on; ~ZEnd() { if (*on) inflateEnd(z); } } zend{&zs, &zs_ready};
-    while (pos + 8 <= f_.size) {
-        if (f_.size - pos >= 5 && memcmp(d + pos, "5WOLB", 5) == 0) break;
+    for (;;) {
+        if (f_.size - pos >= 5 && memcmp(d + pos, "5WOLB", 5) == 0) { eof_marker = true; break; }
+        if (f_.size - pos < 8) break;
         uint64_t sz; memcpy(&sz, d + pos, 8);
         pos += 8;
-        if (pos + sz > f_.size) { err = "truncated BLOW5 record"; return false; }
+        if (sz > f_.size - pos) { err = "truncated BLOW5 record"; return false; } // (not pos + sz: a size field of 2^64 - 1 must not wrap)
+        if (sz < 2) { err = "corrupt BLOW5 record"; return false; }
         Loc l{pos, sz};
         // the read id sits at the start of the (possibly zlib-compressed) body
         std::string id;
         if (rec_press_ == 0) {
             uint16_t il; memcpy(&il, d + pos, 2);
+            if ((uint64_t)il + 2 > sz) { err = "corrupt BLOW5 record"; return false; }
             id.assign((const char *)d + pos + 2, il);
         } else {
             // only the first bytes of the record are inflated: u16 id length + id (a first try of 256 bytes covers every
@@ -123,13 +128,14 @@ bool Slow5File::index_blow5(std::string &err) {
         order_.push_back(id);
         pos += sz;
     }
+    if (!eof_marker) { err = "truncated BLOW5 file (no end-of-file marker)"; return false; } // slow5 specification: every BLOW5 file ends in "5WOLB"
     return true;
 }
 
 // streamvbyte (Lemire) decode of `n` uint32 values: ceil(n/4) control bytes, then 1-4 data bytes per value
 static bool svb_decode(const unsigned char *in, size_t in_len, uint32_t n, std::vector<uint32_t> &out) {
     const size_t nctrl = ((size_t)n + 3) / 4;
-    if (in_len < nctrl) return false;
+    if (in_len < nctrl || (size_t)n > in_len - nctrl) return false; // every value has a control field and at least one data byte: checked BEFORE anything is sized by n
     const unsigned char *ctrl = in, *dp = in + nctrl, *end = in + in_len;
     out.resize(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -155,6 +161,9 @@ bool Slow5File::decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) cons
             int rc = uncompress(inflated.data(), &dl, body, (uLong)blen);
             if (rc == Z_OK) { inflated.resize(dl); break; }
             if (rc != Z_BUF_ERROR) { err = "zlib error in BLOW5 record"; return false; }
+            // Z_BUF_ERROR is "output too small" AND "the stream ends before its end marker": deflate expands by at most 1032 : 1, so a
+            // buffer beyond that says the record is cut short -- not a reason to double the buffer until memory runs out
+            if (cap > blen * 1100 + (1u << 20)) { err = "zlib error in BLOW5 record (incomplete stream)"; return false; }
             cap *= 2;
         }
         body = inflated.data(); blen = inflated.size();
@@ -170,16 +179,16 @@ bool Slow5File::decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) cons
     memcpy(&out.digitisation, body + p, 8); memcpy(&out.offset, body + p + 8, 8); memcpy(&out.range, body + p + 16, 8);
     memcpy(&sampling, body + p + 24, 8); p += 32;
     uint64_t len; memcpy(&len, body + p, 8); p += 8;
-    out.raw.resize(len);
     if (sig_press_ == 0) {
-        if (!need(len * 2)) { err = "corrupt BLOW5 record (signal)"; return false; }
+        if (len > (blen - p) / 2) { err = "corrupt BLOW5 record (signal)"; return false; } // (before the vector is sized by a number the file supplied)
+        out.raw.resize(len);
         memcpy(out.raw.data(), body + p, len * 2);
         return true;
     }
     // svb-zd: in the record len_raw_signal holds the BYTE length of the compressed signal; the compressed
     // block is u32 count + streamvbyte of zig-zag deltas of the int16 samples widened to int32
     const uint64_t clen = len;
-    if (!need(clen) || clen < 4) { err = "corrupt BLOW5 record (svb-zd)"; return false; }
+    if (clen > blen - p || clen < 4) { err = "corrupt BLOW5 record (svb-zd)"; return false; }
     uint32_t count; memcpy(&count, body + p, 4);
     std::vector<uint32_t> zz;
     if (!svb_decode(body + p + 4, clen - 4, count, zz)) { err = "corrupt streamvbyte block"; return false; }
@@ -368,13 +377,14 @@ bool SamBamReader::open(const std::string &path, std::string &err) {
     if (!fill(12, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
     if (memcmp(buf_.data(), "BAM\1", 4) != 0) { err = "not a BAM file"; return false; }
     int32_t l_text; memcpy(&l_text, buf_.data() + 4, 4);
-    if (!fill(12 + (size_t)l_text, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
+    if (l_text < 0 || !fill(12 + (size_t)l_text, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
     bpos_ = 8 + (size_t)l_text;
     int32_t n_ref; memcpy(&n_ref, buf_.data() + bpos_, 4); bpos_ += 4;
+    if (n_ref < 0) { err = "corrupt BAM header"; return false; }
     for (int32_t i = 0; i < n_ref; i++) {
-        if (!fill(bpos_ + 4, err)) return false;
+        if (!fill(bpos_ + 4, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
         int32_t l_name; memcpy(&l_name, buf_.data() + bpos_, 4);
-        if (!fill(bpos_ + 8 + (size_t)l_name, err)) return false;
+        if (l_name < 0 || !fill(bpos_ + 8 + (size_t)l_name, err)) { if (err.empty()) err = "truncated BAM header"; return false; }
         bpos_ += 4 + (size_t)l_name + 4;
     }
     return true;
@@ -387,15 +397,18 @@ bool SamBamReader::fill(size_t need, std::string &err) {
         const unsigned char *b = (const unsigned char *)f_.data + pos_;
         if (b[0] != 0x1f || b[1] != 0x8b || !(b[3] & 4)) { err = "corrupt BGZF block"; return false; }
         uint16_t xlen; memcpy(&xlen, b + 10, 2);
+        if (12u + (size_t)xlen > f_.size - pos_) { err = "corrupt BGZF block"; return false; } // the extra field itself must lie inside the file
         uint32_t bsize = 0; bool found = false;
         for (size_t o = 12; o + 4 <= 12u + xlen;) { // extra subfields: SI1 SI2 SLEN data
             uint16_t slen; memcpy(&slen, b + o + 2, 2);
-            if (b[o] == 'B' && b[o + 1] == 'C' && slen == 2) { uint16_t v; memcpy(&v, b + o + 4, 2); bsize = (uint32_t)v + 1; found = true; }
+            if (b[o] == 'B' && b[o + 1] == 'C' && slen == 2 && o + 6 <= 12u + xlen) { uint16_t v; memcpy(&v, b + o + 4, 2); bsize = (uint32_t)v + 1; found = true; }
             o += 4u + slen;
         }
-        if (!found || pos_ + bsize > f_.size) { err = "corrupt BGZF block"; return false; }
-        const size_t hdr = 12u + xlen, clen = bsize - hdr - 8;
+        const size_t hdr = 12u + xlen;
+        if (!found || bsize > f_.size - pos_ || bsize < hdr + 8) { err = "corrupt BGZF block"; return false; }
+        const size_t clen = bsize - hdr - 8;
         uint32_t isize; memcpy(&isize, b + bsize - 4, 4);
+        if (isize > 65536u) { err = "corrupt BGZF block"; return false; } // (SAM specification 4.1: a block inflates to at most 64 KiB)
         const size_t old = buf_.size();
         buf_.resize(old + isize);
         if (isize) {
@@ -465,19 +478,24 @@ int SamBamReader::next(MoveRec &out, std::string &err) {
     const uint8_t l_read_name = r[8];
     uint16_t n_cigar; memcpy(&n_cigar, r + 12, 2);
     int32_t l_seq; memcpy(&l_seq, r + 16, 4);
+    // every length below comes from the file: compared as sizes against what is left of the record, never added to a pointer first
     const unsigned char *p = r + 32;
-    if (p + l_read_name > rend) { err = "corrupt BAM record"; return -1; }
+    auto left = [&]() { return (size_t)(rend - p); };
+    if ((size_t)l_read_name > left()) { err = "corrupt BAM record"; return -1; }
     out.qname.assign((const char *)p, l_read_name ? l_read_name - 1 : 0); p += l_read_name;
-    p += 4u * n_cigar;
-    if (p + (l_seq + 1) / 2 + l_seq > rend) { err = "corrupt BAM record"; return -1; }
+    if (4u * (size_t)n_cigar > left()) { err = "corrupt BAM record"; return -1; }
+    p += 4u * (size_t)n_cigar;
+    if (l_seq < 0 || ((size_t)l_seq + 1) / 2 + (size_t)l_seq > left()) { err = "corrupt BAM record"; return -1; }
     static const char code[] = "=ACMGRSVTWYHKDBN";
     out.seq.resize((size_t)l_seq);
     for (int32_t i = 0; i < l_seq; i++) out.seq[(size_t)i] = seq_letter(code[(p[i >> 1] >> ((~i & 1) << 2)) & 15]);
-    p += (l_seq + 1) / 2 + l_seq;
-    while (p + 3 <= rend) { // tags
+    p += ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    while (left() >= 3) { // tags
         const char t0 = (char)p[0], t1 = (char)p[1], ty = (char)p[2];
         p += 3;
         int64_t iv = 0; bool is_int = false; size_t adv = 0;
+        const size_t fixed = (ty == 'A' || ty == 'c' || ty == 'C') ? 1 : (ty == 's' || ty == 'S') ? 2 : (ty == 'i' || ty == 'I' || ty == 'f') ? 4 : 0;
+        if (fixed > left()) { err = "corrupt BAM tag"; return -1; } // the value is read below: it must lie inside the record
         switch (ty) {
             case 'A': adv = 1; break;
             case 'c': iv = (int8_t)p[0]; is_int = true; adv = 1; break;
@@ -487,12 +505,12 @@ int SamBamReader::next(MoveRec &out, std::string &err) {
             case 'i': { int32_t v; memcpy(&v, p, 4); iv = v; is_int = true; adv = 4; break; }
             case 'I': { uint32_t v; memcpy(&v, p, 4); iv = v; is_int = true; adv = 4; break; }
             case 'f': adv = 4; break;
-            case 'Z': case 'H': { const unsigned char *z = (const unsigned char *)memchr(p, 0, (size_t)(rend - p)); if (!z) { err = "corrupt BAM tag"; return -1; } adv = (size_t)(z - p) + 1; break; }
+            case 'Z': case 'H': { const unsigned char *z = (const unsigned char *)memchr(p, 0, left()); if (!z) { err = "corrupt BAM tag"; return -1; } adv = (size_t)(z - p) + 1; break; }
             case 'B': {
-                if (p + 5 > rend) { err = "corrupt BAM tag"; return -1; }
+                if (left() < 5) { err = "corrupt BAM tag"; return -1; }
                 const char sub = (char)p[0]; int32_t cnt; memcpy(&cnt, p + 1, 4);
                 const size_t esz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-                if (p + 5 + esz * (size_t)cnt > rend) { err = "corrupt BAM tag"; return -1; }
+                if (cnt < 0 || (size_t)cnt > (left() - 5) / esz) { err = "corrupt BAM tag"; return -1; }
                 if (t0 == 'm' && t1 == 'v') {
                     out.has_mv = true; out.mv_is_Bc = sub == 'c'; out.mv_len = (uint32_t)cnt;
                     if (out.mv_is_Bc && cnt > 0) {
@@ -505,7 +523,7 @@ int SamBamReader::next(MoveRec &out, std::string &err) {
             }
             default: err = "unknown BAM tag type"; return -1;
         }
-        if (p + adv > rend) { err = "corrupt BAM tag"; return -1; }
+        if (adv > left()) { err = "corrupt BAM tag"; return -1; }
         if (is_int && t0 == 'n' && t1 == 's') { out.ns = (uint64_t)iv; out.has_ns = true; }
         if (is_int && t0 == 't' && t1 == 's') { out.ts = (uint64_t)iv; out.has_ts = true; }
         p += adv;

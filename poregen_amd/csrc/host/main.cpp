@@ -7,7 +7,11 @@
 #include <cstdlib>
 #include <unistd.h>
 
+#ifdef PG_REFORM_ONLY // the sanitizer build of the host-only subtool (Makefile: asan): no device code linked
+static int gmove_main(int, char **) { fprintf(stderr, "[poregen] this build holds reform only\n"); return 1; }
+#else
 int gmove_main(int argc, char **argv);
+#endif
 int reform_main(int argc, char **argv);
 
 static double realtime() { struct timeval tp; gettimeofday(&tp, nullptr); return tp.tv_sec + tp.tv_usec * 1e-6; }

@@ -102,6 +102,9 @@ struct pg_ctx {
     bool plan_in_init = false;   // this batch's statistics records were written by its k_batch_init
     bool stats_deferred = false; // PG_FLAG_DEFER_STATS: pg_count left the statistics to pg_stats / pg_collect
     DevBuf cancel_flag; bool cancel_pending = false; uint64_t stats_cancelled = 0; // pgi_stats_gathered: the device's own rank-level early-out
+    // long reads (PgLongState): helper table + per-read histograms in global memory, sized for long_cap helpers; long_want = helpers the
+    // next batch is expected to want (host batches: counted from sig_off; device batches: what the last settled batch wanted, at least 256)
+    DevBuf long_tab, long_hist; uint32_t long_cap = 0, long_use = 0, long_want = 256; uint64_t long_reads_split = 0, long_helpers_short = 0;
 
     PgDevBatch B{};       // current batch (device view)
     bool have_count = false, have_batch_result = false, downloaded = true;
@@ -254,7 +257,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals[0], &c->plan_totals[1], &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec[0], &c->ev_rec[1], &c->ev_len, &c->ev_read, &c->read_needed,
                       &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
                       &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1],
-                      &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->long_tab, &c->long_hist, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
@@ -381,7 +384,8 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(c->job_total.ensure(ns * 8ull)); CTRY(c->job_freq.ensure(ns * 8ull)); // allocated once: callers may cache the pointers
     CTRY(c->totals.ensure(256 * 4)); CTRY(c->dbase.ensure(256 * 4)); CTRY(c->scount.ensure(16)); CTRY(c->errflag.ensure(32));
     CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut), [24] u32 ticket (k_rank_scan)
-    CTRY(c->stat_err[0].ensure(16)); CTRY(c->stat_err[1].ensure(16));
+    CTRY(c->stat_err[0].ensure(32)); CTRY(c->stat_err[1].ensure(32)); // [0..2] statistics flags, [3] pg_div_domain_ok failed, [4..5] long-read counters (PgLongState::cnt)
+    CTRY(hipMemset(c->stat_err[0].p, 0, 32)); CTRY(hipMemset(c->stat_err[1].p, 0, 32));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
     PG_TMARK("create: events, tables, first buffers");
 #undef CTRY
@@ -479,9 +483,14 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
     if (!b->sig_off || !b->seq_off || !b->op_off) return fail(c, PG_ERR_INVALID_ARG, "batch offsets missing");
     const uint64_t ns = b->sig_off[n], nq = b->seq_off[n], no = b->op_off[n];
     if (b->sig_off[0] != 0 || b->seq_off[0] != 0 || b->op_off[0] != 0) return fail(c, PG_ERR_INVALID_ARG, "host batch offsets must start at 0");
-    for (uint32_t r = 0; r < n; r++)
+    uint64_t helpers = 0; // long reads of this batch (PgLongState): their helper slices, counted here (an upper bound: wide reads are not split)
+    for (uint32_t r = 0; r < n; r++) {
         if (b->sig_off[r + 1] < b->sig_off[r] || b->seq_off[r + 1] < b->seq_off[r] || b->op_off[r + 1] < b->op_off[r])
             return fail(c, PG_ERR_INVALID_ARG, "batch offsets of read %u are not monotone", r);
+        const uint64_t L = b->sig_off[r + 1] - b->sig_off[r];
+        if (L > PG_LONG_MIN) { uint32_t S; uint64_t sl; pg_long_geometry(L, &S, &sl); helpers += S - 1; }
+    }
+    c->long_want = (uint32_t)std::min<uint64_t>(helpers, 1u << 22);
     struct Item { DevBuf *d; const void *src; size_t bytes; };
     Item items[] = {{&c->s_sig, b->sig, ns * 2}, {&c->s_sig_off, b->sig_off, (n + 1) * 8ull}, {&c->s_dig, b->digitisation, n * 8ull},
                     {&c->s_off, b->offset, n * 8ull}, {&c->s_range, b->range, n * 8ull}, {&c->s_qs, b->query_start, n * 4ull},
@@ -505,13 +514,19 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
 
 static pg_status check_read_errors(pg_ctx *c) {
     struct { unsigned long long word; int32_t layout, pad; uint32_t gen_count[2]; } ef;
-    int32_t errv[1] = {INT_MAX}, errs[3] = {INT_MAX, 0, 0};
+    int32_t errv[1] = {INT_MAX}, errs[6] = {INT_MAX, 0, 0, 0, 0, 0};
     HIP_TRY(c, hipMemcpy(&ef, c->errflag.p, sizeof ef, hipMemcpyDeviceToHost));
     if (ef.layout) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.n_ops (%llu) is not op_off[n_reads] of the device batch", (unsigned long long)c->B.n_ops);
     if ((uint32_t)(ef.word >> 32) == c->batch_id) errv[0] = (int32_t)(0xFFFFFFFFu - (uint32_t)ef.word); // PgWalkOut::err
     c->gen_reads = ef.gen_count[c->batch_id & 1u];
     if (c->batch_all_matches && c->gen_reads) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.flags says PG_BATCH_ALL_MATCHES but %u reads hold I / D / unknown ops (or fewer ops than k, or more than bases)", c->gen_reads);
-    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 12, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 24, hipMemcpyDeviceToHost));
+    // long reads (PgLongState): what this batch wanted sizes a device batch's next launch; a host batch is counted before it is staged
+    if (errs[4] > 0 || errs[5] > 0) {
+        c->long_reads_split += (uint64_t)errs[5];
+        if ((uint32_t)errs[4] > c->long_use) c->long_helpers_short++;
+    }
+    if (!c->batch_is_host) c->long_want = std::max<uint32_t>(256u, errs[4] > 0 ? (uint32_t)errs[4] : 0u);
     // the rare statistics launch of the NEXT batch is sized by what this one needed (its blocks stride over the list: the
     // size only decides how fast a wide list is worked off; jobs without wide reads pay for 128 workgroups, not 2112)
     c->wide_blocks = errs[1] > 0 ? (uint32_t)errs[1] : 0u;
@@ -557,6 +572,7 @@ static pg_status ensure_stats_buffers(pg_ctx *c) {
     return PG_OK;
 }
 
+static pg_status fill_long(pg_ctx *c, PgLongState &LS, bool ensure);
 // statistics of every read of the current batch: both LDS-histogram variants are queued back to back, each
 // handles the reads whose in-range code interval fits it (no host decision, no sync)
 // plan_done: the records (and the flag reset) were written by this batch's k_batch_init
@@ -571,16 +587,18 @@ static pg_status launch_stats(pg_ctx *c, hipStream_t st, const uint8_t *needed, 
     uint8_t *oor = skip_oor ? c->oor.as<uint8_t>() : nullptr;
     const int range_only = c->prm.scaling != 1; // only the out-of-range flags are wanted
     int32_t *flags = c->stat_err[sl].as<int32_t>(); // [0] lowest failing read, [1] / [2] lengths of the wide / huge list
+    PgLongState LS{};
+    { pg_status sl_ = fill_long(c, LS, false); if (sl_ != PG_OK) return sl_; }
     if (!plan_done) {
         prof_begin(c, "k_read_plan", st);
-        HIP_TRY(c, pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset));
+        HIP_TRY(c, pg_launch_read_plan(st, c->B, needed, c->prm.pa_min, c->prm.pa_max, c->read_plan[sl].p, flags, c->stat_status[sl].as<int32_t>(), flags_are_reset, LS));
         prof_end(c, st);
     }
     const int win = (c->prm.flags & PG_FLAG_DEBUG_NARROW) ? 0 : 15;
     prof_begin(c, "k_read_stats", st);
     HIP_TRY(c, pg_launch_read_stats(st, c->B, c->read_plan[sl].p, c->med[sl].as<double>(), c->mad[sl].as<double>(),
                          c->stat_status[sl].as<int32_t>(), flags, win, c->wide_list[sl].as<uint32_t>(), flags + 1, oor, range_only,
-                         c->gcal[sl].as<double>()));
+                         c->gcal[sl].as<double>(), LS));
     prof_end(c, st);
     // the rare reads (in-range interval wider than 1024 codes; usually none): their workers ride in the launch of the sample-offset
     // scan when that comes next on the same stream (rare_pending); otherwise a launch of their own, here
@@ -614,6 +632,31 @@ static void fill_walk(pg_ctx *c, PgWalkParams &W, PgWalkOut &O) {
     O.oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) ? c->oor.as<uint8_t>() : nullptr;
 }
 
+// the long-read split of the statistics (PgLongState) for the batch in statistics slot c->slot; ensure = size the buffers for this batch
+static pg_status fill_long(pg_ctx *c, PgLongState &LS, bool ensure) {
+    LS = PgLongState{};
+    if (getenv("PGMOVE_NO_LONG_SPLIT")) return PG_OK; // (tests, A/B: every read by one wave)
+    if (ensure) {
+        const char *ov = getenv("PGMOVE_LONG_HELPERS"); // (tests: a cap below what the batch wants)
+        uint32_t want = ov ? (uint32_t)strtoul(ov, nullptr, 10) : c->long_want;
+        if (want > (1u << 22)) want = 1u << 22;
+        if (want > c->long_cap || !c->long_tab.p) {
+            const uint32_t cap = want + want / 4 + 64;
+            HIP_TRY(c, c->long_tab.ensure((size_t)cap * 8));
+            const size_t before = c->long_hist.cap;
+            HIP_TRY(c, c->long_hist.ensure((size_t)cap * PG_LONG_WORDS * 4));
+            if (c->long_hist.cap != before) HIP_TRY(c, hipMemsetAsync(c->long_hist.p, 0, c->long_hist.cap, c->st)); // zero between batches: the last slice of a read leaves it so
+            c->long_cap = cap;
+        }
+        // this batch's helpers: what it is expected to want plus a margin (a batch without long reads launches 64 helper workgroups, not the
+        // thousands an earlier batch needed); PGMOVE_LONG_HELPERS: exactly that many
+        c->long_use = ov ? std::min<uint32_t>(c->long_cap, want) : std::min<uint32_t>(c->long_cap, want + want / 4 + 64);
+    }
+    LS.tab = c->long_tab.as<uint2>(); LS.hist = c->long_hist.as<uint32_t>(); LS.cap = c->long_use;
+    LS.cnt = c->stat_err[c->slot].as<int32_t>() + 4; LS.cnt_next = c->stat_err[c->slot ^ 1].as<int32_t>() + 4;
+    return PG_OK;
+}
+
 static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
     S.keys[0] = c->sk[0].as<uint32_t>(); S.keys[1] = c->sk[1].as<uint32_t>();
     S.vals[0] = c->sv[0].as<uint32_t>(); S.vals[1] = c->sv[1].as<uint32_t>();
@@ -627,7 +670,7 @@ static void fill_sort(pg_ctx *c, PgSortBufs &S, uint32_t n_tiles) {
 // 5000's mean of 28: 218 -> 197 us; k = 9: 837 -> 904). Every choice is correct for every window; PGMOVE_GATHER_LANES overrides
 // (measurements: 4 / 8 / 16 = round 3's k_gather_chunks with that many lanes per event).
 static int gather_lanes(const pg_ctx *c) {
-    static const char *ov = getenv("PGMOVE_GATHER_LANES");
+    const char *ov = getenv("PGMOVE_GATHER_LANES"); // read per collect: a test can switch the form between two jobs of one process
     if (ov) return atoi(ov);
     const uint32_t mw = c->win_hint ? c->win_hint : c->prm.min_dur + (c->prm.max_dur > c->prm.min_dur ? (c->prm.max_dur - c->prm.min_dur) / 8 : 0) + 2 * c->prm.signal_print_margin;
     return mw > 16 ? 1 : 0;
@@ -770,11 +813,13 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     const bool force_generic = (c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) != 0;
+    PgLongState LS{};
+    { pg_status sl_ = fill_long(c, LS, true); if (sl_ != PG_OK) return sl_; }
     prof_begin(c, "k_batch_init", c->st);
     HIP_TRY(c, pg_launch_batch_init(c->st, n, c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
                          c->zero_running ? 1 : 0, overlap ? nullptr : c->stat_err[c->slot].as<int32_t>(), c->B, c->prm.pa_min, c->prm.pa_max,
                          c->plan_in_init ? c->read_plan[c->slot].p : nullptr, c->plan_in_init ? c->stat_status[c->slot].as<int32_t>() : nullptr,
-                         W, O, force_generic ? 1 : 0));
+                         W, O, force_generic ? 1 : 0, LS));
     prof_end(c, c->st);
     c->stat_flags_reset = !overlap;
     c->zero_running = false;
@@ -1078,7 +1123,8 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     prof_begin(c, "k_gather", gst);
     if (chunked)
         HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling,
-                                           c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c)));
+                                           c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c),
+                                           c->prm.scaling == 1 ? c->stat_err[c->slot].as<int32_t>() : nullptr));
     else
         HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(),
                      c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
@@ -1548,6 +1594,14 @@ pg_status pg_kernel_stats(pg_ctx *c, pg_kernel_stat *out, uint32_t cap, uint32_t
         if (out && n < cap) { out[n].name = "stats_cancelled_on_device"; out[n].launches = c->stats_cancelled; out[n].total_ms = 0.0; }
         n++;
     }
+    if (c->long_reads_split) { // reads of the settled batches whose statistics were cut into slices (PgLongState)
+        if (out && n < cap) { out[n].name = "long_reads_split"; out[n].launches = c->long_reads_split; out[n].total_ms = 0.0; }
+        n++;
+    }
+    if (c->long_helpers_short) { // settled batches that wanted more helper waves than were launched (their surplus long reads ran on one wave each)
+        if (out && n < cap) { out[n].name = "long_helpers_short_batches"; out[n].launches = c->long_helpers_short; out[n].total_ms = 0.0; }
+        n++;
+    }
     *n_out = n;
     return PG_OK;
 }
@@ -1558,7 +1612,7 @@ pg_status pg_kernel_stats_reset(pg_ctx *c) {
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
     prof_drain(c);
-    c->prof_acc.clear(); c->prof_names.clear(); c->stats_cancelled = 0;
+    c->prof_acc.clear(); c->prof_names.clear(); c->stats_cancelled = 0; c->long_reads_split = 0; c->long_helpers_short = 0;
     return PG_OK;
 }
 

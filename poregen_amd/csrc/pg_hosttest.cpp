@@ -179,3 +179,31 @@ extern "C" int pgt_samplevec_hugepage(size_t n, long *anon_huge_kb) {
     if (anon_huge_kb) *anon_huge_kb = ahp;
     return hg;
 }
+
+// ---- corrupt-input probes (tests/test_host_corrupt.py): every read of a SLOW5/BLOW5 file / every record of a SAM/BAM file is decoded;
+// returns the number decoded, or -1 with the reader's message in errbuf -- never a crash
+static void put_err(const std::string &e, char *errbuf, size_t cap) { if (errbuf && cap) { const size_t n = e.size() < cap - 1 ? e.size() : cap - 1; memcpy(errbuf, e.data(), n); errbuf[n] = 0; } }
+extern "C" long pgt_slow5_scan(const char *path, char *errbuf, size_t cap) {
+    pgh::Slow5File f; std::string err;
+    if (!f.open(path, err)) { put_err(err, errbuf, cap); return -1; }
+    long n = 0;
+    for (const std::string &id : f.ids_in_file_order()) {
+        pgh::Slow5Rec r;
+        if (!f.get(id, r, err)) { put_err(err, errbuf, cap); return -1; }
+        ++n;
+    }
+    return n;
+}
+extern "C" long pgt_sambam_scan(const char *path, char *errbuf, size_t cap) {
+    pgh::SamBamReader rd; std::string err;
+    if (!rd.open(path, err)) { put_err(err, errbuf, cap); return -1; }
+    long n = 0;
+    for (;;) {
+        pgh::MoveRec m;
+        const int rc = rd.next(m, err);
+        if (rc < 0) { put_err(err, errbuf, cap); return -1; }
+        if (rc == 0) break;
+        ++n;
+    }
+    return n;
+}

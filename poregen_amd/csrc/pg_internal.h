@@ -166,7 +166,8 @@ hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_
 hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
                                   bool sums_ready);
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
-                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes);
+                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes,
+                                   const int32_t *stat_flags /* the batch's statistics flags (may be null): [3] != 0 = the wave / event-pair forms divide instead of using the reciprocal */);
 // pg_text.hip: the dump files' text on the device (flag[0] != 0 afterwards: a sample the fixed-point formatter does not take)
 hipError_t pg_launch_text_lens(hipStream_t st, const double *samples, const uint64_t *samp_off, uint64_t n_events, uint32_t *tlen, uint32_t *flag);
 hipError_t pg_launch_text_write(hipStream_t st, const double *samples, const uint64_t *samp_off, uint64_t n_events, const uint64_t *toff, char *text,
@@ -184,9 +185,38 @@ struct PgStatRec {
     double offset, scale;
     double inv;          // 1.0 / scale: only ever places the candidate windows of the selection (pg_select.h), computed once per read here
     uint32_t sym;        // pg_sym_guard: the symmetric selection path may be tried (pg_select.h)
-    uint32_t pad;
+    uint32_t split;      // long read cut into slices (PgLongState): index of its first helper + 1; 0 = one wave streams the whole read
 };
 enum { PG_STAT_RUN = 0, PG_STAT_SKIP = 1, PG_STAT_BAD = 2 };
+// ---- long reads (round 5): one wave streaming a whole read is 244 dependent passes for a 10^6-sample DNA read -- the tail of the batch.
+// A read above PG_LONG_MIN samples whose in-range interval fits the 1024-bin histogram is cut into slices of PG_LONG_SLICE samples
+// (doubled until at most PG_LONG_MAX_SLICES are left): slice 0 is binned by the read's own wave, the others by HELPER waves -- extra
+// workgroups at the end of k_read_stats' grid, assigned through a table that the record pass fills (a reservation per long read by one
+// atomic add). Every slice adds its LDS histogram to the read's histogram in global memory; the slice that finishes LAST (a counter)
+// takes the sum back, leaves the memory zeroed for the next batch and runs the selection: nobody waits for anybody. The selection is
+// the same code on the same counts, so the results are the one-wave path's bit for bit. A batch that wants more helpers than were
+// launched is still correct: the reads that found no room stay on the one-wave path, and the count the batch wanted sizes the next launch.
+#ifndef PG_LONG_MIN
+#define PG_LONG_MIN 32768u
+#endif
+#ifndef PG_LONG_SLICE
+#define PG_LONG_SLICE 16384u
+#endif
+#define PG_LONG_MAX_SLICES 1024u
+#define PG_LONG_WORDS 1128u   // a read's histogram in global memory: the LDS layout of the 1024-bin histogram (1124 words), [1127] = slices done
+#define PG_LONG_INVALID 0xFFFFFFFFu
+struct PgLongState {
+    uint2 *tab;        // [cap] helper h -> {read, slice}; {PG_LONG_INVALID, -} = reserved by a read that found no room
+    uint32_t *hist;    // [cap][PG_LONG_WORDS], zero between batches; a long read uses the entry of its FIRST helper
+    int32_t *cnt;      // this batch's counters: [0] helpers reserved (may exceed cap), [1] reads that were split
+    int32_t *cnt_next; // the next batch's counters, zeroed by k_batch_init (the reservations of a batch happen in the launch that would reset its own)
+    uint32_t cap;      // helpers this batch may use: table entries, histograms, extra workgroups of k_read_stats
+};
+static inline __host__ __device__ void pg_long_geometry(uint64_t L, uint32_t *slices, uint64_t *slen) {
+    uint64_t sl = PG_LONG_SLICE;
+    while ((L + sl - 1) / sl > PG_LONG_MAX_SLICES) sl *= 2;
+    *slen = sl; *slices = (uint32_t)((L + sl - 1) / sl);
+}
 #define PG_STAT_REC_BYTES 64
 #define PG_HUGE_SCRATCH_WORDS ((size_t)PG_HUGE_BLOCKS * (65536 + 64))
 
@@ -219,7 +249,7 @@ hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_
                           // plan_buf (may be null): also write the statistics record of every read (what k_read_plan does, needed == null)
                           const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf, int32_t *stat_status,
                           // the per-read records, the owner index and the classification of the reads (PgWalkOut)
-                          const PgWalkParams &W, const PgWalkOut &O, int force_generic);
+                          const PgWalkParams &W, const PgWalkOut &O, int force_generic, const PgLongState &LS);
 // tiles of PG_SORT_TILE events; in direct mode (n_slots <= PG_DIRECT_MAX_SLOTS) the count is padded to a multiple of 4:
 // k_rank_count_direct handles 4 tiles per workgroup and writes their counts of a slot as one 16-byte store
 static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
@@ -300,11 +330,11 @@ hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_co
 // flags[0] = lowest failing read (reset to INT_MAX here), flags[1] = length of wide_list (reset to 0 here): reads whose
 // in-range interval needs the PG_STATS_BINS histogram; stat_status[r] is reset to 0
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         int32_t *flags, int32_t *stat_status, bool flags_are_reset);
+                         int32_t *flags, int32_t *stat_status, bool flags_are_reset, const PgLongState &LS);
 // the main statistics launch (one wave per read, 1024 LDS bins); reads that need more put themselves on wide_list
 // gcal (may be null): double[4 * n_reads], per read {offset, scale, median, MAD} for k_gather
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
-                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal);
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal, const PgLongState &LS);
 // pg_finish over several batches: a batch's kept samples stay on the device until then; (k-mer, batch) segments are copied into the
 // job's k-mer-major order by one launch and leave the device once
 struct PgSeg { const double *src; uint64_t dst_off, n; };

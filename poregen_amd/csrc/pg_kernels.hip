@@ -1781,13 +1781,13 @@ template <bool RARE> __global__ __launch_bounds__(256) void k_scan_chained(const
 // read statistics: pA conversion + zero-fill + exact median / MAD (gmove.cpp:754-771)
 // =====================================================================================================
 
-__global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; flags[2] = 0; }
+__global__ void k_stat_flags_init(int32_t *__restrict__ flags) { flags[0] = INT_MAX; flags[1] = 0; flags[2] = 0; flags[3] = 0; } // [3]: a read's calibration is outside pg_div_domain_ok (the dense gathers then divide)
 
 // the record of one read. Reads whose in-range interval does not fit the 1024-bin LDS histogram put THEMSELVES on the lists of
 // the (rare) wide launch when k_read_stats meets them (stats_list_wide): nothing here depends on another thread, so the
 // records can also be written by k_batch_init's launch (eager statistics: one kernel boundary less per batch)
 __device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
-                                              PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status) {
+                                              PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status, const PgLongState &LS) {
     const double offset = B.off[r], scale = B.range[r] / B.dig[r];
     const PgReadPlan p = pg_make_plan(B.dig[r], offset, B.range[r], pa_min, pa_max);
     PgStatRec o;
@@ -1797,16 +1797,24 @@ __device__ __forceinline__ void read_plan_one(const PgDevBatch &B, uint32_t r, c
     o.mode = skip ? PG_STAT_SKIP : (p.status != 0 ? PG_STAT_BAD : PG_STAT_RUN);
     o.offset = offset; o.scale = scale; o.inv = 1.0 / scale;
     o.sym = (p.status == 0 && p.span > 0 && pg_sym_guard(offset, scale, pg_pa(p.c_lo, offset, scale), pg_pa(p.c_lo + p.span - 1, offset, scale))) ? 1u : 0u;
-    o.pad = 0;
+    o.split = 0;
+    if (LS.tab && o.mode == PG_STAT_RUN && o.span > 0 && o.span <= 1024 && o.end - o.beg > PG_LONG_MIN) { // a long read: helpers for its slices 1 .. S - 1
+        uint32_t S; uint64_t slen;
+        pg_long_geometry(o.end - o.beg, &S, &slen);
+        const uint32_t first = (uint32_t)atomicAdd(LS.cnt, (int)(S - 1u)); // (a batch of 2^31 slices is not representable: pg_count refuses 2^31 ops)
+        const bool room = first < LS.cap && S - 1u <= LS.cap - first;
+        for (uint32_t j = 0; j + 1 < S && first + j < LS.cap; ++j) LS.tab[first + j] = room ? make_uint2(r, j + 1u) : make_uint2(PG_LONG_INVALID, 0u);
+        if (room) { o.split = first + 1u; atomicAdd(LS.cnt + 1, 1); }
+    }
     rec[r] = o;
     stat_status[r] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_read_plan(PgDevBatch B, const uint8_t *__restrict__ needed, double pa_min, double pa_max,
-                                                   PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status, int32_t *__restrict__ reset_flags) {
+                                                   PgStatRec *__restrict__ rec, int32_t *__restrict__ stat_status, int32_t *__restrict__ reset_flags, PgLongState LS) {
     const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r == 0 && reset_flags) { reset_flags[0] = INT_MAX; reset_flags[1] = 0; reset_flags[2] = 0; } // as k_stat_flags_init: the lists are k_read_stats' (a later launch)
-    if (r < B.n_reads) read_plan_one(B, r, needed, pa_min, pa_max, rec, stat_status);
+    if (r == 0 && reset_flags) { reset_flags[0] = INT_MAX; reset_flags[1] = 0; reset_flags[2] = 0; reset_flags[3] = 0; } // as k_stat_flags_init: the lists are k_read_stats' (a later launch)
+    if (r < B.n_reads) read_plan_one(B, r, needed, pa_min, pa_max, rec, stat_status, LS);
 }
 
 // a read of the main statistics launch whose interval needs a wider histogram: the list is filled from the front
@@ -2246,6 +2254,7 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 #ifdef PG_PHASE_PROBE
     unsigned long long pg_t_ = 0, pg_acc_[8]; // the rare launches are not profiled
 #endif
+    if (lane == 0 && gcal && !pg_div_domain_ok(m.offset, m.scale)) atomicOr(err + 3, 1); // (never, for a sequencer's calibration: pg_select.h)
     stats_finish<BINS>(hist, lane, r, m, med, mad, gcal, win, oor, range_only PG_PROBE_ARG);
 }
 
@@ -2272,28 +2281,46 @@ __device__ __forceinline__ void stats_one_read(uint32_t *hist, const PgDevBatch 
 __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_eu(PG_STATS_WAVES_PER_EU, PG_STATS_WAVES_PER_EU))) void k_read_stats(PgDevBatch B, const PgStatRec *__restrict__ rec, double *__restrict__ med,
                                                    double *__restrict__ mad, int32_t *__restrict__ status, int32_t *__restrict__ err,
                                                    int win, uint8_t *__restrict__ oor, int range_only, uint32_t *__restrict__ wide_list,
-                                                   int32_t *__restrict__ wide_count, uint32_t keep_cached, double *__restrict__ gcal) {
+                                                   int32_t *__restrict__ wide_count, uint32_t keep_cached, double *__restrict__ gcal, PgLongState LS) {
     __shared__ __attribute__((aligned(16))) uint32_t hist_all[PG_STATS_WPB][StatsGeom<1024>::LDS_WORDS];
+    static_assert(StatsGeom<1024>::LDS_WORDS + 1 <= PG_LONG_WORDS, "a long read's histogram in global memory");
 #if PG_STATS_WPB == 1
     uint32_t *hist = hist_all[0];
-    const uint32_t r = blockIdx.x; // uniform: the record and everything derived from it stay in scalar registers
+    uint32_t r = blockIdx.x; // uniform: the record and everything derived from it stay in scalar registers
 #else
     uint32_t *hist = hist_all[threadIdx.x >> 6];
-    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PG_STATS_WPB + (threadIdx.x >> 6)));
-    if (r >= B.n_reads) return;
+    uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PG_STATS_WPB + (threadIdx.x >> 6)));
 #endif
+    // the workgroups behind the reads' own are HELPERS: slice `slice` of the long read the table names (PgLongState), or nothing
+    uint32_t slice = 0;
+    if (r >= B.n_reads) {
+        const uint32_t h = r - B.n_reads;
+        const uint32_t reserved = LS.tab ? (uint32_t)LS.cnt[0] : 0u;
+        if (h >= LS.cap || h >= reserved) return;
+        const uint2 e = LS.tab[h];
+        if (e.x == PG_LONG_INVALID) return;
+        r = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+    }
     const int lane = lane_id();
     PG_PROBE_BEGIN(0);
     const PgStatRec m = rec[r]; // everything this read needs besides its samples: one scalar load
     PG_MARK(0, 0); // the record
-    if (m.mode != PG_STAT_RUN) { stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, gcal, status, err); return; }
-    if (m.span > 1024) { if (lane == 0) stats_list_wide(r, m.span, B.n_reads, wide_list, wide_count); return; } // for the wider launch
+    if (m.mode != PG_STAT_RUN) { if (slice == 0) stats_no_result(lane, r, m.mode == PG_STAT_BAD ? PGR_ERR_SCALE : 0, med, mad, gcal, status, err); return; }
+    if (m.span > 1024) { if (lane == 0) stats_list_wide(r, m.span, B.n_reads, wide_list, wide_count); return; } // for the wider launch (never split)
     const int16_t *__restrict__ sig = B.sig;
     const int c_lo = m.c_lo;
     const uint32_t c16 = (uint32_t)c_lo & 0xffffu, c2 = c16 | (c16 << 16);
     const uint32_t cap = 1024u + (lane & 31u), cap2 = cap | (cap << 16);
+    uint64_t beg = m.beg, end = m.end;
+    uint32_t n_slices = 1;
+    if (m.split) { // this wave's slice of the read
+        uint64_t slen;
+        pg_long_geometry(m.end - m.beg, &n_slices, &slen);
+        beg = m.beg + (uint64_t)slice * slen;
+        end = beg + slen < m.end ? beg + slen : m.end;
+    }
     // 16-byte vectors fully inside [beg, end): [va, vb); ragged head and tail handled element-wise
-    const uint64_t beg = m.beg, end = m.end, va = (beg + 7) >> 3, vb = end >> 3;
+    const uint64_t va = (beg + 7) >> 3, vb = end >> 3;
     if (va < vb) {
         // passes of eight rows of 64 vectors. The eight 16-byte loads of a pass are UNCONDITIONAL (a lane past the read's
         // last vector re-reads that vector and does not bin it): straight-line code, all eight in flight per lane
@@ -2341,7 +2368,29 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
         stats_zero<1024>(hist, lane);
         for (uint64_t s2 = beg + lane; s2 < end; s2 += WAVE) stats_bin1<1024>(hist, (int)sig[s2], c_lo, lane);
     }
+    if (m.split) {
+        // the slice's counts into the read's histogram in global memory (same padded layout; the dummy bins are never read); whoever adds
+        // the last slice takes the sums back -- leaving zeros for the next batch -- and goes on to the selection
+        uint32_t *__restrict__ gh = LS.hist + (size_t)(m.split - 1u) * PG_LONG_WORDS;
+        // Everything that crosses waves here is an agent-scope atomic, performed where every XCD sees it: RETURNING adds (their results
+        // have arrived = they are performed) in front of the counter's add, exchanges behind it -- no release / acquire fence, which on
+        // this part writes back / invalidates the XCD's whole L2 under the feet of the streaming waves (first form: 400 us for the ragged run)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr uint32_t REAL = 1024u + WAVE; // padded words of the real bins
+        uint32_t seen = 0;
+        for (uint32_t i = lane; i < REAL; i += WAVE) { const uint32_t v = hist[i]; if (v) seen += __hip_atomic_fetch_add(gh + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint32_t one = __ballot(seen != 0xFFFFFFFFu) ? 1u : 1u; // (uses every lane's results, so the counter's add cannot be issued in front of them)
+        uint32_t t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(gh + PG_LONG_WORDS - 1u, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t + 1u != n_slices) return;
+        for (uint32_t i = lane; i < REAL; i += WAVE) hist[i] = __hip_atomic_exchange(gh + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(gh + PG_LONG_WORDS - 1u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (PG_STATS_SETPRIO) __builtin_amdgcn_s_setprio(PG_STATS_SETPRIO); // the selection is a serial chain: let it through in front of the streaming waves
+    if (lane == 0 && gcal && !pg_div_domain_ok(m.offset, m.scale)) atomicOr(err + 3, 1); // (never, for a sequencer's calibration: pg_select.h)
     stats_finish<1024>(hist, lane, r, m, med, mad, gcal, win, oor, range_only PG_PROBE_ARG);
     PG_MARK(0, 4); // selection + stores (slot 3: the prefix scan, marked inside stats_finish)
     PG_PROBE_END(0, r);
@@ -2426,15 +2475,16 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *_
                                                     uint64_t *__restrict__ running, uint32_t n_slots, int zero_running,
                                                     int32_t *__restrict__ stat_flags, PgDevBatch B, double pa_min, double pa_max,
                                                     PgStatRec *__restrict__ plan_rec, int32_t *__restrict__ stat_status,
-                                                    PgWalkParams W, PgWalkOut O, int force_generic, int op_t_aligned) {
+                                                    PgWalkParams W, PgWalkOut O, int force_generic, int op_t_aligned, PgLongState LS) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_reads) read_head_one(B, W, O, i, force_generic);
-    if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status); // eager statistics: see read_plan_one
+    if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status, LS); // eager statistics: see read_plan_one
+    if (i == 0 && LS.cnt_next) { LS.cnt_next[0] = 0; LS.cnt_next[1] = 0; } // the NEXT batch's long-read counters (PgLongState)
     if (i == 0) {
         O.layout_err[0] = (n_reads ? B.op_off[n_reads] : B.n_ops) != B.n_ops; // pg_batch.n_ops is wrong
         O.gen_count[(O.batch_id + 1u) & 1u] = 0; // the next batch's list
     }
-    if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; } // as k_stat_flags_init
+    if (i == 0 && stat_flags) { stat_flags[0] = INT_MAX; stat_flags[1] = 0; stat_flags[2] = 0; stat_flags[3] = 0; } // as k_stat_flags_init
     if (i <= n_reads) read_needed[i] = 0;
     if (zero_running && i < n_slots) running[i] = 0;
     // op-parallel part: 16 ops per thread; any op that is not a match (or not an op at all) sends its read to the generic walk
@@ -2467,13 +2517,13 @@ thread_local hipEvent_t pg_prof_start = nullptr, pg_prof_stop = nullptr;
 
 hipError_t pg_launch_batch_init(hipStream_t st, uint32_t n_reads, uint8_t *read_needed, uint64_t *running, uint32_t n_slots,
                           int zero_running, int32_t *stat_flags, const PgDevBatch &B, double pa_min, double pa_max, void *plan_buf,
-                          int32_t *stat_status, const PgWalkParams &W, const PgWalkOut &O, int force_generic) {
+                          int32_t *stat_status, const PgWalkParams &W, const PgWalkOut &O, int force_generic, const PgLongState &LS) {
     uint64_t n = (n_reads + 1 > n_slots ? n_reads + 1 : n_slots);
     const uint64_t n_op_threads = (B.n_ops + 15) / 16;
     if (n_op_threads > n) n = n_op_threads;
     const int op_t_aligned = ((uintptr_t)B.op_t & 15) == 0;
     PG_LAUNCH(k_batch_init, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n_reads, read_needed, running, n_slots, zero_running,
-              stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status, W, O, force_generic, op_t_aligned);
+              stat_flags, B, pa_min, pa_max, reinterpret_cast<PgStatRec *>(plan_buf), stat_status, W, O, force_generic, op_t_aligned, LS);
     return hipSuccess;
 }
 
@@ -2666,22 +2716,23 @@ hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
 }
 
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
-                         int32_t *flags, int32_t *stat_status, bool flags_are_reset) {
+                         int32_t *flags, int32_t *stat_status, bool flags_are_reset, const PgLongState &LS) {
     if (B.n_reads == 0) { // no record pass: the reset alone
         if (!flags_are_reset) PG_LAUNCH(k_stat_flags_init, dim3(1), dim3(1), 0, st, flags);
         return hipSuccess;
     }
     PG_LAUNCH(k_read_plan, dim3((B.n_reads + 255) / 256), dim3(256), 0, st, B, read_needed, pa_min, pa_max,
-                       reinterpret_cast<PgStatRec *>(plan_buf), stat_status, flags_are_reset ? (int32_t *)nullptr : flags);
+                       reinterpret_cast<PgStatRec *>(plan_buf), stat_status, flags_are_reset ? (int32_t *)nullptr : flags, LS);
     return hipSuccess;
 }
 
 hipError_t pg_launch_read_stats(hipStream_t st, const PgDevBatch &B, const void *plan_buf, double *med, double *mad, int32_t *status, int32_t *err, int win,
-                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal) {
+                                uint32_t *wide_list, int32_t *wide_count, uint8_t *oor, int range_only, double *gcal, const PgLongState &LS) {
     if (B.n_reads == 0) return hipSuccess;
     const PgStatRec *plan = reinterpret_cast<const PgStatRec *>(plan_buf);
-    PG_LAUNCH(k_read_stats, dim3((B.n_reads + PG_STATS_WPB - 1) / PG_STATS_WPB), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count,
-              B.n_reads / PG_STATS_CACHED_FRACTION, gcal);
+    static_assert(PG_STATS_WPB == 1, "the helpers of long reads are addressed as workgroups behind the reads' own");
+    PG_LAUNCH(k_read_stats, dim3(B.n_reads + (LS.tab ? LS.cap : 0u)), dim3(64 * PG_STATS_WPB), 0, st, B, plan, med, mad, status, err, win, oor, range_only, wide_list, wide_count,
+              B.n_reads / PG_STATS_CACHED_FRACTION, gcal, LS);
     return hipSuccess;
 }
 

@@ -19,6 +19,7 @@
 // lengths happens inside the gather's workgroups (chunks of 1024 events, chunk bases from a small reduction), so the lengths
 // are read once and the offsets written once, not read / written / read again by a scan kernel of their own.
 #include "pg_dev.h"
+#include "pg_select.h"
 
 // =====================================================================================================
 // op-sum prefixes: window starts of direct reads without a walk
@@ -755,7 +756,8 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES, 8))) void k_gather_wave(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
         const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
-        double *__restrict__ samples, const double *__restrict__ gcal) {
+        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
+    const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
     __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - offset inside the group (64 bits), read, -
     __shared__ double s_cal_all[4][64 * 4];           // its read's offset, scale, median, MAD
@@ -863,12 +865,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                 const uint32_t a = (uint32_t)((gbase + tb) & 1ull);
                 const uint32_t npairs = (tn + a + 1u) >> 1;
                 double *__restrict__ out = samples + gbase + tb - a; // 16-byte aligned
-                // (x - median) / MAD of gmove.cpp:774 as the hardware's own division sequence computes it -- q0 = a * y, r = a - b * q0 (exact, FMA),
-                // q = q0 + r * y -- with y = the correctly rounded 1 / MAD computed once per event instead of the refined v_rcp_f64 per sample.
-                // With y correctly rounded and q0 within an ulp this last step is Markstein's: q is the correctly rounded a / b (MAD >= 1, nothing
-                // under- or overflows here). tools/div_check.c: 1.4e10 random and near-tie cases without a difference; every parity test and the
-                // fuzzers compare the doubles bit for bit against the oracle's plain division. -DPG_GATHER_DIV_INSN restores the instruction
-                // sequence (FP64 is half rate here and the division is 2/3 of a sample's arithmetic: 948 -> 8xx us at k = 9).
+                // (x - median) / MAD of gmove.cpp:774 through the reciprocal y = 1 / MAD taken once per event (pg_select.h: pg_div_by_recip; the
+                // correctly rounded quotient, DESIGN.md section 6: q0 faithful -> Markstein's step; q0 a second ulp off only where a / b is far
+                // from every rounding midpoint). exact_div (uniform; a read of the batch has a calibration outside pg_div_domain_ok: no
+                // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
+                // arithmetic: 948 -> 8xx us at k = 9.
                 auto conv = [&](int raw, const double4 &c, double y) {
 #ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
                     return (double)raw;
@@ -882,8 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
 #elif defined(PG_GATHER_DIV_INSN)
                         x = num / c.w;
 #else
-                        const double q0 = num * y, r = __builtin_fma(-c.w, q0, num);
-                        x = __builtin_fma(r, y, q0);
+                        x = exact_div ? num / c.w : pg_div_by_recip(num, c.w, y);
 #endif
                     }
                     return x;
@@ -957,7 +957,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
 // masked load inside a trip costs more than it saves). Stores are 16 bytes at 8-byte alignment, 8 bytes for the odd tail of a window.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES, 8))) void k_gather_evpair(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
         const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
-        double *__restrict__ samples, const double *__restrict__ gcal) {
+        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
+    const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
     __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - 2 * first pair slot (64 bits), output offset - 2 * first pair slot, 2 * first pair slot + length
     __shared__ double s_cal_all[4][64 * 6];           // its read's offset, scale, median, MAD; 1 / MAD; -
@@ -1060,12 +1061,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t tn = tot2 - tb < SPAN2 ? tot2 - tb : SPAN2; // pair slots of this tile
                 double *__restrict__ out = samples + gbase;
-                // (x - median) / MAD of gmove.cpp:774 as the hardware's own division sequence computes it -- q0 = a * y, r = a - b * q0 (exact, FMA),
-                // q = q0 + r * y -- with y = the correctly rounded 1 / MAD computed once per event instead of the refined v_rcp_f64 per sample.
-                // With y correctly rounded and q0 within an ulp this last step is Markstein's: q is the correctly rounded a / b (MAD >= 1, nothing
-                // under- or overflows here). tools/div_check.c: 1.4e10 random and near-tie cases without a difference; every parity test and the
-                // fuzzers compare the doubles bit for bit against the oracle's plain division. -DPG_GATHER_DIV_INSN restores the instruction
-                // sequence (FP64 is half rate here and the division is 2/3 of a sample's arithmetic: 948 -> 8xx us at k = 9).
+                // (x - median) / MAD of gmove.cpp:774 through the reciprocal y = 1 / MAD taken once per event (pg_select.h: pg_div_by_recip; the
+                // correctly rounded quotient, DESIGN.md section 6: q0 faithful -> Markstein's step; q0 a second ulp off only where a / b is far
+                // from every rounding midpoint). exact_div (uniform; a read of the batch has a calibration outside pg_div_domain_ok: no
+                // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
+                // arithmetic: 948 -> 8xx us at k = 9.
                 auto conv = [&](int raw, const double4 &c, double y) {
 #ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
                     return (double)raw;
@@ -1079,8 +1079,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
 #elif defined(PG_GATHER_DIV_INSN)
                         x = num / c.w;
 #else
-                        const double q0 = num * y, r = __builtin_fma(-c.w, q0, num);
-                        x = __builtin_fma(r, y, q0);
+                        x = exact_div ? num / c.w : pg_div_by_recip(num, c.w, y);
 #endif
                     }
                     return x;
@@ -1228,15 +1227,15 @@ hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uin
 }
 // lanes: 0 = k_gather_wave (the default); else lanes per kept event (4, 8 or 16) of k_gather_chunks: any value is correct for any window length
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
-                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes) {
+                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes, const int32_t *stat_flags) {
     if (n_kept_cap == 0) return hipSuccess;
     uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
     if (lanes == 1) { // the event-pair form (a lane per pair of samples of ONE window)
-        PG_LAUNCH(k_gather_evpair, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+        PG_LAUNCH(k_gather_evpair, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal, stat_flags);
         return hipSuccess;
     }
     if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
-        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal, stat_flags);
         return hipSuccess;
     }
     if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);

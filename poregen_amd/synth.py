@@ -175,6 +175,87 @@ def make_batch_fast(n_reads=50000, read_len=4000, kind="rna004", seed=20251003, 
     return b.validate_host()
 
 
+def ragged_lengths(total_samples=200_000_000, seed=20251005, lo=2000, hi=200_000, median=12_000, sigma=1.0, huge=1_000_000, huge_frac=0.001):
+    """Read lengths of a ragged DNA run (SURVEY section 5 "long-context", section 7 "hard parts"): lognormal between lo and hi, `huge_frac` of
+    the reads `huge` samples long, cut so that the lengths add up to total_samples exactly."""
+    rng = np.random.default_rng(seed)
+    out = []; tot = 0
+    while tot < total_samples:
+        L = np.clip(np.rint(median * np.exp(sigma * rng.standard_normal(4096))), lo, hi).astype(np.int64)
+        L[rng.random(4096) < huge_frac] = huge
+        out.append(L); tot += int(L.sum())
+    L = np.concatenate(out)
+    cs = np.cumsum(L)
+    n = int(np.searchsorted(cs, total_samples, side="left")) + 1
+    L = L[:n].copy()
+    L[-1] -= int(cs[n - 1]) - total_samples
+    if L[-1] < lo:  # fold a short remainder into the read in front of it
+        L[-2] += L[-1]; L = L[:-1]
+    assert int(L.sum()) == total_samples
+    return L
+
+
+def make_ragged_fast(lengths, kind="dna_r10", seed=20251005, spike_rate=0.005, chunk_samples=20_000_000) -> Batch:
+    """make_batch_fast for reads of DIFFERENT lengths (matches only): one stream of dwells per chunk of consecutive reads, cut at the
+    read boundaries (a dwell that straddles a boundary becomes two ops), same levels / noise / spikes / calibrations as make_batch_fast."""
+    lengths = np.asarray(lengths, np.int64)
+    n_reads = lengths.size
+    rng = np.random.default_rng(seed)
+    rna = kind == "rna004"
+    mean_extra = 5.2 if rna else 1.5
+    p_geom = 1.0 / (1.0 + mean_extra)
+    dig = np.full(n_reads, 2048.0)
+    offset = rng.integers(-260, -229, n_reads).astype(np.float64)
+    rng_range = rng.uniform(280.0, 285.0, n_reads)
+    total = int(lengths.sum())
+    sig = np.empty(total, np.int16)
+    sig_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.uint64)
+    opn_parts, base_parts, nops = [], [], []
+    r0 = 0
+    while r0 < n_reads:
+        r1 = r0 + 1; acc = int(lengths[r0])
+        while r1 < n_reads and acc + int(lengths[r1]) <= chunk_samples:
+            acc += int(lengths[r1]); r1 += 1
+        n_dw = int(acc / (5 * (1 + mean_extra)) * 1.3) + 1024
+        cs = np.cumsum(np.clip(5 * rng.geometric(p_geom, size=n_dw), 5, 200).astype(np.int64))
+        while cs[-1] < acc:  # (never with the 1.3 margin; keep the stream long enough anyway)
+            cs = np.concatenate([cs, cs[-1] + np.cumsum(np.clip(5 * rng.geometric(p_geom, size=n_dw), 5, 200).astype(np.int64))])
+        bounds = np.cumsum(lengths[r0:r1])                       # read ends inside the chunk's stream
+        edges = np.unique(np.concatenate([cs[cs < acc], bounds]))  # op ends: dwell ends and read ends, the last one == acc
+        d = np.diff(np.concatenate([[0], edges]))
+        op_read = np.searchsorted(bounds, edges - d, side="right")  # read (inside the chunk) of every op
+        bases = rng.integers(0, 4, size=d.size)
+        code = np.zeros(d.size, np.uint64)
+        for t in range(5):
+            sh = np.roll(bases, t).astype(np.uint64); sh[:t] = 0
+            code |= sh << np.uint64(2 * t)
+        level = 70.0 + 60.0 * (_splitmix(code).astype(np.float64) / 2.0 ** 64)
+        pa = np.repeat(level, d)
+        pa += rng.standard_normal(pa.size, dtype=np.float32) * np.float32(3.0)
+        sp = np.flatnonzero(rng.random(pa.size, dtype=np.float32) < spike_rate)
+        pa[sp] = np.where(rng.random(sp.size) < 0.5, rng.uniform(5.0, 38.0, sp.size), rng.uniform(182.0, 250.0, sp.size))
+        rr = np.repeat(np.arange(r0, r1), lengths[r0:r1])
+        pa /= (rng_range / dig)[rr]
+        pa -= offset[rr]
+        np.rint(pa, out=pa); np.clip(pa, -32768, 32767, out=pa)
+        sig[int(sig_off[r0]):int(sig_off[r1])] = pa.astype(np.int16)
+        cnt = np.bincount(op_read, minlength=r1 - r0)
+        if rna:  # the fetched sequence is in basecall order: the reverse of the walk order, read by read
+            start = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+            idx = (start + cnt)[op_read] - 1 - (np.arange(d.size) - start[op_read])
+            bases = bases[idx]
+        opn_parts.append(d.astype(np.uint32)); base_parts.append(BASES[bases]); nops.append(cnt)
+        r0 = r1
+    nb = np.concatenate(nops).astype(np.int64)
+    off_b = np.concatenate([[0], np.cumsum(nb)]).astype(np.uint64)
+    op_n = np.concatenate(opn_parts)
+    b = Batch(
+        n_reads=n_reads, sig=sig, sig_off=sig_off, digitisation=dig, offset=offset, range=rng_range, query_start=np.zeros(n_reads, np.int32),
+        target_start=(nb if rna else np.zeros(n_reads)).astype(np.int32), target_end=(np.zeros(n_reads) if rna else nb).astype(np.int32),
+        seq=np.concatenate(base_parts), seq_off=off_b, op_n=op_n, op_t=np.zeros(op_n.size, np.uint8), op_off=off_b.copy())
+    return b.validate_host()
+
+
 def add_indels_fast(b: Batch, del_rate=0.02, ins_rate=0.02, seed=1, rna=True) -> Batch:
     """BASELINE configs[4]'s ss strings at throughput size: a matches-only batch (make_batch_fast) gets, vectorised, `del_rate` of its
     matches a deletion op `nD` in front (n in 1..3: bases of the fetched sequence without samples -- they are inserted into the

@@ -245,7 +245,7 @@ def test_rna_record_without_flag_exits_1(tmp_path):
 def test_blow5_input_equals_ascii_input(tmp_path):
     """The reference's BLOW5 fixture (zlib + svb-zd) through the CLI == the same reads as ASCII SLOW5 through the oracle."""
     import ctypes as C
-    h = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
     h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
     b5 = os.path.join(ROOT, "tests", "golden", "blow5", "example.blow5")
     rng = np.random.default_rng(3)

@@ -343,3 +343,79 @@ def _tiny_reads_case(k, rna, max_ops, indel_every, move_offset):
             eng.submit(b.to_device(torch.device("cuda:0")) if dev else b)
             assert_result_equals_oracle(eng.finish(), o, check_text_slots=2, sample_limit=limit)
             eng.close()
+
+
+@pytest.mark.parametrize("lanes", ["0", "1", "8"])
+def test_calibration_outside_the_reciprocal_domain_still_divides_exactly(monkeypatch, lanes):
+    """The dense gathers replace (x - median) / MAD by a reciprocal taken once per event (pg_select.h: pg_div_by_recip), proved exact
+    for normal numbers end to end. A read whose calibration leaves that domain (offset 1e-300: pA values and differences of 1e-300 next
+    to a MAD of 148) must switch the batch to the division itself: the doubles stay the oracle's bit for bit."""
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    monkeypatch.setenv("PGMOVE_GATHER_LANES", lanes)
+    b = synth.make_batch(40, kind="dna_r10", seed=77)
+    r = 7
+    a, e = int(b.sig_off[r]), int(b.sig_off[r + 1])
+    n = e - a
+    sig = b.sig.copy()
+    q = max(2, n // 50)
+    n_neg = n // 2 - q - q // 2
+    v = np.concatenate([np.full(n_neg, -100), np.full(q, 30000), np.full(q, 0), np.full(n - n_neg - 2 * q, 100)]).astype(np.int16)
+    v = v[np.random.default_rng(3).permutation(n)]  # 0: pA = 1e-300, the read's median; 30000: above pa_max, zero-filled, x - median = -1e-300
+    # the median must be one of the tiny values: as many samples below them as above (the zero-filled ones count below)
+    lo = int((v == -100).sum() + (v == 30000).sum()); hi = int((v == 100).sum())
+    assert lo <= n // 2 < lo + q, (lo, hi, q, n)
+    sig[a:e] = v
+    dig = b.digitisation.copy(); off = b.offset.copy(); rg = b.range.copy()
+    dig[r] = 1.0; off[r] = 1e-300; rg[r] = 1.0
+    b = Batch(**{**b.__dict__, "sig": sig, "digitisation": dig, "offset": off, "range": rg})
+    kmers = generate_kmers(5)
+    p = dict(kmer_size=5, scaling=1, sample_limit=10 ** 6, pa_min=-180.0, pa_max=180.0, min_dur=1, max_dur=10 ** 5)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
+    vals = np.concatenate([o.values(s) for s in range(o.n_slots) if o.counts()[s]])
+    assert np.any((vals != 0) & (np.abs(vals) < 1e-290)), "the case must reach the tiny quotients"
+
+
+def _long_batch(seed=91):
+    """reads of 3 000 ... 1 000 000 samples (the 10^6 one and three more above the split threshold), ragged signal starts"""
+    L = np.array([3000, 40001, 1_000_000, 4000, 32768, 32769, 250_000, 77, 65_537], np.int64)
+    return synth.make_ragged_fast(L, kind="dna_r10", seed=seed)
+
+
+@pytest.mark.parametrize("mode", ["default", "one_stream", "device_batch", "few_helpers", "no_split"])
+def test_long_reads_split_across_waves_equal_the_oracle(monkeypatch, mode):
+    """A read above 32 768 samples is binned by several waves (PgLongState: the read's own wave + helpers, histograms summed in global
+    memory, the last slice runs the selection). Median / MAD and every kept sample stay the oracle's bit for bit: with room for every
+    helper, with room for some (the others' reads stay on one wave), with none, fed from the host and from the device."""
+    if mode == "few_helpers":
+        monkeypatch.setenv("PGMOVE_LONG_HELPERS", "70")   # the 10^6-sample read wants 61, the 250 000 one 15, 65 537: 4, 40 001: 2
+    if mode == "no_split":
+        monkeypatch.setenv("PGMOVE_NO_LONG_SPLIT", "1")
+    b = _long_batch()
+    kmers = generate_kmers(5)
+    p = dict(kmer_size=5, scaling=1, sample_limit=3000)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    q = dict(p, profile=True) if mode != "default" else p
+    if mode == "one_stream":
+        q = dict(p, overlap=False)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **q))
+    if mode == "device_batch":
+        import torch
+        eng.submit(b.to_device(torch.device("cuda", 0)))
+    else:
+        eng.submit(b)
+    res = eng.finish()
+    st = eng.kernel_stats()
+    eng.close()
+    assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
+    split = st.get("long_reads_split", (0, 0.0))[0]
+    if mode == "no_split":
+        assert split == 0
+    elif mode == "few_helpers":
+        assert 1 <= split < 5 and st["long_helpers_short_batches"][0] == 1
+    else:
+        assert split == 5, st   # 40 001, 10^6, 32 769, 250 000, 65 537 (32 768 itself is not above the threshold)

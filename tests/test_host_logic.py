@@ -63,7 +63,7 @@ def test_big_host_vectors_ask_for_huge_pages():
     small ones come from the heap. (A typo once compiled the madvise call out: results are identical, only this shows it.)"""
     import ctypes as C
     import os
-    h = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "poregen_amd", "_pg_hosttest.so"))
+    h = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "poregen_amd", "_pg_hosttest.so")))
     h.pgt_samplevec_hugepage.argtypes = [C.c_size_t, C.POINTER(C.c_long)]
     kb = C.c_long(0)
     big = h.pgt_samplevec_hugepage(1 << 20, C.byref(kb))   # 8 MB

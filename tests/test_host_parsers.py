@@ -14,7 +14,7 @@ B5 = os.path.join(ROOT, "tests", "golden", "blow5")
 
 @pytest.fixture(scope="module")
 def h():
-    lib = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    lib = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
     lib.pgt_format_f8.argtypes = [C.c_double, C.c_char_p]; lib.pgt_format_f8.restype = C.c_size_t
     lib.pgt_tokenize_ss.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; lib.pgt_tokenize_ss.restype = C.c_long
     lib.pgt_fastx_fetch.argtypes = [C.c_char_p, C.c_char_p, C.c_long, C.c_long, C.c_char_p, C.c_size_t]; lib.pgt_fastx_fetch.restype = C.c_long
@@ -152,7 +152,7 @@ def test_compressed_blow5_round_trip(tmp_path):
     ragged lengths, spikes (4-byte deltas) and a few hundred reads."""
     import ctypes as C
     from poregen_amd import synth
-    h = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
     h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
     b = synth.make_batch(200, kind="rna004", seed=3, read_len=5003, spike_rate=0.05)
     big = b.sig.copy(); big[::997] = 32767; big[1::997] = -32768            # extreme deltas: 3- and 4-byte codes

@@ -13,12 +13,12 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE = os.path.join(ROOT, "oracle", "model_oracle")
+ORACLE = os.path.join(os.environ.get("PG_ORACLE_DIR") or os.path.join(ROOT, "oracle"), "model_oracle")
 
 
 @pytest.fixture(scope="module")
 def host():
-    L = C.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    L = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
     L.pgt_fixed8.argtypes = [C.c_double, C.POINTER(C.c_int)]; L.pgt_fixed8.restype = C.c_longlong
     L.pgt_model_texts.argtypes = [C.POINTER(C.c_longlong), C.c_size_t, C.c_char_p, C.c_char_p, C.c_size_t]
     L.pgt_sstdev_text.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_char_p, C.c_char_p, C.c_size_t]

@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "bin", "poregen")
+BIN = os.environ.get("PG_REFORM_BIN") or os.path.join(ROOT, "bin", "poregen")  # PG_REFORM_BIN: the sanitizer build of the subtool (make asan)
 R = os.path.join(ROOT, "tests", "golden", "reform")
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def shim():
-    h = ctypes.CDLL(os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h = ctypes.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
     h.pgt_medmad.argtypes = [ctypes.c_void_p, ctypes.c_uint64] + [ctypes.c_double] * 5 + [ctypes.POINTER(ctypes.c_double)] * 3
     h.pgt_medmad_sym.argtypes = h.pgt_medmad.argtypes
     h.pgt_plan.argtypes = [ctypes.c_double] * 5 + [ctypes.c_void_p]
