@@ -364,7 +364,7 @@ size_t pg_model_format(const pg_model_result *m, uint32_t slot, int32_t which, c
  * running total of the earlier batches, kept as row 0 of the same buffer) are its base (pg_collect_gathered). The per-read
  * statistics are queued behind the issue of the collective and hide it. pg_job_finish returns the job's per-k-mer streams
  * in reference order (slot, then batch, then shard): byte for byte what one context fed the same batches returns.
- * Host batches only. A device may be listed more than once (several shards on one GPU); the exchange then goes through
+ * pg_job_submit takes a host batch and cuts it; pg_job_submit_shards takes one batch per device, host or device-resident. A device may be listed more than once (several shards on one GPU); the exchange then goes through
  * host memory (RCCL needs distinct devices), as it does when librccl cannot be loaded and PG_JOB_EXCHANGE_RCCL is not set. */
 typedef struct pg_job pg_job;
 enum {
@@ -379,6 +379,13 @@ const char *pg_job_last_error(const pg_job *job);       /* job may be NULL: erro
 /* Queues the whole batch on all devices and returns; the batch arrays must stay valid until pg_job_sync / the next
  * pg_job_submit / pg_job_finish has returned (see pg_batch). */
 pg_status   pg_job_submit(pg_job *job, const pg_batch *host_batch);
+/* The same step for shards that already are where they will be worked: shards[g] (g < n_devices, in PAF order) is rank g's part of the
+ * batch as a pg_batch of its own -- PG_LOC_DEVICE arrays resident on devices[g] and complete before the call, or PG_LOC_HOST. Nothing is
+ * cut or copied on the host and, with device shards, nothing crosses PCIe inside the step: a device-resident N-GPU step driven from the
+ * C++ host (src/gmove.cpp:732-969 over N devices; lifetime of the arrays as pg_job_submit). Results: those of pg_job_submit on the
+ * concatenation of the shards. */
+pg_status   pg_job_submit_shards(pg_job *job, const pg_batch *shards, uint32_t n_shards);
+pg_status   pg_job_reset(pg_job *job);                  /* as pg_reset: the next submit starts a new job on the same devices and communicators */
 pg_status   pg_job_sync(pg_job *job);                   /* wait for every device; surfaces per-read errors (lowest shard first) */
 int32_t     pg_job_all_slots_full(pg_job *job);         /* src/gmove.cpp:733-735 for the job */
 int32_t     pg_job_all_slots_full_settled(const pg_job *job); /* as pg_all_slots_full_settled */

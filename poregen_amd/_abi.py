@@ -34,7 +34,7 @@ EXPORTS = [
     "pg_default_params", "pg_last_error", "pg_version", "pg_build_slot_tables", "pg_create", "pg_destroy",
     "pg_reset", "pg_submit", "pg_count", "pg_collect", "pg_stats", "pg_collect_gathered", "pg_job_totals_device", "pg_sync", "pg_finish", "pg_finish_deferred", "pg_fetch_samples", "pg_text", "pg_fetch_text", "pg_text_device", "pg_all_slots_full",
     "pg_last_batch_device", "pg_kernel_stats", "pg_kernel_stats_reset", "pg_set_stream", "pg_model", "pg_model_device", "pg_model_format",
-    "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
+    "pg_job_create", "pg_job_destroy", "pg_job_last_error", "pg_job_submit", "pg_job_submit_shards", "pg_job_reset", "pg_job_sync", "pg_job_all_slots_full", "pg_job_finish",
     "pg_job_finish_deferred", "pg_job_fetch_samples", "pg_job_text", "pg_job_fetch_text",
     "pg_job_uses_rccl", "pg_job_model", "pg_job_kernel_stats", "pg_runtime_init", "pg_all_slots_full_settled", "pg_job_all_slots_full_settled", "pg_poll", "pg_job_poll",
 ]
@@ -171,6 +171,8 @@ def load():
     lib.pg_job_destroy.argtypes = [vp]; lib.pg_job_destroy.restype = None
     lib.pg_job_last_error.argtypes = [vp]; lib.pg_job_last_error.restype = C.c_char_p
     lib.pg_job_submit.argtypes = [vp, C.POINTER(PgBatch)]; lib.pg_job_submit.restype = i32
+    lib.pg_job_submit_shards.argtypes = [vp, C.POINTER(PgBatch), C.c_uint32]; lib.pg_job_submit_shards.restype = i32
+    lib.pg_job_reset.argtypes = [vp]; lib.pg_job_reset.restype = i32
     lib.pg_job_sync.argtypes = [vp]; lib.pg_job_sync.restype = i32
     lib.pg_job_all_slots_full.argtypes = [vp]; lib.pg_job_all_slots_full.restype = i32
     lib.pg_job_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish.restype = i32

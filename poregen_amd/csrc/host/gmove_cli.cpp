@@ -304,7 +304,7 @@ int gmove_main(int argc, char **argv) {
     auto give_up = [&](int code) { if (ctx_ready.valid() && ctx_ready.get() == PG_OK) dev.destroy(); return code; }; // early error exits
 
     pgh::Slow5File s5;
-    if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n", slow5file); return give_up(EXIT_FAILURE); } // gmove.cpp:493-503
+    if (!s5.open(slow5file, err)) { fprintf(stderr, "Error in opening file %s\n[gmove] %s\n", slow5file, err.c_str()); return give_up(EXIT_FAILURE); } // gmove.cpp:493-503 (+ the reader's reason: slow5lib prints its own there)
 
     pgh::FastxIndex fai;
     pgh::SamBamReader sam;
@@ -379,7 +379,7 @@ int gmove_main(int argc, char **argv) {
     // kmer_pick_margin 0 and no indels.
     std::vector<uint8_t> is_one;
     auto add_move_record = [&](const char *read_id, int fastq_len, const std::string &fseq, int stride, uint64_t signal_len, long long trim) -> bool {
-        if (!s5.get(read_id, rec, err)) { fprintf(stderr, "Error in when fetching the read\n"); status = EXIT_FAILURE; return false; }  // gmove.cpp:582-586
+        if (!s5.get(read_id, rec, err)) { fprintf(stderr, "Error in when fetching the read (%s)\n", err.c_str()); status = EXIT_FAILURE; return false; }  // gmove.cpp:582-586
         if (rec.raw.size() != signal_len || trim < 0 || (uint64_t)trim >= rec.raw.size()) {                                    // asserts, gmove.cpp:589-590
             fprintf(stderr, "move record of %s disagrees with the SLOW5 record (signal_len / trim_offset)\n", read_id); status = EXIT_FAILURE; return false;
         }
@@ -479,13 +479,13 @@ int gmove_main(int argc, char **argv) {
                     if (pr == 2) { r.bad = true; r.msg = "ss:Z: tag not found in paf record for " + paf.rid; return; }    // gmove.cpp:1046-1049
                     if (placing) {
                         pgh::Slow5File::RawView v;
-                        if (!s5.raw_view(paf.rid, v, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read"; return; } // gmove.cpp:745-749
+                        if (!s5.raw_view(paf.rid, v, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read (" + r.e2 + ")"; return; } // gmove.cpp:745-749
                         r.b.sig_off.push_back(r.b.sig_off.back() + v.n);
                         r.views.push_back(v); r.pafs.push_back(std::move(paf));
                         r.n_ok++;
                         continue;
                     }
-                    if (!s5.get(paf.rid, r.rec, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read"; return; } // gmove.cpp:745-749
+                    if (!s5.get(paf.rid, r.rec, r.e2)) { r.bad = true; r.msg = "Error in when fetching the read (" + r.e2 + ")"; return; } // gmove.cpp:745-749
                     if (!finish_line(r, paf, r.rec.digitisation, r.rec.offset, r.rec.range)) return;
                     if (i == r.lo) r.b.sig.reserve((r.hi - r.lo) * (r.rec.raw.size() + r.rec.raw.size() / 8)); // reads of a run are of similar length
                     r.b.sig.append(r.rec.raw.data(), r.rec.raw.data() + r.rec.raw.size());

@@ -1230,6 +1230,7 @@ int32_t pg_poll(pg_ctx *c) {
 }
 
 int32_t pg_all_slots_full_settled(const pg_ctx *c) { return c && c->full_slots == c->prm.n_slots; }
+uint64_t pgi_full_slots_settled(const pg_ctx *c) { return c ? c->full_slots : 0; } // pg_job.hip: how many k-mers were complete after the last settled batch
 
 pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     if (!c || !v) return PG_ERR_INVALID_ARG;

@@ -31,6 +31,7 @@
 
 extern "C" void *pgi_stream(pg_ctx *c); // pg_api.hip: the stream the context's chain currently runs on
 extern "C" const double *pgi_fin_dev(pg_ctx *c); // pg_api.hip: where pg_finish_deferred left the context's kept samples on its device (or null)
+extern "C" uint64_t pgi_full_slots_settled(const pg_ctx *c); // pg_api.hip: k-mers complete after the last settled batch
 extern "C" pg_status pgi_skip_stats(pg_ctx *c); // pg_api.hip: a deferred-statistics batch that will keep nothing needs none
 extern "C" pg_status pgi_stats_gathered(pg_ctx *c, const uint64_t *all_counts, uint32_t world, uint32_t rank); // pg_api.hip: pg_stats, cancelled on the device when the rows below `rank` complete every k-mer
 
@@ -108,6 +109,7 @@ struct pg_job {
     std::vector<Worker> workers;
     std::vector<Shard> shard;
     bool use_rccl = false, have_batch = false;
+    uint64_t full_slots_prev = 0;
     std::vector<ncclComm_t> comms;
     std::vector<uint64_t *> gbuf;          // per rank, on its device: uint64[n + 1][n_slots] (see the head of this file)
     std::vector<hipStream_t> comm_st;
@@ -231,11 +233,28 @@ pg_status pg_job_create(const pg_params *p, const int32_t *devices, uint32_t n, 
     return PG_OK;
 }
 
+// phase 1 of rank g: walk, filter, count its shard; the counts land in row 1 + g of the rank's own receive buffer
+static pg_status job_count_shard(pg_job *j, uint32_t g, const pg_batch *q, std::string &msg) {
+    const uint32_t ns = j->n_slots;
+    pg_status st = pg_count(j->ctx[g], q, j->gbuf[g] + (size_t)(1 + g) * ns, PG_LOC_DEVICE);
+    if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
+    hipError_t e = hipSetDevice(j->devices[g]);
+    if (e == hipSuccess) e = hipEventRecord(j->ev_counted[g], (hipStream_t)pgi_stream(j->ctx[g]));
+    if (e == hipSuccess && !j->use_rccl) // host exchange: this rank's row comes down behind its counting kernels
+        e = hipMemcpyAsync(j->host_rows.data() + (size_t)g * ns, j->gbuf[g] + (size_t)(1 + g) * ns, ns * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           (hipStream_t)pgi_stream(j->ctx[g]));
+    if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+    return PG_OK;
+}
+
+// phases 2 and 3 of a batch whose shards have been counted (phase 1: pg_job_submit / pg_job_submit_shards)
+static pg_status job_exchange_and_collect(pg_job *j, std::vector<uint64_t> &&cut, uint64_t nr, const std::vector<uint64_t> &shard_ops);
+
 pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
     if (!j || !b) return PG_ERR_INVALID_ARG;
     if (b->struct_size != sizeof(pg_batch)) return jfail(j, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch");
-    if (b->location != PG_LOC_HOST) return jfail(j, PG_ERR_UNSUPPORTED, "pg_job_submit takes host batches (a device batch lives on one GPU: use pg_submit)");
-    const uint32_t n = j->n, nr = b->n_reads, ns = j->n_slots;
+    if (b->location != PG_LOC_HOST) return jfail(j, PG_ERR_UNSUPPORTED, "pg_job_submit takes host batches (shards that are resident on their devices: pg_job_submit_shards)");
+    const uint32_t n = j->n, nr = b->n_reads;
     if (!b->sig_off || !b->seq_off || !b->op_off) return jfail(j, PG_ERR_INVALID_ARG, "batch offsets missing");
     j->merged = false;
     // contiguous shards of about equal numbers of samples (reads differ in length; any contiguous cut is correct)
@@ -248,6 +267,8 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         cut[g] = r < cut[g - 1] ? cut[g - 1] : r;
     }
     cut[n] = nr;
+    std::vector<uint64_t> shard_ops(n, 0);
+    for (uint32_t g = 0; g < n; ++g) shard_ops[g] = b->op_off[cut[g + 1]] - b->op_off[cut[g]];
     // phase 1, every rank on its own thread: settle + download its previous batch (pg_count does), stage its shard, walk,
     // filter, count -- the counts land in row 1 + g of the rank's own receive buffer
     pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
@@ -272,21 +293,48 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         q.op_n = b->op_n ? b->op_n + b->op_off[lo] : nullptr; q.op_t = b->op_t ? b->op_t + b->op_off[lo] : nullptr; q.op_off = sh.op_off.data();
         // the library stages the signal with 16-byte vectors in mind: a shard that starts at an odd multiple of 8 samples of
         // the caller's buffer is still fine for a HOST batch (it is copied to a fresh, aligned device buffer)
-        st = pg_count(j->ctx[g], &q, j->gbuf[g] + (size_t)(1 + g) * ns, PG_LOC_DEVICE);
-        if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
-        hipError_t e = hipSetDevice(j->devices[g]);
-        if (e == hipSuccess) e = hipEventRecord(j->ev_counted[g], (hipStream_t)pgi_stream(j->ctx[g]));
-        if (e == hipSuccess && !j->use_rccl) // host exchange: this rank's row comes down behind its counting kernels
-            e = hipMemcpyAsync(j->host_rows.data() + (size_t)g * ns, j->gbuf[g] + (size_t)(1 + g) * ns, ns * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                               (hipStream_t)pgi_stream(j->ctx[g]));
-        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
-        return PG_OK;
+        return job_count_shard(j, g, &q, msg);
     });
     if (s != PG_OK) return s;
+    return job_exchange_and_collect(j, std::move(cut), nr, shard_ops);
+}
+
+// The same step for shards that are ALREADY where they will be worked: shards[g] is the batch of rank g -- its reads follow rank g - 1's
+// in PAF order -- as a pg_batch of its own: PG_LOC_DEVICE arrays resident on devices[g] (complete before the call), or PG_LOC_HOST.
+// With device shards nothing crosses PCIe inside the step and nothing is cut or copied on the host: the C++ host drives a device-resident
+// N-GPU step (north_star: "host code stays C++ ... partition the batch across the 8 GPUs").
+pg_status pg_job_submit_shards(pg_job *j, const pg_batch *shards, uint32_t n_shards) {
+    if (!j || !shards) return PG_ERR_INVALID_ARG;
+    const uint32_t n = j->n;
+    if (n_shards != n) return jfail(j, PG_ERR_INVALID_ARG, "pg_job_submit_shards: %u shards for a job of %u devices", n_shards, n);
+    std::vector<uint64_t> cut(n + 1, 0), shard_ops(n, 0);
+    for (uint32_t g = 0; g < n; ++g) {
+        if (shards[g].struct_size != sizeof(pg_batch)) return jfail(j, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch (shard %u)", g);
+        if (shards[g].location != PG_LOC_DEVICE && shards[g].location != PG_LOC_HOST) return jfail(j, PG_ERR_INVALID_ARG, "shard %u: pg_batch.location", g);
+        cut[g + 1] = cut[g] + shards[g].n_reads;
+        shard_ops[g] = shards[g].location == PG_LOC_DEVICE ? shards[g].n_ops : (shards[g].op_off ? shards[g].op_off[shards[g].n_reads] : 0); // (0 = unknown to the host)
+    }
+    j->merged = false;
+    pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        pg_status st = pg_sync(j->ctx[g]);
+        if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
+        j->shard[g].b = shards[g];
+        return job_count_shard(j, g, &j->shard[g].b, msg);
+    });
+    if (s != PG_OK) return s;
+    const uint64_t nr = cut[n];
+    return job_exchange_and_collect(j, std::move(cut), nr, shard_ops);
+}
+
+static pg_status job_exchange_and_collect(pg_job *j, std::vector<uint64_t> &&cut_in, uint64_t nr, const std::vector<uint64_t> &shard_ops) {
+    const uint32_t n = j->n, ns = j->n_slots;
+    std::vector<uint64_t> cut = std::move(cut_in);
+    pg_status s = PG_OK;
     // Nothing behind the completing read is touched by the reference (gmove.cpp:733-735). Was every k-mer complete before this batch?
     // (the last shard's cut of the previous batch saw every accepted event of the job; phase 1 has settled it.) Then no rank computes
     // statistics or gathers anything for this batch: its events only rank behind complete files.
     const bool done_before = j->have_batch && pg_all_slots_full_settled(j->ctx[n - 1]);
+    j->full_slots_prev = j->have_batch ? pgi_full_slots_settled(j->ctx[n - 1]) : 0; // k-mers the job had completed before this batch (the last shard's cut saw them all)
     // phase 2: the exchange
     if (j->use_rccl) {
         for (uint32_t g = 0; g < n; ++g) { JHIP(j, hipSetDevice(j->devices[g])); JHIP(j, hipStreamWaitEvent(j->comm_st[g], j->ev_counted[g], 0)); }
@@ -312,7 +360,17 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
         // wait for the table, cancelled there if the table says so (pgi_stats_gathered). Rank 0 (nothing below it but the earlier
         // batches, which `done_before` covers) keeps its statistics in front of the wait, where they hide the collective.
         // PGMOVE_JOB_DEVICE_RULE=1: the host exchange takes the device's rule too (tests on one GPU).
-        const bool dev_rule = !done_before && g > 0 && j->sample_limit > 0 && (j->use_rccl || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr);
+        // ... but only where completion below this rank is PLAUSIBLE (round 5, advisor): behind the wait the statistics -- the largest
+        // HBM-bound kernel -- no longer hide the collective and the slowest rank's counting chain, in every batch, for a rule that pays in
+        // the one batch that completes the job. Plausible = the ops of the ranks below, spread evenly over the k-mers, could fill what the
+        // earlier batches left open (ops_below / n_slots >= sample_limit * share of k-mers still open; an unknown op count counts as
+        // plausible). configs[2] at the default limit: every rank behind the first; k = 9 (60 ops per k-mer and rank against a limit of
+        // 1000): no rank, the statistics stay in front of the wait. UNMEASURED on more than one GPU (no such node in this pool).
+        uint64_t ops_below = 0; bool ops_known = true;
+        for (uint32_t h = 0; h < g; ++h) { ops_below += shard_ops[h]; if (!shard_ops[h] && cut[h + 1] > cut[h]) ops_known = false; }
+        const double open_share = j->have_batch ? 1.0 - (double)j->full_slots_prev / (double)(ns ? ns : 1) : 1.0;
+        const bool plausible = !ops_known || (double)ops_below / (double)(ns ? ns : 1) >= (double)j->sample_limit * open_share || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr;
+        const bool dev_rule = !done_before && g > 0 && j->sample_limit > 0 && plausible && (j->use_rccl || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr);
         bool skip = done_before;
         if (!skip && !dev_rule && !j->use_rccl && j->sample_limit > 0) {
             skip = true;
@@ -345,6 +403,27 @@ pg_status pg_job_submit(pg_job *j, const pg_batch *b) {
     j->cuts.push_back(std::move(cut));
     j->batch_reads.push_back(nr);
     j->have_batch = true;
+    return PG_OK;
+}
+
+// as pg_reset for the job: the next pg_job_submit starts a new job on the same devices, communicators and buffers
+pg_status pg_job_reset(pg_job *j) {
+    if (!j) return PG_ERR_INVALID_ARG;
+    const uint32_t n = j->n, ns = j->n_slots;
+    pg_status s = on_ranks(j, [&](uint32_t g, std::string &msg) -> pg_status {
+        pg_status st = pg_sync(j->ctx[g]);
+        if (st == PG_OK) st = pg_reset(j->ctx[g]);
+        if (st != PG_OK) { msg = pg_last_error(j->ctx[g]); return st; }
+        hipError_t e = hipSetDevice(j->devices[g]);
+        if (e == hipSuccess && j->comm_st[g]) e = hipStreamSynchronize(j->comm_st[g]);
+        if (e == hipSuccess) e = hipMemsetAsync(j->gbuf[g], 0, (size_t)(n + 1) * ns * sizeof(uint64_t), (hipStream_t)pgi_stream(j->ctx[g])); // row 0: nothing accepted so far
+        if (e != hipSuccess) { msg = hipGetErrorString(e); return PG_ERR_HIP; }
+        return PG_OK;
+    });
+    if (s != PG_OK) return s;
+    std::fill(j->host_row0.begin(), j->host_row0.end(), 0); std::fill(j->host_rows.begin(), j->host_rows.end(), 0);
+    j->cuts.clear(); j->batch_reads.clear(); j->have_batch = false; j->merged = false; j->full_slots_prev = 0;
+    j->samples_on_host = j->samples_on_dev = j->small_on_dev = false;
     return PG_OK;
 }
 

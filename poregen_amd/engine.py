@@ -516,6 +516,16 @@ class GmoveJob:
         self._keep = b
         self._check(self._lib.pg_job_submit(self._h, C.byref(_c_batch(b))))
 
+    def submit_shards(self, shards: Sequence[Batch]):
+        """pg_job_submit_shards: one batch per device of the job, in PAF order, each where it will be worked (a device batch resident
+        on that device, or a host batch): nothing is cut or copied on the host."""
+        self._keep = list(shards)
+        arr = (_abi.PgBatch * len(shards))(*[_c_batch(b) for b in shards])
+        self._check(self._lib.pg_job_submit_shards(self._h, arr, len(shards)))
+
+    def reset(self):
+        self._check(self._lib.pg_job_reset(self._h))
+
     def sync(self):
         self._check(self._lib.pg_job_sync(self._h))
 

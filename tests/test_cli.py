@@ -390,3 +390,37 @@ def test_devices_option_equals_oracle(tmp_path, devopts):
     o = oracle_cli(args2[:-2] + [tmp_path / "cpu2"]); assert o.returncode == 0, o.stderr
     assert_same_dirs(tmp_path / "gpu2", tmp_path / "cpu2")
     assert open(tmp_path / "m_job.txt").read() == open(tmp_path / "m_one.txt").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("damage", ["truncated_record", "zstd_header", "exzd_header", "svb_block"])
+def test_gmove_exits_1_on_a_corrupt_blow5(tmp_path, damage):
+    """A damaged BLOW5 file ends `poregen gmove` with the reader's message and exit status 1 (src/gmove.cpp:493-503, 746-749: slow5lib's
+    failures are `exit(EXIT_FAILURE)` there), whether the damage is met while the file is indexed or when the read is fetched."""
+    import struct
+    import zlib
+    b = synth.make_batch(4, read_len=800, kind="dna_r10", seed=12)
+    synth.write_paf_fastq(b, str(tmp_path / "r"))
+    p = tmp_path / "r.blow5"
+    synth.write_blow5(b, str(p), compress=True)
+    d = bytearray(p.read_bytes())
+    if damage == "truncated_record":
+        d = d[:len(d) - 300]; msg = "BLOW5"
+    elif damage == "zstd_header":
+        d[9] = 2; msg = "record compression other than none/zlib is not supported"
+    elif damage == "exzd_header":
+        d[14] = 2; msg = "signal compression other than none/svb-zd is not supported"
+    else:  # the second record: a valid zlib stream whose streamvbyte block announces more values than it holds
+        hlen = struct.unpack_from("<I", d, 64)[0]; pos = 68 + hlen
+        sz = struct.unpack_from("<Q", d, pos)[0]; pos2 = pos + 8 + sz
+        sz2 = struct.unpack_from("<Q", d, pos2)[0]
+        body = bytearray(zlib.decompress(bytes(d[pos2 + 8:pos2 + 8 + sz2])))
+        idl = struct.unpack_from("<H", body, 0)[0]
+        struct.pack_into("<I", body, 2 + idl + 4 + 32 + 8, 10 ** 6)   # the block's count field
+        z = zlib.compress(bytes(body))
+        d = d[:pos2] + struct.pack("<Q", len(z)) + z + d[pos2 + 8 + sz2:]
+        msg = "corrupt streamvbyte block"
+    p.write_bytes(d)
+    r = subprocess.run([BIN, "gmove", "-k", "5", "--file_limit", "1024", str(p), str(tmp_path / "r.paf"), "--fastq", str(tmp_path / "r.fastq"), str(tmp_path / "out")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and msg in r.stderr, (r.returncode, r.stderr[-400:])

@@ -176,3 +176,49 @@ def test_job_errors():
         job.submit(b); job.finish()
     assert ei.value.status == _abi.PG_ERR_RNA_FLAG and "shard 2" in ei.value.text
     job.close()
+
+
+@pytest.mark.parametrize("devices,exchange,resident", [([0, 0, 0], _abi.PG_JOB_EXCHANGE_HOST, True), ([0], _abi.PG_JOB_EXCHANGE_RCCL, True), ([0, 0], _abi.PG_JOB_EXCHANGE_HOST, False)],
+                         ids=["three_device_shards_one_gpu", "rccl_one_rank_device_shard", "two_host_shards"])
+def test_job_submit_shards_device_resident(devices, exchange, resident):
+    """pg_job_submit_shards: every rank's shard handed over as a batch of its own, already resident on its device (nothing is cut, staged
+    or copied by the host: the device-resident N-GPU step of the C++ host) or on the host. Same streams as the oracle over the
+    concatenation, in two batches, with an empty shard in the second."""
+    import torch
+    wl, b, p = _whitelist_case()
+    o = oracle_for(wl, index_start=51, index_end=250, delimit=True, **p)
+    o.run_batch(b)
+    job = GmoveJob(GmoveParams(kmers=wl[50:250], **p), devices, exchange)
+    n = len(devices)
+    dev = torch.device("cuda", 0)
+    keep = []
+    for lo, hi in ((0, 200), (200, 420)):
+        cuts = [lo + (hi - lo) * g // n for g in range(n + 1)]
+        if lo == 200 and n > 1:
+            cuts[1] = cuts[0]               # rank 0's shard of the second batch is empty
+        shards = [b.slice_reads(cuts[g], cuts[g + 1]) for g in range(n)]
+        if resident:
+            shards = [s.to_device(dev) for s in shards]
+        keep.append(shards)
+        job.submit_shards(shards)
+    res = job.finish()
+    assert_result_equals_oracle(res, o, delimit=True, sample_limit=9)
+    with pytest.raises(PgError):
+        job.submit_shards(keep[0][:-1] if n > 1 else keep[0] + keep[0])   # one batch per device, no more, no fewer
+    job.close()
+
+
+def test_job_reset_starts_a_new_job():
+    b = synth.make_batch(200, kind="rna004", seed=603)
+    p = dict(kmer_size=4, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=25)
+    kmers = generate_kmers(4, rna=True)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    job = GmoveJob(GmoveParams(kmers=kmers, **p), [0, 0])
+    job.submit(b.slice_reads(0, 90)); job.submit(b.slice_reads(90, 200))
+    first = job.finish()
+    assert_result_equals_oracle(first, o, sample_limit=25)
+    job.reset()
+    job.submit(b)                      # the same reads as one batch of a NEW job: nothing of the first job's counts is left
+    again = job.finish()
+    assert_result_equals_oracle(again, o, sample_limit=25)
+    job.close()
