@@ -171,8 +171,9 @@ def load():
     lib.pg_job_destroy.argtypes = [vp]; lib.pg_job_destroy.restype = None
     lib.pg_job_last_error.argtypes = [vp]; lib.pg_job_last_error.restype = C.c_char_p
     lib.pg_job_submit.argtypes = [vp, C.POINTER(PgBatch)]; lib.pg_job_submit.restype = i32
-    lib.pg_job_submit_shards.argtypes = [vp, C.POINTER(PgBatch), C.c_uint32]; lib.pg_job_submit_shards.restype = i32
-    lib.pg_job_reset.argtypes = [vp]; lib.pg_job_reset.restype = i32
+    if hasattr(lib, "pg_job_submit_shards"):  # (a measurement build of an earlier round loaded through bench.py --lib lacks the newer entry points)
+        lib.pg_job_submit_shards.argtypes = [vp, C.POINTER(PgBatch), C.c_uint32]; lib.pg_job_submit_shards.restype = i32
+        lib.pg_job_reset.argtypes = [vp]; lib.pg_job_reset.restype = i32
     lib.pg_job_sync.argtypes = [vp]; lib.pg_job_sync.restype = i32
     lib.pg_job_all_slots_full.argtypes = [vp]; lib.pg_job_all_slots_full.restype = i32
     lib.pg_job_finish.argtypes = [vp, C.POINTER(PgResult)]; lib.pg_job_finish.restype = i32

@@ -616,7 +616,10 @@ int gmove_main(int argc, char **argv) {
         h.sig.resize((size_t)h.sig_off.back()); h.seq.resize((size_t)h.seq_off.back());
         h.op_n.resize((size_t)h.op_off.back()); h.op_t.resize((size_t)h.op_off.back());
         h.qs.resize(h.n()); h.ts.resize(h.n()); h.te.resize(h.n());
-        if (flush() && dev.ok() && dev.sync() == PG_OK && dev.all_full()) { status = EXIT_SUCCESS; stop = true; }
+        if (flush() && dev.ok() && dev.sync() == PG_OK && dev.all_full()) {
+            status = EXIT_SUCCESS; stop = true;
+            fprintf(stderr, "[gmove] the record reported above lies behind the read that completes the last k-mer: the reference stops reading there (gmove.cpp:733-735); ignored\n");
+        }
     }
     if (status == EXIT_SUCCESS && !stop && !flush()) status = EXIT_FAILURE;
     free(line); fclose(paf_fp);

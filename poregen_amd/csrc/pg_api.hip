@@ -82,7 +82,7 @@ struct pg_ctx {
     uint32_t win_hint = 0; // mean kept window of the last settled batch (samples): picks the gather's lanes per event
     // partitioned ranking (1024 < slots <= 2^20; pg_place.hip)
     bool part_mode = false; uint32_t part_hi = 0, part_lo = 0;
-    DevBuf part_elem, part_lodig, part_rbase, part_tile_region, part_ntiles, part_histB, part_Bp, chunk_part[2];
+    DevBuf part_elem, part_lodig, part_rbase, part_tile_region, part_ntiles, part_histB, part_Bp, chunk_part[2], region_state; uint32_t region_epoch = 0; // region_state / region_epoch: k_region_scan_cut
     bool gather_side = false; int gather_side_slot = 0; bool side_used[2] = {false, false}; // the last chunked gather was queued on the second stream (two-stream mode) and nothing on `st` has waited for it yet
     DevBuf med[2], mad[2], gcal[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
@@ -256,7 +256,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->hist, &c->wcnt, &c->totals, &c->dbase, &c->scount, &c->slot_start, &c->slot_end, &c->acc_cnt, &c->running,
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals[0], &c->plan_totals[1], &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec[0], &c->ev_rec[1], &c->ev_len, &c->ev_read, &c->read_needed,
                       &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
-                      &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1],
+                      &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1], &c->region_state,
                       &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->long_tab, &c->long_hist, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
@@ -769,7 +769,10 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     HIP_TRY(c, c->read_needed.ensure(n + 2ull));
     const uint32_t n_tiles = pg_tiles(Nn, direct);
     uint32_t ndig;
-    if (direct) { ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1; if (dense_direct(c, N)) HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4)); }
+    if (direct) {
+        ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1;
+        if (dense_direct(c, N)) { HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4)); HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8)); }
+    }
     else if (c->part_mode) {
         ndig = 1u << c->part_hi;
         const uint32_t tcap = pg_part_tiles_cap(Nn, c->part_hi);
@@ -848,7 +851,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
                                     c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
                                     c->plan_totals[c->slot].as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
-                                    O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr));
+                                    O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr, dense_direct(c, N) ? c->chunk_part[c->slot].as<uint64_t>() : nullptr));
         prof_end(c, c->st);
     } else if (c->part_mode) {
         // partitioned ranking, pass A and the counts of pass B (pg_place.hip): everything pg_count's result needs
@@ -864,9 +867,22 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
             prof_begin(c, "k_part_scatter", c->st);
             HIP_TRY(c, pg_launch_part_scatter(c->st, P, O.ev_slot, N, c->B, W, O));
             prof_end(c, c->st);
+            // pg_submit (base = this context's running counts): the sample_limit cut rides in the region scan's launch, as in the direct ranking
+            PgRegionCutArgs cut{};
+            const bool fuse_cut = c->in_submit && !acc_copy && !getenv("PGMOVE_NO_FUSED_CUT");
+            if (fuse_cut) {
+                const size_t before = c->region_state.cap;
+                HIP_TRY(c, c->region_state.ensure(((size_t)(1u << c->part_hi) + 2) * 8));
+                if (c->region_state.cap != before) HIP_TRY(c, hipMemsetAsync(c->region_state.p, 0, c->region_state.cap, c->st));
+                if (++c->region_epoch > pg_region_cut_epochs()) { c->region_epoch = 1; HIP_TRY(c, hipMemsetAsync(c->region_state.p, 0, c->region_state.cap, c->st)); }
+                HIP_TRY(c, c->keep32.ensure(c->prm.n_slots * 4ull));
+                cut.running = c->running.as<uint64_t>(); cut.keep = c->keep.as<uint64_t>(); cut.ev_off = c->ev_off.as<uint64_t>(); cut.totals = c->plan_totals[c->slot].as<uint64_t>();
+                cut.keep32 = c->keep32.as<uint32_t>(); cut.state = c->region_state.as<uint64_t>(); cut.limit = c->prm.sample_limit; cut.epoch = c->region_epoch;
+            }
             prof_begin(c, "region_counts", c->st, true);
-            HIP_TRY(c, pg_launch_region_counts(c->st, P, c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy));
+            HIP_TRY(c, pg_launch_region_counts(c->st, P, c->prm.n_slots, c->acc_cnt.as<uint64_t>(), acc_copy, fuse_cut ? &cut : nullptr));
             prof_end(c, c->st);
+            c->plan_done = fuse_cut;
         } else {
             HIP_TRY(c, hipMemsetAsync(c->acc_cnt.p, 0, c->prm.n_slots * 8ull, c->st));
             if (acc_copy) HIP_TRY(c, hipMemsetAsync(acc_copy, 0, c->prm.n_slots * 8ull, c->st));
@@ -1079,15 +1095,21 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     uint64_t gather_cap = ke_cap;
     if (chunked) {
-        if (c->rare_pending) { // the rare statistics have no scan launch to ride in
+        // the chunk sums of the kept window lengths: accumulated by k_region_place (partitioned ranking), else one pass over the records;
+        // the rare statistics ride in that pass's launch, or get their own
+        if (!sums_ready) {
+            // the coarse sums are ADDED to: zeroed by the tile scan's extra workgroup where there is one (dense direct ranking; partitioned
+            // ranking, whose placing kernel has filled them by now), else here (the radix-sort ranking, PGMOVE_EMIT1)
+            if (!(direct && dense_direct(c, N)) && !c->part_mode) HIP_TRY(c, hipMemsetAsync(c->chunk_part[c->slot].p, 0, PG_CHUNK_PART_N * 8, c->st));
+            prof_begin(c, "len_partials", c->st);
+            HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->rare_pending ? &c->rare : nullptr));
+            prof_end(c, c->st);
+        } else if (c->rare_pending) {
             prof_begin(c, "k_read_stats_rare", c->st);
             HIP_TRY(c, pg_launch_read_stats_rare(c->st, c->rare));
             prof_end(c, c->st);
-            c->rare_pending = false;
         }
-        prof_begin(c, "len_partials", c->st, true);
-        HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), totals + 2, sums_ready));
-        prof_end(c, c->st);
+        c->rare_pending = false;
     } else {
         prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
         HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec[c->slot].p) + 2, 4, ke_cap, totals, c->samp_off[c->slot].as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
@@ -1103,12 +1125,24 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_total = 0; }
         const uint64_t moderate = std::max<uint64_t>(4ull << 30, std::min<uint64_t>(mem_total / 8, mem_free / 2));
-        if (samp_cap * 8 <= moderate) HIP_TRY(c, c->samples.ensure(samp_cap * 8 + 8));
-        else {
+        bool sized = false;
+        if (samp_cap * 8 <= moderate && !getenv("PGMOVE_SAMPLES_EXACT")) { // (PGMOVE_SAMPLES_EXACT: tests of the exact-size branch)
+            // hipMemGetInfo races with every other context and process on the device (pg_job with one device listed twice, two ranks on one
+            // GPU): a worst-case allocation that fails after all is not an error, the exact size below still fits
+            sized = c->samples.ensure(samp_cap * 8 + 8) == hipSuccess;
+            if (!sized) (void)hipGetLastError();
+        }
+        if (!sized) {
             uint64_t tot[3] = {0, 0, 0};
             HIP_TRY(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, c->st));
-            HIP_TRY(c, hipStreamSynchronize(c->st));
-            HIP_TRY(c, c->samples.ensure((tot[2] + 1) * 8)); // totals[2]: all kept samples (the offset scan's total)
+            if (chunked) { // the kept samples' total is left by the GATHER there (its last chunk); in front of it: the sum of the coarse chunk sums
+                uint64_t coarse[PG_CHUNK_COARSE];
+                HIP_TRY(c, hipMemcpyAsync(coarse, c->chunk_part[c->slot].as<uint64_t>() + PG_CHUNK_FINE, sizeof coarse, hipMemcpyDeviceToHost, c->st));
+                HIP_TRY(c, hipStreamSynchronize(c->st));
+                tot[2] = 0;
+                for (uint64_t v : coarse) tot[2] += v;
+            } else HIP_TRY(c, hipStreamSynchronize(c->st));
+            HIP_TRY(c, c->samples.ensure((tot[2] + 1) * 8)); // all kept samples
             gather_cap = tot[0];
         }
     }
@@ -1122,7 +1156,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", gst);
     if (chunked)
-        HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling,
+        HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), totals + 2, c->prm.scaling,
                                            c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c),
                                            c->prm.scaling == 1 ? c->stat_err[c->slot].as<int32_t>() : nullptr));
     else

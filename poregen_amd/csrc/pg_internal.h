@@ -134,7 +134,13 @@ struct PgSortBufs {
 };
 
 // ---- partitioned ranking (PG_DIRECT_MAX_SLOTS < n_slots <= 2^PG_PART_MAX_KEY_BITS; pg_place.hip) ------------------------------
-#define PG_CHUNK_PART_N 8200u   // entries of the chunked gather's chunk sums (k_partials_scan holds 8192)
+// the chunked gather's chunk sums of kept window lengths: [0, PG_CHUNK_FINE) one per chunk, [PG_CHUNK_FINE, + PG_CHUNK_COARSE) their sums over
+// groups of 64 chunks. Both are ADDED to by the kernel that places the kept events (or written by k_len_partials); a gather workgroup
+// takes its base from them itself -- the coarse sums below its group + the fine sums of its group below it: ~190 values for one wave --
+// so no scan launch stands between the placing kernel and the gather (round 5; k_partials_scan was 6-11 us + a kernel boundary)
+#define PG_CHUNK_FINE 8192u
+#define PG_CHUNK_COARSE 128u
+#define PG_CHUNK_PART_N (PG_CHUNK_FINE + PG_CHUNK_COARSE + 8u)
 #define PG_PART_MAX_KEY_BITS 20
 struct PgPartBufs {
     uint4 *elemA;          // [n_ops + (R + 1) * PG_SORT_TILE] accepted events {slot, window start, length | start's high bits, read}, partitioned by the
@@ -154,8 +160,13 @@ hipError_t pg_launch_part_tile_scan(hipStream_t st, const PgPartBufs &P, uint64_
 hipError_t pg_launch_part_bases(hipStream_t st, const PgPartBufs &P, const PgDevBatch &B, const PgWalkOut &O);
 hipError_t pg_launch_part_scatter(hipStream_t st, const PgPartBufs &P, const uint32_t *ev_slot, uint64_t n, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);
 // acc_cnt / acc_copy (may be null): accepted events per slot
-hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy);
-struct PgKeptOut; struct PgKeptRec;
+// cut (may be null; pg_submit: base = the context's running counts): the sample_limit cut rides in the region scan's launch (k_region_scan_cut) --
+// keep / keep32 / ev_off / totals as pg_launch_slot_plan leaves them, running updated in place; state: >= (2^hi_bits + 1) uint64, zeroed when
+// allocated and whenever the epoch starts again at 1; epoch: the launch's serial number, 1 .. pg_region_cut_epochs()
+struct PgRegionCutArgs { uint64_t *running, *keep, *ev_off, *totals; uint32_t *keep32; uint64_t *state; uint32_t limit, epoch; };
+uint32_t pg_region_cut_epochs(void);
+hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy, const PgRegionCutArgs *cut);
+struct PgKeptOut; struct PgKeptRec; struct PgRareArgs;
 // part / n_kept_cap: the chunked gather's per-chunk sums of kept window lengths are accumulated by this launch (n_kept_cap = 0: not wanted)
 hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, const uint32_t *keep32, const uint64_t *ev_off, const PgWalkOut &O, const PgKeptOut &K,
                                   uint64_t *part, uint64_t n_kept_cap);
@@ -163,10 +174,12 @@ hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t 
 hipError_t pg_launch_rank_emit2(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const uint32_t *hist, const uint64_t *keep, const uint64_t *ev_off,
                                 const uint64_t *totals, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K, const uint32_t *Bp);
 // many kept events: sample offsets inside the gather's workgroups (part: >= 8192 entries of work space)
-hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
-                                  bool sums_ready);
+// (part zeroed beforehand: k_rank_scan's extra workgroup). rare (may be null): the rare statistics ride in the same launch
+hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, const PgRareArgs *rare);
+uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk);
+// total_out: [0] = all kept samples (= samp_off[n_kept], written too), left by the workgroup of the last chunk
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
-                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes,
+                                   uint64_t *samp_off, uint64_t *total_out, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes,
                                    const int32_t *stat_flags /* the batch's statistics flags (may be null): [3] != 0 = the wave / event-pair forms divide instead of using the reciprocal */);
 // pg_text.hip: the dump files' text on the device (flag[0] != 0 afterwards: a sample the fixed-point formatter does not take)
 hipError_t pg_launch_text_lens(hipStream_t st, const double *samples, const uint64_t *samp_off, uint64_t n_events, uint32_t *tlen, uint32_t *flag);
@@ -277,7 +290,8 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
                                  // plan_keep != null (pg_submit: base = the context's running counts): the sample_limit cut rides in the same
                                  // launch (its last workgroup does pg_launch_slot_plan's work); *plan_done says whether it did
                                  uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done,
-                                 const uint32_t *btot /* PgWalkOut::btot */, uint32_t *Bp /* may be null: its prefix, for pg_launch_rank_emit2 */);
+                                 const uint32_t *btot /* PgWalkOut::btot */, uint32_t *Bp /* may be null: its prefix, for pg_launch_rank_emit2 */,
+                                 uint64_t *zero64 /* with Bp: PG_CHUNK_PART_N chunk sums, zeroed by the same extra workgroup (may be null) */);
 hipError_t pg_launch_rank_direct_emit(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                 const uint64_t *keep, const uint64_t *ev_off, const uint64_t *totals, const PgDevBatch &B,
                                 const PgWalkParams &W, const PgWalkOut &O, const PgKeptOut &K);

@@ -1008,8 +1008,6 @@ __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__
         // thread, all 16 loads in flight, one workgroup-wide scan per 65 536 sums (k = 9, 50 000 reads: one trip)
         __shared__ uint32_t bsum[PG_SCAN_WAVES];
         uint32_t carry = 0;
-        // the chunk sums of the kept window lengths (k_region_place adds to them): zeroed here instead of by a fill launch
-        if (zero64) for (uint32_t i = threadIdx.x; i < PG_CHUNK_PART_N; i += PG_SCAN_WAVES * WAVE) zero64[i] = 0;
         for (uint32_t c = 0; c < bp_nb; c += PG_SCAN_WAVES * WAVE * 64) {
             const uint32_t i0 = c + threadIdx.x * 64;
             uint4 v[16];
@@ -1040,6 +1038,9 @@ __global__ __launch_bounds__(PG_SCAN_WAVES * WAVE) void k_rank_scan(uint32_t *__
         if (threadIdx.x == 0) bp_out[bp_nb] = carry;
         return;
     }
+    // the chunk sums of the kept window lengths (k_region_place / k_len_partials add to them): zeroed here instead of by a fill launch, a
+    // slice per workgroup (the extra workgroup above starts last and is the launch's long pole already)
+    if (zero64) for (uint32_t i = blockIdx.x * (PG_SCAN_WAVES * WAVE) + threadIdx.x; i < PG_CHUNK_PART_N; i += (gridDim.x - (bp_out ? 1u : 0u)) * (PG_SCAN_WAVES * WAVE)) zero64[i] = 0;
     if (d < n_digits) {
         uint32_t run = 0;
         const bool want_last = tile_last && d < n_slots;
@@ -2560,7 +2561,7 @@ static uint32_t tiles_for(uint64_t n) { return pg_tiles(n, false); }
 hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, uint64_t n, uint32_t n_slots, const PgSortBufs &S,
                                  uint64_t *acc_cnt, uint64_t *running, uint32_t limit, int32_t *tile_last, uint64_t *acc_copy,
                                  uint64_t *plan_keep, uint64_t *plan_ev_off, uint64_t *plan_totals, uint32_t *plan_ticket, bool *plan_done,
-                                 const uint32_t *btot, uint32_t *Bp) {
+                                 const uint32_t *btot, uint32_t *Bp, uint64_t *zero64) {
     int nbits = 1; while ((1u << nbits) < n_slots) ++nbits;
     const uint32_t n_tiles = pg_tiles(n, true);
     *plan_done = false;
@@ -2569,7 +2570,7 @@ hipError_t pg_launch_rank_direct_count(hipStream_t st, const uint32_t *ev_slot, 
         if (plan_keep) { P.keep = plan_keep; P.ev_off = plan_ev_off; P.plan_totals = plan_totals; P.running_out = running; P.ticket = plan_ticket; *plan_done = true; }
         // Bp (may be null): one extra workgroup leaves the prefix of k_events' block sums for k_rank_emit2's window starts
         PG_LAUNCH(k_rank_scan, dim3(((1u << nbits) + PG_SCAN_WAVES - 1) / PG_SCAN_WAVES + (Bp ? 1u : 0u)), dim3(PG_SCAN_WAVES * WAVE), 0, st, S.hist, n_tiles, S.totals, acc_cnt, n_slots, 1u << nbits,
-                  (const uint64_t *)running, limit, tile_last, acc_copy, P, btot, Bp ? (uint32_t)((n + 255) / 256) : 0u, Bp, (uint64_t *)nullptr);
+                  (const uint64_t *)running, limit, tile_last, acc_copy, P, btot, Bp ? (uint32_t)((n + 255) / 256) : 0u, Bp, Bp ? zero64 : (uint64_t *)nullptr);
     } else {
         PG_HIP(hipMemsetAsync(acc_cnt, 0, sizeof(uint64_t) * n_slots, st));
         if (acc_copy) PG_HIP(hipMemsetAsync(acc_copy, 0, sizeof(uint64_t) * n_slots, st));
@@ -2714,6 +2715,54 @@ hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
     PG_LAUNCH(k_read_stats_rare, dim3(wide_blocks + PG_HUGE_BLOCKS), dim3(64), 0, st, A);
     return hipSuccess;
 }
+
+// sum of the kept window lengths of every chunk of `chunk` events (direct ranking with many kept events: the placing kernel's
+// events go to ~1000 k-mers per tile, nothing to combine there): the fine sum stored, the coarse sum of its group of 64 chunks added to
+// (pg_internal.h: PG_CHUNK_FINE). RARE: workgroups behind the chunks' are four rare-statistics workers each (as k_scan_chained: an
+// empty launch of their own costs a kernel boundary per batch)
+template <bool RARE> __global__ __launch_bounds__(256) void k_len_partials(const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ n_kept_ptr, uint32_t chunk, uint32_t n_chunks,
+                                                                          uint64_t *__restrict__ part, PgRareArgs A) {
+    if (RARE) {
+        __shared__ __attribute__((aligned(16))) uint32_t rare_hist[4][PG_RARE_LDS_WORDS];
+        if (blockIdx.x >= n_chunks) {
+            const uint32_t workers = (gridDim.x - n_chunks) * 4u;
+            rare_worker((blockIdx.x - n_chunks) * 4u + (threadIdx.x >> 6), workers - PG_HUGE_BLOCKS, rare_hist[threadIdx.x >> 6], A);
+            return;
+        }
+    }
+    __shared__ uint64_t wsum[4];
+    const uint64_t n = n_kept_ptr[0], e0 = (uint64_t)blockIdx.x * chunk;
+    uint64_t s = 0;
+    if (e0 < n) {
+        const uint64_t cnt = n - e0 < chunk ? n - e0 : chunk;
+        const uint32_t *__restrict__ lens = reinterpret_cast<const uint32_t *>(rec + e0) + 2;
+        for (uint64_t i0 = threadIdx.x; i0 < cnt; i0 += 4 * 256) { // four independent loads in flight (a chunk of 1024 events: one round trip)
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint64_t i = i0 + (uint64_t)u * 256; v[u] = i < cnt ? lens[4 * i] : 0u; }
+            s += (uint64_t)v[0] + v[1] + v[2] + v[3];
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, WAVE);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        part[blockIdx.x] = t;
+        if (t) atomicAdd(reinterpret_cast<unsigned long long *>(part + PG_CHUNK_FINE + (blockIdx.x >> 6)), (unsigned long long)t);
+    }
+}
+hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, const PgRareArgs *rare) {
+    if (n_kept_cap == 0) { if (rare) return pg_launch_read_stats_rare(st, *rare); return hipSuccess; }
+    uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
+    if (rare && rare->B.n_reads) {
+        const uint32_t want = rare->wide_blocks < 64 ? 64u : (rare->wide_blocks > 2048 ? 2048u : rare->wide_blocks);
+        const uint32_t extra = (want + PG_HUGE_BLOCKS + 3) / 4;
+        PG_LAUNCH(k_len_partials<true>, dim3(n_chunks + extra), dim3(256), 0, st, rec, n_kept_ptr, m * 1024u, n_chunks, part, *rare);
+    } else PG_LAUNCH(k_len_partials<false>, dim3(n_chunks), dim3(256), 0, st, rec, n_kept_ptr, m * 1024u, n_chunks, part, PgRareArgs{});
+    return hipSuccess;
+}
+
 
 hipError_t pg_launch_read_plan(hipStream_t st, const PgDevBatch &B, const uint8_t *read_needed, double pa_min, double pa_max, void *plan_buf,
                          int32_t *flags, int32_t *stat_status, bool flags_are_reset, const PgLongState &LS) {

@@ -11,12 +11,18 @@
 #include "pg_internal.h"
 #include "pg_model.h"
 
+#ifndef PG_MODEL_TINY_BITS
+#define PG_MODEL_TINY_BITS 8
+#endif
+#ifndef PG_MODEL_TINY_WAVES
+#define PG_MODEL_TINY_WAVES 4 // waves per SIMD the one-wave variant is compiled for
+#endif
 namespace {
 
 // loads in flight per thread: the 1024-thread variant must stay within 64 VGPRs (two workgroups per CU), its memory
 // parallelism comes from 32 waves per CU; the 256-thread variant serves short files, where the round trips are the cost
 template <int MT> struct ModelCfg {
-    static constexpr int BITS = MT >= 256 ? 12 : 8;    // window of the radix select; a single wave scans 256 bins, not 4096
+    static constexpr int BITS = MT >= 256 ? 12 : PG_MODEL_TINY_BITS;    // window of the radix select; a single wave scans 256 bins, not 4096
     static constexpr int BINS = 1 << BITS;
     static constexpr int U = MT >= 1024 ? 2 : 8;
     static constexpr int CACHE = MT >= 1024 ? 0 : 16; // keys a thread keeps in registers when the whole file fits (MT * CACHE values)
@@ -195,7 +201,7 @@ template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm
 // needs no workgroup barrier) and SHORT (256 threads, <= 4096 values) convert the whole file once into 16 registers per
 // thread; LONG (1024 threads) re-reads the file per pass. A workgroup whose k-mer belongs to another kernel leaves after two
 // loads. Separate kernels because each needs its own register budget; the host launches only the ones with work.
-template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : 4) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
+template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_WAVES : 4)) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
                                                                       const double *samples, uint32_t drop_first, PgSlotModel *out,
                                                                       PgSlotDwell *dwell) {
     constexpr bool SHORT = KIND != PG_MODEL_LONG; // register-resident

@@ -20,6 +20,7 @@
 // are read once and the offsets written once, not read / written / read again by a scan kernel of their own.
 #include "pg_dev.h"
 #include "pg_select.h"
+#include <type_traits>
 
 // =====================================================================================================
 // op-sum prefixes: window starts of direct reads without a walk
@@ -397,6 +398,90 @@ __global__ __launch_bounds__(1024) void k_region_scan(uint32_t *__restrict__ his
     if (slot < n_slots) { acc_cnt[slot] = run; if (acc_copy) acc_copy[slot] = run; }
 }
 
+// The same + the sample_limit cut of pg_submit (base = the context's running counts; gmove.cpp:925-927, 945-950) in ONE launch (round 5;
+// k_slot_cut behind k_region_scan was 27 us of chained scan + a kernel boundary): a region's workgroup holds its slots' counts in registers,
+// cuts them, scans the kept counts inside the region, PUBLISHES the region's kept total and full count, and adds up the words of the
+// regions in front of it -- every workgroup of the launch publishes after its own column pass and waits for nobody before that, so there
+// is no chain: one round of loads. A word = kept total (40 bits) | complete k-mers (11 bits) << 40 | epoch (13 bits) << 51, one relaxed
+// agent-scope store / load; the epoch is the launch's serial number (1 .. 8191; the host clears the table when it starts again), so
+// nothing is reset between launches but the two counters in front of it (by the workgroup that finishes last). Regions are handed
+// out by ticket: a waiting workgroup only waits for workgroups that have started.
+struct PgRegionCut {
+    const uint64_t *running_in; uint64_t *running_out, *keep, *ev_off, *totals;
+    uint32_t *keep32;
+    uint64_t *state; // [0] lo: regions handed out, hi: regions done; [1 + r] region words
+    uint32_t limit, epoch;
+};
+#define PG_RCUT_EPOCHS 8191u
+__global__ __launch_bounds__(1024) void k_region_scan_cut(uint32_t *__restrict__ histB, const uint32_t *__restrict__ rbase, int lo_bits, uint32_t n_slots, uint32_t R,
+                                                          uint64_t *__restrict__ acc_cnt, PgRegionCut Q) {
+    __shared__ uint32_t sh_r, sh_last; __shared__ uint64_t wsum[16], wfull[16], sh_base, sh_fullb;
+    const uint32_t d = threadIdx.x, ndig = 1u << lo_bits, w = d >> 6;
+    const int lane = lane_id();
+    uint32_t *__restrict__ tickets = reinterpret_cast<uint32_t *>(Q.state);
+    if (d == 0) sh_r = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t r = sh_r;
+    uint32_t run = 0;
+    const uint64_t slot = ((uint64_t)r << lo_bits) | d;
+    const bool mine = d < ndig && slot < n_slots;
+    if (d < ndig) { // exclusive prefixes along the region's tiles (in place), as k_region_scan
+        const uint32_t t0 = rbase[r] / PG_SORT_TILE, t1 = rbase[r + 1] / PG_SORT_TILE;
+        uint32_t t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = histB[(uint64_t)(t + u) * ndig + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { histB[(uint64_t)(t + u) * ndig + d] = run; run += v[u]; }
+        }
+        for (; t < t1; ++t) { const uint32_t v = histB[(uint64_t)t * ndig + d]; histB[(uint64_t)t * ndig + d] = run; run += v; }
+    }
+    uint32_t kp = 0; uint32_t isfull = 0;
+    if (mine) {
+        const uint64_t b = Q.running_in[slot];
+        const uint64_t rm = b >= Q.limit ? 0 : (uint64_t)Q.limit - b;
+        kp = (uint32_t)((uint64_t)run < rm ? run : rm);
+        isfull = (Q.limit > 0 && b + run >= Q.limit) ? 1u : 0u; // at limit 0 no k-mer ever completes (see k_slot_plan)
+        acc_cnt[slot] = run; Q.running_out[slot] = b + run; Q.keep[slot] = kp; Q.keep32[slot] = kp;
+    }
+    const uint32_t inc = wave_incl_scan_u32(kp);
+    const uint32_t nf = (uint32_t)__popcll(__ballot(isfull != 0));
+    if (lane == WAVE - 1) { wsum[w] = inc; wfull[w] = nf; }
+    __syncthreads();
+    uint64_t off = 0, tot = 0, full = 0;
+    for (uint32_t ww = 0; ww < (blockDim.x >> 6); ++ww) { if (ww < w) off += wsum[ww]; tot += wsum[ww]; full += wfull[ww]; }
+    const uint64_t ep = (uint64_t)Q.epoch << 51;
+    uint64_t *__restrict__ words = Q.state + 1;
+    if (d == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(words + r), (unsigned long long)(tot | (full << 40) | ep), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the regions in front: every thread takes some of their words, all requested together; re-asked until they carry this launch's epoch
+    uint64_t bsum = 0, fsum = 0;
+    for (uint32_t i0 = 0; i0 < r; i0 += blockDim.x) {
+        const uint32_t i = i0 + d;
+        uint64_t wv = ep;
+        if (i < r) {
+            do { wv = __hip_atomic_load(reinterpret_cast<unsigned long long *>(words + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if ((wv >> 51) != Q.epoch) __builtin_amdgcn_s_sleep(1); } while ((wv >> 51) != Q.epoch);
+        }
+        bsum += wv & ((1ull << 40) - 1); fsum += (wv >> 40) & 0x7FFull;
+    }
+    for (int o = 32; o >= 1; o >>= 1) { bsum += __shfl_xor(bsum, o, WAVE); fsum += __shfl_xor(fsum, o, WAVE); }
+    __syncthreads(); // (wsum / wfull have been read)
+    if (lane == 0) { wsum[w] = bsum; wfull[w] = fsum; }
+    __syncthreads();
+    if (d == 0) { uint64_t b2 = 0, f2 = 0; for (uint32_t ww = 0; ww < (blockDim.x >> 6); ++ww) { b2 += wsum[ww]; f2 += wfull[ww]; } sh_base = b2; sh_fullb = f2; }
+    __syncthreads();
+    const uint64_t base = sh_base;
+    if (mine) Q.ev_off[slot] = base + off + inc - kp;
+    if (r == R - 1 && d == 0) { // the last region knows the job's totals
+        Q.ev_off[n_slots] = base + tot; Q.totals[0] = base + tot; Q.totals[1] = sh_fullb + full;
+        Q.totals[3] = ~0ull >> 1; // (read as a signed tile index by the direct ranking only)
+    }
+    // slots of a region that lies beyond n_slots entirely hold nothing; the counters for the next launch by whoever finishes last
+    if (d == 0) sh_last = __hip_atomic_fetch_add(tickets + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == R - 1;
+    __syncthreads();
+    if (sh_last && d == 0) { __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
 // pass B proper: the kept events of a region tile leave as records, in k-mer-major order
 __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_region_place(const uint4 *__restrict__ elemA, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
                                                                    const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, int lo_bits, uint32_t n_slots,
@@ -460,10 +545,25 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         if (!part) continue;
         const uint64_t ch = ((uint64_t)dst >> chunk_shift) - c_lo;
         if (ch < PG_PLACE_CSPAN) atomicAdd(&csum[ch], len);
-        else atomicAdd(reinterpret_cast<unsigned long long *>(part + ((uint64_t)dst >> chunk_shift)), (unsigned long long)len); // a region that keeps more than 64 chunks of events
+        else { // a region that keeps more than 64 chunks of events
+            atomicAdd(reinterpret_cast<unsigned long long *>(part + ((uint64_t)dst >> chunk_shift)), (unsigned long long)len);
+            atomicAdd(reinterpret_cast<unsigned long long *>(part + PG_CHUNK_FINE + ((uint64_t)dst >> chunk_shift >> 6)), (unsigned long long)len);
+        }
     }
     __syncthreads();
-    if (part && tid < PG_PLACE_CSPAN && csum[tid]) atomicAdd(reinterpret_cast<unsigned long long *>(part + c_lo + tid), (unsigned long long)csum[tid]); // integer sums: any order
+    if (part && tid < PG_PLACE_CSPAN) { // (the first wave) integer sums: any order. The fine sums, one add per chunk the tile touched ...
+        const uint32_t v = csum[tid];
+        if (v) atomicAdd(reinterpret_cast<unsigned long long *>(part + c_lo + tid), (unsigned long long)v);
+        // ... and the coarse sums of their groups of 64 chunks (pg_internal.h: PG_CHUNK_FINE): the 64 chunks span at most two groups, each
+        // reduced in the wave to ONE add (64 adds to one address per workgroup took this kernel from 159 to 310 us)
+        static_assert(PG_PLACE_CSPAN == WAVE, "one wave holds the tile's chunk sums");
+        const uint64_t g0 = c_lo >> 6;
+        const bool second = ((c_lo + tid) >> 6) != g0;
+        uint64_t a = second ? 0ull : v, b = second ? v : 0ull;
+        for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, WAVE); b += __shfl_xor(b, o, WAVE); }
+        if (tid == 0 && a) atomicAdd(reinterpret_cast<unsigned long long *>(part + PG_CHUNK_FINE + g0), (unsigned long long)a);
+        if (tid == 1 && b) atomicAdd(reinterpret_cast<unsigned long long *>(part + PG_CHUNK_FINE + g0 + 1), (unsigned long long)b);
+    }
 }
 
 // =====================================================================================================
@@ -611,38 +711,15 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
 // sample offsets + gather of many kept events in one kernel (gmove.cpp:773-775, 938-944)
 // =====================================================================================================
 
-// sum of the kept window lengths of every chunk of `chunk` events
-__global__ __launch_bounds__(256) void k_len_partials(const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ n_kept_ptr, uint32_t chunk, uint64_t *__restrict__ part) {
-    __shared__ uint64_t wsum[4];
-    const uint64_t n = n_kept_ptr[0], e0 = (uint64_t)blockIdx.x * chunk;
+// a gather workgroup's base: the kept samples in front of chunk c = the coarse sums of the groups of 64 chunks below its own + the fine
+// sums of its group below it (pg_internal.h: PG_CHUNK_FINE); every wave works it out for itself (three loads per lane and a reduction)
+__device__ __forceinline__ uint64_t chunk_base(const uint64_t *__restrict__ part, uint32_t c) {
+    const uint32_t lane = (uint32_t)lane_id(), nc = c >> 6, f0 = c & ~63u;
     uint64_t s = 0;
-    if (e0 < n) {
-        const uint64_t cnt = n - e0 < chunk ? n - e0 : chunk;
-        const uint32_t *__restrict__ lens = reinterpret_cast<const uint32_t *>(rec + e0) + 2;
-        for (uint64_t i = threadIdx.x; i < cnt; i += 256) s += lens[4 * i];
-    }
+    for (uint32_t i = lane; i < nc; i += WAVE) s += part[PG_CHUNK_FINE + i];
+    if (f0 + lane < c) s += part[f0 + lane];
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, WAVE);
-    if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// exclusive scan of the (<= 8192) chunk sums in place; the total goes where the batch's consumers expect it
-__global__ __launch_bounds__(1024) void k_partials_scan(uint64_t *__restrict__ part, uint32_t n_chunks, const uint64_t *__restrict__ n_kept_ptr,
-                                                        uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out) {
-    __shared__ uint64_t wsum[16];
-    const uint32_t tid = threadIdx.x;
-    uint64_t v[8], s = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const uint32_t c = tid * 8 + i; v[i] = c < n_chunks ? part[c] : 0; s += v[i]; }
-    const uint64_t inc = wave_incl_scan_u64(s);
-    if (lane_id() == WAVE - 1) wsum[tid >> 6] = inc;
-    __syncthreads();
-    uint64_t run = inc - s, tot = 0;
-    for (uint32_t w = 0; w < 16; ++w) { if (w < (tid >> 6)) run += wsum[w]; tot += wsum[w]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const uint32_t c = tid * 8 + i; if (c < n_chunks) part[c] = run; run += v[i]; }
-    if (tid == 0) { samp_off[n_kept_ptr[0]] = tot; *total_out = tot; }
+    return s;
 }
 
 // one workgroup per chunk of sub_per_chunk * PG_G2_SUB kept events: the exclusive scan of their window lengths (chunk base from
@@ -687,17 +764,17 @@ __device__ __forceinline__ void gather_chunk(const PgDevBatch &B, uint64_t total
     }
 }
 template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GC_WAVES, PG_GC_WAVES))) void k_gather_chunks(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec, const uint64_t *__restrict__ part,
-                                                       uint32_t sub_per_chunk, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+                                                       uint32_t sub_per_chunk, uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out, int scaling, double pa_min, double pa_max,
                                                        double *__restrict__ samples, const double *__restrict__ gcal) {
     __shared__ uint4 s_rec[PG_G2_SUB];
     __shared__ uint32_t s_off[PG_G2_SUB];
     __shared__ uint32_t wsum[4];
     const uint64_t n_kept = n_kept_ptr[0];
     const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
-    if (c0 >= n_kept) return;
+    if (c0 >= n_kept) { if (n_kept == 0 && blockIdx.x == 0 && threadIdx.x == 0) { samp_off[0] = 0; total_out[0] = 0; } return; }
     const uint64_t total = B.sig_off[B.n_reads];
     const uint32_t tid = threadIdx.x;
-    uint64_t run = part[blockIdx.x];
+    uint64_t run = chunk_base(part, blockIdx.x);
     for (uint32_t sc = 0; sc < sub_per_chunk; ++sc) {
         const uint64_t e0 = c0 + (uint64_t)sc * PG_G2_SUB;
         if (e0 >= n_kept) break;
@@ -731,6 +808,7 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
         gather_chunk<G, P>(B, total, s_rec, cnt, run, s_off, scaling, pa_min, pa_max, gcal, samples);
         run += tot;
     }
+    if (c0 + (uint64_t)sub_per_chunk * PG_G2_SUB >= n_kept && tid == 0) { samp_off[n_kept] = run; total_out[0] = run; } // the last chunk: all kept samples
 }
 
 // ---- the wave form (round 4): one lane per PAIR OF OUTPUT SAMPLES instead of a lane group per event -------------------------------------
@@ -755,7 +833,7 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
 #define PG_GW_WAVES 3
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES, 8))) void k_gather_wave(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
-        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out, int scaling, double pa_min, double pa_max,
         double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
     const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
@@ -764,13 +842,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
     __shared__ uint2 s_bits_all[4][PG_GW_SPAN / 32];  // x: window starts over this tile of the group's output samples, y: non-empty events in front of the word
     const uint64_t n_kept = n_kept_ptr[0];
     const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
-    if (c0 >= n_kept) return;
+    if (c0 >= n_kept) { if (n_kept == 0 && blockIdx.x == 0 && threadIdx.x == 0) { samp_off[0] = 0; total_out[0] = 0; } return; }
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     uint4 *s_ev = s_ev_all[w]; double *s_cal = s_cal_all[w]; uint2 *s_bits = s_bits_all[w];
     const uint64_t c1 = c0 + (uint64_t)sub_per_chunk * PG_G2_SUB < n_kept ? c0 + (uint64_t)sub_per_chunk * PG_G2_SUB : n_kept;
     const int16_t *__restrict__ sig = B.sig;
-    uint64_t run = part[blockIdx.x];
+    uint64_t run = chunk_base(part, blockIdx.x);
     for (uint64_t seg = c0; seg < c1; seg += PG_GW_SEG) {
         const uint32_t nseg = c1 - seg < PG_GW_SEG ? (uint32_t)(c1 - seg) : PG_GW_SEG;
         // ---- sums of the window lengths per group of 64 events (8 threads x 8 events each)
@@ -870,7 +948,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                 // from every rounding midpoint). exact_div (uniform; a read of the batch has a calibration outside pg_div_domain_ok: no
                 // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
                 // arithmetic: 948 -> 8xx us at k = 9.
-                auto conv = [&](int raw, const double4 &c, double y) {
+                auto conv = [&](auto EX, int raw, const double4 &c, double y) {
 #ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
                     return (double)raw;
 #endif
@@ -883,7 +961,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
 #elif defined(PG_GATHER_DIV_INSN)
                         x = num / c.w;
 #else
-                        x = exact_div ? num / c.w : pg_div_by_recip(num, c.w, y);
+                        if constexpr (decltype(EX)::value) x = num / c.w; else x = pg_div_by_recip(num, c.w, y);
 #endif
                     }
                     return x;
@@ -891,6 +969,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                 // A trip's body is branch-free up to its store, so that the compiler requests the LDS reads and the window samples of all
                 // PG_GW_TRIPS trips together (the first form of this loop had five dependent waits per trip and was bound by exactly that
                 // chain at five waves per SIMD): out-of-range lanes work on a clamped position of the tile and drop the result.
+                auto trips = [&](auto EX) { // (EX: the batch divides with the instruction -- decided once per kernel, compiled twice, no branch per sample)
                 for (uint32_t j0 = lane; j0 < npairs; j0 += 64 * PG_GW_TRIPS) {
                     uint32_t qp[PG_GW_TRIPS][2]; bool v[PG_GW_TRIPS][2]; uint2 bw[PG_GW_TRIPS][2];
 #pragma unroll
@@ -924,8 +1003,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
 #pragma unroll
                     for (int u = 0; u < PG_GW_TRIPS; ++u) {
                         const uint32_t j = j0 + u * 64;
-                        const double x0 = conv(raw[u][0], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][0]), __hiloint2double((int)ee[u][0].w, (int)ee[u][0].z));
-                        const double x1 = conv(raw[u][1], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][1]), __hiloint2double((int)ee[u][1].w, (int)ee[u][1].z));
+                        const double x0 = conv(EX, raw[u][0], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][0]), __hiloint2double((int)ee[u][0].w, (int)ee[u][0].z));
+                        const double x1 = conv(EX, raw[u][1], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][1]), __hiloint2double((int)ee[u][1].w, (int)ee[u][1].z));
 #ifdef PG_PROBE_GC_NOSTORE
                         if (x0 + x1 == 1.2345e300) out[2u * j] = x0;
 #else
@@ -939,11 +1018,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                         else if (v[u][1]) out[2u * j + 1u] = x1;
 #endif
                     }
-                }
+                } };
+                if (exact_div) trips(std::true_type{}); else trips(std::false_type{});
             }
         }
         run += segtot;
     }
+    if (c1 == n_kept && tid == 0) { samp_off[n_kept] = run; total_out[0] = run; } // the last chunk: all kept samples
 }
 
 #ifndef PG_GE_TRIPS
@@ -956,7 +1037,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
 // look-up, one calibration and ONE 8-byte load (profiles/r04_gather_bound.txt 5, 6: scattered loads cost a cycle per lane, and a second,
 // masked load inside a trip costs more than it saves). Stores are 16 bytes at 8-byte alignment, 8 bytes for the odd tail of a window.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES, 8))) void k_gather_evpair(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
-        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, int scaling, double pa_min, double pa_max,
+        const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out, int scaling, double pa_min, double pa_max,
         double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
     const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
@@ -965,7 +1046,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
     __shared__ uint2 s_bits_all[4][PG_GW_SPAN / 64];  // x: first pair slots of the events over this tile of the group's pair slots, y: non-empty events in front of the word
     const uint64_t n_kept = n_kept_ptr[0];
     const uint64_t c0 = (uint64_t)blockIdx.x * sub_per_chunk * PG_G2_SUB;
-    if (c0 >= n_kept) return;
+    if (c0 >= n_kept) { if (n_kept == 0 && blockIdx.x == 0 && threadIdx.x == 0) { samp_off[0] = 0; total_out[0] = 0; } return; }
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     uint4 *s_ev = s_ev_all[w]; double *s_cal = s_cal_all[w]; uint2 *s_bits = s_bits_all[w];
@@ -973,7 +1054,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
     const int16_t *__restrict__ sig = B.sig;
     const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
     const uint64_t total = B.sig_off[B.n_reads];
-    uint64_t run = part[blockIdx.x];
+    uint64_t run = chunk_base(part, blockIdx.x);
     for (uint64_t seg = c0; seg < c1; seg += PG_GW_SEG) {
         const uint32_t nseg = c1 - seg < PG_GW_SEG ? (uint32_t)(c1 - seg) : PG_GW_SEG;
         // ---- sums of the window lengths per group of 64 events (8 threads x 8 events each)
@@ -1066,7 +1147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                 // from every rounding midpoint). exact_div (uniform; a read of the batch has a calibration outside pg_div_domain_ok: no
                 // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
                 // arithmetic: 948 -> 8xx us at k = 9.
-                auto conv = [&](int raw, const double4 &c, double y) {
+                auto conv = [&](auto EX, int raw, const double4 &c, double y) {
 #ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
                     return (double)raw;
 #endif
@@ -1079,7 +1160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
 #elif defined(PG_GATHER_DIV_INSN)
                         x = num / c.w;
 #else
-                        x = exact_div ? num / c.w : pg_div_by_recip(num, c.w, y);
+                        if constexpr (decltype(EX)::value) x = num / c.w; else x = pg_div_by_recip(num, c.w, y);
 #endif
                     }
                     return x;
@@ -1087,6 +1168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                 // A trip: lane j owns pair slot tb + j = samples (2k, 2k + 1) of ONE window: one event look-up, one 8-byte load (the two dwords
                 // that hold both samples whatever the parity of the source index), two conversions, one 16-byte store at 8-byte alignment
                 // (8 bytes for the odd tail of a window). No pair straddles two events, so nothing in a trip branches but the store width.
+                auto trips = [&](auto EX) { // (EX: the batch divides with the instruction -- decided once per kernel, compiled twice, no branch per sample)
                 for (uint32_t j0 = lane; j0 < tn; j0 += 64 * PG_GE_TRIPS) {
                     uint32_t qp[PG_GE_TRIPS]; bool v[PG_GE_TRIPS]; uint2 bw[PG_GE_TRIPS];
 #pragma unroll
@@ -1129,7 +1211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                     for (int u = 0; u < PG_GE_TRIPS; ++u) {
                         const double4 cc = *reinterpret_cast<const double4 *>(s_cal + 6u * ev[u]);
                         const double y = s_cal[6u * ev[u] + 4u];
-                        const double x0 = conv(raw[u][0], cc, y), x1 = conv(raw[u][1], cc, y);
+                        const double x0 = conv(EX, raw[u][0], cc, y), x1 = conv(EX, raw[u][1], cc, y);
                         const uint32_t s2 = 2u * (tb + qp[u]);                 // the pair's first sample, counted in pair slots x 2
                         double *dst = out + (uint32_t)(ee[u].z + s2);          // + (offset of the window in the group - 2 x its first pair slot)
 #ifdef PG_PROBE_GC_NOSTORE
@@ -1140,11 +1222,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                         else if (v[u]) *dst = x0; // the odd tail of a window
 #endif
                     }
-                }
+                } };
+                if (exact_div) trips(std::true_type{}); else trips(std::false_type{});
             }
         }
         run += segtot;
     }
+    if (c1 == n_kept && tid == 0) { samp_off[n_kept] = run; total_out[0] = run; } // the last chunk: all kept samples
 }
 
 // the kept events' lengths and reads as arrays of their own (pg_result / pg_device_view; off the step's path)
@@ -1173,14 +1257,20 @@ hipError_t pg_launch_part_scatter(hipStream_t st, const PgPartBufs &P, const uin
     return hipSuccess;
 }
 
-hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy) {
+uint32_t pg_region_cut_epochs(void) { return PG_RCUT_EPOCHS; }
+hipError_t pg_launch_region_counts(hipStream_t st, const PgPartBufs &P, uint32_t n_slots, uint64_t *acc_cnt, uint64_t *acc_copy, const PgRegionCutArgs *cut) {
     PG_LAUNCH(k_region_count, dim3(P.tilesB_cap), dim3(256), 0, st, (const uint16_t *)P.loA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
               (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, P.histB);
-    PG_LAUNCH(k_region_scan, dim3(1u << P.hi_bits), dim3((1u << P.lo_bits) < 64u ? 64u : (1u << P.lo_bits)), 0, st, P.histB, (const uint32_t *)P.rbase, (int)P.lo_bits, n_slots, acc_cnt, acc_copy);
+    const uint32_t threads = (1u << P.lo_bits) < 64u ? 64u : (1u << P.lo_bits);
+    if (cut && !acc_copy) { // pg_submit: the sample_limit cut rides in the scan's launch
+        PgRegionCut Q{cut->running, cut->running, cut->keep, cut->ev_off, cut->totals, cut->keep32, cut->state, cut->limit, cut->epoch};
+        PG_LAUNCH(k_region_scan_cut, dim3(1u << P.hi_bits), dim3(threads), 0, st, P.histB, (const uint32_t *)P.rbase, (int)P.lo_bits, n_slots, 1u << P.hi_bits, acc_cnt, Q);
+        return hipSuccess;
+    }
+    PG_LAUNCH(k_region_scan, dim3(1u << P.hi_bits), dim3(threads), 0, st, P.histB, (const uint32_t *)P.rbase, (int)P.lo_bits, n_slots, acc_cnt, acc_copy);
     return hipSuccess;
 }
 
-static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk);
 static uint32_t pg_chunk_shift(uint64_t n_kept_cap) {
     uint32_t m = 1, sh = 10;
     if (n_kept_cap) (void)pg_gather_chunks(n_kept_cap, &m);
@@ -1209,38 +1299,29 @@ hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t 
     return hipSuccess;
 }
 
-static uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk) {
+uint32_t pg_gather_chunks(uint64_t n_kept_cap, uint32_t *sub_per_chunk) {
     uint32_t m = 1;
-    while ((n_kept_cap + (uint64_t)m * PG_G2_SUB - 1) / ((uint64_t)m * PG_G2_SUB) > 8192) m *= 2; // k_partials_scan holds 8192 chunk sums
+    while ((n_kept_cap + (uint64_t)m * PG_G2_SUB - 1) / ((uint64_t)m * PG_G2_SUB) > PG_CHUNK_FINE) m *= 2; // the fine chunk sums
     *sub_per_chunk = m;
     return (uint32_t)((n_kept_cap + (uint64_t)m * PG_G2_SUB - 1) / ((uint64_t)m * PG_G2_SUB));
 }
 
-// chunk sums of the kept window lengths + their exclusive scan (part: >= 8192 entries); *total_out = samp_off[n_kept] = all kept samples
-hipError_t pg_launch_len_partials(hipStream_t st, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, uint64_t *part, uint64_t *samp_off, uint64_t *total_out,
-                                  bool sums_ready /* by pg_launch_region_place */) {
-    if (n_kept_cap == 0) return hipSuccess;
-    uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
-    if (!sums_ready) PG_LAUNCH(k_len_partials, dim3(n_chunks), dim3(256), 0, st, rec, n_kept_ptr, m * PG_G2_SUB, part);
-    PG_LAUNCH(k_partials_scan, dim3(1), dim3(1024), 0, st, part, n_chunks, n_kept_ptr, samp_off, total_out);
-    return hipSuccess;
-}
 // lanes: 0 = k_gather_wave (the default); else lanes per kept event (4, 8 or 16) of k_gather_chunks: any value is correct for any window length
 hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t n_kept_cap, const uint64_t *n_kept_ptr, const PgKeptRec *rec, const uint64_t *part,
-                                   uint64_t *samp_off, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes, const int32_t *stat_flags) {
+                                   uint64_t *samp_off, uint64_t *total_out, int scaling, double pa_min, double pa_max, double *samples, const double *gcal, int lanes, const int32_t *stat_flags) {
     if (n_kept_cap == 0) return hipSuccess;
     uint32_t m; const uint32_t n_chunks = pg_gather_chunks(n_kept_cap, &m);
     if (lanes == 1) { // the event-pair form (a lane per pair of samples of ONE window)
-        PG_LAUNCH(k_gather_evpair, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal, stat_flags);
+        PG_LAUNCH(k_gather_evpair, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags);
         return hipSuccess;
     }
     if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
-        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal, stat_flags);
+        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags);
         return hipSuccess;
     }
-    if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
-    else if (lanes <= 8) PG_LAUNCH((k_gather_chunks<8, 3>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
-    else PG_LAUNCH((k_gather_chunks<16, 2>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, scaling, pa_min, pa_max, samples, gcal);
+    if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal);
+    else if (lanes <= 8) PG_LAUNCH((k_gather_chunks<8, 3>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal);
+    else PG_LAUNCH((k_gather_chunks<16, 2>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal);
     return hipSuccess;
 }
 

@@ -366,3 +366,60 @@ def test_config4_full_size_8_rank_shards():
     assert done.size > 20
     for s in done:
         assert np.array_equal(res.slot_values(int(s)).view(np.uint64), o.values(int(s)).view(np.uint64)), int(s)
+
+
+@pytest.mark.parametrize("lanes", ["0", "1", "8"], ids=["gather_wave", "gather_evpair", "gather_chunks8"])
+@pytest.mark.parametrize("extra", ["", "exact_samples", "unfused_cut"])
+def test_k9_every_gather_form_and_both_cut_paths(lanes, extra, monkeypatch):
+    """The three dense gathers (k_gather_wave, k_gather_evpair, the lane-group form) on the SAME k = 9 job -- the library picks one by the
+    mean window, so the others would never see these inputs -- each also with the sample buffer sized exactly (its total then comes from
+    the coarse chunk sums, in front of the gather) and with the sample_limit cut as a launch of its own (k_slot_cut instead of
+    k_region_scan_cut). All slots against the oracle."""
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    monkeypatch.setenv("PGMOVE_GATHER_LANES", lanes)
+    if extra == "exact_samples":
+        monkeypatch.setenv("PGMOVE_SAMPLES_EXACT", "1")
+    if extra == "unfused_cut":
+        monkeypatch.setenv("PGMOVE_NO_FUSED_CUT", "1")
+    b = synth.make_batch(300, kind="dna_r10", seed=20251003 + 41, homopolymer_frac=0.2)
+    p = dict(kmer_size=9, scaling=1, sample_limit=40)
+    kmers = generate_kmers(9)
+    o = oracle_for(kmers, **p)
+    o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b.slice_reads(0, 100)); eng.submit(b.slice_reads(100, 300))
+    res = eng.finish()
+    eng.close()
+    check_invariants(res, 40, b.n_reads)
+    assert np.array_equal(res.counts, o.counts())
+    assert np.array_equal(res.ev_len, o.all_event_lens())
+    assert np.array_equal(res.samples.view(np.uint64), o.all_values().view(np.uint64))
+
+
+@pytest.mark.parametrize("table", ["no_affine", "permuted_list", "sliced_list"])
+def test_k9_slot_tables_that_are_looked_up(table, monkeypatch):
+    """Since round 4 a generated k-mer list is COMPUTED (slot = code + constant); the look-up branch of k_events<2>, and the mixed case -- one
+    table affine, the other looked up -- run only for other lists: PGMOVE_NO_AFFINE=1 (read per pg_create), a --kmer_file in another
+    order, a slice whose other spelling's table is sparse. Dense kernels, all slots against the oracle."""
+    monkeypatch.setenv("PGMOVE_DENSE_MIN", "0")
+    b = synth.make_batch(200, kind="dna_r10", seed=20251003 + 42)
+    full = generate_kmers(9)
+    p = dict(kmer_size=9, scaling=1, sample_limit=30)
+    if table == "no_affine":
+        monkeypatch.setenv("PGMOVE_NO_AFFINE", "1")
+        kmers, o = full, oracle_for(full, **p)
+    elif table == "permuted_list":
+        rng = np.random.default_rng(8)
+        kmers = [full[i] for i in rng.permutation(len(full))[:60000]]
+        o = oracle_for(kmers, **p)
+    else:
+        kmers = full[1000:200000]
+        o = oracle_for(full, index_start=1001, index_end=200000, **p)
+    o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    eng.submit(b)
+    res = eng.finish()
+    eng.close()
+    assert np.array_equal(res.counts, o.counts())
+    assert np.array_equal(res.ev_len, o.all_event_lens())
+    assert np.array_equal(res.samples.view(np.uint64), o.all_values().view(np.uint64))

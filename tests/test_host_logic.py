@@ -63,6 +63,9 @@ def test_big_host_vectors_ask_for_huge_pages():
     small ones come from the heap. (A typo once compiled the madvise call out: results are identical, only this shows it.)"""
     import ctypes as C
     import os
+    import pytest
+    if not os.path.exists("/sys/kernel/mm/transparent_hugepage/enabled"):
+        pytest.skip("kernel without transparent huge pages: madvise(MADV_HUGEPAGE) fails there, which the code ignores by design")
     h = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "poregen_amd", "_pg_hosttest.so")))
     h.pgt_samplevec_hugepage.argtypes = [C.c_size_t, C.POINTER(C.c_long)]
     kb = C.c_long(0)
@@ -72,3 +75,25 @@ def test_big_host_vectors_ask_for_huge_pages():
         pytest.skip("/proc/self/smaps not readable")
     assert big == 1
     assert h.pgt_samplevec_hugepage(1000, C.byref(kb)) == 0
+
+
+def test_ragged_generator_is_consistent_and_the_oracle_accepts_it():
+    """synth.make_ragged_fast (bench.py's ragged_mode): per read the ops add up to the read's samples, the sequence has a base per op, both
+    orientations run through the oracle without an error."""
+    import numpy as np
+    import orc
+    from helpers import oracle_for
+    from poregen_amd import synth
+    from poregen_amd.engine import generate_kmers
+    L = synth.ragged_lengths(600_000, seed=9, huge=150_000, huge_frac=0.02)
+    assert int(L.sum()) == 600_000 and L.min() >= 2000
+    for kind, rna in (("dna_r10", False), ("rna004", True)):
+        b = synth.make_ragged_fast(L, kind=kind, seed=10)
+        assert b.n_reads == L.size and np.array_equal(np.diff(b.sig_off.astype(np.int64)), L)
+        for r in range(b.n_reads):
+            a, e = int(b.op_off[r]), int(b.op_off[r + 1])
+            assert int(b.op_n[a:e].sum()) == int(L[r]) and int(b.seq_off[r + 1] - b.seq_off[r]) == e - a
+        kmers = generate_kmers(5, rna=rna)
+        o = oracle_for(kmers, kmer_size=5, scaling=1, sample_limit=30, rna=rna)
+        assert set(o.run_batch(b)) <= {orc.ORC_OK, orc.ORC_STOPPED}
+        assert int(o.counts().sum()) > 1000
