@@ -22,6 +22,17 @@
 #include "pg_select.h"
 #include <type_traits>
 
+#ifdef PG_PROBE_CAL_EV // measurement build (round 5): the read's calibration ATTACHED to the kept event's record by the placing
+// kernel (a 32-byte entry beside the record, written in the same runs), so that the gather reads it sequentially instead of fetching it
+// from the 1.6 MB table at random. One stream only (the statistics must be complete in front of k_region_place). Results stay correct.
+static double *h_cal_ev; static const double *h_cal_src; // (host side: handed to the two kernels as arguments)
+extern "C" void pg_probe_cal_ev(double *cal_ev, const double *gcal) { h_cal_ev = cal_ev; h_cal_src = gcal; }
+#define PG_CAL_EV_PARAMS , double *__restrict__ g_cal_ev, const double *__restrict__ g_cal_src
+#define PG_CAL_EV_ARGS , h_cal_ev, h_cal_src
+#else
+#define PG_CAL_EV_PARAMS
+#define PG_CAL_EV_ARGS
+#endif
 // =====================================================================================================
 // op-sum prefixes: window starts of direct reads without a walk
 // =====================================================================================================
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(1024) void k_region_scan_cut(uint32_t *__restrict__
 __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_region_place(const uint4 *__restrict__ elemA, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
                                                                    const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, int lo_bits, uint32_t n_slots,
                                                                    const uint32_t *__restrict__ histB, const uint32_t *__restrict__ keep32, const uint64_t *__restrict__ ev_off,
-                                                                   PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift) {
+                                                                   PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift PG_CAL_EV_PARAMS) {
     const uint32_t ndig = 1u << lo_bits, tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     // the tile's elements are requested in front of the look-ups that say how many of them count (the buffer holds every tile of the grid)
@@ -541,6 +552,9 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         const uint32_t dst = jj + L.aux[ndig + d], len = e.z & 0xffffffu;
         if (len == 0) { report_error(O, e.w, (int)e.y); K.rec[dst] = PgKeptRec{0, 0, e.w}; } // the verdict event_element left
         else K.rec[dst] = PgKeptRec{(uint64_t)e.y | ((uint64_t)(e.z >> 24) << 32), len, e.w};
+#ifdef PG_PROBE_CAL_EV
+        if (g_cal_ev) { const double4 cv = *reinterpret_cast<const double4 *>(g_cal_src + 4ull * e.w); *reinterpret_cast<double4 *>(g_cal_ev + 4ull * dst) = cv; }
+#endif
         if (K.read_needed) K.read_needed[e.w] = 1;
         if (!part) continue;
         const uint64_t ch = ((uint64_t)dst >> chunk_shift) - c_lo;
@@ -834,7 +848,7 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES, 8))) void k_gather_wave(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
         const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out, int scaling, double pa_min, double pa_max,
-        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
+        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags PG_CAL_EV_PARAMS) {
     const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
     __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - offset inside the group (64 bits), read, -
@@ -871,7 +885,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
             return (uint32_t)lane < gn ? reinterpret_cast<const uint4 *>(rec + seg + g * 64u)[lane] : make_uint4(0, 0, 0, 0);
         };
         // lanes 2i and 2i + 1 fetch the two halves of event i's (then event 32 + i's) 32-byte calibration record: one request per record
-        auto load_cal = [&](const uint4 &qq, double2 (&c)[2]) {
+        auto load_cal = [&](const uint4 &qq, double2 (&c)[2], uint64_t ebase) {
+            (void)ebase;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int evl = hh * 32 + (lane >> 1);
@@ -880,6 +895,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                 if (ok) {
 #ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event uses one of eight reads' calibrations
                     if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * (rd & 7u) + 2u * (lane & 1));
+#elif defined(PG_PROBE_CAL_EV)
+                    if (gcal) c[hh] = g_cal_ev ? *reinterpret_cast<const double2 *>(g_cal_ev + 4ull * (ebase + (uint64_t)evl) + 2u * (lane & 1))
+                                               : *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1));
 #else
                     if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1)); // {offset, range / digitisation as the statistics used it}, {median, MAD}
 #endif
@@ -889,14 +907,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
         };
         uint4 q_cur = load_rec(w), q_nxt = load_rec(w + 4);
         double2 c_cur[2];
-        load_cal(q_cur, c_cur);
+        load_cal(q_cur, c_cur, seg + (uint64_t)w * 64u);
         for (uint32_t g = w; g * 64u < nseg; g += 4) {
             const uint64_t e0 = seg + g * 64u, gbase = run + (uint32_t)__shfl((int)(ginc - gv), (int)g, WAVE);
             const uint32_t n = nseg - g * 64u < 64u ? nseg - g * 64u : 64u;
             // ---- this group: a record per lane
             const uint4 q = q_cur;
             const double2 c0 = c_cur[0], c1 = c_cur[1];
-            q_cur = q_nxt; load_cal(q_cur, c_cur); q_nxt = load_rec(g + 8);
+            q_cur = q_nxt; load_cal(q_cur, c_cur, seg + (uint64_t)(g + 4) * 64u); q_nxt = load_rec(g + 8);
             const uint32_t len = q.z, nzf = len != 0u;
             const uint32_t inc = wave_incl_scan_u32(len), off = inc - len, tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             const uint32_t idx = wave_incl_scan_u32(nzf) - nzf;
@@ -1295,7 +1313,7 @@ hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t 
     const size_t lds = part_lds_bytes(1u << P.lo_bits);
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PG_RANK_MAX_DIGITS)));
     PG_LAUNCH(k_region_place, dim3(P.tilesB_cap), dim3(PG_PART_THREADS), lds, st, (const uint4 *)P.elemA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
-              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, n_slots, (const uint32_t *)P.histB, keep32, ev_off, O, K, part, chunk_shift);
+              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, n_slots, (const uint32_t *)P.histB, keep32, ev_off, O, K, part, chunk_shift PG_CAL_EV_ARGS);
     return hipSuccess;
 }
 
@@ -1316,7 +1334,7 @@ hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t
         return hipSuccess;
     }
     if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
-        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags);
+        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags PG_CAL_EV_ARGS);
         return hipSuccess;
     }
     if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal);
