@@ -95,7 +95,7 @@ struct pg_ctx {
     uint32_t gen_reads = 0; // generic reads of the last settled batch
     bool batch_all_matches = false; // PG_BATCH_ALL_MATCHES of the current batch (and not PG_FLAG_DEBUG_SPLIT_WALK)
     DevBuf job_total, job_freq; bool have_job_totals = false; // pg_collect_gathered / pg_job_totals_device
-    DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell; // pg_model
+    DevBuf md_ev_off, md_samp_off, md_ev_len, md_samples, md_out, md_dwell, md_class; // pg_model
     bool zero_running = false;
     bool stats_in_flight = false, totals_known = false;
     uint32_t wide_blocks = 0;    // wide-list length of the last settled batch (sizes the next rare launch)
@@ -260,7 +260,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->long_tab, &c->long_hist, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
-                      &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell};
+                      &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell, &c->md_class};
     for (DevBuf *b : bufs) b->release();
     for (auto &hb : c->batches) hb.dsamples.release();
     for (auto &p : c->prof) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1524,9 +1524,10 @@ pg_status pg_fetch_text(pg_ctx *c, uint64_t first, uint64_t n, char *dst) {
 static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[3], const uint64_t *d_ev_off, const uint64_t *d_samp_off,
                            const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out) {
     HIP_TRY(c, c->md_out.ensure((ns + 1) * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure((ns + 1) * sizeof(PgSlotDwell)));
+    HIP_TRY(c, c->md_class.ensure(pg_slot_model_scratch_bytes(ns)));
     prof_begin(c, "k_slot_model", c->st, true);
     HIP_TRY(c, pg_launch_slot_model(c->st, ns, any_kind, d_ev_off, d_samp_off, d_ev_len, d_samples, (flags & PG_MODEL_KEEP_FIRST) ? 0u : 1u,
-                                    c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>()));
+                                    c->md_out.as<PgSlotModel>(), c->md_dwell.as<PgSlotDwell>(), c->md_class.p));
     prof_end(c, c->st);
     c->mo_raw.resize(ns); c->mo_dw.resize(ns);
     if (ns) {

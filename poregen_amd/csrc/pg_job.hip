@@ -162,13 +162,15 @@ void pg_job_destroy(pg_job *j) {
     for (uint32_t g = 0; g < j->ctx.size(); ++g) {
         if (j->ctx[g]) (void)pg_sync(j->ctx[g]);
     }
+    // (a job whose creation failed on a device that does not exist is torn down here too: a refused hipSetDevice must not stay behind
+    // as the calling thread's sticky "last error" -- the next HIP user of the thread, e.g. PyTorch, would report it as its own)
     for (uint32_t g = 0; g < j->n; ++g) {
-        (void)hipSetDevice(j->devices[g]);
+        if (hipSetDevice(j->devices[g]) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (g < j->comm_st.size() && j->comm_st[g]) { (void)hipStreamSynchronize(j->comm_st[g]); }
     }
     for (auto c : j->comms) if (c) (void)rccl().CommDestroy(c);
     for (uint32_t g = 0; g < j->n; ++g) {
-        (void)hipSetDevice(j->devices[g]);
+        if (hipSetDevice(j->devices[g]) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (g < j->comm_st.size() && j->comm_st[g]) (void)hipStreamDestroy(j->comm_st[g]);
         if (g < j->ev_counted.size() && j->ev_counted[g]) (void)hipEventDestroy(j->ev_counted[g]);
         if (g < j->ev_gathered.size() && j->ev_gathered[g]) (void)hipEventDestroy(j->ev_gathered[g]);
@@ -178,6 +180,7 @@ void pg_job_destroy(pg_job *j) {
     for (auto c : j->ctx) if (c) pg_destroy(c);
     for (auto &w : j->workers) w.stop();
     delete j;
+    (void)hipGetLastError();
 }
 
 pg_status pg_job_create(const pg_params *p, const int32_t *devices, uint32_t n, uint32_t exchange, pg_job **out) {

@@ -197,22 +197,45 @@ template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm
     k_hi = q_hi < cnt ? (((uint64_t)bin << low) | c_hi) : above;
 }
 
+// Round 5: the three kernels used to be launched over ALL slots each, a workgroup leaving after two dependent loads when its k-mer belongs
+// to another kernel -- at k = 9 (262 144 k-mers, nearly all of them "tiny") the SHORT and LONG launches were 0.37 + 0.50 ms of mostly
+// empty workgroups next to the 1.24 ms of real work (rocprofv3 GRBM_GUI_ACTIVE, profiles/r05_model_pmc.txt). A record pass classifies the
+// slots once: rec[s] = where the slot's values and events lie + its kind (ONE 32-byte load in the kernels instead of two dependent rounds),
+// and the slots of the two rarer kinds go on lists that their kernels stride over with a small grid.
+struct __attribute__((aligned(16))) PgModelRec { uint64_t first, n, e0; uint32_t nev, kind; };
+__global__ __launch_bounds__(256) void k_model_classify(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
+                                                        PgModelRec *__restrict__ rec, uint32_t *__restrict__ lists /* [2][n_slots] */, uint32_t *__restrict__ counts /* [2] */) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_slots) return;
+    const uint64_t e0 = ev_off[s], e1 = ev_off[s + 1];
+    const uint64_t a0 = samp_off[e0], a1 = samp_off[e1];
+    const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
+    PgModelRec r;
+    r.first = a0 + skip; r.n = a1 - r.first; r.e0 = e0; r.nev = (uint32_t)(e1 - e0); r.kind = (uint32_t)pg_model_kind(r.n);
+    rec[s] = r;
+    if (r.kind != PG_MODEL_TINY) lists[(size_t)(r.kind - 1) * n_slots + atomicAdd(counts + (r.kind - 1), 1u)] = s; // (any order: every slot writes its own result)
+}
+
 // Three kernels share this body, by file size: TINY (one wave, <= 1024 values: k = 9 jobs have 262 144 such files, and a wave
 // needs no workgroup barrier) and SHORT (256 threads, <= 4096 values) convert the whole file once into 16 registers per
 // thread; LONG (1024 threads) re-reads the file per pass. A workgroup whose k-mer belongs to another kernel leaves after two
 // loads. Separate kernels because each needs its own register budget; the host launches only the ones with work.
-template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_WAVES : 4)) void k_slot_model(const uint64_t *ev_off, const uint64_t *samp_off, const uint32_t *ev_len,
-                                                                      const double *samples, uint32_t drop_first, PgSlotModel *out,
-                                                                      PgSlotDwell *dwell) {
+template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_WAVES : 4)) void k_slot_model(const PgModelRec *__restrict__ rec, const uint32_t *__restrict__ list,
+                                                                      const uint32_t *__restrict__ list_n, uint32_t n_slots, const uint32_t *ev_len,
+                                                                      const double *samples, PgSlotModel *out, PgSlotDwell *dwell) {
     constexpr bool SHORT = KIND != PG_MODEL_LONG; // register-resident
     __shared__ ModelSmem<MT> sm;
     constexpr int C = SHORT ? ModelCfg<MT>::CACHE : 0;
-    const uint32_t s = blockIdx.x;
-    const uint64_t e0 = uniform64(ev_off[s]), e1 = uniform64(ev_off[s + 1]);
-    const uint64_t a0 = uniform64(samp_off[e0]), a1 = uniform64(samp_off[e1]);
-    const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
-    const uint64_t first = a0 + skip, n = a1 - first;
-    if (pg_model_kind(n) != KIND) return;
+    // TINY: a workgroup (= a wave) per slot; the rarer kinds: the workgroups stride over their list
+    const uint32_t n_mine = KIND == PG_MODEL_TINY ? n_slots : uniform32(*list_n);
+    for (uint32_t it = blockIdx.x; it < n_mine; it += gridDim.x) {
+    const uint32_t s = KIND == PG_MODEL_TINY ? it : uniform32(list[it]);
+    const uint4 rq0 = *reinterpret_cast<const uint4 *>(rec + s), rq1 = *(reinterpret_cast<const uint4 *>(rec + s) + 1);
+    const uint64_t first = uniform64((uint64_t)rq0.x | ((uint64_t)rq0.y << 32)), n = uniform64((uint64_t)rq0.z | ((uint64_t)rq0.w << 32));
+    const uint64_t e0 = uniform64((uint64_t)rq1.x | ((uint64_t)rq1.y << 32));
+    const uint32_t nev32 = uniform32(rq1.z);
+    if (KIND == PG_MODEL_TINY && uniform32(rq1.w) != (uint32_t)PG_MODEL_TINY) continue; // (gridDim.x == n_slots: the loop ends)
+    if (it != blockIdx.x) __syncthreads(); // the previous slot's shared state has been read by everyone
     uint32_t flags = 0;
     PgSlotModel m{};
     m.n = n;
@@ -269,7 +292,7 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
     }
     // dwell: awk prints one comma count per ';'-separated field: samples - 1 per event, and 0 for the empty last field
     PgSlotDwell dw{};
-    const uint64_t nev = e1 - e0;
+    const uint64_t nev = nev32;
     if (nev > 0) {
         const uint64_t nd = nev + 1;
         auto dkey = [&](uint64_t i) { const uint32_t len = i < nev ? ev_len[e0 + i] : 0u; return (uint64_t)(len ? len - 1 : 0u); };
@@ -284,16 +307,25 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
     }
     dw.flags = flags;
     if (threadIdx.x == 0) { out[s] = m; dwell[s] = dw; }
+    } // slots of this workgroup
 }
 
 } // namespace
 
+size_t pg_slot_model_scratch_bytes(uint32_t n_slots) { return (size_t)n_slots * sizeof(PgModelRec) + 2 * (size_t)n_slots * 4 + 64; }
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
-                                const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell) {
+                                const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell, void *scratch) {
     if (n_slots == 0) return hipSuccess;
     (void)hipGetLastError(); // sticky per-thread state of an unrelated earlier failure
-    if (any_kind[PG_MODEL_TINY]) hipLaunchKernelGGL((k_slot_model<64, PG_MODEL_TINY>), dim3(n_slots), dim3(64), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
-    if (any_kind[PG_MODEL_SHORT]) hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots), dim3(256), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
-    if (any_kind[PG_MODEL_LONG]) hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots), dim3(1024), 0, st, ev_off, samp_off, ev_len, samples, drop_first, out, dwell);
+    // scratch: [2] list lengths (+ padding to 64 bytes), records, the two lists
+    uint32_t *counts = static_cast<uint32_t *>(scratch);
+    PgModelRec *rec = reinterpret_cast<PgModelRec *>(static_cast<char *>(scratch) + 64);
+    uint32_t *lists = reinterpret_cast<uint32_t *>(rec + n_slots);
+    hipError_t e = hipMemsetAsync(counts, 0, 64, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_model_classify, dim3((n_slots + 255) / 256), dim3(256), 0, st, ev_off, samp_off, n_slots, drop_first, rec, lists, counts);
+    if (any_kind[PG_MODEL_TINY]) hipLaunchKernelGGL((k_slot_model<64, PG_MODEL_TINY>), dim3(n_slots), dim3(64), 0, st, (const PgModelRec *)rec, (const uint32_t *)nullptr, (const uint32_t *)nullptr, n_slots, ev_len, samples, out, dwell);
+    if (any_kind[PG_MODEL_SHORT]) hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots < 2048u ? n_slots : 2048u), dim3(256), 0, st, (const PgModelRec *)rec, (const uint32_t *)lists, (const uint32_t *)counts, n_slots, ev_len, samples, out, dwell);
+    if (any_kind[PG_MODEL_LONG]) hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots < 512u ? n_slots : 512u), dim3(1024), 0, st, (const PgModelRec *)rec, (const uint32_t *)(lists + n_slots), (const uint32_t *)(counts + 1), n_slots, ev_len, samples, out, dwell);
     return hipGetLastError();
 }

@@ -303,18 +303,37 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         };
         if (have_row) {
             constexpr int HB = PG_PART_ROWS / 2;
+#ifndef PG_SCATTER_TABLE_PRE
+            // the op sums in front of every op of the wave's 512 from the op_n the lanes hold (as k_rank_emit2, round 5): a wave scan per row
+            // on top of the block-sum prefix at the wave's first op (one uniform load) instead of two table loads per row
+            uint32_t rowpre[PG_PART_ROWS];
+            {
+                const uint64_t seg0 = T0 + w * (PG_PART_ROWS * WAVE);
+                uint32_t runp = Bp[(seg0 < n ? seg0 : (uint64_t)n - 1u) >> 8];
+#pragma unroll
+                for (int r = 0; r < PG_PART_ROWS; ++r) {
+                    const uint32_t inc = wave_incl_scan_u32(opn[r]);
+                    rowpre[r] = runp + inc - opn[r];
+                    runp += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+                }
+            }
+#endif
 #pragma unroll
             for (int r0 = 0; r0 < PG_PART_ROWS; r0 += HB) {
                 uint2 lq[HB]; uint4 fs[HB]; uint32_t pre[HB], rd[HB];
 #pragma unroll
                 for (int i = 0; i < HB; ++i) {
                     const int r = r0 + i;
-                    const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, gs = g < n ? g : (uint64_t)n - 1u; // (n >= 1: the tile exists)
                     rd[i] = read_of(r);
                     const PgReadMeta *mt = O.meta + rd[i];
                     lq[i] = *reinterpret_cast<const uint2 *>(&mt->L);     // L, qs
                     fs[i] = *reinterpret_cast<const uint4 *>(&mt->flags); // flags, opsum0, sig0
+#ifdef PG_SCATTER_TABLE_PRE
+                    const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, gs = g < n ? g : (uint64_t)n - 1u; // (n >= 1: the tile exists)
                     pre[i] = Bp[gs >> 8] + O.cum[gs >> 2] + partial_of(r);
+#else
+                    pre[i] = rowpre[r];
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < HB; ++i) {
@@ -680,10 +699,28 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
             for (int r = 0; r < PG_PART_ROWS; ++r) if (dst[r] != 0xFFFFFFFFu) K.rec[dst[r]] = PgKeptRec{0, 1, 0};
             if (tile_first == 0xFFFFFFFFu)
 #endif
+#ifndef PG_EMIT2_TABLE_PRE
+            // the op sums in front of every op of the wave's 512 (round 5): a wave scan per row over the op_n the lanes hold, from the block-sum
+            // prefix at the wave's first op (a multiple of 256 ops: ONE uniform load) -- the window loop below then needs no load of the op-sum
+            // tables at all (it asked for two per kept row, inside its branches: eight dependent round trips per tile)
+            uint32_t rowpre[PG_PART_ROWS];
+            if (have_row) {
+                const uint64_t seg0 = T0 + w * (PG_PART_ROWS * WAVE);
+                uint32_t runp = Bp[(seg0 < n ? seg0 : (uint64_t)n - 1u) >> 8];
+#pragma unroll
+                for (int r = 0; r < PG_PART_ROWS; ++r) {
+                    const uint32_t inc = wave_incl_scan_u32(opn[r]);
+                    rowpre[r] = runp + inc - opn[r];
+                    runp += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+                }
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < PG_PART_ROWS; ++r) {
+#ifdef PG_EMIT2_TABLE_PRE
                 const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3 (all lanes take part)
                 const uint32_t m4 = (uint32_t)lane & 3u, partial = (m4 > 0 ? v1 : 0u) + (m4 > 1 ? v2 : 0u) + (m4 > 2 ? v3 : 0u);
+#endif
                 if (dst[r] == 0xFFFFFFFFu) continue;
                 const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ge = g + W.sig_move_offset;
                 const uint32_t rel = key[r] >> PG_SLOT_BITS;
@@ -698,7 +735,11 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (gen) { ws = O.m_start[ge]; wl = O.m_len[ge]; }
                 else {
                     wl = have_row ? opn[r] : B.op_n[ge];
+#ifdef PG_EMIT2_TABLE_PRE
                     const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + partial : op_prefix(B, O, Bp, ge); // (all rows' table loads in front of the branches, as k_part_scatter does: 63 -> 64 us here, one register spill)
+#else
+                    const uint32_t pre = have_row ? rowpre[r] : op_prefix(B, O, Bp, ge);
+#endif
                     const uint64_t st = (uint64_t)qs + (uint32_t)(pre - pre0);
                     ws = (uint32_t)st;
                     ok = st + wl <= 0x7fffffffull;
