@@ -15,9 +15,10 @@
 //   (the sample_limit cut: k_slot_keep + offsets, pg_kernels.hip; with a base from other ranks in a multi-GPU job)
 //   k_region_place    pass B: rank inside the slot = region-tile prefix + rank inside the tile; kept events (rank < keep) leave as
 //                     PgKeptRec records at ev_off[slot] + rank, again in runs through the LDS stage
-// Offsets + gather for many kept events (k_len_partials, k_partials_scan, k_gather_chunks): the exclusive scan of the kept window
-// lengths happens inside the gather's workgroups (chunks of 1024 events, chunk bases from a small reduction), so the lengths
-// are read once and the offsets written once, not read / written / read again by a scan kernel of their own.
+// Offsets + gather for many kept events (k_len_partials or the placing kernel's coarse sums, k_gather_chunks): the exclusive scan of
+// the kept window lengths happens inside the gather's workgroups (chunks of 1024 events; a chunk's base = the coarse sums in front of
+// its group of 128 chunks + the fine sums inside it: chunk_base), so the lengths are read once and the offsets written once, and no
+// scan launch stands between the placing kernel and the gather.
 #include "pg_dev.h"
 #include "pg_select.h"
 #include <type_traits>
@@ -778,7 +779,7 @@ __device__ __forceinline__ uint64_t chunk_base(const uint64_t *__restrict__ part
 }
 
 // one workgroup per chunk of sub_per_chunk * PG_G2_SUB kept events: the exclusive scan of their window lengths (chunk base from
-// k_partials_scan), the offsets written for the batch's other consumers, and the gather of the windows -- G lanes per event as k_gather.
+// chunk_base), the offsets written for the batch's other consumers, and the gather of the windows -- G lanes per event as k_gather.
 // The gather is a chain record -> window -> stores per event, and what bounds it is how many of those chains the chip has in flight
 // (random ~25..60-byte reads: scatter_probe): E events per lane group and trip have their loads requested together.
 #ifndef PG_GC_EVENTS

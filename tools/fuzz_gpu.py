@@ -27,6 +27,8 @@ for case in range(n_cases):
         lo = float(rng.uniform(-60, 100)); p.update(pa_min=lo, pa_max=lo + float(rng.choice([30, 120, 250, 600])))
     n_reads = int(rng.choice([1, 7, 60, 300]))
     read_len = int(rng.choice([150, 1000, 4000, 9001]))
+    if n_reads <= 60 and rng.random() < 0.15:
+        read_len = int(rng.choice([33000, 40001, 70000]))   # above the split threshold of the statistics (PgLongState): several waves per read
     b = synth.make_batch(n_reads, read_len=read_len, kind="rna004" if rna else "dna_r10", seed=int(rng.integers(1 << 30)),
                          indel_rate=float(rng.choice([0.0, 0.02, 0.1])), spike_rate=float(rng.choice([0.0, 0.005, 0.2])))
     if rng.random() < 0.4:  # PAF column 3 (query_start) > 0: the walk starts inside the signal; the last match gives the samples back
