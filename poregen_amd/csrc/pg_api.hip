@@ -1521,7 +1521,7 @@ pg_status pg_fetch_text(pg_ctx *c, uint64_t first, uint64_t n, char *dst) {
 }
 
 // launch + download + host finishing of the model reduction over device arrays in pg_result layout
-static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[3], const uint64_t *d_ev_off, const uint64_t *d_samp_off,
+static pg_status model_run(pg_ctx *c, uint32_t ns, const int any_kind[PG_MODEL_KINDS], const uint64_t *d_ev_off, const uint64_t *d_samp_off,
                            const uint32_t *d_ev_len, const double *d_samples, uint32_t flags, pg_model_result *out) {
     HIP_TRY(c, c->md_out.ensure((ns + 1) * sizeof(PgSlotModel))); HIP_TRY(c, c->md_dwell.ensure((ns + 1) * sizeof(PgSlotDwell)));
     HIP_TRY(c, c->md_class.ensure(pg_slot_model_scratch_bytes(ns)));
@@ -1582,11 +1582,11 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
         }
         d_ev_off = c->md_ev_off.as<uint64_t>(); d_samp_off = c->md_samp_off.as<uint64_t>(); d_ev_len = c->md_ev_len.as<uint32_t>();
     }
-    int any_kind[3] = {0, 0, 0}; // which of the three kernels have work (the host holds the offsets since pg_finish)
+    int any_kind[PG_MODEL_KINDS] = {0, 0, 0, 0}; // which of the kernels have work (the host holds the offsets since pg_finish)
     const uint64_t drop = (flags & PG_MODEL_KEEP_FIRST) ? 0 : 1;
     for (uint32_t i = 0; i < ns; i++) {
         const uint64_t all = R.samp_off[R.ev_off[i + 1]] - R.samp_off[R.ev_off[i]], nv = all > drop ? all - drop : 0;
-        any_kind[pg_model_kind(nv)] = 1;
+        any_kind[pg_model_kind(nv, R.ev_off[i + 1] - R.ev_off[i])]++; // (counts: pg_launch_slot_model)
     }
     return model_run(c, ns, any_kind, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
 }
@@ -1596,7 +1596,7 @@ pg_status pg_model_device(pg_ctx *c, uint32_t n_slots, const uint64_t *d_ev_off,
     if (!c || !out) return PG_ERR_INVALID_ARG;
     if (n_slots && (!d_ev_off || !d_samp_off)) return fail(c, PG_ERR_INVALID_ARG, "pg_model_device: ev_off / samp_off missing");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int all_kinds[3] = {1, 1, 1}; // the offsets are not on the host: every kernel looks
+    const int all_kinds[PG_MODEL_KINDS] = {1 << 20, 1 << 20, 1 << 20, 1 << 20}; // the offsets are not on the host: every kernel looks
     return model_run(c, n_slots, all_kinds, d_ev_off, d_samp_off, d_ev_len, d_samples, flags, out);
 }
 

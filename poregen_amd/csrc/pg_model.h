@@ -20,10 +20,16 @@
 #define PG_MODEL_MAX_ABS 4.0e7            /* |sample| the fixed-point view accepts (|units| < 2^52) */
 #define PG_MODEL_LIMB_BITS 20             /* deviations from the slot's first value are split in two 20-bit limbs */
 #define PG_MODEL_MAX_DEV (1ll << 40)      /* |value - first value| in 1e-8 units the moment sums accept (~10995 pA) */
-#define PG_MODEL_TINY_MAX 1024            /* files up to this many values: one wave, values in registers */
+#define PG_MODEL_TINY_MAX 1024            /* files up to this many values and fewer than PG_MODEL_TINY_EVENTS events: one wave, 16 values per lane */
+#define PG_MODEL_TINY_EVENTS 256          /* dwell fields (events + 1) the one-wave kernel holds in registers */
+#define PG_MODEL_MID_MAX 2048             /* ... one wave, 32 values per lane (its own launch over the list of such files) */
+#define PG_MODEL_MID_EVENTS 512
 #define PG_MODEL_SHORT_MAX 4096           /* up to this many: one 256-thread workgroup, values in registers; beyond: re-read per pass */
-enum { PG_MODEL_TINY = 0, PG_MODEL_SHORT = 1, PG_MODEL_LONG = 2 };
-PGM_HD int pg_model_kind(uint64_t n_values) { return n_values <= PG_MODEL_TINY_MAX ? PG_MODEL_TINY : n_values <= PG_MODEL_SHORT_MAX ? PG_MODEL_SHORT : PG_MODEL_LONG; }
+enum { PG_MODEL_TINY = 0, PG_MODEL_MID = 1, PG_MODEL_SHORT = 2, PG_MODEL_LONG = 3, PG_MODEL_KINDS = 4 };
+PGM_HD int pg_model_kind(uint64_t n_values, uint64_t n_events) {
+    return (n_values <= PG_MODEL_TINY_MAX && n_events < PG_MODEL_TINY_EVENTS) ? PG_MODEL_TINY : (n_values <= PG_MODEL_MID_MAX && n_events < PG_MODEL_MID_EVENTS) ? PG_MODEL_MID
+           : n_values <= PG_MODEL_SHORT_MAX ? PG_MODEL_SHORT : PG_MODEL_LONG;
+}
 #define PG_MODEL_MAX_VALUES (1ull << 23)  /* values per slot the moment sums accept (limb^2 sums stay below 2^63) */
 
 // printf("%.8f", x) as an integer number of 1e-8 units: the correctly rounded (ties to even, on the exact binary value,

@@ -11,18 +11,15 @@
 #include "pg_internal.h"
 #include "pg_model.h"
 
-#ifndef PG_MODEL_TINY_BITS
-#define PG_MODEL_TINY_BITS 8
-#endif
 #ifndef PG_MODEL_TINY_WAVES
-#define PG_MODEL_TINY_WAVES 4 // waves per SIMD the one-wave variant is compiled for
+#define PG_MODEL_TINY_WAVES 4 // waves per SIMD the one-wave kernel is compiled for (a lower bound: it takes 6 with its ~80 registers)
 #endif
 namespace {
 
 // loads in flight per thread: the 1024-thread variant must stay within 64 VGPRs (two workgroups per CU), its memory
 // parallelism comes from 32 waves per CU; the 256-thread variant serves short files, where the round trips are the cost
 template <int MT> struct ModelCfg {
-    static constexpr int BITS = MT >= 256 ? 12 : PG_MODEL_TINY_BITS;    // window of the radix select; a single wave scans 256 bins, not 4096
+    static constexpr int BITS = 12;    // window of the radix select
     static constexpr int BINS = 1 << BITS;
     static constexpr int U = MT >= 1024 ? 2 : 8;
     static constexpr int CACHE = MT >= 1024 ? 0 : 16; // keys a thread keeps in registers when the whole file fits (MT * CACHE values)
@@ -197,44 +194,33 @@ template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm
     k_hi = q_hi < cnt ? (((uint64_t)bin << low) | c_hi) : above;
 }
 
-// Round 5: the three kernels used to be launched over ALL slots each, a workgroup leaving after two dependent loads when its k-mer belongs
-// to another kernel -- at k = 9 (262 144 k-mers, nearly all of them "tiny") the SHORT and LONG launches were 0.37 + 0.50 ms of mostly
-// empty workgroups next to the 1.24 ms of real work (rocprofv3 GRBM_GUI_ACTIVE, profiles/r05_model_pmc.txt). A record pass classifies the
-// slots once: rec[s] = where the slot's values and events lie + its kind (ONE 32-byte load in the kernels instead of two dependent rounds),
-// and the slots of the two rarer kinds go on lists that their kernels stride over with a small grid.
-struct __attribute__((aligned(16))) PgModelRec { uint64_t first, n, e0; uint32_t nev, kind; };
-__global__ __launch_bounds__(256) void k_model_classify(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
-                                                        PgModelRec *__restrict__ rec, uint32_t *__restrict__ lists /* [2][n_slots] */, uint32_t *__restrict__ counts /* [2] */) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_slots) return;
+// Where a slot's values and events lie: two dependent rounds of uniform (scalar) loads. Round 5 first put a record pass in front of the
+// kernels (one 32-byte load instead) -- 50 us of scattered offset loads at k = 9 that the one-wave kernel, bound by its arithmetic,
+// hides for nothing; the kernel over all slots now classifies on the way and lists the slots that belong to the others.
+struct FileRef { uint64_t first, n, e0; uint32_t nev; };
+__device__ __forceinline__ FileRef file_ref(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t s, uint32_t drop_first) {
     const uint64_t e0 = ev_off[s], e1 = ev_off[s + 1];
     const uint64_t a0 = samp_off[e0], a1 = samp_off[e1];
     const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
-    PgModelRec r;
-    r.first = a0 + skip; r.n = a1 - r.first; r.e0 = e0; r.nev = (uint32_t)(e1 - e0); r.kind = (uint32_t)pg_model_kind(r.n);
-    rec[s] = r;
-    if (r.kind != PG_MODEL_TINY) lists[(size_t)(r.kind - 1) * n_slots + atomicAdd(counts + (r.kind - 1), 1u)] = s; // (any order: every slot writes its own result)
+    FileRef f; f.first = a0 + skip; f.n = a1 - f.first; f.e0 = e0; f.nev = (uint32_t)(e1 - e0);
+    return f;
 }
 
-// Three kernels share this body, by file size: TINY (one wave, <= 1024 values: k = 9 jobs have 262 144 such files, and a wave
-// needs no workgroup barrier) and SHORT (256 threads, <= 4096 values) convert the whole file once into 16 registers per
-// thread; LONG (1024 threads) re-reads the file per pass. A workgroup whose k-mer belongs to another kernel leaves after two
-// loads. Separate kernels because each needs its own register budget; the host launches only the ones with work.
-template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_WAVES : 4)) void k_slot_model(const PgModelRec *__restrict__ rec, const uint32_t *__restrict__ list,
-                                                                      const uint32_t *__restrict__ list_n, uint32_t n_slots, const uint32_t *ev_len,
+// The two workgroup kernels, by file size: SHORT (256 threads, <= 4096 values) converts the whole file once into 16 registers per
+// thread; LONG (1024 threads) re-reads the file per pass. Both stride over the list of their slots. Separate kernels because each needs
+// its own register budget; the host launches only the ones with work.
+template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : 4) void k_slot_model(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t drop_first,
+                                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n, const uint32_t *ev_len,
                                                                       const double *samples, PgSlotModel *out, PgSlotDwell *dwell) {
     constexpr bool SHORT = KIND != PG_MODEL_LONG; // register-resident
     __shared__ ModelSmem<MT> sm;
     constexpr int C = SHORT ? ModelCfg<MT>::CACHE : 0;
-    // TINY: a workgroup (= a wave) per slot; the rarer kinds: the workgroups stride over their list
-    const uint32_t n_mine = KIND == PG_MODEL_TINY ? n_slots : uniform32(*list_n);
+    const uint32_t n_mine = uniform32(*list_n);
     for (uint32_t it = blockIdx.x; it < n_mine; it += gridDim.x) {
-    const uint32_t s = KIND == PG_MODEL_TINY ? it : uniform32(list[it]);
-    const uint4 rq0 = *reinterpret_cast<const uint4 *>(rec + s), rq1 = *(reinterpret_cast<const uint4 *>(rec + s) + 1);
-    const uint64_t first = uniform64((uint64_t)rq0.x | ((uint64_t)rq0.y << 32)), n = uniform64((uint64_t)rq0.z | ((uint64_t)rq0.w << 32));
-    const uint64_t e0 = uniform64((uint64_t)rq1.x | ((uint64_t)rq1.y << 32));
-    const uint32_t nev32 = uniform32(rq1.z);
-    if (KIND == PG_MODEL_TINY && uniform32(rq1.w) != (uint32_t)PG_MODEL_TINY) continue; // (gridDim.x == n_slots: the loop ends)
+    const uint32_t s = uniform32(list[it]);
+    const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
+    const uint64_t first = uniform64(fr.first), n = uniform64(fr.n), e0 = uniform64(fr.e0);
+    const uint32_t nev32 = uniform32(fr.nev);
     if (it != blockIdx.x) __syncthreads(); // the previous slot's shared state has been read by everyone
     uint32_t flags = 0;
     PgSlotModel m{};
@@ -259,7 +245,7 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
         RegKeys<C> rk;
         rk.cnt = 0;
         if constexpr (SHORT) {
-            static_assert(MT * ModelCfg<MT>::CACHE == (KIND == PG_MODEL_TINY ? PG_MODEL_TINY_MAX : PG_MODEL_SHORT_MAX), "the kernel holds the whole file in registers");
+            static_assert(MT * ModelCfg<MT>::CACHE == PG_MODEL_SHORT_MAX, "the kernel holds the whole file in registers");
             double x[C];
             rk.cnt = n > threadIdx.x ? (int)((n - threadIdx.x + MT - 1) / MT) : 0;
 #pragma unroll
@@ -310,22 +296,310 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
     } // slots of this workgroup
 }
 
+// ---- One wave per file, rewritten in round 5 (the TINY kind: at k = 9 all 262 144 files) ----------------------------------------------
+// The variant of k_slot_model above ran a file through eight DEPENDENT memory rounds (record, first value, values, then the event lengths
+// once per pass of the dwell selection) and through five 8-bit selection windows with seven separate reductions in between: a wave lived
+// 19 us for 4 us of instructions (profiles/r05_model_pmc.txt); with the rounds gone the kernel is bound by its instruction count
+// (262 144 waves on 1024 SIMDs), so the arithmetic per value is what this version is written for:
+//  * the record, then ALL the file's values and event lengths at once (two memory rounds);
+//  * pg_fixed8 through the 2^52 trick: t = p + 1.5 * 2^52 holds rint(p) in its low mantissa bits (|p| < 2^51), so t's BIT PATTERN minus
+//    that of the smallest t is the selection key (one integer subtraction, no conversion), and t - t0 is the deviation from the first
+//    value as an exact double; a file with a value of 2.2e7 or more, or a NaN, is handed to the 256-thread kernel (its list);
+//  * the moments in FP64, every step exact: |d| = ah * 2^20 + al by a scaling and a truncation, the three limb products by FMA (each
+//    < 2^40, a lane's sum of 16 < 2^44, the wave's < 2^50) -- v_mad_u64_u32 is a quarter-rate instruction, v_fma_f64 half rate;
+//  * no validity tests per value: a lane without a value loads the FIRST one (deviation 0, neither minimum nor maximum) and gets a key
+//    above every real one for the selection;
+//  * reductions as DPP chains without LDS or barriers (independent, so they interleave);
+//  * the selection leaves its 8-bit windows as soon as ranking the remaining candidates against each other (one per lane) is cheaper
+//    than another window -- for a med-MAD file after one or two -- in 32-bit arithmetic when the spread allows.
+#define WV_MAGIC 6755399441055744.0             /* 1.5 * 2^52 (even): p + WV_MAGIC has ulp 1 */
+#define WV_MAX_ABS 2.2e7                        /* |x| * 1e8 < 2^51 */
+struct WaveSmem { uint32_t hist[256]; uint64_t cand[64]; };
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+__device__ __forceinline__ uint32_t readlane_k(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t readlane_k(uint64_t v, int l) { return readlane64(v, l); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp64(uint64_t v, uint64_t ident) { // a lane without a source keeps `ident`
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)ident, (int)(uint32_t)v, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(ident >> 32), (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp32(uint32_t v, uint32_t ident) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// op over the wave's 64 lanes (all active), the result uniform: row_shr 1/2/4/8, row_bcast 15 / 31 as wave_incl_scan_u32 (pg_dev.h)
+template <class Op> __device__ __forceinline__ uint64_t wave_reduce64(uint64_t v, uint64_t ident, Op op) {
+    v = op(v, dpp64<0x111, 0xF>(v, ident));
+    v = op(v, dpp64<0x112, 0xF>(v, ident));
+    v = op(v, dpp64<0x114, 0xF>(v, ident));
+    v = op(v, dpp64<0x118, 0xF>(v, ident));
+    v = op(v, dpp64<0x142, 0xA>(v, ident));
+    v = op(v, dpp64<0x143, 0xC>(v, ident));
+    return readlane64(v, 63);
+}
+template <class Op> __device__ __forceinline__ uint32_t wave_reduce32(uint32_t v, uint32_t ident, Op op) {
+    v = op(v, dpp32<0x111, 0xF>(v, ident));
+    v = op(v, dpp32<0x112, 0xF>(v, ident));
+    v = op(v, dpp32<0x114, 0xF>(v, ident));
+    v = op(v, dpp32<0x118, 0xF>(v, ident));
+    v = op(v, dpp32<0x142, 0xA>(v, ident));
+    v = op(v, dpp32<0x143, 0xC>(v, ident));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <class Op> __device__ __forceinline__ double wave_reduce_f64(double v, double ident, Op op) {
+    return __longlong_as_double((long long)wave_reduce64((uint64_t)__double_as_longlong(v), (uint64_t)__double_as_longlong(ident),
+        [&](uint64_t a, uint64_t b) { return (uint64_t)__double_as_longlong(op(__longlong_as_double((long long)a), __longlong_as_double((long long)b))); }));
+}
+__device__ __forceinline__ uint32_t wave_min_k(uint32_t v) { return wave_reduce32(v, ~0u, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint64_t wave_min_k(uint64_t v) { return wave_reduce64(v, ~0ull, op_min); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp32z(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true); }
+__device__ __forceinline__ uint32_t wave_scan32(uint32_t v) {
+    v += dpp32z<0x111, 0xF>(v); v += dpp32z<0x112, 0xF>(v); v += dpp32z<0x114, 0xF>(v); v += dpp32z<0x118, 0xF>(v);
+    v += dpp32z<0x142, 0xA>(v); v += dpp32z<0x143, 0xC>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// Keys of a wave: element u of lane l is key u * 64 + l of n; a lane's elements beyond n hold ~0, real keys are < 2^bits (bits < the
+// key type's width), rows beyond n are never touched.
+// the smallest key whose bits above `hi` exceed `prefix` (the caller knows there is one)
+template <class K, int C> __device__ __forceinline__ K wave_above(const K (&k)[C], uint32_t n, int hi, K prefix) {
+    K a = (K)~(K)0;
+#pragma unroll
+    for (int u = 0; u < C; ++u)
+        if ((uint32_t)u * 64 < n) { if ((K)(k[u] >> hi) > prefix && k[u] < a) a = k[u]; }
+    return wave_min_k(a);
+}
+
+// datamash's two middle order statistics of the n keys. 8-bit windows from the top while that is cheaper than the alternative: the
+// candidates' remaining bits go to LDS, one per lane (<= 64), and every lane counts the candidates below / not above its own -- the
+// lane whose interval holds a rank owns that order statistic.
+template <class K, int C> __device__ void wave_middle(WaveSmem &sm, const K (&k)[C], uint32_t n, int bits, K &k_lo, K &k_hi) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t r_lo = (n - 1) / 2, r_hi = n / 2, cnt = n; // ranks among the candidates; r_lo < cnt, r_hi <= cnt
+    K prefix = 0;
+    int hi = bits; // candidates: the keys with (key >> hi) == prefix
+    const uint32_t window_cost = 40 + 6 * ((n + 63) / 64); // in instructions, against ~5 per candidate of the ranking loop
+    while (hi > 0 && (cnt > 64 || cnt * 5 > window_cost)) {
+        const int wbits = hi >= 8 ? 8 : hi, shift = hi - wbits;
+        const uint32_t mask = (1u << wbits) - 1;
+        __syncthreads();
+        reinterpret_cast<uint4 *>(sm.hist)[lane] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < C; ++u)
+            if ((uint32_t)u * 64 < n) { if ((K)(k[u] >> hi) == prefix) atomicAdd(&sm.hist[(uint32_t)(k[u] >> shift) & mask], 1u); }
+        __syncthreads();
+        const uint4 h = reinterpret_cast<const uint4 *>(sm.hist)[lane];
+        const uint32_t sum = h.x + h.y + h.z + h.w, base = wave_scan32(sum) - sum;
+        const int L = __builtin_ctzll(__ballot(r_lo >= base && r_lo < base + sum)); // exactly one lane: the counts add up to cnt > r_lo
+        uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)base, L);
+        const uint32_t hx = (uint32_t)__builtin_amdgcn_readlane((int)h.x, L), hy = (uint32_t)__builtin_amdgcn_readlane((int)h.y, L),
+                       hz = (uint32_t)__builtin_amdgcn_readlane((int)h.z, L), hw = (uint32_t)__builtin_amdgcn_readlane((int)h.w, L);
+        uint32_t bin = (uint32_t)L * 4, cb = hx;
+        if (r_lo >= below + cb) { below += cb; cb = hy; ++bin;
+            if (r_lo >= below + cb) { below += cb; cb = hz; ++bin;
+                if (r_lo >= below + cb) { below += cb; cb = hw; ++bin; } } }
+        r_lo -= below; r_hi -= below; cnt = cb;
+        prefix = (K)((prefix << wbits) | bin);
+        hi -= wbits;
+    }
+    if (hi == 0) { // every bit settled: the candidates are one value
+        k_lo = prefix;
+        k_hi = r_hi < cnt ? prefix : wave_above<K, C>(k, n, 0, prefix);
+        return;
+    }
+    // (cnt <= 64 here)
+    const K low_mask = (K)(((K)1 << hi) - 1), top = (K)(prefix << hi);
+    K *cand = reinterpret_cast<K *>(sm.cand);
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int u = 0; u < C; ++u)
+        if ((uint32_t)u * 64 < n) {
+            const bool m = (K)(k[u] >> hi) == prefix;
+            const uint64_t b = __ballot(m);
+            if (m) cand[run + lanes_below(b)] = k[u] & low_mask;
+            run += (uint32_t)__builtin_popcountll(b);
+        }
+    __syncthreads();
+    const bool have = lane < cnt;
+    uint32_t lt = 0, le = 0;
+    K mine = (K)~(K)0;
+    if (hi <= 32) { // (always, for 32-bit keys)
+        const uint32_t m32 = have ? (uint32_t)cand[lane] : ~0u;
+        for (uint32_t j = 0; j < cnt; ++j) { const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)m32, (int)j); lt += c < m32; le += c <= m32; }
+        mine = (K)m32;
+    } else {
+        mine = have ? cand[lane] : (K)~(K)0;
+        for (uint32_t j = 0; j < cnt; ++j) { const K c = readlane_k(mine, (int)j); lt += c < mine; le += c <= mine; }
+    }
+    const int l_lo = __builtin_ctzll(__ballot(have && lt <= r_lo && r_lo < le));
+    k_lo = top | readlane_k(mine, l_lo);
+    if (r_hi == r_lo) k_hi = k_lo;
+    else if (r_hi < cnt) k_hi = top | readlane_k(mine, __builtin_ctzll(__ballot(have && lt <= r_hi && r_hi < le)));
+    else k_hi = wave_above<K, C>(k, n, hi, prefix);
+}
+
+__device__ __forceinline__ int64_t f64_to_i64_exact(double v) { return (int64_t)v; } // (uniform values only: a handful per file)
+
+// One file on one wave: C rows of 64 values, D rows of 64 events. Returns false when the file holds a value the conversion cannot take.
+template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, const FileRef &fr, uint32_t s, const uint32_t *__restrict__ ev_len,
+                                                                   const double *__restrict__ samples, PgSlotModel *__restrict__ out, PgSlotDwell *__restrict__ dwell) {
+    constexpr int WV_C = C, WV_D = D;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t first = fr.first, e0 = fr.e0;
+    const uint32_t n = (uint32_t)fr.n, nev = fr.nev, nd = nev ? nev + 1 : 0; // n <= 64 C, nd <= 64 D (pg_model_kind)
+    // every load of the file at once: its values (a lane beyond the end takes the first one) and its events' lengths
+    double x[WV_C];
+    uint32_t len[WV_D];
+#pragma unroll
+    for (int u = 0; u < WV_C; ++u) if ((uint32_t)u * 64 < n) { const uint32_t i = (uint32_t)u * 64 + lane; x[u] = samples[first + (i < n ? i : 0u)]; } else x[u] = 0.0;
+#pragma unroll
+    for (int u = 0; u < WV_D; ++u) if ((uint32_t)u * 64 < nev) { const uint32_t i = (uint32_t)u * 64 + lane; len[u] = ev_len[e0 + (i < nev ? i : 0u)]; } else len[u] = 0;
+    PgSlotModel m{};
+    m.n = n;
+    uint32_t flags = 0;
+    if (n > 0) {
+        // pg_fixed8 of every value, kept as t = units + 1.5 * 2^52
+        double t[WV_C];
+        bool big = false;
+        double tmin = INFINITY, tmax = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < WV_C; ++u)
+            if ((uint32_t)u * 64 < n) {
+                big |= !(fabs(x[u]) < WV_MAX_ABS); // also NaN
+                const double p = x[u] * 1e8, e = fma(x[u], 1e8, -p);
+                double tt = p + WV_MAGIC; // rint(p), ties to even (WV_MAGIC is even)
+                const double f = p - (tt - WV_MAGIC);
+                if (__ballot(fabs(f) == 0.5)) { // p sits on a tie that the addition broke to even; e says on which side the exact product lies
+                    if (f == 0.5 && e > 0.0) tt += 1.0;
+                    else if (f == -0.5 && e < 0.0) tt -= 1.0;
+                }
+                t[u] = tt;
+                tmin = fmin(tmin, tt); tmax = fmax(tmax, tt);
+            } else t[u] = 0.0;
+        if (__ballot(big)) return false; // outside the 2^52 trick (or not a number): the 256-thread kernel converts the general way and reports
+        const double t0 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(t[0]), 0)); // the file's first value
+        double s1 = 0.0, hh = 0.0, hl = 0.0, ll = 0.0;
+#pragma unroll
+        for (int u = 0; u < WV_C; ++u)
+            if ((uint32_t)u * 64 < n) {
+                const double d = t[u] - t0, ad = fabs(d);              // exact: both in [2^52, 2^53)
+                const double ah = trunc(ad * 0x1p-20), al = fma(ah, -0x1p20, ad); // |d| = ah * 2^20 + al, exact
+                s1 += d; hh = fma(ah, ah, hh); hl = fma(ah, al, hl); ll = fma(al, al, ll);
+            }
+        tmin = wave_reduce_f64(tmin, INFINITY, [](double a, double b) { return fmin(a, b); });
+        tmax = wave_reduce_f64(tmax, -INFINITY, [](double a, double b) { return fmax(a, b); });
+        s1 = wave_reduce_f64(s1, 0.0, [](double a, double b) { return a + b; });
+        hh = wave_reduce_f64(hh, 0.0, [](double a, double b) { return a + b; });
+        hl = wave_reduce_f64(hl, 0.0, [](double a, double b) { return a + b; });
+        ll = wave_reduce_f64(ll, 0.0, [](double a, double b) { return a + b; });
+        const bool wide = !(tmax - t0 < 0x1p40 && t0 - tmin < 0x1p40); // some |d| >= PG_MODEL_MAX_DEV: the limb sums above mean nothing
+        flags = wide ? PG_MODEL_BAD_SPREAD : 0u;
+        const int64_t origin = f64_to_i64_exact(t0 - WV_MAGIC);
+        m.origin = origin;
+        m.s1 = wide ? 0 : f64_to_i64_exact(s1);
+        m.s2_hh = wide ? 0 : (uint64_t)f64_to_i64_exact(hh); m.s2_hl = wide ? 0 : (uint64_t)f64_to_i64_exact(hl); m.s2_ll = wide ? 0 : (uint64_t)f64_to_i64_exact(ll);
+        // selection keys: the bit pattern of t above that of the smallest t (one exponent: the difference of the patterns is that of the units)
+        const uint64_t bmin = (uint64_t)__double_as_longlong(tmin), spread = (uint64_t)__double_as_longlong(tmax) - bmin;
+        const int bits = spread ? 64 - __builtin_clzll(spread) : 0; // <= 53
+        const int64_t vmin = f64_to_i64_exact(tmin - WV_MAGIC);
+        if (bits <= 31) {
+            uint32_t key[WV_C];
+#pragma unroll
+            for (int u = 0; u < WV_C; ++u) key[u] = ((uint32_t)u * 64 + lane < n) ? (uint32_t)__double_as_longlong(t[u]) - (uint32_t)bmin : ~0u;
+            uint32_t k_lo, k_hi;
+            wave_middle<uint32_t, WV_C>(sm, key, n, bits, k_lo, k_hi);
+            m.mid_lo = vmin + (int64_t)k_lo; m.mid_hi = vmin + (int64_t)k_hi;
+        } else {
+            uint64_t key[WV_C];
+#pragma unroll
+            for (int u = 0; u < WV_C; ++u) key[u] = ((uint32_t)u * 64 + lane < n) ? (uint64_t)__double_as_longlong(t[u]) - bmin : ~0ull;
+            uint64_t k_lo, k_hi;
+            wave_middle<uint64_t, WV_C>(sm, key, n, bits, k_lo, k_hi);
+            m.mid_lo = vmin + (int64_t)k_lo; m.mid_hi = vmin + (int64_t)k_hi;
+        }
+    }
+    // dwell: awk prints one comma count per ';'-separated field: samples - 1 per event, and 0 for the empty last field
+    PgSlotDwell dw{};
+    if (nd > 0) {
+        uint32_t dk[WV_D], dmx = 0;
+#pragma unroll
+        for (int u = 0; u < WV_D; ++u) {
+            const uint32_t i = (uint32_t)u * 64 + lane;
+            const uint32_t v = (i < nev && len[u]) ? len[u] - 1 : 0u;
+            dmx = v > dmx ? v : dmx;
+            dk[u] = i < nd ? v : ~0u;
+        }
+        dmx = wave_reduce32(dmx, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+        const int bits = dmx ? 32 - __builtin_clz(dmx) : 0;
+        uint32_t k_lo = 0, k_hi = 0;
+        if (bits <= 31) wave_middle<uint32_t, WV_D>(sm, dk, nd, bits, k_lo, k_hi);
+        else k_lo = k_hi = 0; // (a window of 2^31 samples or more: op lengths are below 2^24)
+        dw.n = nd; dw.mid_lo = k_lo; dw.mid_hi = k_hi;
+    }
+    dw.flags = flags;
+    if (lane == 0) { out[s] = m; dwell[s] = dw; }
+    return true;
+}
+
+// The kernel over ALL slots (a wave each): the TINY files are reduced here, the others go on the list of their kind (lists[kind - 1]).
+__global__ __launch_bounds__(64, PG_MODEL_TINY_WAVES) void k_slot_model_wave(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
+                                                                              const uint32_t *__restrict__ ev_len, const double *__restrict__ samples, PgSlotModel *__restrict__ out,
+                                                                              PgSlotDwell *__restrict__ dwell, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
+    __shared__ WaveSmem sm;
+    const uint32_t s = blockIdx.x;
+    if (s >= n_slots) return;
+    const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
+    int kind = pg_model_kind(fr.n, fr.nev);
+    if (kind == PG_MODEL_TINY && !wave_file<PG_MODEL_TINY_MAX / 64, PG_MODEL_TINY_EVENTS / 64>(sm, fr, s, ev_len, samples, out, dwell)) kind = PG_MODEL_SHORT;
+    if (kind == PG_MODEL_SHORT) kind = short_kind; // (the launcher may send the few SHORT files of a job with the LONG ones: one launch less)
+    if (kind != PG_MODEL_TINY && threadIdx.x == 0) lists[(size_t)(kind - 1) * n_slots + atomicAdd(counts + (kind - 1), 1u)] = s; // (any order: every slot writes its own result)
+}
+// The MID files (up to 2048 values and 511 events: at k = 9 the ~3 000 files above the one-wave size): the same code with 32 rows, over their list.
+__global__ __launch_bounds__(64, 2) void k_slot_model_wave_mid(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
+                                                                const uint32_t *__restrict__ ev_len, const double *__restrict__ samples, PgSlotModel *__restrict__ out,
+                                                                PgSlotDwell *__restrict__ dwell, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
+    __shared__ WaveSmem sm;
+    const uint32_t n_mine = uniform32(counts[PG_MODEL_MID - 1]);
+    for (uint32_t it = blockIdx.x; it < n_mine; it += gridDim.x) {
+        const uint32_t s = uniform32(lists[(size_t)(PG_MODEL_MID - 1) * n_slots + it]);
+        const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
+        if (it != blockIdx.x) __syncthreads();
+        if (!wave_file<PG_MODEL_MID_MAX / 64, PG_MODEL_MID_EVENTS / 64>(sm, fr, s, ev_len, samples, out, dwell) && threadIdx.x == 0)
+            lists[(size_t)(short_kind - 1) * n_slots + atomicAdd(counts + (short_kind - 1), 1u)] = s;
+    }
+}
+
 } // namespace
 
-size_t pg_slot_model_scratch_bytes(uint32_t n_slots) { return (size_t)n_slots * sizeof(PgModelRec) + 2 * (size_t)n_slots * 4 + 64; }
-hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[3], const uint64_t *ev_off, const uint64_t *samp_off,
+size_t pg_slot_model_scratch_bytes(uint32_t n_slots) { return 3 * (size_t)n_slots * 4 + 64; }
+hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[4], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell, void *scratch) {
     if (n_slots == 0) return hipSuccess;
     (void)hipGetLastError(); // sticky per-thread state of an unrelated earlier failure
-    // scratch: [2] list lengths (+ padding to 64 bytes), records, the two lists
+    // scratch: [3] list lengths (+ padding to 64 bytes), the lists of the MID, SHORT and LONG slots
     uint32_t *counts = static_cast<uint32_t *>(scratch);
-    PgModelRec *rec = reinterpret_cast<PgModelRec *>(static_cast<char *>(scratch) + 64);
-    uint32_t *lists = reinterpret_cast<uint32_t *>(rec + n_slots);
+    uint32_t *lists = counts + 16;
     hipError_t e = hipMemsetAsync(counts, 0, 64, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_model_classify, dim3((n_slots + 255) / 256), dim3(256), 0, st, ev_off, samp_off, n_slots, drop_first, rec, lists, counts);
-    if (any_kind[PG_MODEL_TINY]) hipLaunchKernelGGL((k_slot_model<64, PG_MODEL_TINY>), dim3(n_slots), dim3(64), 0, st, (const PgModelRec *)rec, (const uint32_t *)nullptr, (const uint32_t *)nullptr, n_slots, ev_len, samples, out, dwell);
-    if (any_kind[PG_MODEL_SHORT]) hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots < 2048u ? n_slots : 2048u), dim3(256), 0, st, (const PgModelRec *)rec, (const uint32_t *)lists, (const uint32_t *)counts, n_slots, ev_len, samples, out, dwell);
-    if (any_kind[PG_MODEL_LONG]) hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots < 512u ? n_slots : 512u), dim3(1024), 0, st, (const PgModelRec *)rec, (const uint32_t *)(lists + n_slots), (const uint32_t *)(counts + 1), n_slots, ev_len, samples, out, dwell);
+    // any_kind[] = how many files of each kind the host knows of (1 = "some" when it does not hold the offsets). A workgroup kernel's launch is
+    // the lifetime of one workgroup (~55 us at k = 9 for 34 SHORT and 28 LONG files): when both kinds together fit one round of the
+    // 1024-thread kernel, the SHORT files go on its list too.
+    const bool merge = any_kind[PG_MODEL_SHORT] > 0 && any_kind[PG_MODEL_LONG] > 0 && any_kind[PG_MODEL_SHORT] + any_kind[PG_MODEL_LONG] <= 512 && !getenv("PGMOVE_MODEL_NO_MERGE");
+    const int short_kind = merge ? PG_MODEL_LONG : PG_MODEL_SHORT;
+    // always: it is also the pass that sorts the slots into the lists (a wave that is not TINY leaves after four scalar loads)
+    hipLaunchKernelGGL(k_slot_model_wave, dim3(n_slots), dim3(64), 0, st, ev_off, samp_off, n_slots, drop_first, ev_len, samples, out, dwell, lists, counts, short_kind);
+    if (any_kind[PG_MODEL_MID]) hipLaunchKernelGGL(k_slot_model_wave_mid, dim3(n_slots < 4096u ? n_slots : 4096u), dim3(64), 0, st, ev_off, samp_off, n_slots, drop_first, ev_len, samples, out, dwell, lists, counts, short_kind);
+    // (the one-wave kernels hand files with values of 2.2e7 and beyond to the 256-thread one)
+    if (!merge && (any_kind[PG_MODEL_SHORT] || any_kind[PG_MODEL_TINY] || any_kind[PG_MODEL_MID]))
+        hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots < 2048u ? n_slots : 2048u), dim3(256), 0, st, ev_off, samp_off, drop_first,
+                           (const uint32_t *)(lists + (size_t)(PG_MODEL_SHORT - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_SHORT - 1)), ev_len, samples, out, dwell);
+    if (any_kind[PG_MODEL_LONG])
+        hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots < 512u ? n_slots : 512u), dim3(1024), 0, st, ev_off, samp_off, drop_first,
+                           (const uint32_t *)(lists + (size_t)(PG_MODEL_LONG - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_LONG - 1)), ev_len, samples, out, dwell);
     return hipGetLastError();
 }

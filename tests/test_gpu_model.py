@@ -240,3 +240,68 @@ def test_model_rejects_a_spread_beyond_the_moment_sums():
         eng.model()
     assert "2^40" in str(ei.value)
     eng.close()
+
+
+def _units(x):
+    return int(Decimal("%.8f" % float(x)).scaleb(8))
+
+
+def test_model_one_wave_kernel_on_constructed_files():
+    """Files built value by value for the one-wave kernels (<= 1024 values and < 256 events; <= 2048 and < 512): sizes around the lane / row /
+    kernel boundaries, even
+    and odd counts, duplicates, products x * 1e8 that land on a half (the tie the FMA's error decides), a spread beyond 2^31 units
+    (64-bit selection keys), values of 2.2e7 and more (outside the 2^52 conversion: the file goes to the 256-thread kernel) and a file
+    of 255 / 256 events (the last one-wave size / the first that is not). Middle order statistics and moments against Python integers."""
+    import torch
+    rng = np.random.default_rng(20251005)
+    files = []   # (values, event lengths)
+    def add(vals, lens=None):
+        vals = np.asarray(vals, dtype=np.float64)
+        if lens is None:
+            k = max(1, len(vals) // 7)
+            cuts = np.sort(rng.choice(np.arange(1, len(vals)), size=min(k, len(vals) - 1), replace=False)) if len(vals) > 1 else np.zeros(0, int)
+            lens = np.diff(np.concatenate([[0], cuts, [len(vals)]]))
+        assert int(np.sum(lens)) == len(vals)
+        files.append((vals, np.asarray(lens, dtype=np.int64)))
+    for n in (1, 2, 3, 63, 64, 65, 127, 128, 129, 700, 1023, 1024):
+        add(rng.normal(0.0, 1.5, n))
+    add(np.round(rng.normal(0.0, 1.0, 500), 2))                                   # many equal values
+    add(np.full(300, 1.25))                                                       # one value
+    add(np.concatenate([np.full(200, -0.5), np.full(200, 0.5)]))                  # the two middles on different values
+    ties = (np.arange(1, 400, 2) + 0.5) * 1e-8                                    # x * 1e8 = k + 1/2 up to the product's rounding
+    add(np.concatenate([ties, -ties]))
+    add(rng.normal(0.0, 1.0, 600) * 40.0)                                         # spread > 2^31 units
+    add(2.3e7 + rng.normal(0.0, 1.0, 100))                                        # beyond the 2^52 conversion
+    add(np.concatenate([-3.9e7 + rng.normal(0.0, 50.0, 333), [-3.9e7 - 5000.0]]))
+    add(np.concatenate([2.2e7 - 5000.0 + rng.normal(0.0, 1.0, 64), [2.2e7 + 1.0]]))       # ... by its last value only
+    add(rng.normal(90.0, 10.0, 255 * 3), np.full(255, 3))                         # 255 events: one wave; first value dropped below
+    add(rng.normal(90.0, 10.0, 256 * 3), np.full(256, 3))                         # 256 events: 256 threads
+    add(rng.normal(0.0, 1.0, 1025))                                               # 1024 values after the first is dropped
+    add(rng.normal(0.0, 1.0, 1026))                                               # 1025: the 32-row wave kernel
+    for n in (1500, 2047, 2049, 2050, 3000):                                      # ... up to 2048 values, then 256 threads
+        add(rng.normal(0.0, 2.0, n))
+    add(rng.normal(90.0, 10.0, 511 * 3), np.full(511, 3))                         # 511 events: the last 32-row size
+    add(rng.normal(90.0, 10.0, 512 * 3), np.full(512, 3))
+    add(np.concatenate([rng.normal(0.0, 1.0, 1800), [9000.0]]) + 2.4e7)            # a 32-row file handed on
+    add(rng.normal(0.0, 1.0, 5000))                                               # 1024 threads
+    counts = np.array([len(l) for _, l in files], np.int64)
+    lens = np.concatenate([l for _, l in files])
+    vals = np.concatenate([v for v, _ in files])
+    dev = torch.device("cuda:0")
+    eng = GmoveEngine(GmoveParams(kmers=generate_kmers(5)[:len(files)], kmer_size=5, scaling=0, sample_limit=10))
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt)).to(dev)
+    for keep_first in (False, True):
+        got = eng.model_device(t(counts, np.int64), t(lens, np.int32), t(vals, np.float64), keep_first=keep_first)
+        for s, (v, l) in enumerate(files):
+            u = [_units(x) for x in (v if keep_first else v[1:])]
+            assert int(got.n_values[s]) == len(u), s
+            if u:
+                su = sorted(u); n = len(u)
+                assert (int(got.mid_lo[s]), int(got.mid_hi[s])) == (su[(n - 1) // 2], su[n // 2]), (s, keep_first)
+                assert int(got.origin[s]) == u[0], s
+                d = [x - u[0] for x in u]
+                assert int(got.sum1[s]) == sum(d), s
+                assert (int(got.sum2_hi[s]) << 64) + int(got.sum2_lo[s]) == sum(x * x for x in d), s
+            dw = sorted([int(x) - 1 for x in l] + [0])
+            assert int(got.dwell_n[s]) == len(dw) and float(got.dwell_median[s]) == (dw[(len(dw) - 1) // 2] + dw[len(dw) // 2]) / 2.0, s
+    eng.close()
