@@ -348,9 +348,30 @@ template <class Op> __device__ __forceinline__ uint32_t wave_reduce32(uint32_t v
     v = op(v, dpp32<0x143, 0xC>(v, ident));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// FP64 reductions. The sum: lanes without a source read zero (bound_ctrl), so no register has to be prepared for them. Minimum and
+// maximum through the instruction itself: fmin() / fmax() would first canonicalise both operands (two more FP64 instructions per step)
+// against signalling NaNs that values which came out of an addition cannot be.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_f64_zero(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64_zero<0x111, 0xF>(v); v += dpp_f64_zero<0x112, 0xF>(v); v += dpp_f64_zero<0x114, 0xF>(v); v += dpp_f64_zero<0x118, 0xF>(v);
+    v += dpp_f64_zero<0x142, 0xA>(v); v += dpp_f64_zero<0x143, 0xC>(v);
+    return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), 63));
+}
+__device__ __forceinline__ double min_f64_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double max_f64_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <class Op> __device__ __forceinline__ double wave_reduce_f64(double v, double ident, Op op) {
     return __longlong_as_double((long long)wave_reduce64((uint64_t)__double_as_longlong(v), (uint64_t)__double_as_longlong(ident),
         [&](uint64_t a, uint64_t b) { return (uint64_t)__double_as_longlong(op(__longlong_as_double((long long)a), __longlong_as_double((long long)b))); }));
+}
+// an integer-valued double as int64: |v| < 2^51 (one addition and the mantissa's low bits instead of the conversion sequence)
+__device__ __forceinline__ int64_t small_f64_to_i64(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v + WV_MAGIC);
+    return (int64_t)(b & ((1ull << 52) - 1)) - (1ll << 51);
 }
 __device__ __forceinline__ uint32_t wave_min_k(uint32_t v) { return wave_reduce32(v, ~0u, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
 __device__ __forceinline__ uint64_t wave_min_k(uint64_t v) { return wave_reduce64(v, ~0ull, op_min); }
@@ -443,15 +464,13 @@ template <class K, int C> __device__ void wave_middle(WaveSmem &sm, const K (&k)
     else k_hi = wave_above<K, C>(k, n, hi, prefix);
 }
 
-__device__ __forceinline__ int64_t f64_to_i64_exact(double v) { return (int64_t)v; } // (uniform values only: a handful per file)
-
 // One file on one wave: C rows of 64 values, D rows of 64 events. Returns false when the file holds a value the conversion cannot take.
 template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, const FileRef &fr, uint32_t s, const uint32_t *__restrict__ ev_len,
                                                                    const double *__restrict__ samples, PgSlotModel *__restrict__ out, PgSlotDwell *__restrict__ dwell) {
     constexpr int WV_C = C, WV_D = D;
     const uint32_t lane = threadIdx.x;
-    const uint64_t first = fr.first, e0 = fr.e0;
-    const uint32_t n = (uint32_t)fr.n, nev = fr.nev, nd = nev ? nev + 1 : 0; // n <= 64 C, nd <= 64 D (pg_model_kind)
+    const uint64_t first = uniform64(fr.first), e0 = uniform64(fr.e0); // (scalar registers: the row guards below are scalar branches)
+    const uint32_t n = uniform32((uint32_t)fr.n), nev = uniform32(fr.nev), nd = nev ? nev + 1 : 0; // n <= 64 C, nd <= 64 D (pg_model_kind)
     // every load of the file at once: its values (a lane beyond the end takes the first one) and its events' lengths
     double x[WV_C];
     uint32_t len[WV_D];
@@ -479,7 +498,7 @@ template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, 
                     else if (f == -0.5 && e < 0.0) tt -= 1.0;
                 }
                 t[u] = tt;
-                tmin = fmin(tmin, tt); tmax = fmax(tmax, tt);
+                tmin = min_f64_raw(tmin, tt); tmax = max_f64_raw(tmax, tt);
             } else t[u] = 0.0;
         if (__ballot(big)) return false; // outside the 2^52 trick (or not a number): the 256-thread kernel converts the general way and reports
         const double t0 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(t[0]), 0)); // the file's first value
@@ -491,22 +510,18 @@ template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, 
                 const double ah = trunc(ad * 0x1p-20), al = fma(ah, -0x1p20, ad); // |d| = ah * 2^20 + al, exact
                 s1 += d; hh = fma(ah, ah, hh); hl = fma(ah, al, hl); ll = fma(al, al, ll);
             }
-        tmin = wave_reduce_f64(tmin, INFINITY, [](double a, double b) { return fmin(a, b); });
-        tmax = wave_reduce_f64(tmax, -INFINITY, [](double a, double b) { return fmax(a, b); });
-        s1 = wave_reduce_f64(s1, 0.0, [](double a, double b) { return a + b; });
-        hh = wave_reduce_f64(hh, 0.0, [](double a, double b) { return a + b; });
-        hl = wave_reduce_f64(hl, 0.0, [](double a, double b) { return a + b; });
-        ll = wave_reduce_f64(ll, 0.0, [](double a, double b) { return a + b; });
+        tmin = wave_reduce_f64(tmin, INFINITY, [](double a, double b) { return min_f64_raw(a, b); });
+        tmax = wave_reduce_f64(tmax, -INFINITY, [](double a, double b) { return max_f64_raw(a, b); });
+        s1 = wave_sum_f64(s1); hh = wave_sum_f64(hh); hl = wave_sum_f64(hl); ll = wave_sum_f64(ll); // exact: integers below 2^50
         const bool wide = !(tmax - t0 < 0x1p40 && t0 - tmin < 0x1p40); // some |d| >= PG_MODEL_MAX_DEV: the limb sums above mean nothing
         flags = wide ? PG_MODEL_BAD_SPREAD : 0u;
-        const int64_t origin = f64_to_i64_exact(t0 - WV_MAGIC);
-        m.origin = origin;
-        m.s1 = wide ? 0 : f64_to_i64_exact(s1);
-        m.s2_hh = wide ? 0 : (uint64_t)f64_to_i64_exact(hh); m.s2_hl = wide ? 0 : (uint64_t)f64_to_i64_exact(hl); m.s2_ll = wide ? 0 : (uint64_t)f64_to_i64_exact(ll);
+        const auto units_of = [](double t) { return (int64_t)((uint64_t)__double_as_longlong(t) & ((1ull << 52) - 1)) - (1ll << 51); }; // t = units + 1.5 * 2^52
+        m.origin = units_of(t0);
+        if (!wide) { m.s1 = small_f64_to_i64(s1); m.s2_hh = (uint64_t)small_f64_to_i64(hh); m.s2_hl = (uint64_t)small_f64_to_i64(hl); m.s2_ll = (uint64_t)small_f64_to_i64(ll); }
         // selection keys: the bit pattern of t above that of the smallest t (one exponent: the difference of the patterns is that of the units)
         const uint64_t bmin = (uint64_t)__double_as_longlong(tmin), spread = (uint64_t)__double_as_longlong(tmax) - bmin;
         const int bits = spread ? 64 - __builtin_clzll(spread) : 0; // <= 53
-        const int64_t vmin = f64_to_i64_exact(tmin - WV_MAGIC);
+        const int64_t vmin = units_of(tmin);
         if (bits <= 31) {
             uint32_t key[WV_C];
 #pragma unroll
@@ -554,7 +569,7 @@ __global__ __launch_bounds__(64, PG_MODEL_TINY_WAVES) void k_slot_model_wave(con
     const uint32_t s = blockIdx.x;
     if (s >= n_slots) return;
     const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
-    int kind = pg_model_kind(fr.n, fr.nev);
+    int kind = (int)uniform32((uint32_t)pg_model_kind(fr.n, fr.nev));
     if (kind == PG_MODEL_TINY && !wave_file<PG_MODEL_TINY_MAX / 64, PG_MODEL_TINY_EVENTS / 64>(sm, fr, s, ev_len, samples, out, dwell)) kind = PG_MODEL_SHORT;
     if (kind == PG_MODEL_SHORT) kind = short_kind; // (the launcher may send the few SHORT files of a job with the LONG ones: one launch less)
     if (kind != PG_MODEL_TINY && threadIdx.x == 0) lists[(size_t)(kind - 1) * n_slots + atomicAdd(counts + (kind - 1), 1u)] = s; // (any order: every slot writes its own result)
