@@ -64,6 +64,7 @@ struct pg_ctx {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}; // per statistics slot
     bool slot_used[2] = {false, false};
+    PgSettlePack *settle_host = nullptr; // host-mapped: what settle_batch learns of a finished batch, packed by one launch (k_settle_pack)
     int slot = 0; // statistics buffers are double-buffered so that batch i+1's statistics overlap batch i's tail
     bool user_stream = false, batch_is_host = false;
     std::string err;
@@ -250,6 +251,7 @@ void pg_destroy(pg_ctx *c) {
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->st2) (void)hipStreamSynchronize(c->st2);
     if (c->st3) (void)hipStreamSynchronize(c->st3);
+    if (c->settle_host) (void)hipHostFree(c->settle_host);
     DevBuf *bufs[] = {&c->table_t, &c->table_u, &c->s_sig, &c->s_sig_off, &c->s_dig, &c->s_off, &c->s_range, &c->s_qs, &c->s_ts,
                       &c->s_te, &c->s_seq, &c->s_seq_off, &c->s_op_n, &c->s_op_t, &c->s_op_off, &c->m_start, &c->m_len, &c->m_base,
                       &c->m_tix, &c->ev_slot, &c->status, &c->errflag, &c->sk[0], &c->sk[1], &c->sv[0], &c->sv[1],
@@ -353,8 +355,20 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
         if (!masked) CTRY(hipStreamCreateWithPriority(&c->st2, hipStreamNonBlocking, prio_low));
     }
     PG_TMARK("create: streams");
-    for (int i = 0; i < 2; i++) { CTRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming)); CTRY(hipEventCreateWithFlags(&c->ev_gathered[i], hipEventDisableTiming)); }
-    CTRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    // The events that order this context's streams against each other -- never waited for by the host (it synchronises the streams). By default
+    // recording an event ends the kernel in front of it with a SYSTEM-scope release (caches written back and invalidated); hipEventDisableSystemFence
+    // leaves the device-scope ordering every kernel boundary has: 5.7 -> 4.6 us behind a record in the kernel trace, the step 2 % shorter.
+    // (PGMOVE_EVENT_SYSTEM_FENCE=1: the default events, for A/B.)
+    auto make_event = [&](hipEvent_t *ev) -> hipError_t {
+        if (!getenv("PGMOVE_EVENT_SYSTEM_FENCE")) {
+            if (hipEventCreateWithFlags(ev, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError(); // a runtime without the flag: the plain event below
+        }
+        return hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    };
+    for (int i = 0; i < 2; i++) { CTRY(make_event(&c->ev_join[i])); CTRY(make_event(&c->ev_gathered[i])); }
+    CTRY(make_event(&c->ev_fork));
+    CTRY(hipHostMalloc((void **)&c->settle_host, sizeof(PgSettlePack), hipHostMallocDefault));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
     // one allocation, the U-spelled table right behind the T-spelled one: a kernel reaches both from ONE uniform base with a 32-bit
     // lane offset (PgWalkParams::table_u == table_t + n_codes)
@@ -412,7 +426,7 @@ pg_status pg_reset(pg_ctx *c) {
 }
 
 static pg_status settle_batch(pg_ctx *c);
-static pg_status check_read_errors(pg_ctx *c);
+static pg_status check_read_errors(pg_ctx *c, const PgSettlePack &pk);
 static pg_status ensure_unpacked(pg_ctx *c);
 
 // copy the finished batch's device results to the host (needed before its buffers are reused)
@@ -512,15 +526,16 @@ static pg_status stage_host_batch(pg_ctx *c, const pg_batch *b) {
     return PG_OK;
 }
 
-static pg_status check_read_errors(pg_ctx *c) {
+static pg_status check_read_errors(pg_ctx *c, const PgSettlePack &pk) {
     struct { unsigned long long word; int32_t layout, pad; uint32_t gen_count[2]; } ef;
     int32_t errv[1] = {INT_MAX}, errs[6] = {INT_MAX, 0, 0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpy(&ef, c->errflag.p, sizeof ef, hipMemcpyDeviceToHost));
+    static_assert(sizeof ef == sizeof pk.errflag, "PgWalkOut's error words");
+    memcpy(&ef, pk.errflag, sizeof ef);
     if (ef.layout) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.n_ops (%llu) is not op_off[n_reads] of the device batch", (unsigned long long)c->B.n_ops);
     if ((uint32_t)(ef.word >> 32) == c->batch_id) errv[0] = (int32_t)(0xFFFFFFFFu - (uint32_t)ef.word); // PgWalkOut::err
     c->gen_reads = ef.gen_count[c->batch_id & 1u];
     if (c->batch_all_matches && c->gen_reads) return fail(c, PG_ERR_INVALID_ARG, "pg_batch.flags says PG_BATCH_ALL_MATCHES but %u reads hold I / D / unknown ops (or fewer ops than k, or more than bases)", c->gen_reads);
-    HIP_TRY(c, hipMemcpy(errs, c->stat_err[c->slot].p, 24, hipMemcpyDeviceToHost));
+    memcpy(errs, pk.stat_err, sizeof errs);
     // long reads (PgLongState): what this batch wanted sizes a device batch's next launch; a host batch is counted before it is staged
     if (errs[4] > 0 || errs[5] > 0) {
         c->long_reads_split += (uint64_t)errs[5];
@@ -537,8 +552,7 @@ static pg_status check_read_errors(pg_ctx *c) {
     if (c->prm.flags & PG_FLAG_STOP_WHEN_FULL) {
         // would the reference have read this line at all? It stops once every k-mer is complete (gmove.cpp:733-735)
         if (c->full_before_batch) return PG_OK; // complete before this batch: none of its reads is looked at
-        uint64_t tot[2] = {0, 0};
-        HIP_TRY(c, hipMemcpy(tot, c->plan_totals[c->slot].p, 16, hipMemcpyDeviceToHost));
+        const uint64_t tot[2] = {pk.n_kept, pk.full_slots};
         // every slot full and nothing kept here: the bases alone (earlier batches / lower ranks) had completed the job
         if (tot[1] == c->prm.n_slots && tot[0] == 0) return PG_OK;
         if (tot[1] == c->prm.n_slots && tot[0] > 0) { // complete inside this batch: at the read of its last kept event
@@ -1173,7 +1187,10 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
                      c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr));
     prof_end(c, gst);
-    HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], gst));
+    // "this slot's statistics buffers have been read": for the statistics stream two batches on (and the side gather). With one stream nobody
+    // waits for it, and a record ends the gather with 4.6 us in which the stream starts nothing (rocprofv3 kernel trace, tools/trace_gaps.py:
+    // every other kernel-to-kernel gap of the chain is 0.0 us).
+    if (c->st2 || c->st3) HIP_TRY(c, hipEventRecord(c->ev_gathered[c->slot], gst));
     if (side) { c->gather_side = true; c->gather_side_slot = c->slot; c->side_used[c->slot] = true; }
     PG_TMARK("collect: buffers + kernels queued");
     if (timing_on()) { HIP_TRY(c, hipStreamSynchronize(c->st)); PG_TMARK("collect: kernels done (sync)"); }
@@ -1185,21 +1202,22 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 // after a collect: wait for the batch, surface per-read errors, learn how many events/samples were kept
 static pg_status settle_batch(pg_ctx *c) {
     if (!c->have_batch_result || c->totals_known) return PG_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->st));
+    // the other streams first: the record is packed on the main one, behind everything that writes what it reads (k_settle_pack: one launch
+    // into host-mapped memory instead of four blocking copies of 8-24 bytes, ~80 -> ~10 us per call)
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
-    pg_status s = check_read_errors(c);
+    HIP_TRY(c, pg_launch_settle_pack(c->st, c->errflag.as<uint32_t>(), c->stat_err[c->slot].as<int32_t>(), c->plan_totals[c->slot].as<uint64_t>(),
+                                     c->samp_off[c->slot].as<uint64_t>(), c->samp_off[c->slot].cap / 8, c->cancel_pending ? c->cancel_flag.as<uint32_t>() : nullptr, c->settle_host));
+    HIP_TRY(c, hipStreamSynchronize(c->st));
+    const PgSettlePack pk = *c->settle_host;
+    pg_status s = check_read_errors(c, pk);
     if (s != PG_OK) { c->have_batch_result = false; c->downloaded = true; return s; }
-    uint64_t tot[2] = {0, 0};
-    HIP_TRY(c, hipMemcpy(tot, c->plan_totals[c->slot].p, 16, hipMemcpyDeviceToHost));
+    const uint64_t tot[2] = {pk.n_kept, pk.full_slots};
     c->cur_n_kept = tot[0]; c->full_slots = tot[1];
-    uint64_t n_samples = 0;
-    HIP_TRY(c, hipMemcpy(&n_samples, c->samp_off[c->slot].as<uint64_t>() + tot[0], 8, hipMemcpyDeviceToHost));
+    const uint64_t n_samples = pk.n_samples;
     c->cur_n_samples = n_samples;
     if (c->cancel_pending) {
-        uint32_t fl[2] = {0, 0};
-        HIP_TRY(c, hipMemcpy(fl, c->cancel_flag.p, 8, hipMemcpyDeviceToHost));
-        if (fl[1]) c->stats_cancelled++;
+        if (pk.cancel[1]) c->stats_cancelled++;
         c->cancel_pending = false;
     }
     if (tot[0]) c->win_hint = (uint32_t)((n_samples + tot[0] - 1) / tot[0]);

@@ -339,6 +339,10 @@ struct PgRareArgs {
 hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t stride, uint64_t n_cap, const uint64_t *n_ptr, uint64_t *out, uint64_t *scratch,
                                   const PgRareArgs *rare, uint64_t *total_out);
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
+// the host's view of a finished batch, packed by one launch into host-mapped memory (pg_api.hip: settle_batch)
+struct PgSettlePack { uint32_t errflag[6]; int32_t stat_err[6]; uint64_t n_kept, full_slots, n_samples; uint32_t cancel[2]; };
+hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const uint64_t *totals, const uint64_t *samp_off,
+                                 uint64_t samp_off_entries, const uint32_t *cancel_flag, PgSettlePack *out);
 // flag[0] = some slot still open below this rank (sum of rows_below rows of all_counts < limit), flag[1] = statistics cancelled; if none
 // is open, the reads' statistics records (plan_buf) are set to "skip"
 hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_counts, uint32_t rows_below, uint32_t n_slots, uint64_t limit, uint32_t *flag, void *plan_buf, uint32_t n_reads);

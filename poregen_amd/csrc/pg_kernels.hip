@@ -2707,6 +2707,25 @@ hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_co
     return hipSuccess;
 }
 
+// What the host wants to know of a finished batch -- the walk's error words, the statistics' flags, the kept totals, the sample total, the
+// cancel flag -- as ONE record in host-mapped memory: four blocking 8..24-byte hipMemcpy calls cost ~80 us per pg_sync (4 us per step of a
+// 20-step timed block); one single-thread kernel and the stream synchronisation that follows anyway cost ~10.
+__global__ void k_settle_pack(const uint32_t *__restrict__ errflag, const int32_t *__restrict__ stat_err, const uint64_t *__restrict__ totals,
+                              const uint64_t *__restrict__ samp_off, uint64_t samp_off_entries, const uint32_t *__restrict__ cancel_flag, PgSettlePack *__restrict__ out) {
+    PgSettlePack p;
+    for (int i = 0; i < 6; ++i) p.errflag[i] = errflag[i];
+    for (int i = 0; i < 6; ++i) p.stat_err[i] = stat_err ? stat_err[i] : (i == 0 ? INT_MAX : 0);
+    p.n_kept = totals[0]; p.full_slots = totals[1];
+    p.n_samples = p.n_kept < samp_off_entries ? samp_off[p.n_kept] : 0; // (a failed batch may leave any total: the host looks at the error words first)
+    p.cancel[0] = cancel_flag ? cancel_flag[0] : 0u; p.cancel[1] = cancel_flag ? cancel_flag[1] : 0u;
+    *out = p;
+}
+hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const uint64_t *totals, const uint64_t *samp_off,
+                                 uint64_t samp_off_entries, const uint32_t *cancel_flag, PgSettlePack *out) {
+    PG_LAUNCH(k_settle_pack, dim3(1), dim3(1), 0, st, errflag, stat_err, totals, samp_off, samp_off_entries, cancel_flag, out);
+    return hipSuccess;
+}
+
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A) {
     if (A.B.n_reads == 0) return hipSuccess;
     // the workers stride over the lists, so any grid is correct; an empty launch costs its dispatch (2112 blocks: 4 us)
