@@ -344,7 +344,12 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
         hipDeviceProp_t prop;
         CTRY(hipGetDeviceProperties(&prop, p->device));
         const int cus = prop.multiProcessorCount;
-        const int withheld = wh ? atoi(wh) : ((c->prm.flags & PG_FLAG_OVERLAP) ? cus / 4 : 0);
+        // A job that can keep many events (n_slots x sample_limit from 2^20 up: configs[2] / [3]) spends most of a batch in the chain's
+        // placing kernels and the gather; the statistics then get half of the chip: one shard of configs[2] 0.403 / 0.404 / 0.393 ->
+        // 0.396 / 0.397 / 0.386 ms, configs[3] 1.373 / 1.318 / 1.346 -> 1.358 / 1.312 / 1.339 ms (three alternating runs on one box,
+        // profiles/r05_probes.txt 7), while the headline (102 400 events at most) loses a fifth with that mask.
+        const bool many_kept = (uint64_t)p->n_slots * p->sample_limit >= (1ull << 20);
+        const int withheld = wh ? atoi(wh) : ((c->prm.flags & PG_FLAG_OVERLAP) ? (many_kept ? cus / 2 : cus / 4) : 0);
         bool masked = false;
         if (withheld > 0 && withheld < cus) {
             std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
