@@ -64,6 +64,9 @@ struct pg_ctx {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr}; // per statistics slot
     bool slot_used[2] = {false, false};
+    // the kept records, their offsets, totals and chunk sums exist twice only for the side gather (PGMOVE_GATHER_SIDE: batch i's gather beside batch
+    // i + 1's chain); without it one set serves every batch (the chain of batch i + 1 follows the gather of batch i on its stream): rslot = 0
+    int rslot = 0; bool side_enabled = false;
     PgSettlePack *settle_host = nullptr; // host-mapped: what settle_batch learns of a finished batch, packed by one launch (k_settle_pack)
     int slot = 0; // statistics buffers are double-buffered so that batch i+1's statistics overlap batch i's tail
     bool user_stream = false, batch_is_host = false;
@@ -373,6 +376,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     };
     for (int i = 0; i < 2; i++) { CTRY(make_event(&c->ev_join[i])); CTRY(make_event(&c->ev_gathered[i])); }
     CTRY(make_event(&c->ev_fork));
+    c->side_enabled = getenv("PGMOVE_GATHER_SIDE") != nullptr;
     CTRY(hipHostMalloc((void **)&c->settle_host, sizeof(PgSettlePack), hipHostMallocDefault));
     const size_t tb = (size_t)c->n_codes * sizeof(int32_t);
     // one allocation, the U-spelled table right behind the T-spelled one: a kernel reaches both from ONE uniform base with a 32-bit
@@ -450,7 +454,7 @@ static pg_status download_last(pg_ctx *c, bool more_coming) {
     HIP_TRY(c, hipMemcpy(h.ev_off.data(), c->ev_off.p, (ns + 1) * 8ull, hipMemcpyDeviceToHost));
     if (h.n_events) {
         { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
-        HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off[c->slot].p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(h.samp_off.data(), c->samp_off[c->rslot].p, (h.n_events + 1) * 8ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_len.data(), c->ev_len.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(h.ev_read.data(), c->ev_read.p, h.n_events * 4ull, hipMemcpyDeviceToHost));
     } else h.samp_off[0] = 0;
@@ -716,7 +720,7 @@ static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
 static pg_status ensure_unpacked(pg_ctx *c) {
     if (c->unpacked) return PG_OK;
     HIP_TRY(c, c->ev_len.ensure((c->cur_n_kept + 1) * 4)); HIP_TRY(c, c->ev_read.ensure((c->cur_n_kept + 1) * 4));
-    HIP_TRY(c, pg_launch_unpack_recs(c->st, c->ev_rec[c->slot].as<PgKeptRec>(), c->cur_n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>()));
+    HIP_TRY(c, pg_launch_unpack_recs(c->st, c->ev_rec[c->rslot].as<PgKeptRec>(), c->cur_n_kept, c->ev_len.as<uint32_t>(), c->ev_read.as<uint32_t>()));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     c->unpacked = true;
     return PG_OK;
@@ -793,7 +797,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     uint32_t ndig;
     if (direct) {
         ndig = 2; while (ndig < c->prm.n_slots) ndig <<= 1;
-        if (dense_direct(c, N)) { HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4)); HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8)); }
+        if (dense_direct(c, N)) { HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4)); HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); if (c->side_enabled) HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8)); }
     }
     else if (c->part_mode) {
         ndig = 1u << c->part_hi;
@@ -801,7 +805,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         HIP_TRY(c, c->part_elem.ensure((size_t)tcap * PG_SORT_TILE * 16)); HIP_TRY(c, c->part_lodig.ensure((size_t)tcap * PG_SORT_TILE * 2)); HIP_TRY(c, c->part_rbase.ensure((ndig + 2) * 4ull));
         HIP_TRY(c, c->part_tile_region.ensure((tcap + 1) * 4ull)); HIP_TRY(c, c->part_ntiles.ensure(16));
         HIP_TRY(c, c->part_histB.ensure(((size_t)tcap << c->part_lo) * 4)); HIP_TRY(c, c->part_Bp.ensure((Nn / 256 + 4) * 4));
-        HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8));
+        HIP_TRY(c, c->chunk_part[0].ensure(PG_CHUNK_PART_N * 8)); if (c->side_enabled) HIP_TRY(c, c->chunk_part[1].ensure(PG_CHUNK_PART_N * 8));
     } else {
         const uint32_t passes = (c->key_bits + PG_RANK_MAX_BITS - 1) / PG_RANK_MAX_BITS;
         ndig = 1u << ((c->key_bits + passes - 1) / passes);
@@ -815,6 +819,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     PG_TMARK("count: work buffers");
     c->full_before_batch = c->full_slots == c->prm.n_slots && c->prm.n_slots > 0;
     c->slot ^= 1; // this batch's statistics buffers
+    c->rslot = c->side_enabled ? c->slot : 0;
     const bool skip_oor = (c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE) != 0; // statistics first: the walk needs their verdict
     const bool eager_stats = skip_oor || (c->prm.scaling == 1 && !(c->prm.flags & PG_FLAG_LAZY_STATS));
     const bool overlap = !skip_oor && (c->prm.flags & PG_FLAG_OVERLAP) != 0;
@@ -872,8 +877,8 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         const bool fuse_plan = c->in_submit;
         HIP_TRY(c, pg_launch_rank_direct_count(c->st, O.ev_slot, N, c->prm.n_slots, S, c->acc_cnt.as<uint64_t>(), c->running.as<uint64_t>(), c->prm.sample_limit,
                                     c->tile_last.as<int32_t>(), acc_copy, fuse_plan ? c->keep.as<uint64_t>() : nullptr, c->ev_off.as<uint64_t>(),
-                                    c->plan_totals[c->slot].as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
-                                    O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr, dense_direct(c, N) ? c->chunk_part[c->slot].as<uint64_t>() : nullptr));
+                                    c->plan_totals[c->rslot].as<uint64_t>(), c->errflag.as<uint32_t>() + 6, &c->plan_done,
+                                    O.btot, dense_direct(c, N) ? c->part_Bp.as<uint32_t>() : nullptr, dense_direct(c, N) ? c->chunk_part[c->rslot].as<uint64_t>() : nullptr));
         prof_end(c, c->st);
     } else if (c->part_mode) {
         // partitioned ranking, pass A and the counts of pass B (pg_place.hip): everything pg_count's result needs
@@ -881,7 +886,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         fill_part(c, P, Nn);
         if (N) {
             prof_begin(c, "part_tile_scan", c->st);
-            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot, c->chunk_part[c->slot].as<uint64_t>()));
+            HIP_TRY(c, pg_launch_part_tile_scan(c->st, P, N, O.btot, c->chunk_part[c->rslot].as<uint64_t>()));
             prof_end(c, c->st);
             prof_begin(c, "k_part_bases", c->st);
             HIP_TRY(c, pg_launch_part_bases(c->st, P, c->B, O));
@@ -898,7 +903,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
                 if (c->region_state.cap != before) HIP_TRY(c, hipMemsetAsync(c->region_state.p, 0, c->region_state.cap, c->st));
                 if (++c->region_epoch > pg_region_cut_epochs()) { c->region_epoch = 1; HIP_TRY(c, hipMemsetAsync(c->region_state.p, 0, c->region_state.cap, c->st)); }
                 HIP_TRY(c, c->keep32.ensure(c->prm.n_slots * 4ull));
-                cut.running = c->running.as<uint64_t>(); cut.keep = c->keep.as<uint64_t>(); cut.ev_off = c->ev_off.as<uint64_t>(); cut.totals = c->plan_totals[c->slot].as<uint64_t>();
+                cut.running = c->running.as<uint64_t>(); cut.keep = c->keep.as<uint64_t>(); cut.ev_off = c->ev_off.as<uint64_t>(); cut.totals = c->plan_totals[c->rslot].as<uint64_t>();
                 cut.keep32 = c->keep32.as<uint32_t>(); cut.state = c->region_state.as<uint64_t>(); cut.limit = c->prm.sample_limit; cut.epoch = c->region_epoch;
             }
             prof_begin(c, "region_counts", c->st, true);
@@ -1013,7 +1018,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
                                   base_location == PG_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->st));
         d_base = c->base_stage.as<uint64_t>();
     }
-    uint64_t *totals = c->plan_totals[c->slot].as<uint64_t>();
+    uint64_t *totals = c->plan_totals[c->rslot].as<uint64_t>();
     // capacity for the kept events of this batch: everything downstream is sized by this bound and reads the
     // actual counts from device memory, so the batch needs no host round trip
     const uint64_t ke_cap = std::min<uint64_t>(N, (uint64_t)ns * c->prm.sample_limit);
@@ -1036,14 +1041,14 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
 
     const uint64_t win_cap = (uint64_t)c->prm.max_dur + 2ull * c->prm.signal_print_margin;
     const uint64_t samp_cap = ke_cap * win_cap;
-    HIP_TRY(c, c->ev_rec[c->slot].ensure((ke_cap + 1) * sizeof(PgKeptRec)));
-    HIP_TRY(c, c->samp_off[c->slot].ensure((ke_cap + 2) * 8));
+    HIP_TRY(c, c->ev_rec[c->rslot].ensure((ke_cap + 1) * sizeof(PgKeptRec)));
+    HIP_TRY(c, c->samp_off[c->rslot].ensure((ke_cap + 2) * 8));
     c->unpacked = false;
 
     PgWalkParams W{}; PgWalkOut O{};
     fill_walk(c, W, O);
     PgKeptOut K{};
-    K.rec = c->ev_rec[c->slot].as<PgKeptRec>();
+    K.rec = c->ev_rec[c->rslot].as<PgKeptRec>();
     // the per-read "owns a kept event" flags are only consumed by the lazy statistics: no scattered byte stores otherwise
     K.read_needed = (c->prm.scaling == 1 && (c->prm.flags & PG_FLAG_LAZY_STATS) && !(c->prm.flags & PG_FLAG_SKIP_OUT_OF_RANGE)) ? c->read_needed.as<uint8_t>() : nullptr;
     // Many kept events (nearly every accepted event kept: large sample_limit, k = 9): the offset scan happens inside the gather's
@@ -1058,7 +1063,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     // Measured (profiles/r04_side_gather.txt): 0-5 % at sample_limit 5000, nothing at k = 9, whatever share of the CUs the gather's stream
     // is given -- the chain's kernels wait inside occupied wave slots, they do not leave CUs free, and the gather needs its CUs (half of them:
     // +14 %). So it is opt-in (PGMOVE_GATHER_SIDE=1), and tests/test_gpu_parity.py runs the suite's cases through it once.
-    const bool gather_side_on = getenv("PGMOVE_GATHER_SIDE") != nullptr;
+    const bool gather_side_on = c->side_enabled; // (PGMOVE_GATHER_SIDE, read when the context is created)
     const bool side = chunked && c->stats_in_flight && c->st2 && !c->user_stream && gather_side_on && (c->prm.flags & PG_FLAG_OVERLAP);
     if (side && !c->st3) { // like the statistics stream: a quarter of every XCD's CUs stays free of it, or the chain's 16-wave workgroups never find room
         const char *wh = getenv("PGMOVE_GATHER_CU_WITHHELD");
@@ -1086,7 +1091,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_gathered[c->gather_side_slot], 0));
         c->gather_side = false;
     }
-    if (chunked) HIP_TRY(c, c->chunk_part[c->slot].ensure(PG_CHUNK_PART_N * 8)); // (partitioned ranking has it already, zeroed by its scan launch in pg_count)
+    if (chunked) HIP_TRY(c, c->chunk_part[c->rslot].ensure(PG_CHUNK_PART_N * 8)); // (partitioned ranking has it already, zeroed by its scan launch in pg_count)
     if (direct) {
         PgSortBufs S{};
         fill_sort(c, S, 0);
@@ -1105,7 +1110,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
               pg_probe_cal_ev(on ? probe_cal.as<double>() : nullptr, on ? c->gcal[c->slot].as<double>() : nullptr); }
 #endif
             prof_begin(c, "k_region_place", c->st);
-            HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part[c->slot].as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
+            HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part[c->rslot].as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
             prof_end(c, c->st);
             sums_ready = chunked;
         }
@@ -1128,9 +1133,9 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         if (!sums_ready) {
             // the coarse sums are ADDED to: zeroed by the tile scan's extra workgroup where there is one (dense direct ranking; partitioned
             // ranking, whose placing kernel has filled them by now), else here (the radix-sort ranking, PGMOVE_EMIT1)
-            if (!(direct && dense_direct(c, N)) && !c->part_mode) HIP_TRY(c, hipMemsetAsync(c->chunk_part[c->slot].p, 0, PG_CHUNK_PART_N * 8, c->st));
+            if (!(direct && dense_direct(c, N)) && !c->part_mode) HIP_TRY(c, hipMemsetAsync(c->chunk_part[c->rslot].p, 0, PG_CHUNK_PART_N * 8, c->st));
             prof_begin(c, "len_partials", c->st);
-            HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->rare_pending ? &c->rare : nullptr));
+            HIP_TRY(c, pg_launch_len_partials(c->st, ke_cap, totals, c->ev_rec[c->rslot].as<PgKeptRec>(), c->chunk_part[c->rslot].as<uint64_t>(), c->rare_pending ? &c->rare : nullptr));
             prof_end(c, c->st);
         } else if (c->rare_pending) {
             prof_begin(c, "k_read_stats_rare", c->st);
@@ -1140,7 +1145,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         c->rare_pending = false;
     } else {
         prof_begin(c, "scan_ev_len", c->st, /*bracket=*/(ke_cap + 4095) / 4096 > 64); // long inputs: three launches (pg_launch_scan_u32_u64)
-        HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec[c->slot].p) + 2, 4, ke_cap, totals, c->samp_off[c->slot].as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
+        HIP_TRY(c, pg_launch_scan_u32_u64(c->st, reinterpret_cast<const uint32_t *>(c->ev_rec[c->rslot].p) + 2, 4, ke_cap, totals, c->samp_off[c->rslot].as<uint64_t>(), c->scan_scratch.as<uint64_t>(),
                                           c->rare_pending ? &c->rare : nullptr, totals + 2));
         c->rare_pending = false;
         prof_end(c, c->st);
@@ -1165,7 +1170,7 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
             HIP_TRY(c, hipMemcpyAsync(tot, totals, 24, hipMemcpyDeviceToHost, c->st));
             if (chunked) { // the kept samples' total is left by the GATHER there (its last chunk); in front of it: the sum of the coarse chunk sums
                 uint64_t coarse[PG_CHUNK_COARSE];
-                HIP_TRY(c, hipMemcpyAsync(coarse, c->chunk_part[c->slot].as<uint64_t>() + PG_CHUNK_FINE, sizeof coarse, hipMemcpyDeviceToHost, c->st));
+                HIP_TRY(c, hipMemcpyAsync(coarse, c->chunk_part[c->rslot].as<uint64_t>() + PG_CHUNK_FINE, sizeof coarse, hipMemcpyDeviceToHost, c->st));
                 HIP_TRY(c, hipStreamSynchronize(c->st));
                 tot[2] = 0;
                 for (uint64_t v : coarse) tot[2] += v;
@@ -1184,12 +1189,12 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
     if (c->stats_in_flight) { HIP_TRY(c, hipStreamWaitEvent(c->st, c->ev_join[c->slot], 0)); c->stats_in_flight = false; }
     prof_begin(c, "k_gather", gst);
     if (chunked)
-        HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(), c->chunk_part[c->slot].as<uint64_t>(), c->samp_off[c->slot].as<uint64_t>(), totals + 2, c->prm.scaling,
+        HIP_TRY(c, pg_launch_gather_chunks(gst, c->B, ke_cap, totals, c->ev_rec[c->rslot].as<PgKeptRec>(), c->chunk_part[c->rslot].as<uint64_t>(), c->samp_off[c->rslot].as<uint64_t>(), totals + 2, c->prm.scaling,
                                            c->prm.pa_min, c->prm.pa_max, c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr, gather_lanes(c),
                                            c->prm.scaling == 1 ? c->stat_err[c->slot].as<int32_t>() : nullptr));
     else
-        HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec[c->slot].as<PgKeptRec>(),
-                     c->samp_off[c->slot].as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
+        HIP_TRY(c, pg_launch_gather(c->st, c->B, gather_cap, totals, c->ev_rec[c->rslot].as<PgKeptRec>(),
+                     c->samp_off[c->rslot].as<uint64_t>(), c->prm.scaling, c->prm.pa_min, c->prm.pa_max, c->med[c->slot].as<double>(), c->mad[c->slot].as<double>(),
                      c->samples.as<double>(), c->prm.scaling == 1 ? c->gcal[c->slot].as<double>() : nullptr));
     prof_end(c, gst);
     // "this slot's statistics buffers have been read": for the statistics stream two batches on (and the side gather). With one stream nobody
@@ -1211,8 +1216,8 @@ static pg_status settle_batch(pg_ctx *c) {
     // into host-mapped memory instead of four blocking copies of 8-24 bytes, ~80 -> ~10 us per call)
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
-    HIP_TRY(c, pg_launch_settle_pack(c->st, c->errflag.as<uint32_t>(), c->stat_err[c->slot].as<int32_t>(), c->plan_totals[c->slot].as<uint64_t>(),
-                                     c->samp_off[c->slot].as<uint64_t>(), c->samp_off[c->slot].cap / 8, c->cancel_pending ? c->cancel_flag.as<uint32_t>() : nullptr, c->settle_host));
+    HIP_TRY(c, pg_launch_settle_pack(c->st, c->errflag.as<uint32_t>(), c->stat_err[c->slot].as<int32_t>(), c->plan_totals[c->rslot].as<uint64_t>(),
+                                     c->samp_off[c->rslot].as<uint64_t>(), c->samp_off[c->rslot].cap / 8, c->cancel_pending ? c->cancel_flag.as<uint32_t>() : nullptr, c->settle_host));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     const PgSettlePack pk = *c->settle_host;
     pg_status s = check_read_errors(c, pk);
@@ -1305,7 +1310,7 @@ pg_status pg_last_batch_device(pg_ctx *c, pg_device_view *v) {
     { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
     v->n_events = c->cur_n_kept; v->n_samples = c->cur_n_samples;
     v->d_keep = c->keep.as<uint64_t>(); v->d_ev_off = c->ev_off.as<uint64_t>(); v->d_ev_len = c->ev_len.as<uint32_t>();
-    v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off[c->slot].as<uint64_t>(); v->d_samples = c->samples.as<double>();
+    v->d_ev_read = c->ev_read.as<uint32_t>(); v->d_samp_off = c->samp_off[c->rslot].as<uint64_t>(); v->d_samples = c->samples.as<double>();
     v->d_med = c->prm.scaling == 1 ? c->med[c->slot].as<double>() : nullptr; v->d_mad = c->prm.scaling == 1 ? c->mad[c->slot].as<double>() : nullptr;
     return PG_OK;
 }
@@ -1525,7 +1530,7 @@ pg_status pg_text(pg_ctx *c, pg_text_result *out) {
     const uint32_t ns = c->prm.n_slots;
     const uint64_t ne = R.n_events;
     const uint64_t *d_samp_off, *d_ev_off;
-    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == ne) { d_samp_off = c->samp_off[c->slot].as<uint64_t>(); d_ev_off = c->ev_off.as<uint64_t>(); } // still there
+    if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == ne) { d_samp_off = c->samp_off[c->rslot].as<uint64_t>(); d_ev_off = c->ev_off.as<uint64_t>(); } // still there
     else {
         HIP_TRY(c, c->tx_samp_off.ensure((ne + 1) * 8ull)); HIP_TRY(c, c->tx_ev_off.ensure((ns + 1) * 8ull));
         HIP_TRY(c, hipMemcpyAsync(c->tx_samp_off.p, R.samp_off, (ne + 1) * 8ull, hipMemcpyHostToDevice, c->st));
@@ -1590,7 +1595,7 @@ pg_status pg_model(pg_ctx *c, uint32_t flags, pg_model_result *out) {
     if (c->batches.size() == 1 && c->have_batch_result && c->cur_n_kept == R.n_events && c->cur_n_samples == R.n_samples) {
         // one batch: its kept events are still on the device, in the same order
         { pg_status su = ensure_unpacked(c); if (su != PG_OK) return su; }
-        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off[c->slot].as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
+        d_ev_off = c->ev_off.as<uint64_t>(); d_samp_off = c->samp_off[c->rslot].as<uint64_t>(); d_ev_len = c->ev_len.as<uint32_t>(); d_samples = c->samples.as<double>();
     } else { // several batches were merged on the host (slot-major): hand the merged arrays back
         HIP_TRY(c, c->md_ev_off.ensure((ns + 1) * 8ull)); HIP_TRY(c, c->md_samp_off.ensure((R.n_events + 1) * 8ull));
         HIP_TRY(c, c->md_ev_len.ensure(R.n_events * 4ull + 4));
