@@ -101,7 +101,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip config3_mode / all_kept_mode / config2_mode / job_layer / hbm_not_mall / pcie_inclusive / end_to_end (profiling and A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="N=1 only: run the multi-GPU step (count, RCCL all_gather, collect) on a one-rank group, to price its overhead")
-    ap.add_argument("--no-defer", action="store_true", help="multi-GPU step: statistics inside pg_count (in front of the all_gather) instead of behind its issue (PG_FLAG_DEFER_STATS)")
+    ap.add_argument("--defer", action="store_true", help="multi-GPU step: the statistics on the chain's stream, queued behind the ISSUE of the all_gather (PG_FLAG_DEFER_STATS), where they hide "
+                    "the collective; default since round 5: on the second stream as at N=1 (one-rank RCCL step 0.169 -> 0.152-0.156 ms; an exposed collective of up to ~70 us costs less than the stream does)")
+    ap.add_argument("--no-defer", action="store_true", help="(the default since round 5; kept for old command lines)")
     ap.add_argument("--lib", default=None, help="measurement builds: path of another libpgmove build to load instead of poregen_amd/libpgmove.so")
     ap.add_argument("--overlap-tail", action="store_true", help="statistics on a second stream next to the cut/emit/scan launches (PG_FLAG_OVERLAP_TAIL)")
     ap.add_argument("--split-walk", action="store_true", help="ss walk and event filter as two launches (PG_FLAG_DEBUG_SPLIT_WALK), for comparison")
@@ -174,7 +176,8 @@ def main():
         side = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(side)
     # multi-GPU step: the statistics are queued between the issue of the all_gather and the wait for it (dist.sharded_step)
-    defer = dist_step and not args.no_defer and not args.lazy and not args.overlap
+    # (the gloo rehearsal synchronises the host between count and collect: statistics queued by pg_count would be waited for there)
+    defer = dist_step and (args.defer or backend == "gloo") and not args.no_defer and not args.lazy and not args.overlap
 
     def timed(params, steps, warmup, extra_blocks=0):
         """warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both sides, MAX over ranks."""
@@ -393,7 +396,7 @@ def main():
             "reads_per_gpu": args.reads, "samples_per_gpu": n_samples, "ss_ops_per_gpu": n_ops, "n_slots": len(kmers),
             "stats_mode": "lazy" if args.lazy else "every read (as the reference)", "parallelism": f"read-shard x{world}",
             "collective": ("all_gather of u64[n_slots] accepted counts per step over " + ("RCCL/xGMI" if backend == "nccl" else backend)) if dist_step else None,
-            "statistics_placement": ("behind the issue of the all_gather (pg_stats)" if defer else "inside pg_count") if dist_step else None,
+            "statistics_placement": ("behind the issue of the all_gather, on the chain's stream (pg_stats, --defer)" if defer else "queued by pg_count on the second stream, as at N=1") if dist_step else None,
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples, "homopolymer_frac": hp_frac,
         },
         "ms_per_step_blocks": {"contract_block": ms_per_step, "min": all_blocks[0], "median": all_blocks[len(all_blocks) // 2], "max": all_blocks[-1], "steps_per_block": args.steps,
