@@ -166,6 +166,8 @@ def main():
     host = synth.make_batch_fast(args.reads, read_len=args.read_len, kind=args.kind, seed=20251003 + 1 + 1000 * rank, homopolymer_frac=hp_frac)
     gen_s = time.time() - t0
     shard = host.to_device(dev)
+    torch.cuda.synchronize()
+    shard.resident = True  # uploaded once, complete: the statistics of a step need not wait for what the step's stream still holds (PG_BATCH_RESIDENT)
     n_samples = host.n_samples
     n_ops = int(host.op_off[-1])
     n_bases = int(host.seq_off[-1])

@@ -63,6 +63,7 @@ class PgBatch(C.Structure):
 
 
 PG_BATCH_ALL_MATCHES = 1
+PG_BATCH_RESIDENT = 2
 
 
 class PgResult(C.Structure):

@@ -828,7 +828,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
         // after the producer of a device batch when the caller drives us on its own stream. A device batch on the
         // context's own stream must be complete when pg_count is called, so nothing on `st` has to be awaited and
         // the statistics of this batch overlap the tail (plan/emit/scan/gather) of the previous one.
-        if (c->batch_is_host || c->user_stream) {
+        if (c->batch_is_host || (c->user_stream && !(b->flags & PG_BATCH_RESIDENT))) { // (PG_BATCH_RESIDENT: the caller vouches that nothing on its stream produces the batch)
             HIP_TRY(c, hipEventRecord(c->ev_fork, c->st));
             HIP_TRY(c, hipStreamWaitEvent(c->st2, c->ev_fork, 0));
         }

@@ -90,6 +90,7 @@ class Batch:
     on_device: bool = False
     n_ops: int = 0   # device batches: op_off[n_reads] when known (pg_batch.n_ops); 0 = the library reads it back (one sync per call)
     all_matches: bool = False  # the batch holds match ops only and the caller vouches for it (PG_BATCH_ALL_MATCHES, verified on the device)
+    resident: bool = False     # device batch, engine on the caller's stream: nothing queued on that stream produces the arrays (PG_BATCH_RESIDENT)
 
     def validate_host(self):
         for name, dt in _BATCH_FIELDS:
@@ -271,7 +272,7 @@ def _c_batch(b: "Batch"):
     cb.location = _abi.PG_LOC_DEVICE if b.on_device else _abi.PG_LOC_HOST
     cb.n_reads = b.n_reads
     cb.n_ops = b.n_ops if b.on_device else 0
-    cb.flags = _abi.PG_BATCH_ALL_MATCHES if b.all_matches else 0
+    cb.flags = (_abi.PG_BATCH_ALL_MATCHES if b.all_matches else 0) | (_abi.PG_BATCH_RESIDENT if (b.resident and b.on_device) else 0)
     for name, _ in _BATCH_FIELDS:
         setattr(cb, name, _ptr(getattr(b, name)))
     return cb

@@ -198,8 +198,10 @@ def test_error_paths():
     eng.close()
 
 
-def test_stream_ordered_count_collect_on_torch_stream():
-    """pg_set_stream: count -> torch op on the counts -> collect, all ordered on one torch stream, no host sync."""
+@pytest.mark.parametrize("resident", [False, True], ids=["produced_on_the_stream", "resident_batches"])
+def test_stream_ordered_count_collect_on_torch_stream(resident):
+    """pg_set_stream: count -> torch op on the counts -> collect, all ordered on one torch stream, no host sync. resident: the shards
+    are complete before the first step and say so (PG_BATCH_RESIDENT): the statistics stream does not wait for the caller's stream."""
     import torch
     b = synth.make_batch(300, kind="rna004", seed=17)
     p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=12)
@@ -212,6 +214,10 @@ def test_stream_ordered_count_collect_on_torch_stream():
         eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
         eng.use_torch_stream(side)
         shards = [b.slice_reads(0, 120).to_device(dev), b.slice_reads(120, 300).to_device(dev)]
+        if resident:
+            torch.cuda.synchronize()
+            for sh in shards:
+                sh.resident = True
         cnt = torch.empty(len(kmers), dtype=torch.int64, device=dev)
         base = torch.zeros(len(kmers), dtype=torch.int64, device=dev)
         results = []
