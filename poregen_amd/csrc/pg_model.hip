@@ -4,10 +4,14 @@
 // :33-52 calculate_dwell_times_medians): dump files -> tr/tail/awk -> datamash median / sstdev. See pg_model.h for
 // why the arithmetic is done on integers of 1e-8 units.
 //
-// One workgroup per slot (= k-mer file). The slot's values are one contiguous range of the kept-sample array, read
-// (2 + ceil(bits/12)) times (+1 when the count is even): min/max + moments, then a radix select that only walks the bits in
-// which the slot's values differ (36 bits for med-MAD scaled data: 3 passes), then the upper middle value. The slot
-// stays in L2 / MALL between the passes (150 k values = 1.2 MB at sample_limit 5000), so HBM sees it about once.
+// A k-mer's file is one contiguous range of the kept-sample array. Four kernels by file size (pg_model.h: pg_model_kind):
+//   k_slot_model_wave       one WAVE per file (<= 1024 values, < 256 events; k = 9: 259 k of 262 k files), values in registers; runs over all
+//                           slots and lists the others by kind
+//   k_slot_model_wave_mid   the same code with 32 rows (<= 2048 values, < 512 events), over its list
+//   k_slot_model<256, SHORT> one workgroup per file (<= 4096 values), values in registers; also every file the wave kernels hand on
+//   k_slot_model<1024, LONG> one workgroup per file, the file read (2 + ceil(bits/12)) times (+1 when the count is even): min/max + moments,
+//                           then a radix select that only walks the bits in which the values differ (36 bits for med-MAD scaled data: 3 passes),
+//                           then the upper middle value; the file stays in L2 / MALL between the passes (150 k values = 1.2 MB at sample_limit 5000)
 #include "pg_internal.h"
 #include "pg_model.h"
 
