@@ -16,7 +16,7 @@
 #include "pg_model.h"
 
 #ifndef PG_MODEL_TINY_WAVES
-#define PG_MODEL_TINY_WAVES 4 // waves per SIMD the one-wave kernel is compiled for (a lower bound: it takes 6 with its ~80 registers)
+#define PG_MODEL_TINY_WAVES 6 // waves per SIMD the one-wave kernel is compiled for: 80 registers and 20 bytes of scratch; k = 9 0.586 (5 waves, 85 registers) -> 0.550 ms, 8 waves (64 registers, 96 bytes of scratch) the same
 #endif
 namespace {
 
