@@ -273,7 +273,7 @@ static inline uint32_t pg_tiles(uint64_t n_events, bool direct) {
 struct PgSlotModel; struct PgSlotDwell; // pg_model.h
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[4], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell,
-                                void *scratch /* >= pg_slot_model_scratch_bytes(n_slots): the slots' records and the lists of the rarer kinds */);
+                                void *scratch /* >= pg_slot_model_scratch_bytes(n_slots): the lists of the rarer kinds */);
 size_t pg_slot_model_scratch_bytes(uint32_t n_slots);
 // the generic walk (one wave per listed read: walk + event loop) over O.gen_list
 hipError_t pg_launch_walk(hipStream_t st, const PgDevBatch &B, const PgWalkParams &W, const PgWalkOut &O);

@@ -201,30 +201,28 @@ template <int MT, class Src> __device__ void block_middle_long(ModelSmem<MT> &sm
 // Where a slot's values and events lie: two dependent rounds of uniform (scalar) loads. Round 5 first put a record pass in front of the
 // kernels (one 32-byte load instead) -- 50 us of scattered offset loads at k = 9 that the one-wave kernel, bound by its arithmetic,
 // hides for nothing; the kernel over all slots now classifies on the way and lists the slots that belong to the others.
-struct FileRef { uint64_t first, n, e0; uint32_t nev; };
+struct __attribute__((aligned(16))) FileRef { uint64_t first, n, e0; uint32_t nev, slot; }; // 32 bytes: also the entry of the per-kind lists (one load in the kernels that stride over them)
 __device__ __forceinline__ FileRef file_ref(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t s, uint32_t drop_first) {
     const uint64_t e0 = ev_off[s], e1 = ev_off[s + 1];
     const uint64_t a0 = samp_off[e0], a1 = samp_off[e1];
     const uint64_t skip = (a1 > a0 && drop_first) ? 1 : 0; // `tail -n +2`: the file's first value never reaches datamash
-    FileRef f; f.first = a0 + skip; f.n = a1 - f.first; f.e0 = e0; f.nev = (uint32_t)(e1 - e0);
+    FileRef f; f.first = a0 + skip; f.n = a1 - f.first; f.e0 = e0; f.nev = (uint32_t)(e1 - e0); f.slot = s;
     return f;
 }
 
 // The two workgroup kernels, by file size: SHORT (256 threads, <= 4096 values) converts the whole file once into 16 registers per
 // thread; LONG (1024 threads) re-reads the file per pass. Both stride over the list of their slots. Separate kernels because each needs
 // its own register budget; the host launches only the ones with work.
-template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : 4) void k_slot_model(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t drop_first,
-                                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n, const uint32_t *ev_len,
+template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LONG ? 8 : 4) void k_slot_model(const FileRef *__restrict__ list, const uint32_t *__restrict__ list_n, const uint32_t *ev_len,
                                                                       const double *samples, PgSlotModel *out, PgSlotDwell *dwell) {
     constexpr bool SHORT = KIND != PG_MODEL_LONG; // register-resident
     __shared__ ModelSmem<MT> sm;
     constexpr int C = SHORT ? ModelCfg<MT>::CACHE : 0;
     const uint32_t n_mine = uniform32(*list_n);
     for (uint32_t it = blockIdx.x; it < n_mine; it += gridDim.x) {
-    const uint32_t s = uniform32(list[it]);
-    const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
-    const uint64_t first = uniform64(fr.first), n = uniform64(fr.n), e0 = uniform64(fr.e0);
-    const uint32_t nev32 = uniform32(fr.nev);
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(list + it), q1 = *(reinterpret_cast<const uint4 *>(list + it) + 1);
+    const uint64_t first = uniform64((uint64_t)q0.x | ((uint64_t)q0.y << 32)), n = uniform64((uint64_t)q0.z | ((uint64_t)q0.w << 32)), e0 = uniform64((uint64_t)q1.x | ((uint64_t)q1.y << 32));
+    const uint32_t nev32 = uniform32(q1.z), s = uniform32(q1.w);
     if (it != blockIdx.x) __syncthreads(); // the previous slot's shared state has been read by everyone
     uint32_t flags = 0;
     PgSlotModel m{};
@@ -475,26 +473,26 @@ template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, 
     const uint32_t lane = threadIdx.x;
     const uint64_t first = uniform64(fr.first), e0 = uniform64(fr.e0); // (scalar registers: the row guards below are scalar branches)
     const uint32_t n = uniform32((uint32_t)fr.n), nev = uniform32(fr.nev), nd = nev ? nev + 1 : 0; // n <= 64 C, nd <= 64 D (pg_model_kind)
-    // every load of the file at once: its values (a lane beyond the end takes the first one) and its events' lengths
-    double x[WV_C];
+    // every load of the file at once: its events' lengths and its values (a lane beyond the end takes the first one), each value turned into
+    // t = pg_fixed8 + 1.5 * 2^52 as it arrives. (More than 32 rows: in two halves, so that at most 32 raw rows are held beside the t's.)
     uint32_t len[WV_D];
 #pragma unroll
-    for (int u = 0; u < WV_C; ++u) if ((uint32_t)u * 64 < n) { const uint32_t i = (uint32_t)u * 64 + lane; x[u] = samples[first + (i < n ? i : 0u)]; } else x[u] = 0.0;
-#pragma unroll
     for (int u = 0; u < WV_D; ++u) if ((uint32_t)u * 64 < nev) { const uint32_t i = (uint32_t)u * 64 + lane; len[u] = ev_len[e0 + (i < nev ? i : 0u)]; } else len[u] = 0;
-    PgSlotModel m{};
-    m.n = n;
-    uint32_t flags = 0;
-    if (n > 0) {
-        // pg_fixed8 of every value, kept as t = units + 1.5 * 2^52
-        double t[WV_C];
-        bool big = false;
-        double tmin = INFINITY, tmax = -INFINITY;
+    double t[WV_C];
+    bool big = false;
+    double tmin = INFINITY, tmax = -INFINITY;
+    constexpr int CH = WV_C > 32 ? 32 : WV_C;
 #pragma unroll
-        for (int u = 0; u < WV_C; ++u)
+    for (int h = 0; h < WV_C; h += CH) {
+        double x[CH];
+#pragma unroll
+        for (int v = 0; v < CH; ++v) { const int u = h + v; if ((uint32_t)u * 64 < n) { const uint32_t i = (uint32_t)u * 64 + lane; x[v] = samples[first + (i < n ? i : 0u)]; } else x[v] = 0.0; }
+#pragma unroll
+        for (int v = 0; v < CH; ++v) {
+            const int u = h + v;
             if ((uint32_t)u * 64 < n) {
-                big |= !(fabs(x[u]) < WV_MAX_ABS); // also NaN
-                const double p = x[u] * 1e8, e = fma(x[u], 1e8, -p);
+                big |= !(fabs(x[v]) < WV_MAX_ABS); // also NaN
+                const double p = x[v] * 1e8, e = fma(x[v], 1e8, -p);
                 double tt = p + WV_MAGIC; // rint(p), ties to even (WV_MAGIC is even)
                 const double f = p - (tt - WV_MAGIC);
                 if (__ballot(fabs(f) == 0.5)) { // p sits on a tie that the addition broke to even; e says on which side the exact product lies
@@ -504,6 +502,12 @@ template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, 
                 t[u] = tt;
                 tmin = min_f64_raw(tmin, tt); tmax = max_f64_raw(tmax, tt);
             } else t[u] = 0.0;
+        }
+    }
+    PgSlotModel m{};
+    m.n = n;
+    uint32_t flags = 0;
+    if (n > 0) {
         if (__ballot(big)) return false; // outside the 2^52 trick (or not a number): the 256-thread kernel converts the general way and reports
         const double t0 = __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(t[0]), 0)); // the file's first value
         double s1 = 0.0, hh = 0.0, hl = 0.0, ll = 0.0;
@@ -568,7 +572,7 @@ template <int C, int D> __device__ __forceinline__ bool wave_file(WaveSmem &sm, 
 // The kernel over ALL slots (a wave each): the TINY files are reduced here, the others go on the list of their kind (lists[kind - 1]).
 __global__ __launch_bounds__(64, PG_MODEL_TINY_WAVES) void k_slot_model_wave(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
                                                                               const uint32_t *__restrict__ ev_len, const double *__restrict__ samples, PgSlotModel *__restrict__ out,
-                                                                              PgSlotDwell *__restrict__ dwell, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
+                                                                              PgSlotDwell *__restrict__ dwell, FileRef *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
     __shared__ WaveSmem sm;
     const uint32_t s = blockIdx.x;
     if (s >= n_slots) return;
@@ -576,49 +580,51 @@ __global__ __launch_bounds__(64, PG_MODEL_TINY_WAVES) void k_slot_model_wave(con
     int kind = (int)uniform32((uint32_t)pg_model_kind(fr.n, fr.nev));
     if (kind == PG_MODEL_TINY && !wave_file<PG_MODEL_TINY_MAX / 64, PG_MODEL_TINY_EVENTS / 64>(sm, fr, s, ev_len, samples, out, dwell)) kind = PG_MODEL_SHORT;
     if (kind == PG_MODEL_SHORT) kind = short_kind; // (the launcher may send the few SHORT files of a job with the LONG ones: one launch less)
-    if (kind != PG_MODEL_TINY && threadIdx.x == 0) lists[(size_t)(kind - 1) * n_slots + atomicAdd(counts + (kind - 1), 1u)] = s; // (any order: every slot writes its own result)
+    if (kind != PG_MODEL_TINY && threadIdx.x == 0) lists[(size_t)(kind - 1) * n_slots + atomicAdd(counts + (kind - 1), 1u)] = fr; // (any order: every slot writes its own result)
 }
 // The MID files (up to 2048 values and 511 events: at k = 9 the ~3 000 files above the one-wave size): the same code with 32 rows, over their list.
 __global__ __launch_bounds__(64, 2) void k_slot_model_wave_mid(const uint64_t *__restrict__ ev_off, const uint64_t *__restrict__ samp_off, uint32_t n_slots, uint32_t drop_first,
                                                                 const uint32_t *__restrict__ ev_len, const double *__restrict__ samples, PgSlotModel *__restrict__ out,
-                                                                PgSlotDwell *__restrict__ dwell, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
+                                                                PgSlotDwell *__restrict__ dwell, FileRef *__restrict__ lists, uint32_t *__restrict__ counts, int short_kind) {
     __shared__ WaveSmem sm;
     const uint32_t n_mine = uniform32(counts[PG_MODEL_MID - 1]);
     for (uint32_t it = blockIdx.x; it < n_mine; it += gridDim.x) {
-        const uint32_t s = uniform32(lists[(size_t)(PG_MODEL_MID - 1) * n_slots + it]);
-        const FileRef fr = file_ref(ev_off, samp_off, s, drop_first);
+        const FileRef fr = lists[(size_t)(PG_MODEL_MID - 1) * n_slots + it];
+        const uint32_t s = uniform32(fr.slot);
         if (it != blockIdx.x) __syncthreads();
         if (!wave_file<PG_MODEL_MID_MAX / 64, PG_MODEL_MID_EVENTS / 64>(sm, fr, s, ev_len, samples, out, dwell) && threadIdx.x == 0)
-            lists[(size_t)(short_kind - 1) * n_slots + atomicAdd(counts + (short_kind - 1), 1u)] = s;
+            lists[(size_t)(short_kind - 1) * n_slots + atomicAdd(counts + (short_kind - 1), 1u)] = fr;
     }
 }
 
 } // namespace
 
-size_t pg_slot_model_scratch_bytes(uint32_t n_slots) { return 3 * (size_t)n_slots * 4 + 64; }
+size_t pg_slot_model_scratch_bytes(uint32_t n_slots) { return 3 * (size_t)n_slots * sizeof(FileRef) + 64; }
 hipError_t pg_launch_slot_model(hipStream_t st, uint32_t n_slots, const int any_kind[4], const uint64_t *ev_off, const uint64_t *samp_off,
                                 const uint32_t *ev_len, const double *samples, uint32_t drop_first, PgSlotModel *out, PgSlotDwell *dwell, void *scratch) {
     if (n_slots == 0) return hipSuccess;
     (void)hipGetLastError(); // sticky per-thread state of an unrelated earlier failure
-    // scratch: [3] list lengths (+ padding to 64 bytes), the lists of the MID, SHORT and LONG slots
+    // scratch: [3] list lengths (+ padding to 64 bytes), the lists of the MID, SHORT and LONG files (FileRef entries)
     uint32_t *counts = static_cast<uint32_t *>(scratch);
-    uint32_t *lists = counts + 16;
-    hipError_t e = hipMemsetAsync(counts, 0, 64, st);
-    if (e != hipSuccess) return e;
-    // any_kind[] = how many files of each kind the host knows of (1 = "some" when it does not hold the offsets). A workgroup kernel's launch is
+    FileRef *lists = reinterpret_cast<FileRef *>(counts + 16);
+    // any_kind[] = how many files of each kind the host knows of (1 << 20 = "some" when it does not hold the offsets). A workgroup kernel's launch is
     // the lifetime of one workgroup (~55 us at k = 9 for 34 SHORT and 28 LONG files): when both kinds together fit one round of the
     // 1024-thread kernel, the SHORT files go on its list too.
     const bool merge = any_kind[PG_MODEL_SHORT] > 0 && any_kind[PG_MODEL_LONG] > 0 && any_kind[PG_MODEL_SHORT] + any_kind[PG_MODEL_LONG] <= 512 && !getenv("PGMOVE_MODEL_NO_MERGE");
     const int short_kind = merge ? PG_MODEL_LONG : PG_MODEL_SHORT;
-    // always: it is also the pass that sorts the slots into the lists (a wave that is not TINY leaves after four scalar loads)
+    const hipError_t e = hipMemsetAsync(counts, 0, 64, st);
+    if (e != hipSuccess) return e;
+    // the one-wave kernel over all slots, always: it is also the pass that sorts the slots into the lists (a wave that is not TINY leaves after four
+    // scalar loads). (Lists written by the host when it holds the offsets and no file is TINY: measured at k = 5, two small uploads cost what
+    // the launch does -- 60.8 against 60.0 us for the model of the headline job.)
     hipLaunchKernelGGL(k_slot_model_wave, dim3(n_slots), dim3(64), 0, st, ev_off, samp_off, n_slots, drop_first, ev_len, samples, out, dwell, lists, counts, short_kind);
     if (any_kind[PG_MODEL_MID]) hipLaunchKernelGGL(k_slot_model_wave_mid, dim3(n_slots < 4096u ? n_slots : 4096u), dim3(64), 0, st, ev_off, samp_off, n_slots, drop_first, ev_len, samples, out, dwell, lists, counts, short_kind);
     // (the one-wave kernels hand files with values of 2.2e7 and beyond to the 256-thread one)
     if (!merge && (any_kind[PG_MODEL_SHORT] || any_kind[PG_MODEL_TINY] || any_kind[PG_MODEL_MID]))
-        hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots < 2048u ? n_slots : 2048u), dim3(256), 0, st, ev_off, samp_off, drop_first,
-                           (const uint32_t *)(lists + (size_t)(PG_MODEL_SHORT - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_SHORT - 1)), ev_len, samples, out, dwell);
+        hipLaunchKernelGGL((k_slot_model<256, PG_MODEL_SHORT>), dim3(n_slots < 2048u ? n_slots : 2048u), dim3(256), 0, st,
+                           (const FileRef *)(lists + (size_t)(PG_MODEL_SHORT - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_SHORT - 1)), ev_len, samples, out, dwell);
     if (any_kind[PG_MODEL_LONG])
-        hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots < 512u ? n_slots : 512u), dim3(1024), 0, st, ev_off, samp_off, drop_first,
-                           (const uint32_t *)(lists + (size_t)(PG_MODEL_LONG - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_LONG - 1)), ev_len, samples, out, dwell);
+        hipLaunchKernelGGL((k_slot_model<1024, PG_MODEL_LONG>), dim3(n_slots < 512u ? n_slots : 512u), dim3(1024), 0, st,
+                           (const FileRef *)(lists + (size_t)(PG_MODEL_LONG - 1) * n_slots), (const uint32_t *)(counts + (PG_MODEL_LONG - 1)), ev_len, samples, out, dwell);
     return hipGetLastError();
 }
