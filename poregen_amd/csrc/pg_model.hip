@@ -210,6 +210,19 @@ __device__ __forceinline__ FileRef file_ref(const uint64_t *__restrict__ ev_off,
     return f;
 }
 
+// pg_fixed8 for the device: below 2.2e7 the correctly rounded product sits in the low mantissa bits of p + 1.5 * 2^52 (|p| < 2^51; the sum
+// rounds to even at an ulp of 1 exactly as rint does), the FMA's error decides an exact tie as in pg_fixed8 -- the same integer, without the
+// conversion sequence (a dozen instructions per value and pass of the kernels below); anything else takes the shared function.
+__device__ __forceinline__ int64_t fixed8_dev(double x, bool &bad) {
+    if (!(fabs(x) < 2.2e7)) return pg_fixed8(x, bad);
+    const double p = x * 1e8, e = fma(x, 1e8, -p);
+    double t = p + 6755399441055744.0;
+    const double f = p - (t - 6755399441055744.0);
+    if (f == 0.5 && e > 0.0) t += 1.0;
+    else if (f == -0.5 && e < 0.0) t -= 1.0;
+    return (int64_t)((uint64_t)__double_as_longlong(t) & ((1ull << 52) - 1)) - (1ll << 51);
+}
+
 // The two workgroup kernels, by file size: SHORT (256 threads, <= 4096 values) converts the whole file once into 16 registers per
 // thread; LONG (1024 threads) re-reads the file per pass. Both stride over the list of their slots. Separate kernels because each needs
 // its own register budget; the host launches only the ones with work.
@@ -229,12 +242,12 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
     m.n = n;
     if (n > 0) {
         bool bad = false, wide = false;
-        const int64_t origin = pg_fixed8(samples[first], bad);
+        const int64_t origin = fixed8_dev(samples[first], bad);
         // pass A: range and moments about the first value
         uint64_t mn = ~0ull, mx = 0, hh = 0, hl = 0, ll = 0;
         int64_t s1 = 0;
         auto account = [&](double x) {
-            const int64_t v = pg_fixed8(x, bad);
+            const int64_t v = fixed8_dev(x, bad);
             const uint64_t key = (uint64_t)v ^ (1ull << 63); // order-preserving
             mn = op_min(mn, key); mx = op_max(mx, key);
             const int64_t d = v - origin;
@@ -269,7 +282,7 @@ template <int MT, int KIND> __global__ __launch_bounds__(MT, KIND == PG_MODEL_LO
             else {
                 auto key_at = [&](uint64_t i) {
                     bool b2 = false;
-                    return ((uint64_t)pg_fixed8(samples[first + i], b2) ^ (1ull << 63)) - mn;
+                    return ((uint64_t)fixed8_dev(samples[first + i], b2) ^ (1ull << 63)) - mn;
                 };
                 const GlobalKeys<MT, decltype(key_at)> gk{n, key_at};
                 block_middle_long<MT>(sm, gk, n, bits, k_lo, k_hi);
