@@ -668,7 +668,14 @@ static pg_status fill_long(pg_ctx *c, PgLongState &LS, bool ensure) {
             HIP_TRY(c, c->long_tab.ensure((size_t)cap * 8));
             const size_t before = c->long_hist.cap;
             HIP_TRY(c, c->long_hist.ensure((size_t)cap * PG_LONG_WORDS * 4));
-            if (c->long_hist.cap != before) HIP_TRY(c, hipMemsetAsync(c->long_hist.p, 0, c->long_hist.cap, c->st)); // zero between batches: the last slice of a read leaves it so
+            if (c->long_hist.cap != before) {
+                // zero between batches: the last slice of a read leaves it so. The statistics that add into it may run on the second
+                // stream, which is not ordered behind this stream's work (it waits for the staging copies at most): the fill must have
+                // FINISHED before anything of this batch is queued there. Growth is rare (the first long batch, or one that wants more
+                // helpers than any before), so the host waits for it (advisor r05: a fill of cap x 4512 bytes raced the first slices' adds).
+                HIP_TRY(c, hipMemsetAsync(c->long_hist.p, 0, c->long_hist.cap, c->st));
+                HIP_TRY(c, hipStreamSynchronize(c->st));
+            }
             c->long_cap = cap;
         }
         // this batch's helpers: what it is expected to want plus a margin (a batch without long reads launches 64 helper workgroups, not the
