@@ -39,7 +39,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PRE_WARM_STEPS = 300   # untimed settling steps in front of the contract's warm-up (see timed())
 
 
 def relaunch_under_torchrun(args):
@@ -90,6 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pre-warm", type=int, default=0, help="extra untimed settling steps in front of --warmup (round 5 ran 300 by default; now opt-in, and counted in the reported `warmup`)")
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=4000)
     ap.add_argument("--kind", default="rna004")
@@ -205,13 +205,14 @@ def main():
             if world > 1:
                 dist.barrier()
 
-        # Settling, in front of the contract's W warm-up steps and just as untimed: a fixed number of steps on every rank (they hold a
-        # collective at N > 1). The driver's command is --steps 20 --warmup 5 -- 3 ms of timed work 0.7 ms after the first launch -- and the
-        # first block of a run read 5 % slower than the blocks behind it (profiles/r05_bench_blocks.txt): clocks and caches were still
-        # on their way up. Reported as pre_warm_steps.
-        for _ in range(PRE_WARM_STEPS):
+        # The contract: W untimed steps, then exactly K timed ones. (Round 5 put 300 settling steps in front by default -- the first block of
+        # a run reads ~5 % slower than the blocks behind it, profiles/r05_bench_blocks.txt; that is now opt-in, --pre-warm N, and the
+        # reported `warmup` is the number of untimed steps actually run. The settled figure is what the two blocks behind the contract's
+        # block show: ms_per_step_blocks.)
+        for _ in range(args.pre_warm):
             step()
-        fence()
+        if args.pre_warm:
+            fence()
         for _ in range(warmup):
             step()
         fence()
@@ -390,7 +391,7 @@ def main():
 
     out = {
         "metric": "signal samples/sec aggregated into k-mer buckets", "value": value, "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pre_warm_steps": PRE_WARM_STEPS, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup + args.pre_warm, "pre_warm_steps": args.pre_warm, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16 in / f64 arithmetic",
         "data": "synthetic",
         "config": {
@@ -402,7 +403,7 @@ def main():
             "kept_events_rank0": kept_events, "kept_samples_rank0": kept_samples, "homopolymer_frac": hp_frac,
         },
         "ms_per_step_blocks": {"contract_block": ms_per_step, "min": all_blocks[0], "median": all_blocks[len(all_blocks) // 2], "max": all_blocks[-1], "steps_per_block": args.steps,
-                               "note": "value / ms_per_step are the first block (exactly --steps timed steps); two more blocks of the same length follow it"},
+                               "note": "value / ms_per_step are the first block (exactly --steps timed steps behind exactly `warmup` untimed ones); two more blocks of the same length follow it: the settled figure"},
         "roofline": roofline,
         "whole_step": whole_step,
         "whole_step_frac": whole_step["frac"],
@@ -454,7 +455,8 @@ def mode_run(shard, host, kmers, q, what, steps=10):
     import torch
     from poregen_amd.engine import GmoveEngine, GmoveParams
     e = GmoveEngine(GmoveParams(kmers=kmers, **q))
-    for _ in range(30):
+    MODE_WARMUP = 30
+    for _ in range(MODE_WARMUP):
         e.reset(); e.submit(shard)
     e.sync()
     blocks = []  # three timed blocks: boxes (and minutes) differ by several per cent, one number says little
@@ -481,7 +483,7 @@ def mode_run(shard, host, kmers, q, what, steps=10):
     pe.close()
     n_ops, n_bases = int(host.op_off[-1]), int(host.seq_off[-1])
     balg = b_alg(host.n_samples, host.n_reads, n_ops, n_bases, ksm, ke, len(kmers))
-    return {"workload": what, "sample_limit": q["sample_limit"], "ms_per_step": ms, "ms_per_step_blocks": {"min": min(blocks), "median": ms, "max": max(blocks), "steps_per_block": steps},
+    return {"workload": what, "sample_limit": q["sample_limit"], "ms_per_step": ms, "ms_per_step_blocks": {"min": min(blocks), "median": ms, "max": max(blocks), "steps_per_block": steps, "warmup_steps": MODE_WARMUP},
             "value": host.n_samples / (ms * 1e-3), "unit": "samples/s",
             "kept_events": ke, "kept_samples": ksm, "algorithmic_bytes": balg, "whole_step_frac": balg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "whole_step_frac_blocks": {"min": balg / (max(blocks) * 1e-3) / 1e9 / HBM_PEAK_GBS, "max": balg / (min(blocks) * 1e-3) / 1e9 / HBM_PEAK_GBS},

@@ -714,9 +714,6 @@ static bool dense_direct(const pg_ctx *c, uint64_t n_ops) {
     return c->prm.n_slots <= PG_DIRECT_MAX_SLOTS && std::min<uint64_t>(n_ops, (uint64_t)c->prm.n_slots * c->prm.sample_limit) > dense_min() && !getenv("PGMOVE_EMIT1");
 }
 
-#ifdef PG_PROBE_CAL_EV
-extern "C" void pg_probe_cal_ev(double *, const double *); // pg_place.hip (measurement build)
-#endif
 static void fill_part(pg_ctx *c, PgPartBufs &P, uint64_t n_ops) {
     P.elemA = c->part_elem.as<uint4>(); P.loA = c->part_lodig.as<uint16_t>(); P.hist = c->hist.as<uint32_t>(); P.totals = c->totals.as<uint32_t>(); P.rbase = c->part_rbase.as<uint32_t>();
     P.tile_region = c->part_tile_region.as<uint32_t>(); P.n_tilesB = c->part_ntiles.as<uint32_t>(); P.histB = c->part_histB.as<uint32_t>();
@@ -1110,12 +1107,6 @@ static pg_status collect_impl(pg_ctx *c, const uint64_t *base, int32_t base_loca
         PgPartBufs P{};
         fill_part(c, P, N ? N : 1);
         if (N) {
-#ifdef PG_PROBE_CAL_EV
-            { static DevBuf probe_cal;
-              const bool on = chunked && c->prm.scaling == 1 && !c->stats_in_flight;
-              if (on) HIP_TRY(c, probe_cal.ensure((ke_cap + 1) * 32));
-              pg_probe_cal_ev(on ? probe_cal.as<double>() : nullptr, on ? c->gcal[c->slot].as<double>() : nullptr); }
-#endif
             prof_begin(c, "k_region_place", c->st);
             HIP_TRY(c, pg_launch_region_place(c->st, P, ns, c->keep32.as<uint32_t>(), c->ev_off.as<uint64_t>(), O, K, chunked ? c->chunk_part[c->rslot].as<uint64_t>() : nullptr, chunked ? ke_cap : 0));
             prof_end(c, c->st);

@@ -117,11 +117,7 @@ __device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, u
                                             const double *__restrict__ med, const double *__restrict__ mad, const double *__restrict__ gcal, GatherRegs<P> &R) {
     const uint32_t *__restrict__ sig32 = reinterpret_cast<const uint32_t *>(B.sig);
     if (gcal) { // offset, scale, median, MAD of the read as one 32-byte record (written by the statistics kernels): four lanes, one transaction
-#ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event reads read 0's record
-        R.h = sub < 4u ? reinterpret_cast<const uint64_t *>(gcal)[sub] : 0ull;
-#else
         R.h = sub < 4u ? reinterpret_cast<const uint64_t *>(gcal)[4ull * rd + sub] : 0ull;
-#endif
     } else {
         const uint64_t *arr = sub == 0 ? reinterpret_cast<const uint64_t *>(B.off + rd) : (sub == 1 ? reinterpret_cast<const uint64_t *>(B.range + rd)
                               : (sub == 2 ? reinterpret_cast<const uint64_t *>(B.dig + rd) : (sub == 3 ? reinterpret_cast<const uint64_t *>(med + rd) : reinterpret_cast<const uint64_t *>(mad + rd))));
@@ -135,10 +131,6 @@ __device__ __forceinline__ void gather_load(const PgDevBatch &B, uint32_t sub, u
         const uint64_t d = d0 + (t >> 1);
         R.q[ps] = make_uint2(0u, 0u);
         if (t < len) {
-#ifdef PG_PROBE_GC_NOREAD // timing probe only (results are garbage): no window loads at all -- what records + calibration + conversion + stores cost
-            R.q[ps] = make_uint2((uint32_t)src + t, len);
-            continue;
-#endif
 #ifdef PG_GATHER_NT
             if (2 * d + 3 < total) { typedef unsigned pg_u2 __attribute__((ext_vector_type(2), aligned(4))); const pg_u2 x = __builtin_nontemporal_load(reinterpret_cast<const pg_u2 *>(sig32 + d)); R.q[ps] = make_uint2(x.x, x.y); }
 #else
@@ -171,22 +163,13 @@ __device__ __forceinline__ void gather_finish(const PgDevBatch &B, uint32_t sub,
         // gmove.cpp:774. (Round 3 tried the division's reciprocal refinement once per event -- it depends on the divisor alone while
         // v_div_scale leaves the operands as they are -- and a multiplication + two FMAs per sample: bit-identical, 5 % SLOWER at k = 9
         // (1027 vs 971 us): the gather is bound by the 64-byte sectors its windows pull over the fabric, not by FP64 issue.)
-#ifdef PG_PROBE_GC_NODIV // timing probe only (results are garbage): what the exact FP64 division costs
-        if (scaling) x = (x - md) * ma;
-#else
         if (scaling) x = (x - md) / ma;
-#endif
         return x;
     };
     auto emit2 = [&](uint32_t t, const uint2 &qq) { // this lane's two samples t, t+1 = halves of dwords d, d+1
         const int s0 = odd ? (int)qq.x >> 16 : (int)(short)(qq.x & 0xffffu);
         const int s1 = odd ? (int)(short)(qq.y & 0xffffu) : (int)qq.x >> 16;
         const double x0 = conv(s0);
-#ifdef PG_PROBE_GC_NOSTORE // timing probe only (results are garbage): loads + conversion, no sample stores (the condition never holds)
-        if (t + 1 < len) { const double x1 = conv(s1); if (x0 + x1 == 1.2345e300) samples[dst + t] = x1; }
-        else if (x0 == 1.2345e300) samples[dst + t] = x0;
-        return;
-#endif
         if (t + 1 < len) {
             const double x1 = conv(s1);
             *reinterpret_cast<double2 *>(samples + dst + t) = make_double2(x0, x1); // 16 bytes, 8-byte aligned (streaming "nt" stores: measured, slower -- 21.0 -> 23.5 us, 260 -> 368 us at 2.1 M events)

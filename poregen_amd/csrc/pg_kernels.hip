@@ -2179,16 +2179,8 @@ __device__ __forceinline__ void stats_finish(uint32_t *hist, int lane, uint32_t 
 #else
     const bool try_sym = m.sym != 0;
 #endif
-#ifdef PG_PROBE_NO_SELECT // timing probe only: what the kernel costs without any selection (results are garbage)
-    if (lane == 0) { med[r] = (double)lane_end; mad[r] = 1.0; }
-    return;
-#endif
-#ifdef PG_PROBE_SYM_ONLY // measurement: symmetric path, then straight to the general search
-    if (win == 0 || !(try_sym && stats_select_sym<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end))) {
-#else
     if (win == 0 || !((try_sym && stats_select_sym<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end)) ||
                       stats_select_fast<BINS>(hist, lane, pl, L, m.offset, m.scale, m0, m1, lane_end, m.inv))) {
-#endif
 #ifdef PG_COUNT_FALLBACKS
         if (lane == 0) atomicAdd(&g_pg_fallbacks, 1ull);
 #endif
@@ -2350,15 +2342,8 @@ __global__ __launch_bounds__(64 * PG_STATS_WPB) __attribute__((amdgpu_waves_per_
             }
             if (p == 0) stats_zero<1024>(hist, lane); // behind the first pass's loads: the histogram is cleared while they are in flight
             PG_MARK(0, 1); // the samples have arrived
-#ifdef PG_PROBE_NO_BIN // timing probe only: the samples are consumed, nothing is binned (results are garbage)
-            { int acc_ = 0;
-#pragma unroll
-              for (int u = 0; u < 8; ++u) acc_ ^= q[u].x ^ q[u].y ^ q[u].z ^ q[u].w;
-              if (acc_ == 0x12345678) hist[lane] = 1; }
-#else
 #pragma unroll
             for (int u = 0; u < 8; ++u) if ((uint32_t)(u * WAVE + lane) <= last) stats_bin8<1024>(hist, q[u], c2, cap2);
-#endif
             PG_MARK(0, 2); // binned
         }
         if ((va << 3) != beg || (vb << 3) != end) {

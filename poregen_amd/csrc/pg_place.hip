@@ -23,17 +23,6 @@
 #include "pg_select.h"
 #include <type_traits>
 
-#ifdef PG_PROBE_CAL_EV // measurement build (round 5): the read's calibration ATTACHED to the kept event's record by the placing
-// kernel (a 32-byte entry beside the record, written in the same runs), so that the gather reads it sequentially instead of fetching it
-// from the 1.6 MB table at random. One stream only (the statistics must be complete in front of k_region_place). Results stay correct.
-static double *h_cal_ev; static const double *h_cal_src; // (host side: handed to the two kernels as arguments)
-extern "C" void pg_probe_cal_ev(double *cal_ev, const double *gcal) { h_cal_ev = cal_ev; h_cal_src = gcal; }
-#define PG_CAL_EV_PARAMS , double *__restrict__ g_cal_ev, const double *__restrict__ g_cal_src
-#define PG_CAL_EV_ARGS , h_cal_ev, h_cal_src
-#else
-#define PG_CAL_EV_PARAMS
-#define PG_CAL_EV_ARGS
-#endif
 // =====================================================================================================
 // op-sum prefixes: window starts of direct reads without a walk
 // =====================================================================================================
@@ -304,7 +293,6 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         };
         if (have_row) {
             constexpr int HB = PG_PART_ROWS / 2;
-#ifndef PG_SCATTER_TABLE_PRE
             // the op sums in front of every op of the wave's 512 from the op_n the lanes hold (as k_rank_emit2, round 5): a wave scan per row
             // on top of the block-sum prefix at the wave's first op (one uniform load) instead of two table loads per row
             uint32_t rowpre[PG_PART_ROWS];
@@ -318,7 +306,6 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                     runp += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
                 }
             }
-#endif
 #pragma unroll
             for (int r0 = 0; r0 < PG_PART_ROWS; r0 += HB) {
                 uint2 lq[HB]; uint4 fs[HB]; uint32_t pre[HB], rd[HB];
@@ -329,12 +316,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                     const PgReadMeta *mt = O.meta + rd[i];
                     lq[i] = *reinterpret_cast<const uint2 *>(&mt->L);     // L, qs
                     fs[i] = *reinterpret_cast<const uint4 *>(&mt->flags); // flags, opsum0, sig0
-#ifdef PG_SCATTER_TABLE_PRE
-                    const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, gs = g < n ? g : (uint64_t)n - 1u; // (n >= 1: the tile exists)
-                    pre[i] = Bp[gs >> 8] + O.cum[gs >> 2] + partial_of(r);
-#else
                     pre[i] = rowpre[r];
-#endif
                 }
 #pragma unroll
                 for (int i = 0; i < HB; ++i) {
@@ -517,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_region_scan_cut(uint32_t *__restrict__
 __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_region_place(const uint4 *__restrict__ elemA, const uint32_t *__restrict__ n_tilesB, const uint32_t *__restrict__ tile_region,
                                                                    const uint32_t *__restrict__ rbase, const uint32_t *__restrict__ totals, int lo_bits, uint32_t n_slots,
                                                                    const uint32_t *__restrict__ histB, const uint32_t *__restrict__ keep32, const uint64_t *__restrict__ ev_off,
-                                                                   PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift PG_CAL_EV_PARAMS) {
+                                                                   PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift) {
     const uint32_t ndig = 1u << lo_bits, tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
     // the tile's elements are requested in front of the look-ups that say how many of them count (the buffer holds every tile of the grid)
@@ -572,9 +554,6 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
         const uint32_t dst = jj + L.aux[ndig + d], len = e.z & 0xffffffu;
         if (len == 0) { report_error(O, e.w, (int)e.y); K.rec[dst] = PgKeptRec{0, 0, e.w}; } // the verdict event_element left
         else K.rec[dst] = PgKeptRec{(uint64_t)e.y | ((uint64_t)(e.z >> 24) << 32), len, e.w};
-#ifdef PG_PROBE_CAL_EV
-        if (g_cal_ev) { const double4 cv = *reinterpret_cast<const double4 *>(g_cal_src + 4ull * e.w); *reinterpret_cast<double4 *>(g_cal_ev + 4ull * dst) = cv; }
-#endif
         if (K.read_needed) K.read_needed[e.w] = 1;
         if (!part) continue;
         const uint64_t ch = ((uint64_t)dst >> chunk_shift) - c_lo;
@@ -695,12 +674,6 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 const uint32_t rank = s_hcol[d] + ((cnt[w * half + (d >> 1)] >> sh) & 0xffffu) + lrank[r];
                 dst[r] = (valid[r] && rank < s_keep[d]) ? s_off[d] + rank : 0xFFFFFFFFu;
             }
-#ifdef PG_PROBE_EMIT2_NOWIN // timing probe only (results are garbage): no window work, one store per kept event
-#pragma unroll
-            for (int r = 0; r < PG_PART_ROWS; ++r) if (dst[r] != 0xFFFFFFFFu) K.rec[dst[r]] = PgKeptRec{0, 1, 0};
-            if (tile_first == 0xFFFFFFFFu)
-#endif
-#ifndef PG_EMIT2_TABLE_PRE
             // the op sums in front of every op of the wave's 512 (round 5): a wave scan per row over the op_n the lanes hold, from the block-sum
             // prefix at the wave's first op (a multiple of 256 ops: ONE uniform load) -- the window loop below then needs no load of the op-sum
             // tables at all (it asked for two per kept row, inside its branches: eight dependent round trips per tile)
@@ -715,13 +688,8 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                     runp += (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
                 }
             }
-#endif
 #pragma unroll
             for (int r = 0; r < PG_PART_ROWS; ++r) {
-#ifdef PG_EMIT2_TABLE_PRE
-                const uint32_t v1 = dpp_zero<0x111, 0xF>(opn[r]), v2 = dpp_zero<0x112, 0xF>(opn[r]), v3 = dpp_zero<0x113, 0xF>(opn[r]); // lanes - 1, - 2, - 3 (all lanes take part)
-                const uint32_t m4 = (uint32_t)lane & 3u, partial = (m4 > 0 ? v1 : 0u) + (m4 > 1 ? v2 : 0u) + (m4 > 2 ? v3 : 0u);
-#endif
                 if (dst[r] == 0xFFFFFFFFu) continue;
                 const uint64_t g = T0 + w * (PG_PART_ROWS * WAVE) + r * WAVE + lane, ge = g + W.sig_move_offset;
                 const uint32_t rel = key[r] >> PG_SLOT_BITS;
@@ -736,11 +704,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (gen) { ws = O.m_start[ge]; wl = O.m_len[ge]; }
                 else {
                     wl = have_row ? opn[r] : B.op_n[ge];
-#ifdef PG_EMIT2_TABLE_PRE
-                    const uint32_t pre = have_row ? Bp[ge >> 8] + O.cum[ge >> 2] + partial : op_prefix(B, O, Bp, ge); // (all rows' table loads in front of the branches, as k_part_scatter does: 63 -> 64 us here, one register spill)
-#else
                     const uint32_t pre = have_row ? rowpre[r] : op_prefix(B, O, Bp, ge);
-#endif
                     const uint64_t st = (uint64_t)qs + (uint32_t)(pre - pre0);
                     ws = (uint32_t)st;
                     ok = st + wl <= 0x7fffffffull;
@@ -805,11 +769,7 @@ __device__ __forceinline__ void gather_chunk(const PgDevBatch &B, uint64_t total
             const uint32_t i = i0 + u * STEP;
             const uint4 r = s_rec[i < cnt ? i : 0u]; // every lane of the group reads the same 16 bytes: a broadcast
             so[u] = s_off[i < cnt ? i : 0u];
-#ifdef PG_PROBE_GC_CLAMP16 // timing probe only (results are garbage): the first 16 samples of every window -- what a sweep without the long windows' passes costs
-            len[u] = i < cnt ? (r.z < 16u ? r.z : 16u) : 0u; src[u] = (uint64_t)r.x | ((uint64_t)r.y << 32);
-#else
             len[u] = i < cnt ? r.z : 0u; src[u] = (uint64_t)r.x | ((uint64_t)r.y << 32);
-#endif
             if (i < cnt) gather_load<G, P>(B, sub, r.w, len[u], src[u], total, scaling, nullptr, nullptr, gcal, R[u]);
         }
 #pragma unroll
@@ -857,10 +817,8 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
 #pragma unroll
         for (int i = 0; i < PT; ++i) { s_off[tid * PT + i] = off; off += v[i]; }
         __syncthreads();
-#ifndef PG_PROBE_NO_SOFF // (timing probe: what the offsets' stores cost)
 #pragma unroll
         for (int i = 0; i < PG_G2_SUB / 256; ++i) { const uint32_t x = i * 256 + tid; if (x < cnt) samp_off[e0 + x] = run + s_off[x]; }
-#endif
         gather_chunk<G, P>(B, total, s_rec, cnt, run, s_off, scaling, pa_min, pa_max, gcal, samples);
         run += tot;
     }
@@ -890,7 +848,7 @@ template <int G, int P> __global__ __launch_bounds__(256) __attribute__((amdgpu_
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES, 8))) void k_gather_wave(PgDevBatch B, const uint64_t *__restrict__ n_kept_ptr, const PgKeptRec *__restrict__ rec,
         const uint64_t *__restrict__ part, uint32_t sub_per_chunk /* in units of PG_G2_SUB */, uint64_t *__restrict__ samp_off, uint64_t *__restrict__ total_out, int scaling, double pa_min, double pa_max,
-        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags PG_CAL_EV_PARAMS) {
+        double *__restrict__ samples, const double *__restrict__ gcal, const int32_t *__restrict__ stat_flags) {
     const bool exact_div = stat_flags && stat_flags[3] != 0; // (uniform) pg_select.h: pg_div_domain_ok failed for a read of the batch
     __shared__ uint32_t gsum[PG_GW_SEG / 64];
     __shared__ uint4 s_ev_all[4][64];                 // per non-empty event of the wave's group: source index - offset inside the group (64 bits), read, -
@@ -927,42 +885,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
             return (uint32_t)lane < gn ? reinterpret_cast<const uint4 *>(rec + seg + g * 64u)[lane] : make_uint4(0, 0, 0, 0);
         };
         // lanes 2i and 2i + 1 fetch the two halves of event i's (then event 32 + i's) 32-byte calibration record: one request per record
-        auto load_cal = [&](const uint4 &qq, double2 (&c)[2], uint64_t ebase) {
-            (void)ebase;
+        auto load_cal = [&](const uint4 &qq, double2 (&c)[2]) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int evl = hh * 32 + (lane >> 1);
                 const uint32_t rd = (uint32_t)__shfl((int)qq.w, evl, WAVE), ok = (uint32_t)__shfl((int)qq.z, evl, WAVE);
                 c[hh] = make_double2(0.0, 0.0);
                 if (ok) {
-#ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event uses one of eight reads' calibrations
-                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * (rd & 7u) + 2u * (lane & 1));
-#elif defined(PG_PROBE_CAL_EV)
-                    if (gcal) c[hh] = g_cal_ev ? *reinterpret_cast<const double2 *>(g_cal_ev + 4ull * (ebase + (uint64_t)evl) + 2u * (lane & 1))
-                                               : *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1));
-#else
                     if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1)); // {offset, range / digitisation as the statistics used it}, {median, MAD}
-#endif
                     else c[hh] = (lane & 1) ? make_double2(0.0, 1.0) : make_double2(B.off[rd], B.range[rd] / B.dig[rd]);
                 }
             }
         };
         uint4 q_cur = load_rec(w), q_nxt = load_rec(w + 4);
         double2 c_cur[2];
-        load_cal(q_cur, c_cur, seg + (uint64_t)w * 64u);
+        load_cal(q_cur, c_cur);
         for (uint32_t g = w; g * 64u < nseg; g += 4) {
             const uint64_t e0 = seg + g * 64u, gbase = run + (uint32_t)__shfl((int)(ginc - gv), (int)g, WAVE);
             const uint32_t n = nseg - g * 64u < 64u ? nseg - g * 64u : 64u;
             // ---- this group: a record per lane
             const uint4 q = q_cur;
             const double2 c0 = c_cur[0], c1 = c_cur[1];
-            q_cur = q_nxt; load_cal(q_cur, c_cur, seg + (uint64_t)(g + 4) * 64u); q_nxt = load_rec(g + 8);
+            q_cur = q_nxt; load_cal(q_cur, c_cur); q_nxt = load_rec(g + 8);
             const uint32_t len = q.z, nzf = len != 0u;
             const uint32_t inc = wave_incl_scan_u32(len), off = inc - len, tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             const uint32_t idx = wave_incl_scan_u32(nzf) - nzf;
-#ifndef PG_PROBE_NO_SOFF
             if ((uint32_t)lane < n) samp_off[e0 + lane] = gbase + off;
-#endif
             __builtin_amdgcn_wave_barrier(); // (the previous group's trips have read the stage)
             if (nzf) {
                 const uint64_t srcbase = ((uint64_t)q.x | ((uint64_t)q.y << 32)) - off;
@@ -1009,20 +957,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                 // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
                 // arithmetic: 948 -> 8xx us at k = 9.
                 auto conv = [&](auto EX, int raw, const double4 &c, double y) {
-#ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
-                    return (double)raw;
-#endif
                     const double pA = ((double)raw + c.x) * c.y;                 // TO_PICOAMPS, poregen.h:30
                     double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;          // gmove.cpp:756-759
                     if (scaling) {
                         const double num = x - c.z;
-#if defined(PG_PROBE_GC_NODIV)
-                        x = num * c.w;
-#elif defined(PG_GATHER_DIV_INSN)
-                        x = num / c.w;
-#else
                         if constexpr (decltype(EX)::value) x = num / c.w; else x = pg_div_by_recip(num, c.w, y);
-#endif
                     }
                     return x;
                 };
@@ -1054,29 +993,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GW_WAVES
                     for (int u = 0; u < PG_GW_TRIPS; ++u)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-#ifdef PG_PROBE_GC_NOREAD
-                            raw[u][h] = (int)(ee[u][h].x + qp[u][h]);
-#else
                             raw[u][h] = sig[((uint64_t)ee[u][h].x | ((uint64_t)ee[u][h].y << 32)) + tb + qp[u][h]];
-#endif
                         }
 #pragma unroll
                     for (int u = 0; u < PG_GW_TRIPS; ++u) {
                         const uint32_t j = j0 + u * 64;
                         const double x0 = conv(EX, raw[u][0], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][0]), __hiloint2double((int)ee[u][0].w, (int)ee[u][0].z));
                         const double x1 = conv(EX, raw[u][1], *reinterpret_cast<const double4 *>(s_cal + 4u * ev[u][1]), __hiloint2double((int)ee[u][1].w, (int)ee[u][1].z));
-#ifdef PG_PROBE_GC_NOSTORE
-                        if (x0 + x1 == 1.2345e300) out[2u * j] = x0;
-#else
-#ifndef PG_GW_PLAIN_STORE // streaming ("nt") stores: 974 -> 911 us at k = 9 (the calibration table and the records stay in the L2 longer)
                         typedef double pg_d2 __attribute__((ext_vector_type(2)));
                         if (v[u][0] && v[u][1]) { pg_d2 xx; xx.x = x0; xx.y = x1; __builtin_nontemporal_store(xx, reinterpret_cast<pg_d2 *>(out + 2u * j)); }
-#else
-                        if (v[u][0] && v[u][1]) *reinterpret_cast<double2 *>(out + 2u * j) = make_double2(x0, x1);
-#endif
                         else if (v[u][0]) out[2u * j] = x0;
                         else if (v[u][1]) out[2u * j + 1u] = x1;
-#endif
                     }
                 } };
                 if (exact_div) trips(std::true_type{}); else trips(std::false_type{});
@@ -1144,11 +1071,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                 const uint32_t rd = (uint32_t)__shfl((int)qq.w, evl, WAVE), ok = (uint32_t)__shfl((int)qq.z, evl, WAVE);
                 c[hh] = make_double2(0.0, 0.0);
                 if (ok) {
-#ifdef PG_PROBE_NO_GCAL // timing probe only (results are garbage): every event uses one of eight reads' calibrations
-                    if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * (rd & 7u) + 2u * (lane & 1));
-#else
                     if (gcal) c[hh] = *reinterpret_cast<const double2 *>(gcal + 4ull * rd + 2u * (lane & 1)); // {offset, range / digitisation as the statistics used it}, {median, MAD}
-#endif
                     else c[hh] = (lane & 1) ? make_double2(0.0, 1.0) : make_double2(B.off[rd], B.range[rd] / B.dig[rd]);
                 }
             }
@@ -1167,9 +1090,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
             const uint32_t inc = wave_incl_scan_u32(len), off = inc - len;
             const uint32_t idx = wave_incl_scan_u32(nzf) - nzf;
             const uint32_t len2 = (len + 1u) >> 1, inc2 = wave_incl_scan_u32(len2), off2 = inc2 - len2, tot2 = (uint32_t)__builtin_amdgcn_readlane((int)inc2, WAVE - 1); // pair slots: lanes own samples (2k, 2k + 1) of ONE window
-#ifndef PG_PROBE_NO_SOFF
             if ((uint32_t)lane < n) samp_off[e0 + lane] = gbase + off;
-#endif
             __builtin_amdgcn_wave_barrier(); // (the previous group's trips have read the stage)
             if (nzf) {
                 const uint64_t srcbase = ((uint64_t)q.x | ((uint64_t)q.y << 32)) - 2ull * off2;
@@ -1208,20 +1129,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                 // sequencer's) or -DPG_GATHER_DIV_INSN: the division itself. FP64 is half rate here and the division was 2/3 of a sample's
                 // arithmetic: 948 -> 8xx us at k = 9.
                 auto conv = [&](auto EX, int raw, const double4 &c, double y) {
-#ifdef PG_PROBE_GC_NOCONV // timing probe only (results are garbage): no arithmetic, no calibration reads
-                    return (double)raw;
-#endif
                     const double pA = ((double)raw + c.x) * c.y;                 // TO_PICOAMPS, poregen.h:30
                     double x = (pA < pa_min || pA > pa_max) ? 0.0 : pA;          // gmove.cpp:756-759
                     if (scaling) {
                         const double num = x - c.z;
-#if defined(PG_PROBE_GC_NODIV)
-                        x = num * c.w;
-#elif defined(PG_GATHER_DIV_INSN)
-                        x = num / c.w;
-#else
                         if constexpr (decltype(EX)::value) x = num / c.w; else x = pg_div_by_recip(num, c.w, y);
-#endif
                     }
                     return x;
                 };
@@ -1253,15 +1165,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                     if (!__ballot(tail)) { // (wave-uniform; only the wave that holds the batch's last samples takes the other side)
 #pragma unroll
                         for (int u = 0; u < PG_GE_TRIPS; ++u) {
-#ifdef PG_PROBE_GC_NOREAD
-                            raw[u][0] = (int)(ee[u].x + qp[u]); raw[u][1] = raw[u][0] + 1;
-#else
                             typedef uint32_t pg_a2 __attribute__((ext_vector_type(2), aligned(4)));
                             const pg_a2 qq = *reinterpret_cast<const pg_a2 *>(sig32 + (i0[u] >> 1));
                             const uint64_t v64 = ((uint64_t)qq.y << 32) | qq.x;
                             const uint32_t sh = (uint32_t)(i0[u] & 1u) * 16u;
                             raw[u][0] = (int)(short)(uint16_t)(v64 >> sh); raw[u][1] = (int)(short)(uint16_t)(v64 >> (sh + 16u));
-#endif
                         }
                     } else {
 #pragma unroll
@@ -1274,13 +1182,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PG_GE_WAVES
                         const double x0 = conv(EX, raw[u][0], cc, y), x1 = conv(EX, raw[u][1], cc, y);
                         const uint32_t s2 = 2u * (tb + qp[u]);                 // the pair's first sample, counted in pair slots x 2
                         double *dst = out + (uint32_t)(ee[u].z + s2);          // + (offset of the window in the group - 2 x its first pair slot)
-#ifdef PG_PROBE_GC_NOSTORE
-                        if (x0 + x1 == 1.2345e300) *dst = x0;
-#else
                         typedef double pg_d2 __attribute__((ext_vector_type(2), aligned(8)));
                         if (v[u] && s2 + 1u < ee[u].w) { pg_d2 xx; xx.x = x0; xx.y = x1; __builtin_nontemporal_store(xx, reinterpret_cast<pg_d2 *>(dst)); }
                         else if (v[u]) *dst = x0; // the odd tail of a window
-#endif
                     }
                 } };
                 if (exact_div) trips(std::true_type{}); else trips(std::false_type{});
@@ -1355,7 +1259,7 @@ hipError_t pg_launch_region_place(hipStream_t st, const PgPartBufs &P, uint32_t 
     const size_t lds = part_lds_bytes(1u << P.lo_bits);
     PG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_region_place), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds_bytes(PG_RANK_MAX_DIGITS)));
     PG_LAUNCH(k_region_place, dim3(P.tilesB_cap), dim3(PG_PART_THREADS), lds, st, (const uint4 *)P.elemA, (const uint32_t *)P.n_tilesB, (const uint32_t *)P.tile_region,
-              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, n_slots, (const uint32_t *)P.histB, keep32, ev_off, O, K, part, chunk_shift PG_CAL_EV_ARGS);
+              (const uint32_t *)P.rbase, (const uint32_t *)P.totals, (int)P.lo_bits, n_slots, (const uint32_t *)P.histB, keep32, ev_off, O, K, part, chunk_shift);
     return hipSuccess;
 }
 
@@ -1376,7 +1280,7 @@ hipError_t pg_launch_gather_chunks(hipStream_t st, const PgDevBatch &B, uint64_t
         return hipSuccess;
     }
     if (lanes == 0) { // the wave form: a lane per pair of output samples, a wave per 64 events
-        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags PG_CAL_EV_ARGS);
+        PG_LAUNCH(k_gather_wave, dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal, stat_flags);
         return hipSuccess;
     }
     if (lanes <= 4) PG_LAUNCH((k_gather_chunks<4, 4>), dim3(n_chunks), dim3(256), 0, st, B, n_kept_ptr, rec, part, m, samp_off, total_out, scaling, pa_min, pa_max, samples, gcal);

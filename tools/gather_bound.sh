@@ -1,6 +1,7 @@
 #!/bin/bash
 # What bounds k_gather_chunks at k = 9: the product kernel built without window reads / without sample stores /
 # without the FP64 division (tools: make variant NAME=gc_* EXTRA=-DPG_PROBE_GC_*), one box, plus one PMC pass of the default build.
+# Round 6: the PG_PROBE_GC_* branches left the product sources; apply tools/probe/r05_timing_probes.patch (patch -p0 -R style: see its header) to a scratch copy first.
 #   bash tools/gather_bound.sh <tag>    -> gpurun_out/<tag>/summary.txt
 set -o pipefail
 tag=$1; shift
