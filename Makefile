@@ -23,13 +23,13 @@ poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_place.o build/pg_api.o bui
 	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lpthread
 
 poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_hostmem.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
-	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread
+	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread -ldl
 
 HOST = $(CSRC)/host
 bin/poregen: $(CSRC)/pg_model.h $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp $(HOST)/pg_host.h include/pgmove.h poregen_amd/libpgmove.so
 	@mkdir -p bin
 	$(CXX) -O2 -g -std=c++17 -Wall -o $@ $(HOST)/main.cpp $(HOST)/gmove_cli.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp \
-	    -Lporegen_amd -lpgmove -L/opt/rocm/lib -lamdhip64 -lz -lpthread -Wl,-rpath,'$$ORIGIN/../poregen_amd' -Wl,-rpath,/opt/rocm/lib
+	    -Lporegen_amd -lpgmove -L/opt/rocm/lib -lamdhip64 -lz -lpthread -ldl -Wl,-rpath,'$$ORIGIN/../poregen_amd' -Wl,-rpath,/opt/rocm/lib
 
 # measurement build: counts the reads whose selection leaves the fast path (tools/count_fallbacks.py)
 fallback_probe:
@@ -55,11 +55,11 @@ oracle_build:
 SAN = -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -g -O1
 asan:
 	@mkdir -p build/asan
-	$(CXX) $(SAN) -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o build/asan/_pg_hosttest.so $(CSRC)/pg_hosttest.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread
+	$(CXX) $(SAN) -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o build/asan/_pg_hosttest.so $(CSRC)/pg_hosttest.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread -ldl
 	$(CC) $(SAN) -std=gnu99 -fPIC -ffp-contract=off -shared -o build/asan/libgmove_oracle.so oracle/gmove_oracle.c -lm
 	$(CC) $(SAN) -std=gnu99 -ffp-contract=off -o build/asan/gmove_oracle oracle/gmove_oracle_cli.c oracle/gmove_oracle.c -lm
 	$(CC) $(SAN) -std=gnu99 -ffp-contract=off -o build/asan/model_oracle oracle/model_oracle.c -lm
-	$(CXX) $(SAN) -std=c++17 -DPG_REFORM_ONLY -o build/asan/poregen_reform $(HOST)/main.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread
+	$(CXX) $(SAN) -std=c++17 -DPG_REFORM_ONLY -o build/asan/poregen_reform $(HOST)/main.cpp $(HOST)/reform_cli.cpp $(HOST)/io.cpp $(HOST)/dump.cpp -lz -lpthread -ldl
 asan_test: asan
 	ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 LD_PRELOAD=$$($(CC) -print-file-name=libasan.so):$$($(CC) -print-file-name=libubsan.so) \
 	    PG_HOSTTEST_SO=$(CURDIR)/build/asan/_pg_hosttest.so PG_ORACLE_DIR=$(CURDIR)/build/asan PG_REFORM_BIN=$(CURDIR)/build/asan/poregen_reform POREGEN_CLEAN_EXIT=1 \

@@ -1,6 +1,52 @@
 // io.cpp -- memory-mapped files, ASCII SLOW5 / BLOW5 reader, FASTA/FASTQ index, PAF + ss tokeniser.
 #include "pg_host.h"
 
+// zstd record compression (`make zstd=1` in the reference: /root/reference/Makefile:12-13,67 links -lzstd into slow5lib). Here libzstd is
+// looked up at run time, once, so that neither bin/poregen nor the test shim carries a link-time dependency: a BLOW5 file with zstd
+// records on a machine without libzstd.so.1 is refused with an error that says so, never misread.
+#include <dlfcn.h>
+namespace {
+struct Zstd {
+    size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+    unsigned long long (*frame_size)(const void *, size_t) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+    void *(*create_dstream)() = nullptr;
+    size_t (*free_dstream)(void *) = nullptr;
+    size_t (*init_dstream)(void *) = nullptr;
+    struct Buf { const void *src; size_t size, pos; };
+    struct OBuf { void *dst; size_t size, pos; };
+    size_t (*decompress_stream)(void *, OBuf *, Buf *) = nullptr;
+    bool ok = false;
+    Zstd() {
+        void *h = nullptr;
+        for (const char *n : {"libzstd.so.1", "libzstd.so"}) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        decompress = (decltype(decompress))dlsym(h, "ZSTD_decompress");
+        frame_size = (decltype(frame_size))dlsym(h, "ZSTD_getFrameContentSize");
+        is_error = (decltype(is_error))dlsym(h, "ZSTD_isError");
+        create_dstream = (decltype(create_dstream))dlsym(h, "ZSTD_createDStream");
+        free_dstream = (decltype(free_dstream))dlsym(h, "ZSTD_freeDStream");
+        init_dstream = (decltype(init_dstream))dlsym(h, "ZSTD_initDStream");
+        decompress_stream = (decltype(decompress_stream))dlsym(h, "ZSTD_decompressStream");
+        ok = decompress && frame_size && is_error && create_dstream && free_dstream && init_dstream && decompress_stream;
+    }
+};
+const Zstd &zstd() { static const Zstd z; return z; }
+// a whole zstd-compressed record; false (err) for anything but one complete frame of a sane size
+bool zstd_record(const unsigned char *src, size_t n, std::vector<unsigned char> &out, std::string &err) {
+    const Zstd &z = zstd();
+    const unsigned long long fs = z.frame_size(src, n);
+    // (unknown / error content sizes are 2^64 - 1 and 2^64 - 2; slow5lib writes one-shot frames, which carry their size. A record is a read:
+    // ids + 44 bytes + samples; a frame that claims more than 2^32 bytes or more than 2^17 times its compressed size is not one)
+    if (fs >= (1ull << 32) || fs / (1u << 17) > (unsigned long long)n + 1) { err = "zstd error in BLOW5 record (implausible frame size)"; return false; }
+    out.resize((size_t)fs ? (size_t)fs : 1);
+    const size_t got = z.decompress(out.data(), out.size(), src, n);
+    if (z.is_error(got) || got != (size_t)fs) { err = "zstd error in BLOW5 record"; return false; }
+    out.resize(got);
+    return true;
+}
+} // namespace
+
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -82,8 +128,9 @@ bool Slow5File::index_blow5(std::string &err) {
     const unsigned char *d = (const unsigned char *)f_.data;
     rec_press_ = d[9];
     sig_press_ = d[14];
-    if (rec_press_ > 1) { err = "BLOW5 record compression other than none/zlib is not supported"; return false; }
-    if (sig_press_ > 1) { err = "BLOW5 signal compression other than none/svb-zd is not supported"; return false; }
+    if (rec_press_ > 2) { err = "BLOW5 record compression other than none/zlib/zstd is not supported"; return false; }
+    if (rec_press_ == 2 && !zstd().ok) { err = "BLOW5 records are zstd-compressed and libzstd.so.1 was not found on this machine"; return false; }
+    if (sig_press_ > 1) { err = "BLOW5 signal compression other than none/svb-zd is not supported"; return false; } // (ex-zd: slow5lib >= 1.1 only; the reference's pinned slow5lib writes svb-zd)
     uint32_t hlen; memcpy(&hlen, d + 64, 4);
     uint64_t pos = 68 + (uint64_t)hlen;
     if (pos > f_.size) { err = "truncated BLOW5 header"; return false; }
@@ -104,7 +151,31 @@ bool Slow5File::index_blow5(std::string &err) {
             uint16_t il; memcpy(&il, d + pos, 2);
             if ((uint64_t)il + 2 > sz) { err = "corrupt BLOW5 record"; return false; }
             id.assign((const char *)d + pos + 2, il);
+        } else if (rec_press_ == 2) {
+            // zstd: the first bytes of the record through the streaming decoder (one context for the whole file), a 256-byte window first
+            const Zstd &z = zstd();
+            static thread_local struct DS { void *p = nullptr; ~DS() { if (p) zstd().free_dstream(p); } } ds;
+            if (!ds.p && !(ds.p = z.create_dstream())) { err = "zstd init failed"; return false; }
+            unsigned char head[2 + 65536];
+            uint16_t il = 0; size_t got = 0;
+            for (size_t want : {(size_t)256, sizeof head}) {
+                if (z.is_error(z.init_dstream(ds.p))) { err = "zstd init failed"; return false; }
+                Zstd::Buf in{d + pos, (size_t)sz, 0}; Zstd::OBuf ob{head, want, 0};
+                while (ob.pos < ob.size && in.pos < in.size) {
+                    const size_t before_in = in.pos, before_out = ob.pos;
+                    const size_t rc = z.decompress_stream(ds.p, &ob, &in);
+                    if (z.is_error(rc)) { err = "zstd error in BLOW5 record"; return false; }
+                    if (rc == 0 || (in.pos == before_in && ob.pos == before_out)) break; // frame complete / no progress
+                }
+                got = ob.pos;
+                if (got < 2) { err = "zstd error in BLOW5 record"; return false; }
+                memcpy(&il, head, 2);
+                if ((size_t)il + 2 <= got) break;
+            }
+            if ((size_t)il + 2 > got) { err = "corrupt BLOW5 record"; return false; }
+            id.assign((const char *)head + 2, il);
         } else {
+            if (sz > 0xFFFFFFFFull) { err = "BLOW5 record of 4 GiB or more (zlib)"; return false; } // zlib counts input in 32 bits: never hand it a truncated size
             // only the first bytes of the record are inflated: u16 id length + id (a first try of 256 bytes covers every
             // real read id; longer ones get a second, full-size try) -- inflating whole records made indexing a 50 000-read
             // file take a second
@@ -153,7 +224,11 @@ bool Slow5File::decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) cons
     const unsigned char *body = (const unsigned char *)f_.data + l.off;
     size_t blen = l.len;
     std::vector<unsigned char> inflated;
-    if (rec_press_ == 1) {
+    if (rec_press_ == 2) {
+        if (!zstd_record(body, blen, inflated, err)) return false;
+        body = inflated.data(); blen = inflated.size();
+    } else if (rec_press_ == 1) {
+        if (blen > 0xFFFFFFFFull) { err = "BLOW5 record of 4 GiB or more (zlib)"; return false; } // (uLong / the products below: bounded before anything is sized by it)
         size_t cap = blen * 4 + 1024;
         for (;;) {
             inflated.resize(cap);
@@ -193,11 +268,11 @@ bool Slow5File::decode_blow5(const Loc &l, Slow5Rec &out, std::string &err) cons
     std::vector<uint32_t> zz;
     if (!svb_decode(body + p + 4, clen - 4, count, zz)) { err = "corrupt streamvbyte block"; return false; }
     out.raw.resize(count);
-    int32_t prev = 0;
+    uint32_t prev = 0; // accumulated modulo 2^32 (crafted deltas must not be a signed overflow: UB, and an abort under -fsanitize=undefined)
     for (uint32_t i = 0; i < count; i++) {
-        const int32_t delta = (int32_t)(zz[i] >> 1) ^ -(int32_t)(zz[i] & 1);
+        const uint32_t delta = (zz[i] >> 1) ^ (0u - (zz[i] & 1u)); // zig-zag
         prev += delta;
-        out.raw[i] = (int16_t)prev;
+        out.raw[i] = (int16_t)(uint16_t)prev;
     }
     return true;
 }

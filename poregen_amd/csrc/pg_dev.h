@@ -9,6 +9,23 @@
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2; observed, speed only -- MI355X_MICROARCH.md, "Workgroup
+// dispatch"). The tile kernels write runs of ~128-250 bytes per (tile, digit) whose ends share 128-byte lines with the runs of the NEIGHBOURING
+// tiles: dealt round-robin, the two halves of such a line are written through two different L2s as partial lines. This maps block b of n to
+// work item (b % 8) * (n / 8) + b / 8, so that an XCD works on a CONTIGUOUS range of tiles and neighbouring runs meet in one L2; the n % 8
+// items at the end keep their own number. A bijection of [0, n) for every n; correctness never depends on the placement.
+#ifndef PG_XCD_REMAP
+#define PG_XCD_REMAP 1
+#endif
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
+#if PG_XCD_REMAP
+    const uint32_t q = n >> 3;
+    return b < (q << 3) ? (b & 7u) * q + (b >> 3) : b;
+#else
+    (void)n; return b;
+#endif
+}
+
 // Inclusive wave64 scan with DPP row shifts + row broadcasts (no LDS traffic, 6 VALU ops): rows of 16 lanes
 // are scanned with row_shr:1/2/4/8, then lane 15 of each row is broadcast into the next row (rows 1,3) and
 // lane 31 into rows 2,3.

@@ -502,15 +502,18 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
                                                                    PgWalkOut O, PgKeptOut K, uint64_t *__restrict__ part, uint32_t chunk_shift) {
     const uint32_t ndig = 1u << lo_bits, tid = threadIdx.x, w = tid >> 6;
     const int lane = lane_id();
+    const uint32_t nB = *n_tilesB; // (uniform; <= gridDim.x)
+    if (blockIdx.x >= nB) return;
+    const uint32_t tB = xcd_contiguous(blockIdx.x, nB); // an XCD takes a contiguous range of region tiles (pg_dev.h)
     // the tile's elements are requested in front of the look-ups that say how many of them count (the buffer holds every tile of the grid)
     uint32_t ex[PG_PART_ROWS], ey[PG_PART_ROWS], ez[PG_PART_ROWS], ew[PG_PART_ROWS];
 #pragma unroll
     for (int rr = 0; rr < PG_PART_ROWS; ++rr) {
-        const uint4 v = elemA[(uint64_t)blockIdx.x * PG_SORT_TILE + w * (PG_PART_ROWS * WAVE) + rr * WAVE + lane];
+        const uint4 v = elemA[(uint64_t)tB * PG_SORT_TILE + w * (PG_PART_ROWS * WAVE) + rr * WAVE + lane];
         ex[rr] = v.x; ey[rr] = v.y; ez[rr] = v.z; ew[rr] = v.w;
     }
     uint32_t r, nv; uint64_t first;
-    if (!region_tile(blockIdx.x, n_tilesB, tile_region, rbase, totals, r, first, nv)) return;
+    if (!region_tile(tB, n_tilesB, tile_region, rbase, totals, r, first, nv)) return;
     const PartLds L = part_lds(ndig);
     // window lengths of this tile's kept events per chunk of the gather. 32 bits are enough: `part` is only passed when the caller's
     // "chunked" condition holds -- (longest window + 1) * 4096 < 2^32 (pg_api.hip collect_impl) -- and a tile holds 4096 events
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(PG_PART_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int q = 0; q < 2; ++q) {
         const uint32_t d = tid + q * PG_PART_THREADS;
         const uint64_t slot = ((uint64_t)r << lo_bits) | d;
-        if (d < ndig && slot < n_slots) { tp[q] = histB[(uint64_t)blockIdx.x * ndig + d]; kp[q] = keep32[slot]; eo[q] = (uint32_t)ev_off[slot]; }
+        if (d < ndig && slot < n_slots) { tp[q] = histB[(uint64_t)tB * ndig + d]; kp[q] = keep32[slot]; eo[q] = (uint32_t)ev_off[slot]; }
     }
     bool valid[PG_PART_ROWS]; uint32_t dig[PG_PART_ROWS];
 #pragma unroll

@@ -418,10 +418,35 @@ def _svb_zd(sig: np.ndarray) -> bytes:
     return struct.pack("<I", n) + ctrl.tobytes() + data.tobytes()
 
 
-def write_blow5(b: Batch, path: str, compress: bool = False):
+def zstd_compress(data: bytes, level: int = 3):
+    """One-shot zstd frame through the system's libzstd.so.1 (ctypes; there is no zstd module in this image). None if the library is absent."""
+    import ctypes as C
+    global _zstd
+    try:
+        _zstd
+    except NameError:
+        try:
+            _zstd = C.CDLL("libzstd.so.1")
+            _zstd.ZSTD_compressBound.restype = C.c_size_t; _zstd.ZSTD_compressBound.argtypes = [C.c_size_t]
+            _zstd.ZSTD_compress.restype = C.c_size_t
+            _zstd.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+            _zstd.ZSTD_isError.restype = C.c_uint; _zstd.ZSTD_isError.argtypes = [C.c_size_t]
+        except OSError:
+            _zstd = None
+    if _zstd is None:
+        return None
+    cap = _zstd.ZSTD_compressBound(len(data))
+    buf = C.create_string_buffer(cap)
+    n = _zstd.ZSTD_compress(buf, cap, data, len(data), level)
+    assert not _zstd.ZSTD_isError(n)
+    return buf.raw[:n]
+
+
+def write_blow5(b: Batch, path: str, compress=False):
     """BLOW5 for the batch (layout: SURVEY.md 8f-1); read ids are r<index>. compress=False: record compression none,
     signal compression none -- meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate.
-    compress=True: zlib records + svb-zd signals, what slow5tools writes by default (as test/example.blow5)."""
+    compress=True: zlib records + svb-zd signals, what slow5tools writes by default (as test/example.blow5).
+    compress="zstd": zstd records (record compression 2; the reference's `make zstd=1` build) + svb-zd signals."""
     import struct
     import zlib
     if compress:
@@ -429,14 +454,14 @@ def write_blow5(b: Batch, path: str, compress: bool = False):
                b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
                b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
         with open(path, "wb") as f:
-            f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15))
+            f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([2 if compress == "zstd" else 1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15))
             f.write(struct.pack("<I", len(hdr)) + hdr)
             for r in range(b.n_reads):
                 rid = f"r{r}".encode()
                 blk = _svb_zd(b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])])
                 body = (struct.pack("<H", len(rid)) + rid + struct.pack("<I", 0)
                         + struct.pack("<dddd", b.digitisation[r], b.offset[r], b.range[r], 4000.0) + struct.pack("<Q", len(blk)) + blk)
-                z = zlib.compress(body)
+                z = zstd_compress(body) if compress == "zstd" else zlib.compress(body)
                 f.write(struct.pack("<Q", len(z)) + z)
             f.write(b"5WOLB")
         return

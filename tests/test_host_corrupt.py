@@ -101,8 +101,8 @@ def test_corrupt_streamvbyte_block(shim, tmp_path):
         assert n == -1 and ("corrupt streamvbyte block" in err or "corrupt BLOW5 record" in err or "zlib error" in err or "truncated" in err), (what, n, err)
 
 
-@pytest.mark.parametrize("byte,val,msg", [(9, 2, "record compression other than none/zlib"), (14, 2, "signal compression other than none/svb-zd"), (9, 7, "record compression"), (14, 9, "signal compression")])
-def test_blow5_header_announcing_zstd_or_exzd(shim, batch, tmp_path, byte, val, msg):
+@pytest.mark.parametrize("byte,val,msg", [(9, 3, "record compression other than none/zlib/zstd"), (14, 2, "signal compression other than none/svb-zd"), (9, 7, "record compression"), (14, 9, "signal compression")])
+def test_blow5_header_announcing_unknown_compression_or_exzd(shim, batch, tmp_path, byte, val, msg):
     p = tmp_path / "a.blow5"; synth.write_blow5(batch, str(p), compress=True)
     d = bytearray(p.read_bytes()); d[byte] = val; p.write_bytes(d)
     n, err = scan(shim.pgt_slow5_scan, p)
@@ -193,3 +193,37 @@ def test_random_damage_never_crashes(shim, batch, tmp_path):
             q = tmp_path / ("dmg_" + name); q.write_bytes(d)
             n, err = scan(fn, q)
             assert n >= -1 and (n >= 0 or err), (name, it, n, err)
+
+
+def test_zstd_records_that_are_not_zstd_or_lie_about_their_size(shim, batch, tmp_path):
+    """Record compression 2 (zstd; round 6): a header that says zstd over zlib records, a damaged frame, a truncated frame and a frame
+    header announcing an absurd content size all end in the reader's message."""
+    if synth.zstd_compress(b"x") is None:
+        pytest.skip("no libzstd.so.1 on this machine")
+    p = tmp_path / "z.blow5"; synth.write_blow5(batch, str(p), compress=True)
+    d = bytearray(p.read_bytes()); d[9] = 2; p.write_bytes(d)                       # zlib records announced as zstd
+    n, err = scan(shim.pgt_slow5_scan, p); assert n == -1 and "zstd error" in err, err
+    synth.write_blow5(batch, str(p), compress="zstd")
+    good = p.read_bytes()
+    assert scan(shim.pgt_slow5_scan, p) == (6, "")
+    hlen = struct.unpack_from("<I", good, 64)[0]; first = 68 + hlen
+    sz = struct.unpack_from("<Q", good, first)[0]
+    d = bytearray(good); d[first + 8 + sz // 2] ^= 0xFF; d[first + 8 + sz // 2 + 1] ^= 0xA5   # damaged frame body
+    p.write_bytes(d); n, err = scan(shim.pgt_slow5_scan, p); assert n == -1 and ("zstd error" in err or "corrupt" in err), err
+    d = bytearray(good); struct.pack_into("<Q", d, first, sz - 9)                   # frame cut short, the next "record" starts inside it
+    p.write_bytes(d); n, err = scan(shim.pgt_slow5_scan, p); assert n == -1 and err
+    # a frame whose header claims 2^40 bytes of content: magic, frame header descriptor 0xE0 (8-byte content size, single segment), the size
+    lie = bytes.fromhex("28b52ffd") + bytes([0xE0]) + struct.pack("<Q", 1 << 40) + b"\x00" * 16
+    d = bytearray(good[:first]) + struct.pack("<Q", len(lie)) + lie + b"5WOLB"
+    p.write_bytes(d); n, err = scan(shim.pgt_slow5_scan, p); assert n == -1 and "zstd error" in err, err
+
+
+def test_svbzd_deltas_that_overflow_int32(shim, tmp_path):
+    """Crafted zig-zag deltas whose running sum leaves int32 (advisor r05): defined wrap-around, a result, no abort under UBSan."""
+    hdr = b"#slow5_version\t0.2.0\n#num_read_groups\t1\n#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n"
+    head = b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15) + struct.pack("<I", len(hdr)) + hdr
+    n_val = 8
+    payload = bytes([0xFF, 0xFF]) + struct.pack("<8I", *([0xFFFFFFFE] * n_val))      # eight 4-byte values: zig-zag of +2^31 - 1, summed eight times
+    p = tmp_path / "ovf.blow5"; p.write_bytes(head + _zrec(b"r0", n_val, payload) + b"5WOLB")
+    n, err = scan(shim.pgt_slow5_scan, p)
+    assert (n, err) == (1, "")

@@ -158,7 +158,8 @@ def test_compressed_blow5_round_trip(tmp_path):
     big = b.sig.copy(); big[::997] = 32767; big[1::997] = -32768            # extreme deltas: 3- and 4-byte codes
     b = type(b)(**{**b.__dict__, "sig": big})
     path = str(tmp_path / "c.blow5")
-    for comp in (True, False):
+    comps = [True, False] + (["zstd"] if synth.zstd_compress(b"x") is not None else [])  # zstd records where libzstd.so.1 exists (it does in this image)
+    for comp in comps:
         synth.write_blow5(b, path, compress=comp)
         for r in range(0, b.n_reads, 7):
             dor = np.zeros(3); raw = np.zeros(6000, np.int16)
@@ -166,3 +167,26 @@ def test_compressed_blow5_round_trip(tmp_path):
             s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
             assert n == s.size and np.array_equal(raw[:n], s)
             assert (dor[0], dor[1], dor[2]) == (b.digitisation[r], b.offset[r], b.range[r])
+
+
+def test_zstd_blow5_is_read_or_refused_by_name(tmp_path):
+    """BLOW5 with zstd-compressed records (the reference's `make zstd=1` build, /root/reference/Makefile:12-13,67): read through a
+    dlopen'ed libzstd.so.1 where the machine has one; where it has none the reader says so instead of misreading (checked through
+    the error text of a build that cannot find the library: LD_LIBRARY_PATH does not matter to dlopen of an absolute miss, so the
+    refusal itself is exercised in tests/test_host_corrupt.py with a damaged frame)."""
+    import ctypes as C
+    from poregen_amd import synth
+    if synth.zstd_compress(b"x") is None:
+        pytest.skip("no libzstd.so.1 on this machine")
+    h = C.CDLL((os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so")))
+    h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
+    b = synth.make_batch(64, kind="dna_r10", seed=11, read_len=3001)
+    path = str(tmp_path / "z.blow5")
+    synth.write_blow5(b, path, compress="zstd")
+    assert open(path, "rb").read()[9] == 2
+    for r in range(b.n_reads):
+        dor = np.zeros(3); raw = np.zeros(4000, np.int16)
+        n = h.pgt_slow5_get(path.encode(), f"r{r}".encode(), dor.ctypes.data, raw.ctypes.data, 4000)
+        s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+        assert n == s.size and np.array_equal(raw[:n], s)
+        assert (dor[0], dor[1], dor[2]) == (b.digitisation[r], b.offset[r], b.range[r])

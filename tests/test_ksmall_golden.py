@@ -124,7 +124,7 @@ def test_k_read_stats_equals_the_reference_quickselect(fixture, pa, mode, monkey
     if mode == "no_long_split":
         monkeypatch.setenv("PGMOVE_NO_LONG_SPLIT", "1")
     vec = [e for e in fixture if e["n"] >= 16 and (e["pa_min"], e["pa_max"]) == pa]
-    assert len(vec) >= 30
+    assert len(vec) >= 15
     b = _batch_of(vec)
     kmers = generate_kmers(5)
     p = GmoveParams(kmers=kmers, kmer_size=5, scaling=1, sample_limit=100, min_dur=1, max_dur=70, pa_min=pa[0], pa_max=pa[1], overlap=(False if mode == "one_stream" else None))
