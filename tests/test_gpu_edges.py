@@ -419,3 +419,22 @@ def test_long_reads_split_across_waves_equal_the_oracle(monkeypatch, mode):
         assert 1 <= split < 5 and st["long_helpers_short_batches"][0] == 1
     else:
         assert split == 5, st   # 40 001, 10^6, 32 769, 250 000, 65 537 (32 768 itself is not above the threshold)
+
+
+def test_long_histograms_are_zero_before_the_statistics_stream_uses_them():
+    """Advisor r05 (high): in the default two-stream mode the zero-fill of a freshly grown long-read histogram buffer was queued on the chain's
+    stream while the statistics that add into it ran on the second one. Several thousand helpers (a fill of tens of MB) from a HOST batch, then a
+    second batch that reuses the buffer as the first left it: medians, MADs and every kept sample are the oracle's."""
+    L = np.full(400, 200_000, np.int64); L[::7] = 150_001; L[3::11] = 40_000          # 12 / 9 / 2 helper slices per read: ~4 300 helpers
+    b1 = synth.make_ragged_fast(L, kind="dna_r10", seed=61)
+    b2 = synth.make_ragged_fast(L[::-1].copy(), kind="dna_r10", seed=62)
+    kmers = generate_kmers(5)
+    p = dict(kmer_size=5, scaling=1, sample_limit=4000)
+    o = oracle_for(kmers, **p); o.run_batch(b1); o.run_batch(b2)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))                                   # the library's default: PG_FLAG_OVERLAP
+    eng.submit(b1); eng.submit(b2)
+    res = eng.finish()
+    st = eng.kernel_stats()
+    eng.close()
+    assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
+    assert st.get("long_reads_split", (0, 0.0))[0] == 2 * L.size and st.get("long_helpers_short_batches", (0, 0.0))[0] == 0, st
