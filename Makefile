@@ -15,14 +15,14 @@ all: poregen_amd/libpgmove.so poregen_amd/_pg_hosttest.so bin/poregen oracle_bui
 # libpgmove.so deliberately does NOT carry a DT_NEEDED on libamdhip64: a process must hold exactly one HIP
 # runtime, and under Python that has to be the copy PyTorch bundles (poregen_amd/_abi.py preloads it
 # RTLD_GLOBAL); the CLI links /opt/rocm's libamdhip64 itself.
-build/%.o: $(CSRC)/%.hip $(CSRC)/pg_internal.h $(CSRC)/pg_dev.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h include/pgmove.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/pg_job_rule.h $(CSRC)/pg_internal.h $(CSRC)/pg_dev.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h include/pgmove.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 poregen_amd/libpgmove.so: build/pg_kernels.o build/pg_place.o build/pg_api.o build/pg_model.o build/pg_job.o build/pg_text.o
 	$(CXX) -shared -o $@ $^ -Wl,--allow-shlib-undefined -ldl -lpthread
 
-poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_hostmem.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
+poregen_amd/_pg_hosttest.so: $(CSRC)/pg_hosttest.cpp $(CSRC)/pg_job_rule.h $(CSRC)/pg_hostmem.h $(CSRC)/pg_select.h $(CSRC)/pg_model.h $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp $(CSRC)/host/pg_host.h
 	$(CXX) -O2 -std=c++17 -fPIC -shared -ffp-contract=off -I$(CSRC) -o $@ $(CSRC)/pg_hosttest.cpp $(CSRC)/host/io.cpp $(CSRC)/host/dump.cpp -lz -lpthread -ldl
 
 HOST = $(CSRC)/host

@@ -201,6 +201,15 @@ int gmove_main(int argc, char **argv) {
     const size_t n_shards = devices.empty() ? 1 : devices.size();
     if (!batch_reads_set) batch_reads = (uint32_t)std::min<uint64_t>(20000ull * n_shards, 0x7fffffffull);
     const size_t batch_samples_cap = ((size_t)1 << 29) * n_shards; // and so does the byte budget of a batch (1 GB of samples per device)
+    // The reference stops reading once every k-mer of the WHOLE list is complete (gmove.cpp:733-735): at the default sample_limit that is a few
+    // thousand reads into the file. A first batch of 20 000 reads then does ~6 x the reference's work before anyone can look,
+    // so a whole-list job at the default batch size ramps up: 2 048 reads per device, then twice that, ... up to --batch_reads -- the job ends
+    // within a factor of two of the completing read, a job that never completes pays four small batches. An explicit --batch_reads, or a
+    // slice (which reads every line anyway), keeps its one size. (POREGEN_BATCH_RAMP=0: off, =N: first batch of N reads per device.)
+    uint32_t ramp_reads = batch_reads; // reads of the NEXT batch; doubled by next_batch_reads() up to batch_reads
+    bool ramp_armed = !batch_reads_set; // ... and only for a job on the whole list (known below: whole_list)
+    if (const char *rv = getenv("POREGEN_BATCH_RAMP")) { const long v = atol(rv); if (v <= 0) ramp_armed = false; else { ramp_armed = true; ramp_reads = (uint32_t)std::min<uint64_t>((uint64_t)v * n_shards, batch_reads); } }
+    else if (ramp_armed) ramp_reads = (uint32_t)std::min<uint64_t>(2048ull * n_shards, batch_reads);
     if (getenv("POREGEN_BATCH_PROBE")) fprintf(stderr, "[batch probe] batch_reads %u (%zu device%s x %u)\n", batch_reads, n_shards, n_shards == 1 ? "" : "s", (unsigned)(batch_reads / n_shards));
     // the HIP runtime takes 0.1-0.2 s to come up: it starts NOW, on a thread of its own, next to the directory set-up, the k-mer list,
     // the file indices and the parsing of the first batch; the context is created behind it
@@ -287,6 +296,9 @@ int gmove_main(int argc, char **argv) {
     }
     prm.scaling = scaling; prm.allow_rna = opt.flag_rna; prm.pa_min = opt.pa_min; prm.pa_max = opt.pa_max;
     const bool whole_list = slot_kmers.size() == kmers.size(); // only then can the reference's loop end early (gmove.cpp:733-735)
+    if (!whole_list || !ramp_armed) ramp_reads = batch_reads; // the ramp of the batch sizes (above) is for jobs that can end early
+    auto next_batch_reads = [&]() -> uint32_t { const uint32_t v = ramp_reads; ramp_reads = (uint32_t)std::min<uint64_t>(2ull * ramp_reads, batch_reads); return v; };
+    uint32_t this_batch_reads = next_batch_reads();
     prm.n_slots = (uint32_t)slot_kmers.size(); prm.flags = PG_FLAG_ONE_STREAM /* a job of a few batches: no second hardware queue (15-20 ms) */ | (whole_list ? PG_FLAG_STOP_WHEN_FULL : 0) | (lazy ? PG_FLAG_LAZY_STATS : 0) | (is_paf ? 0 : PG_FLAG_SHORT_READS_OK) | (is_bam ? PG_FLAG_SKIP_OUT_OF_RANGE : 0);
     prm.device = device;
     prm.table_t = table_t.data(); prm.table_u = table_u.data();
@@ -367,6 +379,7 @@ int gmove_main(int argc, char **argv) {
         t_device += secs(tf0, clk::now());
         cur ^= 1;
         hbs[cur].clear();
+        this_batch_reads = next_batch_reads();
         // every k-mer of the WHOLE list complete: the reference stops reading (gmove.cpp:733-735). With a slice it reads on (and would
         // still fail on a malformed later line), so we do too. Asked without waiting: this is the state behind the batch before the one
         // just queued; a batch too many changes nothing in the output (its events rank behind the complete files').
@@ -438,7 +451,7 @@ int gmove_main(int argc, char **argv) {
         while (!stop && !eof && status == EXIT_SUCCESS) {
             size_t n_lines = 0;
             const clk::time_point tp0 = clk::now();
-            while (n_lines < batch_reads) {
+            while (n_lines < this_batch_reads) {
                 if ((got = getline(&line, &cap, paf_fp)) == -1) { eof = true; break; }
                 if (n_lines == lines.size()) lines.emplace_back();
                 lines[n_lines++].assign(line, (size_t)got);
@@ -605,7 +618,7 @@ int gmove_main(int argc, char **argv) {
         hbs[cur].seq.insert(hbs[cur].seq.end(), seq.begin(), seq.end()); hbs[cur].seq_off.push_back(hbs[cur].seq.size());
         hbs[cur].op_off.push_back(hbs[cur].op_n.size());
         if (++count_reads % 10000 == 0) fprintf(stderr, "*"); // PROGRESS_BATCH_SIZE
-        if (hbs[cur].n() >= batch_reads || hbs[cur].sig.size() >= batch_samples_cap) { if (!flush()) { status = EXIT_FAILURE; flush_failed = true; break; } }
+        if (hbs[cur].n() >= this_batch_reads || hbs[cur].sig.size() >= batch_samples_cap) { if (!flush()) { status = EXIT_FAILURE; flush_failed = true; break; } }
     }
     if (status == EXIT_FAILURE && !is_paf && !flush_failed && whole_list) {
         // A RECORD error (a failed submit / device error is never rescued): the reference may never have read that record -- it stops once

@@ -207,3 +207,10 @@ extern "C" long pgt_sambam_scan(const char *path, char *errbuf, size_t cap) {
     }
     return n;
 }
+
+// the placement of a rank's statistics relative to the count exchange (pg_job_rule.h): 1 = behind the wait, 0 = in front of it
+#include "pg_job_rule.h"
+extern "C" int pgt_job_stats_rule(uint32_t rank, const uint64_t *shard_ops, const uint64_t *shard_reads, uint32_t n_slots, uint64_t sample_limit,
+                                  int have_batch, uint64_t full_slots_prev, const char *mode) {
+    return (int)pg_job_stats_place(rank, shard_ops, shard_reads, n_slots, sample_limit, have_batch != 0, full_slots_prev, mode && *mode ? mode : nullptr);
+}

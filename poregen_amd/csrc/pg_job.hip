@@ -12,6 +12,7 @@
 // queued on the compute stream behind its ISSUE and hide its latency. Host code only; every kernel lives in pg_kernels.hip.
 // RCCL is resolved with dlopen at the first job that needs it, so libpgmove.so carries no DT_NEEDED on it (a process must
 // hold one copy: PyTorch's under Python, /opt/rocm's otherwise).
+#include "pg_job_rule.h"
 #include "../../include/pgmove.h"
 #include "pg_internal.h"
 #include "pg_hostmem.h"
@@ -314,6 +315,18 @@ pg_status pg_job_submit_shards(pg_job *j, const pg_batch *shards, uint32_t n_sha
     for (uint32_t g = 0; g < n; ++g) {
         if (shards[g].struct_size != sizeof(pg_batch)) return jfail(j, PG_ERR_INVALID_ARG, "pg_batch.struct_size mismatch (shard %u)", g);
         if (shards[g].location != PG_LOC_DEVICE && shards[g].location != PG_LOC_HOST) return jfail(j, PG_ERR_INVALID_ARG, "shard %u: pg_batch.location", g);
+        if (shards[g].location == PG_LOC_DEVICE && shards[g].n_reads) {
+            // a device shard must live on the device that works it (advisor r05): one attribute query per shard and submit. A pointer the
+            // runtime does not know (or managed / host memory) is refused here rather than faulting inside the first kernel that reads it.
+            const void *probe[] = {shards[g].sig, shards[g].sig_off, shards[g].op_n, shards[g].seq};
+            for (const void *ptr : probe) {
+                hipPointerAttribute_t at; memset(&at, 0, sizeof at);
+                const hipError_t e = ptr ? hipPointerGetAttributes(&at, ptr) : hipErrorInvalidValue;
+                if (e != hipSuccess) { (void)hipGetLastError(); return jfail(j, PG_ERR_INVALID_ARG, "shard %u: a PG_LOC_DEVICE array is not device memory known to the runtime", g); }
+                if (at.type != hipMemoryTypeDevice || at.device != j->devices[g])
+                    return jfail(j, PG_ERR_INVALID_ARG, "shard %u: its arrays live on device %d, the job works it on device %d", g, at.device, j->devices[g]);
+            }
+        }
         cut[g + 1] = cut[g] + shards[g].n_reads;
         shard_ops[g] = shards[g].location == PG_LOC_DEVICE ? shards[g].n_ops : (shards[g].op_off ? shards[g].op_off[shards[g].n_reads] : 0); // (0 = unknown to the host)
     }
@@ -368,12 +381,14 @@ static pg_status job_exchange_and_collect(pg_job *j, std::vector<uint64_t> &&cut
         // the one batch that completes the job. Plausible = the ops of the ranks below, spread evenly over the k-mers, could fill what the
         // earlier batches left open (ops_below / n_slots >= sample_limit * share of k-mers still open; an unknown op count counts as
         // plausible). configs[2] at the default limit: every rank behind the first; k = 9 (60 ops per k-mer and rank against a limit of
-        // 1000): no rank, the statistics stay in front of the wait. UNMEASURED on more than one GPU (no such node in this pool).
-        uint64_t ops_below = 0; bool ops_known = true;
-        for (uint32_t h = 0; h < g; ++h) { ops_below += shard_ops[h]; if (!shard_ops[h] && cut[h + 1] > cut[h]) ops_known = false; }
-        const double open_share = j->have_batch ? 1.0 - (double)j->full_slots_prev / (double)(ns ? ns : 1) : 1.0;
-        const bool plausible = !ops_known || (double)ops_below / (double)(ns ? ns : 1) >= (double)j->sample_limit * open_share || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr;
-        const bool dev_rule = !done_before && g > 0 && j->sample_limit > 0 && plausible && (j->use_rccl || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr);
+        // 1000): no rank, the statistics stay in front of the wait. UNMEASURED on more than one GPU (no such node in this pool): the rule lives
+        // in pg_job_rule.h, is unit-tested there and can be overridden (PGMOVE_JOB_STATS_RULE=front|behind|auto).
+        std::vector<uint64_t> reads_below(g ? g : 1, 0);
+        for (uint32_t h = 0; h < g; ++h) reads_below[h] = cut[h + 1] - cut[h];
+        // (PGMOVE_JOB_DEVICE_RULE=1: the rule of the device exchange on the host exchange too, every rank > 0 behind the wait: tests on one GPU)
+        const char *rule_mode = getenv("PGMOVE_JOB_DEVICE_RULE") ? "behind" : getenv("PGMOVE_JOB_STATS_RULE");
+        const bool behind = pg_job_stats_place(g, shard_ops.data(), reads_below.data(), ns, j->sample_limit, j->have_batch, j->full_slots_prev, rule_mode) == PG_JOB_STATS_BEHIND;
+        const bool dev_rule = !done_before && behind && (j->use_rccl || getenv("PGMOVE_JOB_DEVICE_RULE") != nullptr);
         bool skip = done_before;
         if (!skip && !dev_rule && !j->use_rccl && j->sample_limit > 0) {
             skip = true;

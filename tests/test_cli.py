@@ -424,3 +424,39 @@ def test_gmove_exits_1_on_a_corrupt_blow5(tmp_path, damage):
     r = subprocess.run([BIN, "gmove", "-k", "5", "--file_limit", "1024", str(p), str(tmp_path / "r.paf"), "--fastq", str(tmp_path / "r.fastq"), str(tmp_path / "out")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and msg in r.stderr, (r.returncode, r.stderr[-400:])
+
+
+@pytest.mark.gpu
+def test_whole_list_job_ramps_its_batches_and_stops_near_the_completing_read(tmp_path):
+    """The reference stops reading at the read that completes the last k-mer (gmove.cpp:733-735). A whole-list job at the default batch
+    size ramps its batches (2 048 reads, 4 096, ...; POREGEN_BATCH_RAMP=N: N, 2N, ...) so that it ends within a factor of two of that read
+    instead of working through a first batch of 20 000: same directory as the oracle CLI, far fewer reads read than the file holds; an
+    explicit --batch_reads and a slice keep their one size."""
+    import re
+    b = synth.make_batch(1500, read_len=3000, kind="rna004", seed=17)
+    pre = str(tmp_path / "syn")
+    synth.write_blow5(b, pre + ".blow5"); synth.write_paf_fastq(b, pre)
+    args = [pre + ".blow5", pre + ".paf", "--fastq", pre + ".fastq", "-k", "3", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40",
+            "--file_limit", "64", "--sample_limit", "20"]
+    synth.write_files(b, pre)                                                # (the oracle CLI reads ASCII SLOW5)
+    o = oracle_cli([pre + ".slow5"] + args[1:] + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+
+    def reads_read(r):
+        m = re.search(r"\[gmove\] (\d+) reads, (\d+) samples", r.stderr)
+        assert m, r.stderr
+        return int(m.group(1))
+    r = cli(args + [tmp_path / "gpu"], env=dict(os.environ, POREGEN_BATCH_RAMP="16")); assert r.returncode == 0, r.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
+    n_ramp = reads_read(r)
+    r1 = cli(args + [tmp_path / "gpu1"]); assert r1.returncode == 0, r1.stderr          # default: first batch 2 048 > the file: one batch
+    assert_same_dirs(tmp_path / "gpu1", tmp_path / "cpu")
+    assert reads_read(r1) == 1500
+    assert n_ramp < 600, n_ramp                                                           # 16 + 32 + ... : a small multiple of the completing read
+    r2 = cli(args + [tmp_path / "gpu2", "--batch_reads", "700"], env=dict(os.environ, POREGEN_BATCH_RAMP="0")); assert r2.returncode == 0
+    assert_same_dirs(tmp_path / "gpu2", tmp_path / "cpu")
+    assert reads_read(r2) in (700, 1400)
+    sl = [x if x != "64" else "10" for x in args]                                        # a slice reads every line, in batches of one size
+    r3 = cli(sl + [tmp_path / "gpu3"], env=dict(os.environ, POREGEN_BATCH_RAMP="16")); assert r3.returncode == 0, r3.stderr
+    assert reads_read(r3) == 1500
+    o3 = oracle_cli([pre + ".slow5"] + sl[1:] + [tmp_path / "cpu3"]); assert o3.returncode == 0
+    assert_same_dirs(tmp_path / "gpu3", tmp_path / "cpu3")

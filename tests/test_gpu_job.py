@@ -205,6 +205,13 @@ def test_job_submit_shards_device_resident(devices, exchange, resident):
     assert_result_equals_oracle(res, o, delimit=True, sample_limit=9)
     with pytest.raises(PgError):
         job.submit_shards(keep[0][:-1] if n > 1 else keep[0] + keep[0])   # one batch per device, no more, no fewer
+    if resident:
+        # a "device" shard whose samples live in pinned HOST memory: refused by name (hipPointerGetAttributes), not a fault in the first kernel
+        bad = keep[0][0]
+        host_sig = torch.zeros(bad.sig.numel(), dtype=bad.sig.dtype).pin_memory()
+        lie = type(bad)(**{**bad.__dict__, "sig": host_sig})
+        with pytest.raises(PgError, match="device"):
+            job.submit_shards([lie] + keep[0][1:])
     job.close()
 
 

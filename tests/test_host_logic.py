@@ -1,6 +1,9 @@
 """Host-side logic of the Python layer (no GPU): k-mer list, slice reconciliation, generator, shard bounds,
 dump text assembly."""
 import ctypes as C
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import numpy as np
 
@@ -97,3 +100,35 @@ def test_ragged_generator_is_consistent_and_the_oracle_accepts_it():
         o = oracle_for(kmers, kmer_size=5, scaling=1, sample_limit=30, rna=rna)
         assert set(o.run_batch(b)) <= {orc.ORC_OK, orc.ORC_STOPPED}
         assert int(o.counts().sum()) > 1000
+
+
+def test_where_a_ranks_statistics_go_relative_to_the_count_exchange():
+    """pg_job_rule.h (pg_job.hip): in front of the wait for the exchanged table unless completion of every k-mer below the rank is
+    plausible in this batch. Hand-made tables for BASELINE configs[2] (8 ranks x 50 000 reads, 6.5 M ops per rank, 1024 k-mers) at limit
+    100 / 5000 and configs[3] (k = 9, 15.9 M ops per rank, 262 144 k-mers, limit 1000). PROVISIONAL: unmeasured on more than one GPU."""
+    import ctypes as C
+    h = C.CDLL(os.environ.get("PG_HOSTTEST_SO") or os.path.join(ROOT, "poregen_amd", "_pg_hosttest.so"))
+    h.pgt_job_stats_rule.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_uint64, C.c_char_p]
+
+    def place(rank, ops, reads, n_slots, limit, have_batch=False, full_prev=0, mode=b""):
+        o = np.asarray(ops, np.uint64); r = np.asarray(reads, np.uint64)
+        return h.pgt_job_stats_rule(rank, o.ctypes.data, r.ctypes.data, n_slots, limit, int(have_batch), full_prev, mode)
+    FRONT, BEHIND = 0, 1
+    c2_ops, c2_reads = [6_500_000] * 8, [50_000] * 8
+    # configs[2], limit 100 and 5000: 6 348 ops per k-mer and rank -- one rank below is enough to make completion plausible at both limits
+    assert [place(g, c2_ops, c2_reads, 1024, 100) for g in range(8)] == [FRONT] + [BEHIND] * 7
+    assert [place(g, c2_ops, c2_reads, 1024, 5000) for g in range(8)] == [FRONT] + [BEHIND] * 7
+    assert [place(g, c2_ops, c2_reads, 1024, 20000) for g in range(8)] == [FRONT] * 4 + [BEHIND] * 4     # 20 000 / 6 348 = 3.15: from rank 4 on
+    # configs[3]: 60.7 ops per k-mer and rank against a limit of 1000: no rank of 8 (it would take 17)
+    k9_ops, k9_reads = [15_900_000] * 8, [50_000] * 8
+    assert [place(g, k9_ops, k9_reads, 262144, 1000) for g in range(8)] == [FRONT] * 8
+    # ... unless the earlier batches left only a few k-mers open: 97 % complete -> 30 per open k-mer are enough
+    assert place(1, k9_ops, k9_reads, 262144, 1000, have_batch=True, full_prev=int(262144 * 0.97)) == BEHIND
+    assert place(1, k9_ops, k9_reads, 262144, 1000, have_batch=True, full_prev=int(262144 * 0.90)) == FRONT
+    # an op count the host was not told (0 with reads in the shard) counts as plausible; an empty shard below does not
+    assert place(2, [15_900_000, 0], [50_000, 50_000], 262144, 1000) == BEHIND
+    assert place(2, [15_900_000, 0], [50_000, 0], 262144, 1000) == FRONT
+    # rank 0 and sample_limit 0 (no k-mer ever completes) never wait; the overrides
+    assert place(0, c2_ops, c2_reads, 1024, 100, mode=b"behind") == FRONT and place(3, c2_ops, c2_reads, 1024, 0, mode=b"behind") == FRONT
+    assert place(3, c2_ops, c2_reads, 1024, 100, mode=b"front") == FRONT and place(3, k9_ops, k9_reads, 262144, 1000, mode=b"behind") == BEHIND
+    assert place(3, c2_ops, c2_reads, 1024, 100, mode=b"auto") == BEHIND
