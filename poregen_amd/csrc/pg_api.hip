@@ -90,6 +90,12 @@ struct pg_ctx {
     bool gather_side = false; int gather_side_slot = 0; bool side_used[2] = {false, false}; // the last chunked gather was queued on the second stream (two-stream mode) and nothing on `st` has waited for it yet
     DevBuf med[2], mad[2], gcal[2], read_plan[2], stat_status[2], stat_err[2], wide_list[2];
     bool stat_flags_reset = false; // stat_err[slot] was reset by k_batch_init of the current batch
+    // long-read counters (PgLongState::cnt), a ring of four entries of four words: batch number b uses entry b & 3 and its k_batch_init zeroes
+    // entry (b + 2) & 3. Round 5 kept them beside the statistics flags of the two slots, zeroed by the batch in front -- but the reservations
+    // of batch b + 1 (k_read_plan on the statistics stream, released by the gather of batch b - 1) are not ordered behind k_batch_init of
+    // batch b on the chain's stream: both start when that gather ends, and a zero could wipe reservations. Two batches of distance put the
+    // zeroing in front of the gather the reserving launch waits for.
+    DevBuf long_ring; uint32_t long_seq = 0;
     DevBuf meta, huge_scratch, oor;
     DevBuf blk_read, gen_flag, gen_list, cum, btot, tile_read; // PgWalkOut: owner index, generic-read list, block sums of op_n
     uint32_t batch_id = 0;  // serial number of the batch being counted (tags gen_flag entries and the error word)
@@ -262,7 +268,7 @@ void pg_destroy(pg_ctx *c) {
                       &c->keep, &c->keep32, &c->tile_last, &c->ev_off, &c->plan_totals[0], &c->plan_totals[1], &c->base_stage, &c->dmerged, &c->dseg, &c->ev_rec[0], &c->ev_rec[1], &c->ev_len, &c->ev_read, &c->read_needed,
                       &c->tx_samp_off, &c->tx_ev_off, &c->tx_len, &c->tx_off, &c->tx_text, &c->tx_slot_off, &c->tx_flag,
                       &c->part_elem, &c->part_lodig, &c->part_rbase, &c->part_tile_region, &c->part_ntiles, &c->part_histB, &c->part_Bp, &c->chunk_part[0], &c->chunk_part[1], &c->region_state,
-                      &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->long_tab, &c->long_hist, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
+                      &c->samp_off[0], &c->samp_off[1], &c->cancel_flag, &c->long_tab, &c->long_hist, &c->long_ring, &c->scan_scratch, &c->samples, &c->med[0], &c->mad[0], &c->gcal[0], &c->gcal[1], &c->read_plan[0], &c->stat_status[0], &c->stat_err[0], &c->wide_list[0],
                       &c->med[1], &c->mad[1], &c->read_plan[1], &c->stat_status[1], &c->stat_err[1], &c->wide_list[1], &c->meta, &c->huge_scratch, &c->oor,
                       &c->blk_read, &c->gen_flag, &c->gen_list, &c->cum, &c->btot, &c->tile_read,
                       &c->job_total, &c->job_freq, &c->md_ev_off, &c->md_samp_off, &c->md_ev_len, &c->md_samples, &c->md_out, &c->md_dwell, &c->md_class};
@@ -409,6 +415,7 @@ pg_status pg_create(const pg_params *p, pg_ctx **out) {
     CTRY(hipMemset(c->errflag.p, 0, 32)); // [0] u64 error word, [8] i32 layout flag, [16] u32 gen_count[2] (PgWalkOut), [24] u32 ticket (k_rank_scan)
     CTRY(c->stat_err[0].ensure(32)); CTRY(c->stat_err[1].ensure(32)); // [0..2] statistics flags, [3] pg_div_domain_ok failed, [4..5] long-read counters (PgLongState::cnt)
     CTRY(hipMemset(c->stat_err[0].p, 0, 32)); CTRY(hipMemset(c->stat_err[1].p, 0, 32));
+    CTRY(c->long_ring.ensure(64)); CTRY(hipMemset(c->long_ring.p, 0, 64));
     CTRY(hipMemset(c->running.p, 0, ns * 8ull));
     PG_TMARK("create: events, tables, first buffers");
 #undef CTRY
@@ -683,7 +690,7 @@ static pg_status fill_long(pg_ctx *c, PgLongState &LS, bool ensure) {
         c->long_use = ov ? std::min<uint32_t>(c->long_cap, want) : std::min<uint32_t>(c->long_cap, want + want / 4 + 64);
     }
     LS.tab = c->long_tab.as<uint2>(); LS.hist = c->long_hist.as<uint32_t>(); LS.cap = c->long_use;
-    LS.cnt = c->stat_err[c->slot].as<int32_t>() + 4; LS.cnt_next = c->stat_err[c->slot ^ 1].as<int32_t>() + 4;
+    LS.cnt = c->long_ring.as<int32_t>() + 4u * (c->long_seq & 3u); LS.cnt_next = c->long_ring.as<int32_t>() + 4u * ((c->long_seq + 2u) & 3u);
     return PG_OK;
 }
 
@@ -848,6 +855,7 @@ pg_status pg_count(pg_ctx *c, const pg_batch *b, uint64_t *counts_out, int32_t c
     fill_walk(c, W, O);
     const bool force_generic = (c->prm.flags & PG_FLAG_DEBUG_SPLIT_WALK) != 0;
     PgLongState LS{};
+    ++c->long_seq; // this batch's entry of the long-read counter ring
     { pg_status sl_ = fill_long(c, LS, true); if (sl_ != PG_OK) return sl_; }
     prof_begin(c, "k_batch_init", c->st);
     HIP_TRY(c, pg_launch_batch_init(c->st, n, c->read_needed.as<uint8_t>(), c->running.as<uint64_t>(), c->prm.n_slots,
@@ -1214,7 +1222,7 @@ static pg_status settle_batch(pg_ctx *c) {
     // into host-mapped memory instead of four blocking copies of 8-24 bytes, ~80 -> ~10 us per call)
     if (c->st2) HIP_TRY(c, hipStreamSynchronize(c->st2));
     if (c->st3) HIP_TRY(c, hipStreamSynchronize(c->st3));
-    HIP_TRY(c, pg_launch_settle_pack(c->st, c->errflag.as<uint32_t>(), c->stat_err[c->slot].as<int32_t>(), c->plan_totals[c->rslot].as<uint64_t>(),
+    HIP_TRY(c, pg_launch_settle_pack(c->st, c->errflag.as<uint32_t>(), c->stat_err[c->slot].as<int32_t>(), c->long_ring.as<int32_t>() + 4u * (c->long_seq & 3u), c->plan_totals[c->rslot].as<uint64_t>(),
                                      c->samp_off[c->rslot].as<uint64_t>(), c->samp_off[c->rslot].cap / 8, c->cancel_pending ? c->cancel_flag.as<uint32_t>() : nullptr, c->settle_host));
     HIP_TRY(c, hipStreamSynchronize(c->st));
     const PgSettlePack pk = *c->settle_host;

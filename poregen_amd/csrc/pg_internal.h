@@ -222,7 +222,7 @@ struct PgLongState {
     uint2 *tab;        // [cap] helper h -> {read, slice}; {PG_LONG_INVALID, -} = reserved by a read that found no room
     uint32_t *hist;    // [cap][PG_LONG_WORDS], zero between batches; a long read uses the entry of its FIRST helper
     int32_t *cnt;      // this batch's counters: [0] helpers reserved (may exceed cap), [1] reads that were split
-    int32_t *cnt_next; // the next batch's counters, zeroed by k_batch_init (the reservations of a batch happen in the launch that would reset its own)
+    int32_t *cnt_next; // the counters of the batch after the next one, zeroed by k_batch_init (a ring of four entries: pg_api.hip, pg_ctx::long_ring)
     uint32_t cap;      // helpers this batch may use: table entries, histograms, extra workgroups of k_read_stats
 };
 static inline __host__ __device__ void pg_long_geometry(uint64_t L, uint32_t *slices, uint64_t *slen) {
@@ -341,7 +341,7 @@ hipError_t pg_launch_scan_u32_u64(hipStream_t st, const uint32_t *in, uint32_t s
 hipError_t pg_launch_read_stats_rare(hipStream_t st, const PgRareArgs &A);
 // the host's view of a finished batch, packed by one launch into host-mapped memory (pg_api.hip: settle_batch)
 struct PgSettlePack { uint32_t errflag[6]; int32_t stat_err[6]; uint64_t n_kept, full_slots, n_samples; uint32_t cancel[2]; };
-hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const uint64_t *totals, const uint64_t *samp_off,
+hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const int32_t *long_cnt, const uint64_t *totals, const uint64_t *samp_off,
                                  uint64_t samp_off_entries, const uint32_t *cancel_flag, PgSettlePack *out);
 // flag[0] = some slot still open below this rank (sum of rows_below rows of all_counts < limit), flag[1] = statistics cancelled; if none
 // is open, the reads' statistics records (plan_buf) are set to "skip"

@@ -2478,7 +2478,7 @@ __global__ __launch_bounds__(256) void k_batch_init(uint32_t n_reads, uint8_t *_
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_reads) read_head_one(B, W, O, i, force_generic);
     if (plan_rec && i < n_reads) read_plan_one(B, i, nullptr, pa_min, pa_max, plan_rec, stat_status, LS); // eager statistics: see read_plan_one
-    if (i == 0 && LS.cnt_next) { LS.cnt_next[0] = 0; LS.cnt_next[1] = 0; } // the NEXT batch's long-read counters (PgLongState)
+    if (i == 0 && LS.cnt_next) { LS.cnt_next[0] = 0; LS.cnt_next[1] = 0; } // the long-read counters of the batch AFTER the next one (PgLongState: a ring of four, pg_api.hip)
     if (i == 0) {
         O.layout_err[0] = (n_reads ? B.op_off[n_reads] : B.n_ops) != B.n_ops; // pg_batch.n_ops is wrong
         O.gen_count[(O.batch_id + 1u) & 1u] = 0; // the next batch's list
@@ -2708,19 +2708,20 @@ hipError_t pg_launch_stats_cancel_if_full(hipStream_t st, const uint64_t *all_co
 // What the host wants to know of a finished batch -- the walk's error words, the statistics' flags, the kept totals, the sample total, the
 // cancel flag -- as ONE record in host-mapped memory: four blocking 8..24-byte hipMemcpy calls cost ~80 us per pg_sync (4 us per step of a
 // 20-step timed block); one single-thread kernel and the stream synchronisation that follows anyway cost ~10.
-__global__ void k_settle_pack(const uint32_t *__restrict__ errflag, const int32_t *__restrict__ stat_err, const uint64_t *__restrict__ totals,
+__global__ void k_settle_pack(const uint32_t *__restrict__ errflag, const int32_t *__restrict__ stat_err, const int32_t *__restrict__ long_cnt, const uint64_t *__restrict__ totals,
                               const uint64_t *__restrict__ samp_off, uint64_t samp_off_entries, const uint32_t *__restrict__ cancel_flag, PgSettlePack *__restrict__ out) {
     PgSettlePack p;
     for (int i = 0; i < 6; ++i) p.errflag[i] = errflag[i];
-    for (int i = 0; i < 6; ++i) p.stat_err[i] = stat_err ? stat_err[i] : (i == 0 ? INT_MAX : 0);
+    for (int i = 0; i < 4; ++i) p.stat_err[i] = stat_err ? stat_err[i] : (i == 0 ? INT_MAX : 0);
+    p.stat_err[4] = long_cnt[0]; p.stat_err[5] = long_cnt[1]; // the batch's long-read counters (PgLongState::cnt: a ring beside the two statistics slots)
     p.n_kept = totals[0]; p.full_slots = totals[1];
     p.n_samples = p.n_kept < samp_off_entries ? samp_off[p.n_kept] : 0; // (a failed batch may leave any total: the host looks at the error words first)
     p.cancel[0] = cancel_flag ? cancel_flag[0] : 0u; p.cancel[1] = cancel_flag ? cancel_flag[1] : 0u;
     *out = p;
 }
-hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const uint64_t *totals, const uint64_t *samp_off,
+hipError_t pg_launch_settle_pack(hipStream_t st, const uint32_t *errflag, const int32_t *stat_err, const int32_t *long_cnt, const uint64_t *totals, const uint64_t *samp_off,
                                  uint64_t samp_off_entries, const uint32_t *cancel_flag, PgSettlePack *out) {
-    PG_LAUNCH(k_settle_pack, dim3(1), dim3(1), 0, st, errflag, stat_err, totals, samp_off, samp_off_entries, cancel_flag, out);
+    PG_LAUNCH(k_settle_pack, dim3(1), dim3(1), 0, st, errflag, stat_err, long_cnt, totals, samp_off, samp_off_entries, cancel_flag, out);
     return hipSuccess;
 }
 

@@ -233,12 +233,18 @@ def test_stream_ordered_count_collect_on_torch_stream(resident):
         assert np.array_equal(vals.view(np.uint64), o.values(s).view(np.uint64))
 
 
+@pytest.mark.parametrize("fence", ["no_system_fence", "system_fence"])
 @pytest.mark.parametrize("mode", ["overlap", "overlap_tail"])
-def test_overlap_mode_same_bits(mode):
-    """PG_FLAG_OVERLAP_TAIL: the same second stream, forked behind the counting kernels (next to pg_collect's small launches).
+def test_overlap_mode_same_bits(mode, fence, monkeypatch):
+    """Both kinds of event between the streams (advisor r05): the default hipEventDisableSystemFence events -- med / MAD / calibration written on
+    the statistics stream and read by the gather on the other rest on the device-scope release / acquire every kernel boundary has -- and
+    the plain events (PGMOVE_EVENT_SYSTEM_FENCE=1, read when the context is created).
+    PG_FLAG_OVERLAP_TAIL: the same second stream, forked behind the counting kernels (next to pg_collect's small launches).
     PG_FLAG_OVERLAP: the statistics kernels of a batch on a second stream (double-buffered med/MAD), joined before
     the gather. Several batches back to back, host- and device-resident: the same bits as the oracle."""
     import torch
+    if fence == "system_fence":
+        monkeypatch.setenv("PGMOVE_EVENT_SYSTEM_FENCE", "1")
     b = synth.make_batch(700, kind="rna004", seed=31, indel_rate=0.02)
     p = dict(kmer_size=5, rna=True, scaling=1, min_dur=20, max_dur=40, sample_limit=60)
     kmers = generate_kmers(5, rna=True)
