@@ -407,7 +407,7 @@ def test_gmove_exits_1_on_a_corrupt_blow5(tmp_path, damage):
     if damage == "truncated_record":
         d = d[:len(d) - 300]; msg = "BLOW5"
     elif damage == "zstd_header":
-        d[9] = 2; msg = "record compression other than none/zlib is not supported"
+        d[9] = 2; msg = "zstd"   # zlib records announced as zstd (round 6 reads zstd): "zstd error in BLOW5 record", or "libzstd.so.1 was not found"
     elif damage == "exzd_header":
         d[14] = 2; msg = "signal compression other than none/svb-zd is not supported"
     else:  # the second record: a valid zlib stream whose streamvbyte block announces more values than it holds
