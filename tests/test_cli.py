@@ -460,3 +460,19 @@ def test_whole_list_job_ramps_its_batches_and_stops_near_the_completing_read(tmp
     assert reads_read(r3) == 1500
     o3 = oracle_cli([pre + ".slow5"] + sl[1:] + [tmp_path / "cpu3"]); assert o3.returncode == 0
     assert_same_dirs(tmp_path / "gpu3", tmp_path / "cpu3")
+
+
+@pytest.mark.gpu
+def test_gmove_reads_zstd_compressed_blow5(tmp_path):
+    """`poregen gmove` on a BLOW5 file with zstd-compressed records (the reference's `make zstd=1` build, /root/reference/Makefile:12-13,67):
+    the same output directory as the oracle CLI on the ASCII SLOW5 of the same reads."""
+    if synth.zstd_compress(b"x") is None:
+        pytest.skip("no libzstd.so.1 on this machine")
+    b = synth.make_batch(120, read_len=3000, kind="rna004", seed=23)
+    pre = str(tmp_path / "syn")
+    synth.write_files(b, pre)
+    synth.write_blow5(b, pre + ".blow5", compress="zstd")
+    args = [pre + ".paf", "--fastq", pre + ".fastq", "-k", "3", "--rna", "--scaling", "1", "--min_dur", "20", "--max_dur", "40", "--file_limit", "64", "--sample_limit", "50"]
+    r = cli([pre + ".blow5"] + args + [tmp_path / "gpu"]); assert r.returncode == 0, r.stderr
+    o = oracle_cli([pre + ".slow5"] + args + [tmp_path / "cpu"]); assert o.returncode == 0, o.stderr
+    assert_same_dirs(tmp_path / "gpu", tmp_path / "cpu")
