@@ -316,7 +316,7 @@ def main():
     # note of MI355X_MICROARCH.md): measured offline on the headline workload and committed under profiles/
     traffic = None; trace_ms = None; traffic_source = None
     headline = args.reads == 50000 and args.read_len == 4000 and args.kind == "rna004" and args.k == 5
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
             if headline:
@@ -327,7 +327,7 @@ def main():
             pass
     # the committed rocprofv3 kernel trace of this command (profiles/): its average duration of the same kernel, for comparison
     trace_name = None
-    for name in ("r05_kernel_stats.csv", "r04_kernel_stats.csv", "r03_kernel_stats.csv", "r02_kernel_stats.csv"):
+    for name in ("r06_kernel_stats.csv", "r05_kernel_stats.csv", "r04_kernel_stats.csv", "r03_kernel_stats.csv", "r02_kernel_stats.csv"):
         try:
             import csv
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
@@ -340,7 +340,7 @@ def main():
     trace2_ms = None  # the same kernel in the committed trace of the DEFAULT command (two streams: it shares the chip there by design)
     try:
         import csv
-        two = next(n for n in ("r05_kernel_stats_two_streams.csv", "r04_kernel_stats_two_streams.csv", "r03_kernel_stats_two_streams.csv") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        two = next(n for n in ("r06_kernel_stats_two_streams.csv", "r05_kernel_stats_two_streams.csv", "r04_kernel_stats_two_streams.csv", "r03_kernel_stats_two_streams.csv") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         for row in csv.DictReader(open(os.path.join(ROOT, "profiles", two))):
             if row["Name"].startswith("k_read_stats(") and headline:
                 trace2_ms = float(row["AverageNs"]) * 1e-6

@@ -35,7 +35,9 @@ for case in range(n_cases):
             args += ["--kmer_pick_margin", str(int(rng.integers(0, 4)))]
             blow5 = rng.random() < 0.5  # the product reads a BLOW5 of the same reads (zlib + svb-zd half of the time), the oracle the ASCII SLOW5
             if blow5:
-                synth.write_blow5(b, pre + ".blow5", compress=bool(rng.integers(0, 2)))
+                comp = [False, True, "zstd"][int(rng.integers(0, 3))]  # none / zlib + svb-zd / zstd + svb-zd (round 6)
+                if comp == "zstd" and synth.zstd_compress(b"x") is None: comp = True
+                synth.write_blow5(b, pre + ".blow5", compress=comp)
             if rng.random() < 0.2: args += ["--margin", str(int(rng.integers(1, 4)))]
         else:
             b = synth.make_batch(n_reads, read_len=int(rng.choice([600, 4000])), kind="dna_r10", seed=int(rng.integers(1 << 30)))
@@ -54,10 +56,11 @@ for case in range(n_cases):
             continue
         gargs = [a[:-4] + ".bam" if (front == "sam" and use_bam and a.endswith(".sam")) else a for a in args] if front != "paf" else \
                 [a[:-6] + ".blow5" if (blow5 and a.endswith(".slow5")) else a for a in args]
-        extra = ["--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))]
+        extra = ["--batch_reads", str(int(rng.choice([1, 7, 64, 20000])))] if rng.random() < 0.7 else []  # (no --batch_reads: the ramp of a whole-list job)
         if rng.random() < 0.25:  # the job layer: several shards on the one GPU of the box (host exchange), or one rank over RCCL
             extra += ["--devices", str(rng.choice(["0,0", "0,0,0,0", "0"]))]
         env = dict(os.environ)
+        if not extra and rng.random() < 0.7: env["POREGEN_BATCH_RAMP"] = str(int(rng.choice([1, 3, 16])))  # tiny first batches: 1, 2, 4, ... reads
         if rng.random() < 0.3: env["PGMOVE_HOLD_MIN_BYTES"] = "1"  # small batches' samples stay on the device too (device merge, device text)
         g = subprocess.run([BIN, "gmove"] + gargs + [os.path.join(d, "gpu")] + extra, capture_output=True, text=True, env=env)
         ok = (o.returncode == 0) == (g.returncode == 0)
