@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--sample-limit", type=int, default=100)
     ap.add_argument("--lazy", action="store_true", help="statistics only for reads that own a kept event")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc child passes of this command (~1 min)")
     ap.add_argument("--no-lazy-extra", action="store_true", help="skip the extra lazy-statistics / two-stream measurements (profiling runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip config3_mode / all_kept_mode / config2_mode / job_layer / hbm_not_mall / pcie_inclusive / end_to_end (profiling and A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -356,6 +357,16 @@ def main():
                     "step the statistics share the chip with the ranking kernels by design",
         "committed_trace_two_streams_avg_launch_ms": trace2_ms,
     }
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_live_traffic:
+        lt = live_traffic(args)
+        if lt and "bytes" in lt:
+            roofline["traffic_committed"] = {"bytes": traffic, "source": traffic_source}
+            roofline["traffic"] = lt["bytes"]
+            roofline["traffic_source"] = ("MEASURED beside this run: two child passes of this command under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE, separate, one stream), "
+                                          "averaged over k_read_stats' launches: FETCH_SIZE %.0f KB x 2 (gfx950) + WRITE_SIZE %.0f KB" % (lt["fetch_kb"], lt["write_kb"]))
+            roofline["traffic_over_algorithmic"] = lt["bytes"] / stats_bytes
+        elif lt:
+            roofline["traffic_live_error"] = lt["error"]
     kernels_ms = {k: v[1] / n_prof for k, v in ks.items()}
     balg = b_alg(n_samples, host.n_reads, n_ops, n_bases, kept_samples, kept_events, len(kmers))
     whole_step = {"algorithmic_bytes": balg, "bytes_per_sample": balg / n_samples, "ms_per_step": ms_per_step,
@@ -731,6 +742,43 @@ def end_to_end(host, args):
         first = out["runs"][f"sample_limit_{args.sample_limit}"]
         out.update(value=first["value"], value_over_all_input=first["value_over_all_input"], wall_s=first["wall_s"], unit="samples/s", stages=first["stages"])
         return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def live_traffic(args, timeout_s=170):
+    """HBM bytes per launch of the dominant kernel, MEASURED beside this run: two child passes of this very command under rocprofv3
+    (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separately -- MI355X_MICROARCH.md, HBM / rocprofv3 section), on one stream like the per-kernel
+    times, the counters averaged over k_read_stats' launches, FETCH_SIZE doubled (the gfx950 correction for wide streaming reads).
+    Children, not exec: this process has initialised the GPU. None if rocprofv3 is absent or a pass fails (the committed figure stays)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    d = tempfile.mkdtemp(prefix="pg_pmc_", dir="/tmp")
+    try:
+        kb = {}
+        for name in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", name, "--output-format", "csv", "-d", os.path.join(d, name), "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--one-stream", "--no-cpu-baseline", "--no-lazy-extra", "--no-extras", "--reads", str(args.reads), "--read-len", str(args.read_len), "--kind", args.kind,
+                   "--k", str(args.k), "--sample-limit", str(args.sample_limit)] + (["--lib", args.lib] if args.lib else [])
+            env = dict(os.environ, TMPDIR="/tmp")
+            for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(v, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {name}: rc {r.returncode}: " + r.stderr[-200:]}
+            vals = []
+            for f in glob.glob(os.path.join(d, name, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == name and row.get("Kernel_Name", "").split("(")[0].strip() == "k_read_stats":
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return {"error": f"no {name} rows for k_read_stats"}
+            kb[name] = sum(vals) / len(vals)
+        return {"fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"], "bytes": (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0}
+    except Exception as e:  # (a profiler that is missing a library, a timeout: the committed figure stays)
+        return {"error": repr(e)[:200]}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
