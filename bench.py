@@ -746,7 +746,7 @@ def end_to_end(host, args):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def live_traffic(args, timeout_s=170):
+def live_traffic(args, timeout_s=90):
     """HBM bytes per launch of the dominant kernel, MEASURED beside this run: two child passes of this very command under rocprofv3
     (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separately -- MI355X_MICROARCH.md, HBM / rocprofv3 section), on one stream like the per-kernel
     times, the counters averaged over k_read_stats' launches, FETCH_SIZE doubled (the gfx950 correction for wide streaming reads).
