@@ -389,7 +389,10 @@ pg_status   pg_job_submit(pg_job *job, const pg_batch *host_batch);
  * batch as a pg_batch of its own -- PG_LOC_DEVICE arrays resident on devices[g] and complete before the call, or PG_LOC_HOST. Nothing is
  * cut or copied on the host and, with device shards, nothing crosses PCIe inside the step: a device-resident N-GPU step driven from the
  * C++ host (src/gmove.cpp:732-969 over N devices; lifetime of the arrays as pg_job_submit). Results: those of pg_job_submit on the
- * concatenation of the shards. */
+ * concatenation of the shards. A PG_LOC_DEVICE shard whose sig / sig_off / op_n / seq are not device memory on devices[g] is refused with
+ * PG_ERR_INVALID_ARG (hipPointerGetAttributes, once per array and call) before anything is launched on it.
+ * Where a rank's statistics are queued relative to the count exchange is a PROVISIONAL rule (csrc/pg_job_rule.h; no run on more than one
+ * GPU exists yet): PGMOVE_JOB_STATS_RULE=front|behind|auto in the environment overrides it; results never depend on it. */
 pg_status   pg_job_submit_shards(pg_job *job, const pg_batch *shards, uint32_t n_shards);
 pg_status   pg_job_reset(pg_job *job);                  /* as pg_reset: the next submit starts a new job on the same devices and communicators */
 pg_status   pg_job_sync(pg_job *job);                   /* wait for every device; surfaces per-read errors (lowest shard first) */
