@@ -444,6 +444,7 @@ def main():
                                         "BASELINE configs[2]'s limit on the headline reads: sample_limit 5000, every accepted event is kept")
         out["hbm_not_mall"] = hbm_not_mall(shard, kmers, p, dev)
         out["pcie_inclusive"] = pcie_inclusive(host, kmers, p)
+        out["early_stop_mode"] = early_stop_mode(host, kmers, p, dev)
         del shard
         torch.cuda.empty_cache()
         out["config3_mode"] = config3_mode(dev)
@@ -684,6 +685,43 @@ def hbm_not_mall(shard, kmers, p, dev, copies=8):
     del big
     return {"reads": shard.n_reads * copies, "signal_bytes": 2 * n_samples, "k_read_stats_ms": ms, "GB/s": nbytes / (ms * 1e-3) / 1e9,
             "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernels_sum_ms_per_step": step_ms}
+
+
+def early_stop_mode(host, kmers, p, dev, jobs=20):
+    """The same reads as the reference works through them: in PAF order until every k-mer is complete, then no further (gmove.cpp:733-735).
+    The headline step streams the whole 50 000-read batch, of which the reference would have read the first few thousand (`useful`); here the
+    device-resident reads are submitted in the CLI's ramp (2 048 reads, 4 096, 8 192, ...; PG_FLAG_STOP_WHEN_FULL) and the job ends with the
+    batch that completes the list. value = samples of the reads the JOB submitted / its time: what a caller who feeds a device sees per job."""
+    import torch
+    from poregen_amd.engine import GmoveEngine, GmoveParams
+    parts, lo, size = [], 0, 2048
+    while lo < host.n_reads:
+        hi = min(host.n_reads, lo + size)
+        parts.append(host.slice_reads(lo, hi).to_device(dev)); lo = hi; size *= 2
+    e = GmoveEngine(GmoveParams(kmers=kmers, stop_when_full=True, **p))
+
+    def job():
+        e.reset()
+        n = 0
+        for b in parts:
+            e.submit(b); n += b.n_reads
+            if e.all_slots_full():   # (waits for the batch: the decision the CLI takes from pg_poll one batch late)
+                break
+        return n
+    for _ in range(3):
+        n_read = job()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(jobs):
+        n_read = job()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / jobs * 1e3
+    complete = e.all_slots_full()
+    e.close()
+    samples = int(host.sig_off[n_read])
+    return {"batches": [int(b.n_reads) for b in parts], "reads_submitted": int(n_read), "samples_submitted": samples, "all_kmers_complete": bool(complete),
+            "ms_per_job": ms, "value": samples / (ms * 1e-3), "unit": "samples/s",
+            "note": "one job = reset, ramped device-resident batches until every k-mer is complete (a host wait per batch); compare `useful` of the headline step"}
 
 
 def pcie_inclusive(host, kmers, p, steps=4):
