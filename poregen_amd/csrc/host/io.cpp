@@ -38,6 +38,25 @@ bool zstd_record(const unsigned char *src, size_t n, std::vector<unsigned char> 
     const unsigned long long fs = z.frame_size(src, n);
     // (unknown / error content sizes are 2^64 - 1 and 2^64 - 2; slow5lib writes one-shot frames, which carry their size. A record is a read:
     // ids + 44 bytes + samples; a frame that claims more than 2^32 bytes or more than 2^17 times its compressed size is not one)
+    if (fs == ~0ull) { // a frame without its content size (a writer that streamed the record): through the streaming decoder, buffer grown as needed
+        void *ds = z.create_dstream();
+        if (!ds || z.is_error(z.init_dstream(ds))) { if (ds) z.free_dstream(ds); err = "zstd init failed"; return false; }
+        out.resize(n * 4 + 4096);
+        Zstd::Buf in{src, n, 0}; Zstd::OBuf ob{out.data(), out.size(), 0};
+        bool done = false, bad = false;
+        while (!done && !bad) {
+            const size_t before_in = in.pos, before_out = ob.pos;
+            const size_t rc = z.decompress_stream(ds, &ob, &in);
+            if (z.is_error(rc)) bad = true;
+            else if (rc == 0) done = true;
+            else if (ob.pos == ob.size) { if (out.size() >= (1ull << 32)) bad = true; else { out.resize(out.size() * 2); ob.dst = out.data(); ob.size = out.size(); } }
+            else if (in.pos == before_in && ob.pos == before_out) bad = true; // no progress with room left: the frame is cut short
+        }
+        z.free_dstream(ds);
+        if (bad) { err = "zstd error in BLOW5 record"; return false; }
+        out.resize(ob.pos);
+        return true;
+    }
     if (fs >= (1ull << 32) || fs / (1u << 17) > (unsigned long long)n + 1) { err = "zstd error in BLOW5 record (implausible frame size)"; return false; }
     out.resize((size_t)fs ? (size_t)fs : 1);
     const size_t got = z.decompress(out.data(), out.size(), src, n);

@@ -418,8 +418,9 @@ def _svb_zd(sig: np.ndarray) -> bytes:
     return struct.pack("<I", n) + ctrl.tobytes() + data.tobytes()
 
 
-def zstd_compress(data: bytes, level: int = 3):
-    """One-shot zstd frame through the system's libzstd.so.1 (ctypes; there is no zstd module in this image). None if the library is absent."""
+def zstd_compress(data: bytes, level: int = 3, streamed: bool = False):
+    """One-shot zstd frame through the system's libzstd.so.1 (ctypes; there is no zstd module in this image). None if the library is absent.
+    streamed: through ZSTD_compressStream instead -- a frame WITHOUT its content size in the header (what a writer that streams records produces)."""
     import ctypes as C
     global _zstd
     try:
@@ -435,6 +436,21 @@ def zstd_compress(data: bytes, level: int = 3):
             _zstd = None
     if _zstd is None:
         return None
+    if streamed:
+        class _B(C.Structure):
+            _fields_ = [("p", C.c_void_p), ("size", C.c_size_t), ("pos", C.c_size_t)]
+        _zstd.ZSTD_createCStream.restype = C.c_void_p
+        _zstd.ZSTD_initCStream.argtypes = [C.c_void_p, C.c_int]; _zstd.ZSTD_initCStream.restype = C.c_size_t
+        _zstd.ZSTD_compressStream.argtypes = [C.c_void_p, C.POINTER(_B), C.POINTER(_B)]; _zstd.ZSTD_compressStream.restype = C.c_size_t
+        _zstd.ZSTD_endStream.argtypes = [C.c_void_p, C.POINTER(_B)]; _zstd.ZSTD_endStream.restype = C.c_size_t
+        _zstd.ZSTD_freeCStream.argtypes = [C.c_void_p]
+        cs = _zstd.ZSTD_createCStream(); _zstd.ZSTD_initCStream(cs, level)
+        src = C.create_string_buffer(data, len(data)); dst = C.create_string_buffer(_zstd.ZSTD_compressBound(len(data)) + 64)
+        i = _B(C.cast(src, C.c_void_p), len(data), 0); o = _B(C.cast(dst, C.c_void_p), len(dst), 0)
+        assert not _zstd.ZSTD_isError(_zstd.ZSTD_compressStream(cs, C.byref(o), C.byref(i))) and i.pos == len(data)
+        assert _zstd.ZSTD_endStream(cs, C.byref(o)) == 0
+        _zstd.ZSTD_freeCStream(cs)
+        return dst.raw[:o.pos]
     cap = _zstd.ZSTD_compressBound(len(data))
     buf = C.create_string_buffer(cap)
     n = _zstd.ZSTD_compress(buf, cap, data, len(data), level)
@@ -446,7 +462,8 @@ def write_blow5(b: Batch, path: str, compress=False):
     """BLOW5 for the batch (layout: SURVEY.md 8f-1); read ids are r<index>. compress=False: record compression none,
     signal compression none -- meant for throughput-sized CLI runs where ASCII SLOW5 parsing would dominate.
     compress=True: zlib records + svb-zd signals, what slow5tools writes by default (as test/example.blow5).
-    compress="zstd": zstd records (record compression 2; the reference's `make zstd=1` build) + svb-zd signals."""
+    compress="zstd": zstd records (record compression 2; the reference's `make zstd=1` build) + svb-zd signals; "zstd-stream": the same with
+    frames that do not carry their content size."""
     import struct
     import zlib
     if compress:
@@ -454,14 +471,14 @@ def write_blow5(b: Batch, path: str, compress=False):
                b"#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\n"
                b"#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\n")
         with open(path, "wb") as f:
-            f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([2 if compress == "zstd" else 1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15))
+            f.write(b"BLOW5\x01" + bytes([0, 2, 0]) + bytes([2 if compress in ("zstd", "zstd-stream") else 1]) + struct.pack("<I", 1) + bytes([1]) + bytes(64 - 15))
             f.write(struct.pack("<I", len(hdr)) + hdr)
             for r in range(b.n_reads):
                 rid = f"r{r}".encode()
                 blk = _svb_zd(b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])])
                 body = (struct.pack("<H", len(rid)) + rid + struct.pack("<I", 0)
                         + struct.pack("<dddd", b.digitisation[r], b.offset[r], b.range[r], 4000.0) + struct.pack("<Q", len(blk)) + blk)
-                z = zstd_compress(body) if compress == "zstd" else zlib.compress(body)
+                z = zstd_compress(body, streamed=(compress == "zstd-stream")) if compress in ("zstd", "zstd-stream") else zlib.compress(body)
                 f.write(struct.pack("<Q", len(z)) + z)
             f.write(b"5WOLB")
         return

@@ -182,11 +182,12 @@ def test_zstd_blow5_is_read_or_refused_by_name(tmp_path):
     h.pgt_slow5_get.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t]; h.pgt_slow5_get.restype = C.c_long
     b = synth.make_batch(64, kind="dna_r10", seed=11, read_len=3001)
     path = str(tmp_path / "z.blow5")
-    synth.write_blow5(b, path, compress="zstd")
-    assert open(path, "rb").read()[9] == 2
-    for r in range(b.n_reads):
-        dor = np.zeros(3); raw = np.zeros(4000, np.int16)
-        n = h.pgt_slow5_get(path.encode(), f"r{r}".encode(), dor.ctypes.data, raw.ctypes.data, 4000)
-        s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
-        assert n == s.size and np.array_equal(raw[:n], s)
-        assert (dor[0], dor[1], dor[2]) == (b.digitisation[r], b.offset[r], b.range[r])
+    for mode in ("zstd", "zstd-stream"):   # one-shot frames (slow5lib) and frames without their content size (a streaming writer)
+        synth.write_blow5(b, path, compress=mode)
+        assert open(path, "rb").read()[9] == 2
+        for r in range(b.n_reads):
+            dor = np.zeros(3); raw = np.zeros(4000, np.int16)
+            n = h.pgt_slow5_get(path.encode(), f"r{r}".encode(), dor.ctypes.data, raw.ctypes.data, 4000)
+            s = b.sig[int(b.sig_off[r]):int(b.sig_off[r + 1])]
+            assert n == s.size and np.array_equal(raw[:n], s)
+            assert (dor[0], dor[1], dor[2]) == (b.digitisation[r], b.offset[r], b.range[r])
