@@ -438,3 +438,24 @@ def test_long_histograms_are_zero_before_the_statistics_stream_uses_them():
     eng.close()
     assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
     assert st.get("long_reads_split", (0, 0.0))[0] == 2 * L.size and st.get("long_helpers_short_batches", (0, 0.0))[0] == 0, st
+
+
+def test_back_to_back_steps_with_long_reads_keep_their_helper_counters_apart():
+    """The bench loop's shape (reset + submit again and again, no host wait in between) on a batch with long reads, two streams: the helper
+    reservations of step i + 1 (statistics stream) and the zeroing by step i's k_batch_init (chain's stream) are only ordered through the
+    gather two steps back -- round 6 keeps the counters in a ring of four so that this is enough. The last step's result is the oracle's."""
+    import torch
+    L = np.array([3000, 70_000, 5000, 300_000, 40_001, 4000, 120_000, 33_000, 2500, 65_537] * 3, np.int64)
+    b = synth.make_ragged_fast(L, kind="dna_r10", seed=77)
+    kmers = generate_kmers(5)
+    p = dict(kmer_size=5, scaling=1, sample_limit=2000)
+    o = oracle_for(kmers, **p); o.run_batch(b)
+    eng = GmoveEngine(GmoveParams(kmers=kmers, **p))
+    d = b.to_device(torch.device("cuda", 0))
+    for _ in range(40):
+        eng.reset(); eng.submit(d)
+    res = eng.finish()
+    st = eng.kernel_stats()
+    eng.close()
+    assert_result_equals_oracle(res, o, sample_limit=p["sample_limit"])
+    assert st.get("long_helpers_short_batches", (0, 0.0))[0] == 0, st
