@@ -16,9 +16,12 @@
  *   (2) the reference tests' cross-format invariant (table path == PAF path at --kmer_pick_margin 0,
  *       test/test_gmove.sh:79-80,95-96), and
  *   (3) the reference tests' exit-status expectations (test_gmove.sh:50,58,66);
- *   (4) for the SAM/BAM path only the invariant BAM == table (test_gmove.sh:85-86,101-102): no known answers exist.
- * No reference-held golden output exists, so by the rules of this build: "parity unpinned" with
- * respect to reference-owned expected values; see DESIGN.md 6.
+ *   (4) for the SAM/BAM path only the invariant BAM == table (test_gmove.sh:85-86,101-102): no known answers exist;
+ *   (5) round 6, for orc_median / orc_madf and the zero-filled pA vector in front of them (gmove.cpp:142-184, 751-771) ONLY: the
+ *       reference's own quickselect -- src/ksort.h:233-259, the one file of the path that compiles here -- built where it lies into
+ *       oracle/_ref/libref_selection.so (ref_selection.c) and run on 216 seeded reads: tests/golden/ksmall_vectors.json.
+ * No reference-held golden output exists for the path as a whole, so by the rules of this build: "parity unpinned" with
+ * respect to reference-owned expected values, except the selection (5); see DESIGN.md 6.
  */
 #ifndef GMOVE_ORACLE_H
 #define GMOVE_ORACLE_H
